@@ -1,0 +1,143 @@
+/* libnmrf_hip.so -- C ABI of the MI355X (gfx950) NMRF-Stereo inference hot path.
+ *
+ * Every entry point is `extern "C"`, takes raw DEVICE pointers + sizes + a
+ * hipStream_t (passed as void*), enqueues on that stream, never allocates,
+ * never synchronises, never throws; returns 0 on success or a negative
+ * NMRF_E* code (nmrf_strerror() gives text).  All tensors are dense
+ * row-major fp32 unless stated; "token-major" = [tokens, channels] with token
+ * index ((b*H + y)*W + x)*N + n  (pixel-major, label-minor -- the reference's
+ * '(b h w) n c' order, nmrf/models/NMP.py:191,347).
+ *
+ * Each declaration cites the reference interface it replaces
+ * (file:line relative to the reference repo root).
+ */
+#ifndef NMRF_HIP_H
+#define NMRF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NMRF_OK 0
+#define NMRF_EINVAL -1      /* bad size / unsupported configuration */
+#define NMRF_ELAUNCH -2     /* hipGetLastError() after the launch was not hipSuccess */
+#define NMRF_ENULL -3       /* null pointer */
+
+const char *nmrf_strerror(int code);
+/* ABI version of this header; bumps on any signature change. */
+int nmrf_abi_version(void);
+
+/* A2  group-wise correlation volume.
+ * replaces build_correlation_volume + the permute of DPN.forward
+ * (nmrf/models/submodule.py:4-23, nmrf/models/DPN.py:117).
+ * f1,f2 [B,C,H,W] (NCHW) -> vol [B*H*W, G, D]; vol[p,g,d] = mean_{c in group g} f1[c,y,x]*f2[c,y,x-d], 0 for x<d.
+ * C % G == 0, D <= 64. */
+int nmrf_cost_volume_f32(const float *f1, const float *f2, int B, int C, int H, int W, int D, int G,
+                         float *vol, void *stream);
+
+/* A3  Conv1d(G->8,k5,p2)-ReLU-Conv1d(8->16)-ReLU-Conv1d(16->1) along D, softmax over D.
+ * replaces DPN.mlp + softmax (nmrf/models/DPN.py:32-38,118-119).
+ * vol [P,G,D]; w0 [8,G,5] b0[8] w1 [16,8,5] b1[16] w2 [1,16,5] b2[1] -> prob [P,D].  G<=4, D<=64. */
+int nmrf_dpn_filter_softmax_f32(const float *vol, const float *w0, const float *b0, const float *w1,
+                                const float *b1, const float *w2, const float *b2, int64_t P, int G, int D,
+                                float *prob, void *stream);
+
+/* A4  label-seed NMS + top-k with ATen-CPU tie order.
+ * replaces max_pool1d / masked assign / torch.topk (nmrf/models/DPN.py:120-125).
+ * prob [P,D] -> seeds [P,K] int64, sorted by suppressed prob desc; ties resolved exactly as
+ * libstdc++ nth_element+sort on (value,index) pairs (ATen TopKImpl.h), bit-exact.
+ * do_nms=0 skips the suppression (plain top-k).  D<=64, K<=8, K*64>D. */
+int nmrf_nms_topk_f32(const float *prob, int64_t P, int D, int K, float eps, int do_nms,
+                      int64_t *seeds, void *stream);
+
+/* A6  seed features: 9-tap x G-group cost gather + Fourier(31) of the seed.
+ * replaces Propagation.sample_cost and fourier_coord_embed (nmrf/models/NMP.py:619-634,35-51,646-647).
+ * vol [P,G,D], seeds [P,N] int64 -> cost [P*N, G*9] (group-major, tap-minor, taps clamped to [0,D-1]),
+ * enc [P*N, 31] = [sin(c*2^i) i<15 | cos(c*2^i) | c], c = seed*normalizer.  enc may be NULL. */
+int nmrf_seed_features_f32(const float *vol, const int64_t *seeds, int64_t P, int G, int D, int N,
+                           float normalizer, float *cost, float *enc, void *stream);
+
+/* Fourier(31) of arbitrary fp32 coordinates (labels / refined disparity).
+ * replaces fourier_coord_embed call sites nmrf/models/NMP.py:743,846.
+ * coord [T] -> enc rows of 31 floats written at enc + t*ld (ld >= 31). */
+int nmrf_fourier_embed_f32(const float *coord, int64_t T, float normalizer, float *enc, int ld, void *stream);
+
+/* LayerNorm(x) concatenated with a per-token (extra_div=1) or per-pixel (extra_div=N) side vector;
+ * builds the q/k(/v) GEMM operand of every message-passing layer in one pass.
+ * replaces norm1 + torch.cat (nmrf/models/NMP.py:92-93,344-346,545-548).
+ * x [T,C] (C==128), gamma,beta [C], extra [T/extra_div, E] (or NULL with E=0)
+ * -> out[t, 0:C] = LN(x[t]) (eps), out[t, C:C+E] = extra[t/extra_div], out[t, C+E:ld] = 0.  ld>=C+E, ld%4==0. */
+int nmrf_ln_concat_f32(const float *x, const float *gamma, const float *beta, float eps, const float *extra,
+                       int E, int extra_div, int64_t T, int C, float *out, int ld, void *stream);
+
+/* A7  cross-stripe attention with LePE, both stripe directions in one call (SPLIT_SIZE==1).
+ * replaces CSWinAttention.forward x2 + cat (nmrf/models/NMP.py:429-505,568-570).
+ * qkv [T,3C] token-major (q|k|v, each C=128 = 2 halves x 2 heads x 32); half 0 -> vertical stripes
+ * (one per image column), half 1 -> horizontal stripes (one per image row).  q is scaled by 32^-0.5.
+ * lepe_v, lepe_h: depthwise 3x3 kernels [C/2,1,3,3] of attns.0 / attns.1.  -> out [T,C]. */
+int nmrf_stripe_attn_f32(const float *qkv, const float *lepe_v, const float *lepe_h, int B, int H, int W, int N,
+                         int C, float *out, void *stream);
+
+/* A9  warp right maps at x-label, group correlation, concat.
+ * replaces Inference.sample_fmap x2 + corr + cat (nmrf/models/NMP.py:683-741, 839-844).
+ * labels [B*H*W*N]; f1,f2 [B,Cf,H,W]; g1,g2 [B,Cg,H,W] (NCHW);
+ * -> out[t, 0:Cf]=f1, [Cf:2Cf]=warp(f2), [2Cf:2Cf+groups]=mean over Cg/groups channels of g1*warp(g2); row stride ld.
+ * Sampling reproduces F.grid_sample(bilinear, zeros, align_corners=True) incl. its normalise/unnormalise round trip. */
+int nmrf_warp_corr_concat_f32(const float *labels, const float *f1, const float *f2, const float *g1,
+                              const float *g2, int B, int H, int W, int N, int Cf, int Cg, int groups,
+                              float *out, int ld, void *stream);
+
+/* A10(i)  per-pixel self-edge attention over the N sibling labels.
+ * replaces the attention core of BasicAttention.forward_pre (nmrf/models/NMP.py:97-103).
+ * qkv [T,3C] (q|k|v), heads*32==C, N<=8 -> out [T,C]. */
+int nmrf_self_attn_f32(const float *qkv, int64_t T, int N, int C, int heads, float *out, void *stream);
+
+/* A10(ii)/A13  (shifted-)window attention with relative-position q/k/v embeddings.
+ * replaces WindowAttention.forward incl. roll, partition, masks (nmrf/models/NMP.py:185-289, 803-826).
+ * qkv [B,Hp,Wp,N,3C]; table [(2*win-1)^2, 3C] (= relative_position_enc_table; per head 96 cols eq|ek|ev);
+ * Hp%win==0, Wp%win==0; shift in [0,win); sibling_mask!=0 forbids attention between different labels of one pixel.
+ * -> out [B,Hp,Wp,N,C] (already un-rolled). heads*32==C. */
+int nmrf_window_attn_f32(const float *qkv, const float *table, int B, int Hp, int Wp, int N, int C, int heads,
+                         int win, int shift, int sibling_mask, float *out, void *stream);
+
+/* A11/A12  coarse heads epilogue: relu(label+delta), winner-take-all over N by score (first max),
+ * x2, 4x4 lower median.  replaces NMRF.forward (nmrf/models/NMRF.py:219-232).
+ * delta, score [T,64] (token-major, 64 = 8x8 sub-pixels hs-major); labels [T] -> disp_curr [B, 2H, 2W] (1/4-px units). */
+int nmrf_wta_median_f32(const float *delta, const float *score, const float *labels, int B, int H, int W, int N,
+                        float *disp_curr, void *stream);
+
+/* A14  refinement epilogue: relu(disp_curr+delta), 4x4 pixel shuffle, x4, crop.
+ * replaces NMRF.forward (nmrf/models/NMRF.py:240-251) + InputPadder.unpad (nmrf/utils/frame_utils.py:277-281).
+ * delta [B*H4*W4,16], disp_curr [B,H4,W4] -> disp_pred [B,4H4,4W4] (1/4-px units), disp [B,outH,outW] = 4*pred cropped. */
+int nmrf_refine_epilogue_f32(const float *delta, const float *disp_curr, int B, int H4, int W4, int outH, int outW,
+                             float *disp_pred, float *disp, void *stream);
+
+/* A15  multi-scale deformable attention.
+ * replaces ms_deform_attn_forward / ms_deform_attn_backward of the reference extension
+ * (ops/src/vision.cpp:13-16, ops/src/cuda/ms_deform_attn_cuda.cu:20-153, ops/src/cuda/ms_deform_im2col_cuda.cuh).
+ * value [B,S,M,D]; shapes [L,2] int64 (H,W) ON DEVICE; lvl_start [L] int64 ON DEVICE;
+ * loc [B,Lq,M,L,P,2] (x,y in [0,1]); w [B,Lq,M,L,P] -> out [B,Lq,M*D].
+ * backward: grad_value must be zero-filled by the caller (accumulated with atomics);
+ * grad_loc / grad_w are fully written. */
+int nmrf_msda_forward_f32(const float *value, const int64_t *shapes, const int64_t *lvl_start, const float *loc,
+                          const float *w, int B, int S, int M, int D, int L, int Lq, int P, float *out, void *stream);
+int nmrf_msda_forward_f64(const double *value, const int64_t *shapes, const int64_t *lvl_start, const double *loc,
+                          const double *w, int B, int S, int M, int D, int L, int Lq, int P, double *out, void *stream);
+int nmrf_msda_backward_f32(const float *value, const int64_t *shapes, const int64_t *lvl_start, const float *loc,
+                           const float *w, const float *grad_out, int B, int S, int M, int D, int L, int Lq, int P,
+                           float *grad_value, float *grad_loc, float *grad_w, void *stream);
+int nmrf_msda_backward_f64(const double *value, const int64_t *shapes, const int64_t *lvl_start, const double *loc,
+                           const double *w, const double *grad_out, int B, int S, int M, int D, int L, int Lq, int P,
+                           double *grad_value, double *grad_loc, double *grad_w, void *stream);
+
+/* Self-test: fills out[32*32] with the 32x32 product A*B computed by one wave of
+ * v_mfma_f32_32x32x2_f32 (A [32,K], B [K,32] row-major, K even <= 64); pins the operand/accumulator
+ * lane layout every attention kernel relies on. */
+int nmrf_selftest_mfma_f32(const float *A, const float *Bm, int K, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NMRF_HIP_H */

@@ -1,0 +1,73 @@
+"""ctypes binding of libnmrf_hip.so (the C ABI declared in include/nmrf_hip.h).
+
+The library is loaded lazily and EXPLICITLY: if it is missing the product raises
+-- there is no CPU or eager-PyTorch fallback for the hot path.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnmrf_hip.so")
+ABI_VERSION = 1
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_L = ctypes.c_int64
+_F = ctypes.c_float
+
+# name -> argtypes (return type is always int unless listed in _RESTYPE)
+PROTOTYPES = {
+    "nmrf_abi_version": [],
+    "nmrf_cost_volume_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "nmrf_dpn_filter_softmax_f32": [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P],
+    "nmrf_nms_topk_f32": [_P, _L, _I, _I, _F, _I, _P, _P],
+    "nmrf_seed_features_f32": [_P, _P, _L, _I, _I, _I, _F, _P, _P, _P],
+    "nmrf_fourier_embed_f32": [_P, _L, _F, _P, _I, _P],
+    "nmrf_ln_concat_f32": [_P, _P, _P, _F, _P, _I, _I, _L, _I, _P, _I, _P],
+    "nmrf_stripe_attn_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
+    "nmrf_warp_corr_concat_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
+    "nmrf_self_attn_f32": [_P, _L, _I, _I, _I, _P, _P],
+    "nmrf_window_attn_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    "nmrf_wta_median_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "nmrf_refine_epilogue_f32": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
+    "nmrf_msda_forward_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    "nmrf_msda_forward_f64": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    "nmrf_msda_backward_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "nmrf_msda_backward_f64": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "nmrf_selftest_mfma_f32": [_P, _P, _I, _P, _P],
+}
+
+_lib = None
+
+
+class NmrfHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Return the loaded CDLL; raise loudly if libnmrf_hip.so is absent or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NmrfHipError(
+            "libnmrf_hip.so not found at %s.  The NMRF hot path has no CPU/PyTorch fallback: build the HIP "
+            "library first (python -m nmrf_amd.build, or __graft_entry__.build())." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = _I
+    lib.nmrf_strerror.argtypes = [_I]
+    lib.nmrf_strerror.restype = ctypes.c_char_p
+    ver = lib.nmrf_abi_version()
+    if ver != ABI_VERSION:
+        raise NmrfHipError("libnmrf_hip.so ABI %d != binding ABI %d: rebuild" % (ver, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().nmrf_strerror(code).decode()
+        raise NmrfHipError("%s failed: %s (code %d)" % (what, msg, code))

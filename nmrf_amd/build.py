@@ -1,0 +1,74 @@
+"""Build libnmrf_hip.so (gfx950) in-tree with hipcc.  No GPU is needed to compile.
+
+    python -m nmrf_amd.build            # incremental
+    python -m nmrf_amd.build --force
+"""
+import concurrent.futures as cf
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libnmrf_hip.so")
+OBJDIR = os.path.join(HERE, "build")
+ARCH = "gfx950"
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (need ROCm to build libnmrf_hip.so)")
+
+
+def _sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _deps_mtime():
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(os.path.dirname(HERE), "include", "nmrf_hip.h"))
+    return max(os.path.getmtime(h) for h in hdrs)
+
+
+def build_library(force=False, verbose=True):
+    hipcc = _hipcc()
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    hdr_t = _deps_mtime()
+    jobs = []
+    objs = []
+    for src in _sources():
+        obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t)
+        if stale:
+            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return cmd, r.returncode, r.stdout + r.stderr
+
+    if jobs:
+        with cf.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            for cmd, rc, log in ex.map(run, jobs):
+                if verbose:
+                    print("[nmrf_amd.build]", os.path.basename(cmd[-3]), "rc=%d" % rc)
+                if rc != 0:
+                    raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), log))
+    if jobs or not os.path.exists(LIB):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        cmd, rc, log = run(cmd)
+        if rc != 0:
+            raise RuntimeError("link failed: %s\n%s" % (" ".join(cmd), log))
+        if verbose:
+            print("[nmrf_amd.build] linked", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build_library(force="--force" in sys.argv)

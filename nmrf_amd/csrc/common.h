@@ -1,0 +1,43 @@
+// Shared device/host helpers for the gfx950 kernels of libnmrf_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "../../include/nmrf_hip.h"
+
+#define NMRF_WAVE 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int nmrf_launch_status() {
+    return hipGetLastError() == hipSuccess ? NMRF_OK : NMRF_ELAUNCH;
+}
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- v_mfma_f32_32x32x2_f32 lane layout (MI355X guide, cdna_hip_programming.md section 3) -------------
+//   A operand: lane l holds A[i = l&31][k = l>>5]          (one f32)
+//   B operand: lane l holds B[k = l>>5][j = l&31]          (one f32)
+//   C/D      : reg r of lane l is D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
+// mfma_row(r, hi) is that row map; the attention kernels use it for the "key index" of S^T and
+// for the "channel index" of O^T.
+__device__ __forceinline__ int mfma_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void stg4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }

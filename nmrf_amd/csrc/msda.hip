@@ -1,0 +1,203 @@
+// A15: multi-scale deformable attention, forward and backward (fp32 / fp64).
+//
+// value [B,S,M,D] keeps the head's D channels contiguous, so a thread that owns CH consecutive
+// channels of one (b, query, head) reads each bilinear tap as one vector.  HBM/L2-bound gather.
+// Forward : one thread = (b, q, m, channel chunk); loops levels x points.
+// Backward: one thread = one sample (b, q, m, l, p); loops all D channels, so grad_loc / grad_w need no
+//           cross-thread reduction (the reference needs seven shared-memory reduction variants for that);
+//           grad_value is scattered with hardware float atomics.
+// Sampling convention (ms_deform_im2col_cuda.cuh:285-288): h_im = loc_y*H - 0.5, zero outside,
+// identical to grid_sample(align_corners=False).
+#include "common.h"
+
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void msda_fwd_kernel(const T *__restrict__ value, const int64_t *__restrict__ shapes,
+        const int64_t *__restrict__ lvl_start, const T *__restrict__ loc, const T *__restrict__ wgt, int B, int S, int M,
+        int D, int L, int Lq, int P, T *__restrict__ out) {
+    const int chunks = D / CH;
+    const int64_t total = (int64_t)B * Lq * M * chunks;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ck = (int)(i % chunks);
+        const int64_t bqm = i / chunks;                        // (b*Lq + q)*M + m
+        const int m = (int)(bqm % M);
+        const int b = (int)(bqm / ((int64_t)M * Lq));
+        const T *lp = loc + bqm * L * P * 2;
+        const T *wp = wgt + bqm * L * P;
+        T acc[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) acc[c] = 0;
+        for (int l = 0; l < L; ++l) {
+            const int Hh = (int)shapes[2 * l], Ww = (int)shapes[2 * l + 1];
+            const T *vbase = value + (((size_t)b * S + (size_t)lvl_start[l]) * M + m) * D + ck * CH;
+            for (int p = 0; p < P; ++p) {
+                const T w_im = lp[(l * P + p) * 2] * Ww - (T)0.5;
+                const T h_im = lp[(l * P + p) * 2 + 1] * Hh - (T)0.5;
+                const T aw = wp[l * P + p];
+                if (h_im > -1 && w_im > -1 && h_im < Hh && w_im < Ww) {
+                    const int h0 = (int)floor(h_im), w0 = (int)floor(w_im);
+                    const T lh = h_im - h0, lw = w_im - w0, hh = 1 - lh, hw = 1 - lw;
+                    const T tw[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+                    T s[CH];
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) s[c] = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int yy = h0 + (k >> 1), xx = w0 + (k & 1);
+                        if (yy >= 0 && yy < Hh && xx >= 0 && xx < Ww) {
+                            const T *v = vbase + ((size_t)yy * Ww + xx) * M * D;
+#pragma unroll
+                            for (int c = 0; c < CH; ++c) s[c] += tw[k] * v[c];
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) acc[c] += s[c] * aw;
+                }
+            }
+        }
+        T *o = out + bqm * D + ck * CH;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) o[c] = acc[c];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void msda_bwd_kernel(const T *__restrict__ value, const int64_t *__restrict__ shapes,
+        const int64_t *__restrict__ lvl_start, const T *__restrict__ loc, const T *__restrict__ wgt,
+        const T *__restrict__ gout, int B, int S, int M, int D, int L, int Lq, int P, T *__restrict__ gvalue,
+        T *__restrict__ gloc, T *__restrict__ gw) {
+    const int64_t total = (int64_t)B * Lq * M * L * P;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int l = (int)((i / P) % L);
+        const int64_t bqm = i / ((int64_t)L * P);
+        const int m = (int)(bqm % M);
+        const int b = (int)(bqm / ((int64_t)M * Lq));
+        const int Hh = (int)shapes[2 * l], Ww = (int)shapes[2 * l + 1];
+        const T w_im = loc[i * 2] * Ww - (T)0.5;
+        const T h_im = loc[i * 2 + 1] * Hh - (T)0.5;
+        const T aw = wgt[i];
+        T g_w = 0, g_x = 0, g_y = 0;
+        if (h_im > -1 && w_im > -1 && h_im < Hh && w_im < Ww) {
+            const int h0 = (int)floor(h_im), w0 = (int)floor(w_im);
+            const T lh = h_im - h0, lw = w_im - w0, hh = 1 - lh, hw = 1 - lw;
+            const T tw[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+            // d(weight_k)/d(w_im), d(weight_k)/d(h_im)   (ms_deform_im2col_cuda.cuh:112-156)
+            const T dwx[4] = {-hh, hh, -lh, lh};
+            const T dwy[4] = {-hw, -lw, hw, lw};
+            const size_t voff = (((size_t)b * S + (size_t)lvl_start[l]) * M + m) * D;
+            const T *go = gout + bqm * D;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int yy = h0 + (k >> 1), xx = w0 + (k & 1);
+                if (yy >= 0 && yy < Hh && xx >= 0 && xx < Ww) {
+                    const size_t o = voff + ((size_t)yy * Ww + xx) * M * D;
+                    T dot = 0;
+                    for (int c = 0; c < D; ++c) {
+                        const T g = go[c];
+                        dot += g * value[o + c];
+                        atomicAdd(gvalue + o + c, tw[k] * aw * g);
+                    }
+                    g_w += tw[k] * dot;
+                    g_x += dwx[k] * dot;
+                    g_y += dwy[k] * dot;
+                }
+            }
+        }
+        gw[i] = g_w;
+        gloc[i * 2] = Ww * g_x * aw;
+        gloc[i * 2 + 1] = Hh * g_y * aw;
+    }
+}
+
+static inline unsigned grid_for(int64_t total) {
+    int64_t blocks = ceil_div64(total, 256);
+    return (unsigned)(blocks > 65536 ? 65536 : (blocks < 1 ? 1 : blocks));
+}
+
+template <typename T>
+static int msda_forward(const T *value, const int64_t *shapes, const int64_t *lvl_start, const T *loc, const T *w, int B,
+                        int S, int M, int D, int L, int Lq, int P, T *out, void *stream) {
+    if (!value || !shapes || !lvl_start || !loc || !w || !out) return NMRF_ENULL;
+    if (B < 1 || S < 1 || M < 1 || D < 1 || L < 1 || Lq < 1 || P < 1) return NMRF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (D % 4 == 0) {
+        hipLaunchKernelGGL((msda_fwd_kernel<T, 4>), dim3(grid_for((int64_t)B * Lq * M * (D / 4))), dim3(256), 0, st, value,
+                           shapes, lvl_start, loc, w, B, S, M, D, L, Lq, P, out);
+    } else {
+        hipLaunchKernelGGL((msda_fwd_kernel<T, 1>), dim3(grid_for((int64_t)B * Lq * M * D)), dim3(256), 0, st, value,
+                           shapes, lvl_start, loc, w, B, S, M, D, L, Lq, P, out);
+    }
+    return nmrf_launch_status();
+}
+
+template <typename T>
+static int msda_backward(const T *value, const int64_t *shapes, const int64_t *lvl_start, const T *loc, const T *w,
+                         const T *gout, int B, int S, int M, int D, int L, int Lq, int P, T *gvalue, T *gloc, T *gw,
+                         void *stream) {
+    if (!value || !shapes || !lvl_start || !loc || !w || !gout || !gvalue || !gloc || !gw) return NMRF_ENULL;
+    if (B < 1 || S < 1 || M < 1 || D < 1 || L < 1 || Lq < 1 || P < 1) return NMRF_EINVAL;
+    hipLaunchKernelGGL((msda_bwd_kernel<T>), dim3(grid_for((int64_t)B * Lq * M * L * P)), dim3(256), 0,
+                       (hipStream_t)stream, value, shapes, lvl_start, loc, w, gout, B, S, M, D, L, Lq, P, gvalue, gloc, gw);
+    return nmrf_launch_status();
+}
+
+extern "C" int nmrf_msda_forward_f32(const float *value, const int64_t *shapes, const int64_t *lvl_start, const float *loc,
+                                     const float *w, int B, int S, int M, int D, int L, int Lq, int P, float *out,
+                                     void *stream) {
+    return msda_forward<float>(value, shapes, lvl_start, loc, w, B, S, M, D, L, Lq, P, out, stream);
+}
+extern "C" int nmrf_msda_forward_f64(const double *value, const int64_t *shapes, const int64_t *lvl_start,
+                                     const double *loc, const double *w, int B, int S, int M, int D, int L, int Lq, int P,
+                                     double *out, void *stream) {
+    return msda_forward<double>(value, shapes, lvl_start, loc, w, B, S, M, D, L, Lq, P, out, stream);
+}
+extern "C" int nmrf_msda_backward_f32(const float *value, const int64_t *shapes, const int64_t *lvl_start,
+                                      const float *loc, const float *w, const float *grad_out, int B, int S, int M, int D,
+                                      int L, int Lq, int P, float *grad_value, float *grad_loc, float *grad_w,
+                                      void *stream) {
+    return msda_backward<float>(value, shapes, lvl_start, loc, w, grad_out, B, S, M, D, L, Lq, P, grad_value, grad_loc,
+                                grad_w, stream);
+}
+extern "C" int nmrf_msda_backward_f64(const double *value, const int64_t *shapes, const int64_t *lvl_start,
+                                      const double *loc, const double *w, const double *grad_out, int B, int S, int M,
+                                      int D, int L, int Lq, int P, double *grad_value, double *grad_loc, double *grad_w,
+                                      void *stream) {
+    return msda_backward<double>(value, shapes, lvl_start, loc, w, grad_out, B, S, M, D, L, Lq, P, grad_value, grad_loc,
+                                 grad_w, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// misc: MFMA lane-layout self-test, error strings, ABI version
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void selftest_mfma_kernel(const float *__restrict__ A, const float *__restrict__ Bm, int K,
+                                                          float *__restrict__ out) {
+    const int lane = threadIdx.x, i = lane & 31, hi = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 2) {
+        const float a = A[i * K + k0 + hi];          // A[i][k]
+        const float b = Bm[(k0 + hi) * 32 + i];      // B[k][j]
+        acc = mfma32(a, b, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[mfma_row(r, hi) * 32 + i] = acc[r];
+}
+
+extern "C" int nmrf_selftest_mfma_f32(const float *A, const float *Bm, int K, float *out, void *stream) {
+    if (!A || !Bm || !out) return NMRF_ENULL;
+    if (K < 2 || K > 64 || (K & 1)) return NMRF_EINVAL;
+    hipLaunchKernelGGL(selftest_mfma_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, Bm, K, out);
+    return nmrf_launch_status();
+}
+
+extern "C" const char *nmrf_strerror(int code) {
+    switch (code) {
+        case NMRF_OK: return "ok";
+        case NMRF_EINVAL: return "invalid size or unsupported configuration";
+        case NMRF_ELAUNCH: return "HIP kernel launch failed";
+        case NMRF_ENULL: return "null pointer argument";
+        default: return "unknown error";
+    }
+}
+
+extern "C" int nmrf_abi_version(void) { return 1; }

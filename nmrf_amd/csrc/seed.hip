@@ -1,0 +1,380 @@
+// Label-seed extraction kernels:
+//   cost volume -> 1-D conv filter + softmax -> NMS + tie-exact top-k -> seed features.
+// All HBM-bound / latency-bound; no matrix cores (tiny FLOP counts).
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// A2: group-wise correlation volume.  One block = one (b, g, y, 64-wide x tile).
+// The 64 channels of the group are streamed through LDS in chunks of CK: f1 tile [CK][64],
+// f2 tile [CK][64+D-1] (left halo, zero for x<0).  Wave w of the block owns disparities
+// {w, w+4, w+8, ...}; lane = x, so the f2 reads of one wave are consecutive LDS addresses.
+// ------------------------------------------------------------------------------------------------
+#define CV_CK 16
+#define CV_TX 64
+#define CV_MAXD 64
+
+__global__ __launch_bounds__(256) void cost_volume_kernel(const float *__restrict__ f1, const float *__restrict__ f2,
+                                                          int C, int H, int W, int D, int G, float *__restrict__ vol) {
+    __shared__ float s1[CV_CK][CV_TX];
+    __shared__ float s2[CV_CK][CV_TX + CV_MAXD];
+    const int x0 = blockIdx.x * CV_TX;
+    const int y = blockIdx.y;
+    const int b = blockIdx.z / G, g = blockIdx.z % G;
+    const int cpg = C / G;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int halo = D - 1;
+    const size_t plane = (size_t)H * W;
+    const float *p1 = f1 + ((size_t)b * C + (size_t)g * cpg) * plane + (size_t)y * W;
+    const float *p2 = f2 + ((size_t)b * C + (size_t)g * cpg) * plane + (size_t)y * W;
+
+    float acc[CV_MAXD / 4];
+#pragma unroll
+    for (int j = 0; j < CV_MAXD / 4; ++j) acc[j] = 0.f;
+
+    for (int c0 = 0; c0 < cpg; c0 += CV_CK) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < CV_CK * CV_TX; i += 256) {
+            int c = i / CV_TX, xx = i % CV_TX;
+            int x = x0 + xx;
+            s1[c][xx] = (c0 + c < cpg && x < W) ? p1[(size_t)(c0 + c) * plane + x] : 0.f;
+        }
+        const int w2 = CV_TX + halo;
+        for (int i = threadIdx.x; i < CV_CK * w2; i += 256) {
+            int c = i / w2, xx = i % w2;
+            int x = x0 - halo + xx;
+            s2[c][xx] = (c0 + c < cpg && x >= 0 && x < W) ? p2[(size_t)(c0 + c) * plane + x] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int c = 0; c < CV_CK; ++c) {
+            float a = s1[c][lane];
+#pragma unroll
+            for (int j = 0; j < CV_MAXD / 4; ++j) {
+                int d = wv + 4 * j;
+                if (d < D) acc[j] = fmaf(a, s2[c][lane + halo - d], acc[j]);
+            }
+        }
+    }
+    const int x = x0 + lane;
+    if (x < W) {
+        const float inv = 1.0f / (float)cpg;
+        float *o = vol + ((((size_t)b * H + y) * W + x) * G + g) * D;
+#pragma unroll
+        for (int j = 0; j < CV_MAXD / 4; ++j) {
+            int d = wv + 4 * j;
+            if (d < D) o[d] = acc[j] * inv;
+        }
+    }
+}
+
+extern "C" int nmrf_cost_volume_f32(const float *f1, const float *f2, int B, int C, int H, int W, int D, int G,
+                                    float *vol, void *stream) {
+    if (!f1 || !f2 || !vol) return NMRF_ENULL;
+    if (B < 1 || C < 1 || H < 1 || W < 1 || G < 1 || C % G || D < 1 || D > CV_MAXD) return NMRF_EINVAL;
+    dim3 grid((W + CV_TX - 1) / CV_TX, H, B * G);
+    hipLaunchKernelGGL(cost_volume_kernel, grid, dim3(256), 0, (hipStream_t)stream, f1, f2, C, H, W, D, G, vol);
+    return nmrf_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// A3: Conv1d(G->8)-ReLU-Conv1d(8->16)-ReLU-Conv1d(16->1) along D (k=5, zero pad 2) + softmax.
+// One wave = one pixel, lane = disparity bin.  Activations go through a wave-private LDS strip
+// [ch][2+64+2] (zero guard cells realise the padding); softmax max/sum are wave shuffles.
+// Weights are wave-uniform -> scalar loads.
+// ------------------------------------------------------------------------------------------------
+#define FS_PPB 4   // pixels (waves) per block
+#define FS_LD 68
+
+__global__ __launch_bounds__(256) void dpn_filter_softmax_kernel(const float *__restrict__ vol,
+        const float *__restrict__ w0, const float *__restrict__ b0, const float *__restrict__ w1,
+        const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ b2,
+        int64_t P, int G, int D, float *__restrict__ prob) {
+    __shared__ float sa[FS_PPB][16][FS_LD];   // input (G ch) then layer-2 output (16 ch)
+    __shared__ float sb[FS_PPB][8][FS_LD];    // layer-1 output
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t p = (int64_t)blockIdx.x * FS_PPB + wv;
+    const bool live = p < P;                    // whole wave uniform
+    const bool in = lane < D;
+    // guard cells
+    for (int i = threadIdx.x; i < FS_PPB * 16 * 4; i += 256) {
+        int q = i / 64, ch = (i / 4) % 16, k = i % 4;
+        sa[q][ch][k < 2 ? k : 64 + k] = 0.f;
+        if (ch < 8) sb[q][ch][k < 2 ? k : 64 + k] = 0.f;
+    }
+    if (live) {
+        for (int g = 0; g < G; ++g) sa[wv][g][2 + lane] = in ? vol[((size_t)p * G + g) * D + lane] : 0.f;
+    }
+    __syncthreads();
+    float h1[8];
+    if (live) {
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            float s = b0[o];
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int k = 0; k < 5; ++k) s = fmaf(w0[(o * G + g) * 5 + k], sa[wv][g][lane + k], s);
+            h1[o] = in ? fmaxf(s, 0.f) : 0.f;
+        }
+#pragma unroll
+        for (int o = 0; o < 8; ++o) sb[wv][o][2 + lane] = h1[o];
+    }
+    __syncthreads();
+    float h2[16];
+    if (live) {
+#pragma unroll
+        for (int o = 0; o < 16; ++o) {
+            float s = b1[o];
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int k = 0; k < 5; ++k) s = fmaf(w1[(o * 8 + c) * 5 + k], sb[wv][c][lane + k], s);
+            h2[o] = in ? fmaxf(s, 0.f) : 0.f;
+        }
+    }
+    __syncthreads();   // everyone finished reading sa (input) before it is overwritten
+    if (live) {
+#pragma unroll
+        for (int o = 0; o < 16; ++o) sa[wv][o][2 + lane] = h2[o];
+    }
+    __syncthreads();
+    if (live) {
+        float s = b2[0];
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) s = fmaf(w2[c * 5 + k], sa[wv][c][lane + k], s);
+        float logit = in ? s : -INFINITY;
+        float m = wave_max(logit);
+        float e = in ? expf(logit - m) : 0.f;
+        float z = wave_sum(e);
+        if (in) prob[(size_t)p * D + lane] = e / z;
+    }
+}
+
+extern "C" int nmrf_dpn_filter_softmax_f32(const float *vol, const float *w0, const float *b0, const float *w1,
+                                           const float *b1, const float *w2, const float *b2, int64_t P, int G, int D,
+                                           float *prob, void *stream) {
+    if (!vol || !w0 || !b0 || !w1 || !b1 || !w2 || !b2 || !prob) return NMRF_ENULL;
+    if (P < 1 || G < 1 || G > 16 || D < 1 || D > 64) return NMRF_EINVAL;
+    dim3 grid((unsigned)ceil_div64(P, FS_PPB));
+    hipLaunchKernelGGL(dpn_filter_softmax_kernel, grid, dim3(256), 0, (hipStream_t)stream, vol, w0, b0, w1, b1, w2, b2,
+                       P, G, D, prob);
+    return nmrf_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// A4: NMS + top-k with the tie order of ATen's CPU top-k (libstdc++ nth_element + sort).
+// One LANE = one pixel; its D (value,index) pairs live in an LDS column (element j of lane l at
+// [j][l], so lanes that are at the same step hit different banks).  The steps are the ones of
+// oracle/topk_ref.c, same comparator, same swaps -> bit-identical indices.
+// ------------------------------------------------------------------------------------------------
+#define TK_MAXD 64
+struct TkQ {
+    float *v;       // [TK_MAXD][64]
+    int *i;
+    int lane;
+    __device__ __forceinline__ float &V(int j) { return v[j * 64 + lane]; }
+    __device__ __forceinline__ int &I(int j) { return i[j * 64 + lane]; }
+};
+__device__ __forceinline__ bool tk_gt(float xv, float yv) { return (isnan(xv) && !isnan(yv)) || (xv > yv); }
+
+__device__ void tk_insertion_sort(TkQ q, int first, int last) {
+    if (first == last) return;
+    for (int i = first + 1; i < last; ++i) {
+        float vv = q.V(i);
+        int vi = q.I(i);
+        if (tk_gt(vv, q.V(first))) {
+            for (int j = i; j > first; --j) { q.V(j) = q.V(j - 1); q.I(j) = q.I(j - 1); }
+            q.V(first) = vv; q.I(first) = vi;
+        } else {
+            int j = i;
+            while (tk_gt(vv, q.V(j - 1))) { q.V(j) = q.V(j - 1); q.I(j) = q.I(j - 1); --j; }
+            q.V(j) = vv; q.I(j) = vi;
+        }
+    }
+}
+
+__device__ void tk_adjust_heap(TkQ q, int start, int hole, int len, float vv, int vi) {
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (tk_gt(q.V(start + child), q.V(start + child - 1))) child--;
+        q.V(start + hole) = q.V(start + child); q.I(start + hole) = q.I(start + child);
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        q.V(start + hole) = q.V(start + child - 1); q.I(start + hole) = q.I(start + child - 1);
+        hole = child - 1;
+    }
+    int parent = (hole - 1) / 2;
+    while (hole > top && tk_gt(q.V(start + parent), vv)) {
+        q.V(start + hole) = q.V(start + parent); q.I(start + hole) = q.I(start + parent);
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    q.V(start + hole) = vv; q.I(start + hole) = vi;
+}
+
+__device__ void tk_heap_select(TkQ q, int first, int middle, int last) {
+    int len = middle - first;
+    if (len >= 2) {
+        for (int parent = (len - 2) / 2;; --parent) {
+            tk_adjust_heap(q, first, parent, len, q.V(first + parent), q.I(first + parent));
+            if (parent == 0) break;
+        }
+    }
+    for (int i = middle; i < last; ++i)
+        if (tk_gt(q.V(i), q.V(first))) {
+            float vv = q.V(i); int vi = q.I(i);
+            q.V(i) = q.V(first); q.I(i) = q.I(first);
+            tk_adjust_heap(q, first, 0, len, vv, vi);
+        }
+}
+
+__device__ void tk_nth_element(TkQ q, int n, int nth) {
+    int first = 0, last = n;
+    if (first == last || nth == last) return;
+    int depth = 2 * (31 - __clz(n));
+    while (last - first > 3) {
+        if (depth == 0) {
+            tk_heap_select(q, first, nth + 1, last);
+            float tv = q.V(first); int ti = q.I(first);
+            q.V(first) = q.V(nth); q.I(first) = q.I(nth);
+            q.V(nth) = tv; q.I(nth) = ti;
+            return;
+        }
+        --depth;
+        int a = first + 1, b = first + (last - first) / 2, c = last - 1, m;
+        float va = q.V(a), vb = q.V(b), vc = q.V(c);
+        if (tk_gt(va, vb)) m = tk_gt(vb, vc) ? b : (tk_gt(va, vc) ? c : a);
+        else               m = tk_gt(va, vc) ? a : (tk_gt(vb, vc) ? c : b);
+        { float tv = q.V(first); int ti = q.I(first);
+          q.V(first) = q.V(m); q.I(first) = q.I(m); q.V(m) = tv; q.I(m) = ti; }
+        const float pv = q.V(first);
+        int lo = first + 1, hi = last;
+        for (;;) {
+            while (tk_gt(q.V(lo), pv)) ++lo;
+            --hi;
+            while (tk_gt(pv, q.V(hi))) --hi;
+            if (!(lo < hi)) break;
+            float tv = q.V(lo); int ti = q.I(lo);
+            q.V(lo) = q.V(hi); q.I(lo) = q.I(hi); q.V(hi) = tv; q.I(hi) = ti;
+            ++lo;
+        }
+        if (lo <= nth) first = lo; else last = lo;
+    }
+    tk_insertion_sort(q, first, last);
+}
+
+__global__ __launch_bounds__(64) void nms_topk_kernel(const float *__restrict__ prob, int64_t P, int D, int K, float eps,
+                                                     int do_nms, int64_t *__restrict__ seeds) {
+    __shared__ float sv[TK_MAXD * 64];
+    __shared__ int si[TK_MAXD * 64];
+    const int lane = threadIdx.x;
+    const int64_t p0 = (int64_t)blockIdx.x * 64;
+    const int rows = (int)((P - p0) < 64 ? (P - p0) : 64);
+    // coalesced staging: element (row r, bin j) of the tile is at linear index r*D + j
+    for (int i = lane; i < rows * D; i += 64) {
+        int r = i / D, j = i - r * D;
+        sv[j * 64 + r] = prob[(size_t)p0 * D + i];
+    }
+    __syncthreads();
+    if (lane >= rows) return;
+    TkQ q{sv, si, lane};
+    if (do_nms) {
+        float prev = -INFINITY, cur = q.V(0);
+        for (int j = 0; j < D; ++j) {
+            float nxt = (j + 1 < D) ? q.V(j + 1) : -INFINITY;
+            bool any_nan = isnan(prev) || isnan(cur) || isnan(nxt);
+            float m = any_nan ? NAN : fmaxf(fmaxf(prev, nxt), cur);     // max_pool1d(k=3,p=1), NaN-propagating
+            float out = (cur != m && cur > eps) ? eps : cur;            // DPN.py:121-124
+            q.V(j) = out;
+            prev = cur; cur = nxt;
+        }
+    }
+    for (int j = 0; j < D; ++j) q.I(j) = j;
+    tk_nth_element(q, D, K - 1);
+    tk_insertion_sort(q, 0, K - 1);
+    for (int j = 0; j < K; ++j) seeds[(size_t)(p0 + lane) * K + j] = (int64_t)q.I(j);
+}
+
+extern "C" int nmrf_nms_topk_f32(const float *prob, int64_t P, int D, int K, float eps, int do_nms, int64_t *seeds,
+                                 void *stream) {
+    if (!prob || !seeds) return NMRF_ENULL;
+    if (P < 1 || D < 1 || D > TK_MAXD || K < 1 || K > 8 || K > D || K * 64 <= D) return NMRF_EINVAL;
+    dim3 grid((unsigned)ceil_div64(P, 64));
+    hipLaunchKernelGGL(nms_topk_kernel, grid, dim3(64), 0, (hipStream_t)stream, prob, P, D, K, eps, do_nms, seeds);
+    return nmrf_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// A6: 9-tap x G-group cost gather and Fourier(31) of the integer seed.
+// Fourier op order (H2): c = coord*normalizer ; f = c * 2^i (exact) ; full-range sinf/cosf.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void fourier_write(float coord, float normalizer, int f, float *row) {
+    // f in [0,16): f<15 -> sin/cos of band f ; f==15 -> the scaled coordinate itself
+    float c = coord * normalizer;
+    if (f < 15) {
+        float arg = c * (float)(1 << f);
+        float s, co;
+        sincosf(arg, &s, &co);
+        row[f] = s;
+        row[15 + f] = co;
+    } else {
+        row[30] = c;
+    }
+}
+
+__global__ __launch_bounds__(256) void seed_features_kernel(const float *__restrict__ vol, const int64_t *__restrict__ seeds,
+        int64_t P, int G, int D, int N, float normalizer, float *__restrict__ cost, float *__restrict__ enc) {
+    const int per = G * 9;
+    const int slots = per + 16;                       // cost entries + 16 Fourier work items per token
+    const int64_t total = P * N * slots;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t t = i / slots;
+        int j = (int)(i - t * slots);
+        int64_t p = t / N;
+        int seed = (int)seeds[t];
+        if (j < per) {
+            int g = j / 9, tap = j - g * 9;
+            int d = seed + tap - 4;
+            d = d < 0 ? 0 : (d > D - 1 ? D - 1 : d);
+            cost[t * per + j] = vol[((size_t)p * G + g) * D + d];
+        } else if (enc) {
+            fourier_write((float)seed, normalizer, j - per, enc + t * 31);
+        }
+    }
+}
+
+extern "C" int nmrf_seed_features_f32(const float *vol, const int64_t *seeds, int64_t P, int G, int D, int N,
+                                      float normalizer, float *cost, float *enc, void *stream) {
+    if (!vol || !seeds || !cost) return NMRF_ENULL;
+    if (P < 1 || G < 1 || D < 1 || N < 1) return NMRF_EINVAL;
+    int64_t total = P * N * (G * 9 + 16);
+    int64_t blocks = ceil_div64(total, 256);
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(seed_features_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, vol, seeds, P, G,
+                       D, N, normalizer, cost, enc);
+    return nmrf_launch_status();
+}
+
+__global__ __launch_bounds__(256) void fourier_embed_kernel(const float *__restrict__ coord, int64_t T, float normalizer,
+                                                           float *__restrict__ enc, int ld) {
+    const int64_t total = T * 16;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t t = i >> 4;
+        fourier_write(coord[t], normalizer, (int)(i & 15), enc + t * ld);
+    }
+}
+
+extern "C" int nmrf_fourier_embed_f32(const float *coord, int64_t T, float normalizer, float *enc, int ld, void *stream) {
+    if (!coord || !enc) return NMRF_ENULL;
+    if (T < 1 || ld < 31) return NMRF_EINVAL;
+    int64_t blocks = ceil_div64(T * 16, 256);
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(fourier_embed_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, coord, T,
+                       normalizer, enc, ld);
+    return nmrf_launch_status();
+}

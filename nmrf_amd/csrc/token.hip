@@ -1,0 +1,317 @@
+// Per-token / per-pixel HBM-bound kernels (SURVEY section 8 rows A7/A10 prologue, A9, A10(i), A12, A14).
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm(x) | extra  -> GEMM operand.  32 lanes per token (C == 128: one float4 per lane),
+// two tokens per wave, statistics by half-wave shuffles.  Two-pass variance like ATen.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_concat_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+        const float *__restrict__ beta, float eps, const float *__restrict__ extra, int E, int extra_div, int64_t T,
+        float *__restrict__ out, int ld) {
+    const int sub = threadIdx.x & 31;
+    const int64_t t = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 5;
+    if (t >= T) return;                                  // whole 32-lane group exits together
+    float4 v = ldg4(x + t * 128 + sub * 4);
+    float s = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s * (1.0f / 128.0f);
+    float4 d = make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
+    float q = (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / 128.0f) + eps);
+    float4 g = ldg4(gamma + sub * 4), bt = ldg4(beta + sub * 4);
+    float4 r = make_float4(d.x * rstd * g.x + bt.x, d.y * rstd * g.y + bt.y, d.z * rstd * g.z + bt.z,
+                           d.w * rstd * g.w + bt.w);
+    float *o = out + t * ld;
+    stg4(o + sub * 4, r);
+    const float *e = extra ? extra + (t / extra_div) * E : nullptr;
+    for (int j = 128 + sub; j < ld; j += 32) o[j] = (j - 128 < E) ? e[j - 128] : 0.f;
+}
+
+extern "C" int nmrf_ln_concat_f32(const float *x, const float *gamma, const float *beta, float eps, const float *extra,
+                                  int E, int extra_div, int64_t T, int C, float *out, int ld, void *stream) {
+    if (!x || !gamma || !beta || !out || (E > 0 && !extra)) return NMRF_ENULL;
+    if (C != 128 || T < 1 || E < 0 || extra_div < 1 || ld < C + E || (ld & 3)) return NMRF_EINVAL;
+    dim3 grid((unsigned)ceil_div64(T * 32, 256));
+    hipLaunchKernelGGL(ln_concat_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, gamma, beta, eps, extra, E,
+                       extra_div, T, out, ld);
+    return nmrf_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// A10(i): self-edge attention among the N sibling labels of one pixel.
+// One thread = one (token, head): 32-wide q in registers, N keys/values streamed as float4.
+// ------------------------------------------------------------------------------------------------
+#define SA_MAXN 8
+__global__ __launch_bounds__(256) void self_attn_kernel(const float *__restrict__ qkv, int64_t T, int N, int C, int heads,
+                                                       float scale, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= T * heads) return;
+    const int64_t t = i / heads;
+    const int h = (int)(i - t * heads);
+    const int64_t t0 = (t / N) * N;
+    const size_t ld = (size_t)3 * C;
+    float q[32];
+    {
+        const float *qp = qkv + t * ld + h * 32;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float4 v = ldg4(qp + c * 4);
+            q[c * 4 + 0] = v.x; q[c * 4 + 1] = v.y; q[c * 4 + 2] = v.z; q[c * 4 + 3] = v.w;
+        }
+    }
+    float logit[SA_MAXN];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < SA_MAXN; ++j) {
+        if (j < N) {
+            const float *kp = qkv + (t0 + j) * ld + C + h * 32;
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float4 v = ldg4(kp + c * 4);
+                s = fmaf(q[c * 4 + 0], v.x, s); s = fmaf(q[c * 4 + 1], v.y, s);
+                s = fmaf(q[c * 4 + 2], v.z, s); s = fmaf(q[c * 4 + 3], v.w, s);
+            }
+            logit[j] = s * scale;
+            m = fmaxf(m, logit[j]);
+        } else {
+            logit[j] = -INFINITY;
+        }
+    }
+    float z = 0.f;
+#pragma unroll
+    for (int j = 0; j < SA_MAXN; ++j) { logit[j] = (j < N) ? expf(logit[j] - m) : 0.f; z += logit[j]; }
+    const float rz = 1.0f / z;
+    float o[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) o[c] = 0.f;
+#pragma unroll
+    for (int j = 0; j < SA_MAXN; ++j) {
+        if (j < N) {
+            const float pj = logit[j] * rz;
+            const float *vp = qkv + (t0 + j) * ld + 2 * C + h * 32;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float4 v = ldg4(vp + c * 4);
+                o[c * 4 + 0] = fmaf(pj, v.x, o[c * 4 + 0]); o[c * 4 + 1] = fmaf(pj, v.y, o[c * 4 + 1]);
+                o[c * 4 + 2] = fmaf(pj, v.z, o[c * 4 + 2]); o[c * 4 + 3] = fmaf(pj, v.w, o[c * 4 + 3]);
+            }
+        }
+    }
+    float *op = out + t * C + h * 32;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) stg4(op + c * 4, make_float4(o[c * 4], o[c * 4 + 1], o[c * 4 + 2], o[c * 4 + 3]));
+}
+
+extern "C" int nmrf_self_attn_f32(const float *qkv, int64_t T, int N, int C, int heads, float *out, void *stream) {
+    if (!qkv || !out) return NMRF_ENULL;
+    if (T < 1 || N < 1 || N > SA_MAXN || T % N || heads < 1 || heads * 32 != C) return NMRF_EINVAL;
+    dim3 grid((unsigned)ceil_div64(T * heads, 256));
+    hipLaunchKernelGGL(self_attn_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, T, N, C, heads,
+                       1.0f / sqrtf(32.0f), out);
+    return nmrf_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// A9: warp right feature maps at x - label, group correlation, concat -> [T, 2Cf+groups].
+// One block = one (b, y, 64-wide x tile); wave = label n (loops if N > 4), lane = x, so every
+// per-channel NCHW read is coalesced for f1/g1 and near-coalesced for the warped f2/g2 taps.
+// The sampling position reproduces grid_sample(align_corners=True)'s float round trip (H6).
+// ------------------------------------------------------------------------------------------------
+struct WarpTaps {
+    int off[4];     // y*W + x of the four taps (clamped in range)
+    float w[4];     // weight, already zeroed for out-of-range taps
+};
+
+__device__ __forceinline__ WarpTaps make_taps(float label, int x, int y, int H, int W) {
+    // reference grid (NMP.py:696-704): gx = 2*(x + (-d))/(W-1) - 1 ; gy = 2*(y + 0)/(H-1) - 1
+    float gx = 2.0f * ((float)x + (-label)) / (float)(W - 1) - 1.0f;
+    float gy = 2.0f * ((float)y + 0.0f) / (float)(H - 1) - 1.0f;
+    // ATen vectorised CPU grid_sampler, align_corners=True: (g + 1) * ((size-1)/2)
+    float ix = (gx + 1.0f) * ((float)(W - 1) / 2.0f);
+    float iy = (gy + 1.0f) * ((float)(H - 1) / 2.0f);
+    float x0f = floorf(ix), y0f = floorf(iy);
+    float wx1 = ix - x0f, wy1 = iy - y0f;
+    float wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+    // floorf of a value up to ~1e9 would overflow int; labels are O(W) so clamp defensively
+    x0f = fminf(fmaxf(x0f, -2.0f), (float)W);
+    y0f = fminf(fmaxf(y0f, -2.0f), (float)H);
+    int x0 = (int)x0f, y0 = (int)y0f;
+    WarpTaps t;
+    const float wy[2] = {wy0, wy1}, wx[2] = {wx0, wx1};
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            int xx = x0 + dx, yy = y0 + dy;
+            bool ok = xx >= 0 && xx < W && yy >= 0 && yy < H;
+            int xc = xx < 0 ? 0 : (xx >= W ? W - 1 : xx);
+            int yc = yy < 0 ? 0 : (yy >= H ? H - 1 : yy);
+            t.off[dy * 2 + dx] = yc * W + xc;
+            t.w[dy * 2 + dx] = ok ? wy[dy] * wx[dx] : 0.f;
+        }
+    return t;
+}
+
+__device__ __forceinline__ float warp_fetch(const float *__restrict__ plane, const WarpTaps &t) {
+    // nw*v + ne*v + sw*v + se*v in ATen's order; zero-weight taps are skipped (0*finite adds exactly 0)
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (t.w[k] != 0.f) r += plane[t.off[k]] * t.w[k];
+    return r;
+}
+
+__global__ __launch_bounds__(256) void warp_corr_concat_kernel(const float *__restrict__ labels,
+        const float *__restrict__ f1, const float *__restrict__ f2, const float *__restrict__ g1,
+        const float *__restrict__ g2, int H, int W, int N, int Cf, int Cg, int groups, float *__restrict__ out, int ld) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane;
+    const int y = blockIdx.y, b = blockIdx.z;
+    if (x >= W) return;
+    const size_t plane = (size_t)H * W;
+    const int pix = y * W + x;
+    const int cpg = Cg / groups;
+    for (int n = wv; n < N; n += 4) {
+        const int64_t t = (((int64_t)b * H + y) * W + x) * N + n;
+        const WarpTaps tp = make_taps(labels[t], x, y, H, W);
+        float *o = out + t * ld;
+        const float *pf1 = f1 + (size_t)b * Cf * plane, *pf2 = f2 + (size_t)b * Cf * plane;
+        for (int c = 0; c < Cf; c += 4) {
+            float a[4], w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                a[k] = pf1[(size_t)(c + k) * plane + pix];
+                w[k] = warp_fetch(pf2 + (size_t)(c + k) * plane, tp);
+            }
+            stg4(o + c, make_float4(a[0], a[1], a[2], a[3]));
+            stg4(o + Cf + c, make_float4(w[0], w[1], w[2], w[3]));
+        }
+        const float *pg1 = g1 + (size_t)b * Cg * plane, *pg2 = g2 + (size_t)b * Cg * plane;
+        const float inv = 1.0f / (float)cpg;
+        for (int g = 0; g < groups; g += 4) {
+            float r[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float s = 0.f;
+                for (int c = 0; c < cpg; ++c) {
+                    size_t ch = (size_t)((g + k) * cpg + c) * plane;
+                    s = fmaf(pg1[ch + pix], warp_fetch(pg2 + ch, tp), s);
+                }
+                r[k] = s * inv;
+            }
+            stg4(o + 2 * Cf + g, make_float4(r[0], r[1], r[2], r[3]));
+        }
+    }
+}
+
+extern "C" int nmrf_warp_corr_concat_f32(const float *labels, const float *f1, const float *f2, const float *g1,
+                                         const float *g2, int B, int H, int W, int N, int Cf, int Cg, int groups,
+                                         float *out, int ld, void *stream) {
+    if (!labels || !f1 || !f2 || !g1 || !g2 || !out) return NMRF_ENULL;
+    if (B < 1 || H < 2 || W < 2 || N < 1 || Cf < 4 || (Cf & 3) || groups < 4 || (groups & 3) || Cg % groups ||
+        ld < 2 * Cf + groups || (ld & 3))
+        return NMRF_EINVAL;
+    dim3 grid((W + 63) / 64, H, B);
+    hipLaunchKernelGGL(warp_corr_concat_kernel, grid, dim3(256), 0, (hipStream_t)stream, labels, f1, f2, g1, g2, H, W, N,
+                       Cf, Cg, groups, out, ld);
+    return nmrf_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// A11/A12: relu(label+delta) -> WTA over N by score (first max wins) -> x2 -> 4x4 lower median.
+// One thread = one 1/4-res output pixel = one 4x4 block of full-res sub-pixels, all inside a single
+// 1/8 cell, so it reads 4 float4 rows of delta and of score per label.
+// ------------------------------------------------------------------------------------------------
+#define WTA_MAXN 8
+__global__ __launch_bounds__(256) void wta_median_kernel(const float *__restrict__ delta, const float *__restrict__ score,
+        const float *__restrict__ labels, int B, int H, int W, int N, float *__restrict__ disp_curr) {
+    const int H4 = 2 * H, W4 = 2 * W;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * H4 * W4) return;
+    const int xq = (int)(i % W4), yq = (int)((i / W4) % H4), b = (int)(i / ((int64_t)W4 * H4));
+    const int y = yq >> 1, x = xq >> 1;
+    const int64_t t0 = (((int64_t)b * H + y) * W + x) * N;
+    const int j0 = (4 * (yq & 1)) * 8 + 4 * (xq & 1);     // sub-pixel index hs*8+ws of the block's corner
+    float best_s[16], val[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { best_s[k] = -INFINITY; val[k] = 0.f; }
+    for (int n = 0; n < N; ++n) {
+        const float lab = labels[t0 + n];
+        const float *dp = delta + (t0 + n) * 64 + j0, *sp = score + (t0 + n) * 64 + j0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float4 d4 = ldg4(dp + r * 8), s4 = ldg4(sp + r * 8);
+            const float dd[4] = {d4.x, d4.y, d4.z, d4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int k = r * 4 + c;
+                // torch.max returns the first maximal index; a NaN score also wins (ATen max semantics)
+                bool take = (n == 0) || (ss[c] > best_s[k]) || (isnan(ss[c]) && !isnan(best_s[k]));
+                if (take) { best_s[k] = ss[c]; val[k] = fmaxf(lab + dd[c], 0.f) * 2.0f; }
+            }
+        }
+    }
+    // lower median of 16 = element of rank 7 (0-based) under a stable order
+    float med = val[0];
+#pragma unroll
+    for (int a = 0; a < 16; ++a) {
+        int rank = 0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) rank += (val[c] < val[a]) || (val[c] == val[a] && c < a);
+        if (rank == 7) med = val[a];
+    }
+    disp_curr[i] = med;
+}
+
+extern "C" int nmrf_wta_median_f32(const float *delta, const float *score, const float *labels, int B, int H, int W,
+                                   int N, float *disp_curr, void *stream) {
+    if (!delta || !score || !labels || !disp_curr) return NMRF_ENULL;
+    if (B < 1 || H < 1 || W < 1 || N < 1 || N > WTA_MAXN) return NMRF_EINVAL;
+    dim3 grid((unsigned)ceil_div64((int64_t)B * 4 * H * W, 256));
+    hipLaunchKernelGGL(wta_median_kernel, grid, dim3(256), 0, (hipStream_t)stream, delta, score, labels, B, H, W, N,
+                       disp_curr);
+    return nmrf_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// A14: relu(disp_curr + delta) -> 4x4 pixel shuffle -> disp_pred ; x4 + crop -> disp.
+// One thread = one 1/4-res cell: reads 16 deltas (4 float4), writes a 4x4 patch (row-wise float4).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void refine_epilogue_kernel(const float *__restrict__ delta,
+        const float *__restrict__ disp_curr, int B, int H4, int W4, int outH, int outW, float *__restrict__ disp_pred,
+        float *__restrict__ disp) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * H4 * W4) return;
+    const int xq = (int)(i % W4), yq = (int)((i / W4) % H4), b = (int)(i / ((int64_t)W4 * H4));
+    const float base = disp_curr[i];
+    const int Hf = 4 * H4, Wf = 4 * W4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float4 d4 = ldg4(delta + i * 16 + r * 4);
+        float4 p = make_float4(fmaxf(base + d4.x, 0.f), fmaxf(base + d4.y, 0.f), fmaxf(base + d4.z, 0.f),
+                               fmaxf(base + d4.w, 0.f));
+        const int Y = 4 * yq + r, X = 4 * xq;
+        stg4(disp_pred + ((size_t)b * Hf + Y) * Wf + X, p);
+        if (Y < outH) {
+            const float pv[4] = {p.x, p.y, p.z, p.w};
+            float *o = disp + ((size_t)b * outH + Y) * outW;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (X + c < outW) o[X + c] = pv[c] * 4.0f;
+        }
+    }
+}
+
+extern "C" int nmrf_refine_epilogue_f32(const float *delta, const float *disp_curr, int B, int H4, int W4, int outH,
+                                        int outW, float *disp_pred, float *disp, void *stream) {
+    if (!delta || !disp_curr || !disp_pred || !disp) return NMRF_ENULL;
+    if (B < 1 || H4 < 1 || W4 < 1 || outH < 1 || outW < 1 || outH > 4 * H4 || outW > 4 * W4) return NMRF_EINVAL;
+    dim3 grid((unsigned)ceil_div64((int64_t)B * H4 * W4, 256));
+    hipLaunchKernelGGL(refine_epilogue_kernel, grid, dim3(256), 0, (hipStream_t)stream, delta, disp_curr, B, H4, W4, outH,
+                       outW, disp_pred, disp);
+    return nmrf_launch_status();
+}

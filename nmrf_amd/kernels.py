@@ -1,0 +1,191 @@
+"""Tensor-level wrappers over the C ABI: validate, allocate outputs with torch, pass raw device
+pointers and the CURRENT torch stream.  PyTorch is plumbing here (memory + streams); all arithmetic
+of these ops happens in libnmrf_hip.so.  Every wrapper refuses non-CUDA tensors: there is no
+fallback path."""
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(*tensors, dtype=torch.float32):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.NmrfHipError("NMRF hot-path kernels run on the MI355X only: got a %s tensor "
+                                    "(no CPU fallback exists by design)" % t.device)
+        if not t.is_contiguous():
+            raise _lib.NmrfHipError("tensor must be contiguous")
+        if dtype is not None and t.dtype != dtype:
+            raise _lib.NmrfHipError("expected %s, got %s" % (dtype, t.dtype))
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def mfma_selftest(a, bm):
+    _chk(a, bm)
+    k = a.shape[1]
+    out = torch.empty(32, 32, device=a.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_selftest_mfma_f32(_p(a), _p(bm), k, _p(out), _stream()), "mfma selftest")
+    return out
+
+
+def cost_volume(f1, f2, num_disp, groups):
+    """[B,C,H,W] x2 -> [B*H*W, G, D]"""
+    _chk(f1, f2)
+    b, c, h, w = f1.shape
+    vol = torch.empty(b * h * w, groups, num_disp, device=f1.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_cost_volume_f32(_p(f1), _p(f2), b, c, h, w, num_disp, groups, _p(vol), _stream()),
+               "cost_volume")
+    return vol
+
+
+def dpn_filter_softmax(vol, w0, b0, w1, b1, w2, b2):
+    _chk(vol, w0, b0, w1, b1, w2, b2)
+    p, g, d = vol.shape
+    prob = torch.empty(p, d, device=vol.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_dpn_filter_softmax_f32(_p(vol), _p(w0), _p(b0), _p(w1), _p(b1), _p(w2), _p(b2), p, g, d,
+                                                       _p(prob), _stream()), "dpn_filter_softmax")
+    return prob
+
+
+def nms_topk(prob, k, eps, do_nms=True):
+    _chk(prob)
+    p, d = prob.shape
+    seeds = torch.empty(p, k, device=prob.device, dtype=torch.int64)
+    _lib.check(_lib.load().nmrf_nms_topk_f32(_p(prob), p, d, k, float(eps), int(do_nms), _p(seeds), _stream()),
+               "nms_topk")
+    return seeds
+
+
+def seed_features(vol, seeds, normalizer):
+    _chk(vol)
+    _chk(seeds, dtype=torch.int64)
+    p, g, d = vol.shape
+    n = seeds.shape[1]
+    cost = torch.empty(p * n, g * 9, device=vol.device, dtype=torch.float32)
+    enc = torch.empty(p * n, 31, device=vol.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_seed_features_f32(_p(vol), _p(seeds), p, g, d, n, float(normalizer), _p(cost), _p(enc),
+                                                  _stream()), "seed_features")
+    return cost, enc
+
+
+def fourier_embed(coord, normalizer):
+    _chk(coord)
+    t = coord.numel()
+    enc = torch.empty(t, 31, device=coord.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_fourier_embed_f32(_p(coord), t, float(normalizer), _p(enc), 31, _stream()),
+               "fourier_embed")
+    return enc
+
+
+def ln_concat(x, gamma, beta, extra=None, extra_div=1, ld=None, eps=1e-5):
+    """-> [T, ld] = [LN(x) | extra[t // extra_div] | 0-pad]"""
+    _chk(x, gamma, beta, extra)
+    t, c = x.shape
+    e = 0 if extra is None else extra.shape[-1]
+    if ld is None:
+        ld = (c + e + 3) // 4 * 4
+    out = torch.empty(t, ld, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_ln_concat_f32(_p(x), _p(gamma), _p(beta), float(eps), _p(extra), e, extra_div, t, c,
+                                              _p(out), ld, _stream()), "ln_concat")
+    return out
+
+
+def stripe_attn(qkv, lepe_v, lepe_h, b, h, w, n):
+    _chk(qkv, lepe_v, lepe_h)
+    t, c3 = qkv.shape
+    c = c3 // 3
+    assert t == b * h * w * n
+    out = torch.empty(t, c, device=qkv.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_stripe_attn_f32(_p(qkv), _p(lepe_v), _p(lepe_h), b, h, w, n, c, _p(out), _stream()),
+               "stripe_attn")
+    return out
+
+
+def warp_corr_concat(labels, f1, f2, g1, g2, n, groups=32, ld=None):
+    _chk(labels, f1, f2, g1, g2)
+    b, cf, h, w = f1.shape
+    cg = g1.shape[1]
+    if ld is None:
+        ld = 2 * cf + groups
+    t = b * h * w * n
+    assert labels.numel() == t
+    out = torch.empty(t, ld, device=f1.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_warp_corr_concat_f32(_p(labels), _p(f1), _p(f2), _p(g1), _p(g2), b, h, w, n, cf, cg,
+                                                     groups, _p(out), ld, _stream()), "warp_corr_concat")
+    return out
+
+
+def self_attn(qkv, n, heads):
+    _chk(qkv)
+    t, c3 = qkv.shape
+    c = c3 // 3
+    out = torch.empty(t, c, device=qkv.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_self_attn_f32(_p(qkv), t, n, c, heads, _p(out), _stream()), "self_attn")
+    return out
+
+
+def window_attn(qkv, table, b, hp, wp, n, heads, win, shift, sibling_mask):
+    _chk(qkv, table)
+    t, c3 = qkv.shape
+    c = c3 // 3
+    assert t == b * hp * wp * n
+    out = torch.empty(t, c, device=qkv.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_window_attn_f32(_p(qkv), _p(table), b, hp, wp, n, c, heads, win, shift,
+                                                int(bool(sibling_mask)), _p(out), _stream()), "window_attn")
+    return out
+
+
+def wta_median(delta, score, labels, b, h, w, n):
+    _chk(delta, score, labels)
+    out = torch.empty(b, 2 * h, 2 * w, device=delta.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_wta_median_f32(_p(delta), _p(score), _p(labels), b, h, w, n, _p(out), _stream()),
+               "wta_median")
+    return out
+
+
+def refine_epilogue(delta, disp_curr, out_h, out_w):
+    _chk(delta, disp_curr)
+    b, h4, w4 = disp_curr.shape
+    pred = torch.empty(b, 4 * h4, 4 * w4, device=delta.device, dtype=torch.float32)
+    disp = torch.empty(b, out_h, out_w, device=delta.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_refine_epilogue_f32(_p(delta), _p(disp_curr), b, h4, w4, out_h, out_w, _p(pred), _p(disp),
+                                                    _stream()), "refine_epilogue")
+    return disp, pred
+
+
+def msda_forward(value, shapes, lvl_start, loc, w):
+    dt = value.dtype
+    if dt not in (torch.float32, torch.float64):
+        raise _lib.NmrfHipError("msda supports fp32/fp64")
+    _chk(value, loc, w, dtype=dt)
+    _chk(shapes, lvl_start, dtype=torch.int64)
+    b, s, m, d = value.shape
+    _, lq, _, l, p, _ = loc.shape
+    out = torch.empty(b, lq, m * d, device=value.device, dtype=dt)
+    fn = _lib.load().nmrf_msda_forward_f32 if dt == torch.float32 else _lib.load().nmrf_msda_forward_f64
+    _lib.check(fn(_p(value), _p(shapes), _p(lvl_start), _p(loc), _p(w), b, s, m, d, l, lq, p, _p(out), _stream()),
+               "msda_forward")
+    return out
+
+
+def msda_backward(value, shapes, lvl_start, loc, w, grad_out):
+    dt = value.dtype
+    _chk(value, loc, w, grad_out, dtype=dt)
+    _chk(shapes, lvl_start, dtype=torch.int64)
+    b, s, m, d = value.shape
+    _, lq, _, l, p, _ = loc.shape
+    gv = torch.zeros_like(value)
+    gl = torch.empty_like(loc)
+    gw = torch.empty_like(w)
+    fn = _lib.load().nmrf_msda_backward_f32 if dt == torch.float32 else _lib.load().nmrf_msda_backward_f64
+    _lib.check(fn(_p(value), _p(shapes), _p(lvl_start), _p(loc), _p(w), _p(grad_out), b, s, m, d, l, lq, p, _p(gv), _p(gl),
+                  _p(gw), _stream()), "msda_backward")
+    return gv, gl, gw

@@ -1,0 +1,71 @@
+"""Stock PyTorch-ROCm CNN feature encoder (OUT OF hot-path scope by north_star: runs on MIOpen).
+
+Parameter names follow the reference's `Backbone` (nmrf/models/backbone.py:16-98) so released
+checkpoints load with strict=True: conv1, layer{1,2,3}.{0,1}.{conv1,conv2,downsample.0}, conv2.
+"""
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _norm(kind, ch):
+    if kind == "instance":
+        return nn.InstanceNorm2d(ch)
+    if kind == "batch":
+        return nn.BatchNorm2d(ch)
+    raise ValueError("Invalid backbone normalization type: %s" % kind)
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, cin, cout, norm="instance", stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.relu = nn.ReLU(inplace=True)
+        self.norm1 = _norm(norm, cout)
+        self.norm2 = _norm(norm, cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.norm3 = _norm(norm, cout)
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride), self.norm3)
+
+    def forward(self, x):
+        y = self.relu(self.norm1(self.conv1(x)))
+        y = self.relu(self.norm2(self.conv2(y)))
+        if self.downsample is not None:
+            x = self.downsample(x)
+        return self.relu(x + y)
+
+
+class Backbone(nn.Module):
+    """7x7/s2 stem, three residual stages (64 @1/2, 96 @1/4, 128 @1/4), 1x1 to output_dim.
+    Returns [1/4-res map, 1/8-res map (2x2 average)]."""
+
+    def __init__(self, output_dim=128, norm="instance"):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.norm1 = _norm(norm, 64)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.layer1 = nn.Sequential(ResidualBlock(64, 64, norm, 1), ResidualBlock(64, 64, norm, 1))
+        self.layer2 = nn.Sequential(ResidualBlock(64, 96, norm, 2), ResidualBlock(96, 96, norm, 1))
+        self.layer3 = nn.Sequential(ResidualBlock(96, 128, norm, 1), ResidualBlock(128, 128, norm, 1))
+        self.conv2 = nn.Conv2d(128, output_dim, 1)
+        self.output_dim = output_dim
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    def forward(self, x):
+        x = 2 * (x / 255.0) - 1.0
+        x = self.relu1(self.norm1(self.conv1(x)))
+        x = self.conv2(self.layer3(self.layer2(self.layer1(x))))
+        return [x, F.avg_pool2d(x, 2, 2)]
+
+
+def create_backbone(cfg):
+    kind = cfg.BACKBONE.MODEL_TYPE
+    if kind == "resnet":
+        return Backbone(cfg.BACKBONE.OUT_CHANNELS, cfg.BACKBONE.NORM_FN)
+    if kind == "swin":
+        from .swin_neck import SwinAdaptor
+        return SwinAdaptor(cfg.BACKBONE.OUT_CHANNELS, cfg.BACKBONE.DROP_PATH)
+    raise ValueError("Do not find %s" % kind)

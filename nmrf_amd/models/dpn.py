@@ -1,0 +1,61 @@
+"""Disparity proposal network (nmrf/models/DPN.py) on the HIP seed kernels: rows A3-A8 of SURVEY 8(a)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import kernels as K
+from .nmp import MLP, Propagation, PropagationLayer
+
+
+class DPN(nn.Module):
+    def __init__(self, cost_group, num_proposals, feat_dim, context_dim, num_prop_layers, prop_embed_dim, mlp_ratio,
+                 split_size, prop_n_heads, normalize_before=True, **_unused):
+        super().__init__()
+        # 1-D filter along the disparity axis; parameters only -- evaluated by nmrf_dpn_filter_softmax_f32
+        self.mlp = nn.Sequential(nn.Conv1d(cost_group, 8, 5, 1, 2), nn.ReLU(inplace=True),
+                                 nn.Conv1d(8, 16, 5, 1, 2), nn.ReLU(inplace=True), nn.Conv1d(16, 1, 5, 1, 2))
+        self.eps = 1e-3
+        self.num_proposals = num_proposals
+        self.cost_group = cost_group
+        # visual context (stock convs)
+        self.proj = nn.Sequential(nn.Conv2d(feat_dim, 128, 3, 1, 1, bias=False), nn.InstanceNorm2d(128),
+                                  nn.ReLU(inplace=True), nn.Conv2d(128, context_dim, 1, 1, 0, bias=False))
+        layers = nn.ModuleList(PropagationLayer(prop_embed_dim, mlp_ratio, context_dim, split_size, prop_n_heads,
+                                                normalize_before) for _ in range(num_prop_layers))
+        self.propagation = Propagation(prop_embed_dim, cost_group, layers, nn.LayerNorm(prop_embed_dim))
+        self.prop_head = MLP(prop_embed_dim, prop_embed_dim, 1, 3)
+        for m in self.modules():
+            if isinstance(m, (nn.Conv1d, nn.Conv2d)):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=.02)
+                nn.init.zeros_(m.bias) if m.bias is not None else None
+        nn.init.zeros_(self.prop_head.layers[-1].weight)
+        nn.init.zeros_(self.prop_head.layers[-1].bias)
+
+    @classmethod
+    def from_config(cls, cfg):
+        return cls(cost_group=cfg.DPN.COST_GROUP, num_proposals=cfg.DPN.NUM_PROPOSALS,
+                   feat_dim=cfg.BACKBONE.OUT_CHANNELS, context_dim=cfg.DPN.CONTEXT_DIM,
+                   num_prop_layers=cfg.NMP.NUM_PROP_LAYERS, prop_embed_dim=cfg.NMP.PROP_EMBED_DIM,
+                   mlp_ratio=cfg.NMP.MLP_RATIO, split_size=cfg.NMP.SPLIT_SIZE, prop_n_heads=cfg.NMP.PROP_N_HEADS,
+                   normalize_before=cfg.NMP.NORMALIZE_BEFORE)
+
+    def seeds(self, cost_volume):
+        """cost_volume [P,G,D] -> (prob [P,D], label_seeds [P,K] int64)   (DPN.py:117-125)"""
+        m = self.mlp
+        prob = K.dpn_filter_softmax(cost_volume, m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias)
+        return prob, K.nms_topk(prob, self.num_proposals, self.eps)
+
+    def forward(self, cost_volume, fmap1_list):
+        """cost_volume: [B,G,D,H,W] (reference layout) or token-major [B*H*W,G,D].
+        Returns (cost_volume [P,G,D], prob [P,D], label_seeds [P,N] float, labels [1,P,N])."""
+        if cost_volume.dim() == 5:
+            b, g, d, h, w = cost_volume.shape
+            cost_volume = cost_volume.permute(0, 3, 4, 1, 2).reshape(b * h * w, g, d).contiguous()
+        prob, seeds = self.seeds(cost_volume)
+        context = self.proj(fmap1_list[0]).permute(0, 2, 3, 1).contiguous()
+        memory, seeds_f = self.propagation(cost_volume, seeds, context)
+        outputs = self.prop_head(memory).view(-1, *seeds_f.shape)
+        labels = F.relu(outputs + seeds_f[None])
+        return cost_volume, prob, seeds_f, labels

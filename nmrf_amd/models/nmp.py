@@ -1,0 +1,320 @@
+"""Neural message passing blocks of NMRF on the HIP kernels.
+
+The module tree and parameter names mirror nmrf/models/NMP.py so that reference checkpoints load
+with strict=True.  The arithmetic does not: every block is
+    [HIP] LayerNorm+concat  ->  [hipBLASLt] one fused q|k|v GEMM  ->  [HIP] attention kernel
+    ->  [hipBLASLt] proj / MLP GEMMs
+on token-major fp32 buffers [T, C] with T = B*H*W*N.  q/k/v weights are fused (and the K dimension
+padded to a multiple of 4 with zero columns) once per parameter version.
+There is no CPU path: the kernels raise on non-CUDA tensors.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import kernels as K
+
+FOURIER_DIM = 31        # 15 sin + 15 cos + the scaled coordinate (NMP.py:35-51)
+
+
+class MLP(nn.Module):
+    """Linear-ReLU stack (NMP.py:54-66); params `layers.{i}`."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        dims = [input_dim] + [hidden_dim] * (num_layers - 1) + [output_dim]
+        self.num_layers = num_layers
+        self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+
+    def forward(self, x):
+        for i, layer in enumerate(self.layers):
+            x = layer(x)
+            if i < self.num_layers - 1:
+                x = F.relu(x)
+        return x
+
+
+class Mlp(nn.Module):
+    """fc1 - GELU(erf) - fc2 (timm's Mlp as used at NMP.py:337,537,675); params fc1, fc2."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None):
+        super().__init__()
+        hidden_features = hidden_features or in_features
+        out_features = out_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.fc2 = nn.Linear(hidden_features, out_features)
+
+    def forward(self, x):
+        return self.fc2(F.gelu(self.fc1(x)))
+
+
+class _FusedCache:
+    """Caches tensors derived from parameters, keyed on (data_ptr, version) of the sources."""
+
+    def __init__(self):
+        self._key = None
+        self._val = None
+
+    def get(self, params, builder):
+        key = tuple((p.data_ptr(), p._version, p.device) for p in params)
+        if key != self._key:
+            with torch.no_grad():
+                self._val = builder()
+            self._key = key
+        return self._val
+
+
+def _pad_cols(w, k):
+    return w if w.shape[1] == k else F.pad(w, (0, k - w.shape[1]))
+
+
+def _ln(x, norm):
+    return K.ln_concat(x, norm.weight, norm.bias, None, 1, x.shape[1], norm.eps)
+
+
+# --------------------------------------------------------------------------------------------------
+# self edges (BasicAttention, NMP.py:70-139)
+# --------------------------------------------------------------------------------------------------
+class BasicAttention(nn.Module):
+    def __init__(self, dim, qk_dim, num_heads=8, normalize_before=True):
+        super().__init__()
+        if not normalize_before:
+            raise NotImplementedError("only NORMALIZE_BEFORE=True (every shipped config) has a HIP path")
+        self.num_heads = num_heads
+        self.norm1 = nn.LayerNorm(dim)
+        self.q, self.k, self.v = nn.Linear(qk_dim, dim), nn.Linear(qk_dim, dim), nn.Linear(dim, dim)
+        self.proj = nn.Linear(dim, dim)
+        self._fused = _FusedCache()
+
+    def _weights(self):
+        def build():
+            kp = (self.q.in_features + 3) // 4 * 4
+            w = torch.cat((_pad_cols(self.q.weight, kp), _pad_cols(self.k.weight, kp), _pad_cols(self.v.weight, kp)), 0)
+            return w.contiguous(), torch.cat((self.q.bias, self.k.bias, self.v.bias)).contiguous(), kp
+        return self._fused.get((self.q.weight, self.k.weight, self.v.weight, self.q.bias, self.k.bias, self.v.bias), build)
+
+    def forward(self, label_rep, abs_encoding, n):
+        """label_rep [T,C], abs_encoding [T,31] -> [T,C]; n = labels per pixel."""
+        w, b, kp = self._weights()
+        a = K.ln_concat(label_rep, self.norm1.weight, self.norm1.bias, abs_encoding, 1, kp, self.norm1.eps)
+        msg = K.self_attn(F.linear(a, w, b), n, self.num_heads)
+        return label_rep + self.proj(msg)
+
+
+# --------------------------------------------------------------------------------------------------
+# neighbour edges in (shifted) windows (WindowAttention / SwinNMP, NMP.py:142-398)
+# --------------------------------------------------------------------------------------------------
+class WindowAttention(nn.Module):
+    def __init__(self, dim, window_size, shift_size, num_heads):
+        super().__init__()
+        self.dim, self.window_size, self.shift_size, self.num_heads = dim, window_size, shift_size, num_heads
+        wh, ww = window_size
+        self.relative_position_enc_table = nn.Parameter(torch.zeros((2 * wh - 1) * (2 * ww - 1), dim * 3))
+        ys, xs = torch.meshgrid(torch.arange(wh), torch.arange(ww), indexing="ij")
+        coords = torch.stack((ys.reshape(-1), xs.reshape(-1)))
+        rel = coords[:, :, None] - coords[:, None, :]
+        idx = (rel[0] + wh - 1) * (2 * ww - 1) + (rel[1] + ww - 1)
+        self.register_buffer("relative_position_index", idx)      # state-dict parity; the kernel derives it itself
+
+    def forward(self, qkv, dims, sibling_mask):
+        """qkv [T,3C] token-major on the padded grid dims=(B,Hp,Wp,N) -> [T,C]."""
+        b, hp, wp, n = dims
+        return K.window_attn(qkv, self.relative_position_enc_table, b, hp, wp, n, self.num_heads,
+                             self.window_size[0], self.shift_size, sibling_mask)
+
+
+class SwinNMP(nn.Module):
+    def __init__(self, dim, qkv_dim, num_heads, window_size=7, shift_size=0, mlp_ratio=4., normalize_before=True):
+        super().__init__()
+        if not normalize_before:
+            raise NotImplementedError("only NORMALIZE_BEFORE=True (every shipped config) has a HIP path")
+        assert 0 <= shift_size < window_size
+        self.dim, self.window_size, self.shift_size = dim, window_size, shift_size
+        self.qkv = nn.Linear(qkv_dim, 3 * dim)
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = WindowAttention(dim, (window_size, window_size), shift_size, num_heads)
+        self.proj = nn.Linear(dim, dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+        self._fused = _FusedCache()
+
+    def _weights(self):
+        def build():
+            kp = (self.qkv.in_features + 3) // 4 * 4
+            return _pad_cols(self.qkv.weight, kp).contiguous(), kp
+        return self._fused.get((self.qkv.weight,), build)
+
+    def forward(self, label_rep, abs_encoding, dims, sibling_mask):
+        w, kp = self._weights()
+        a = K.ln_concat(label_rep, self.norm1.weight, self.norm1.bias, abs_encoding, 1, kp, self.norm1.eps)
+        msg = self.attn(F.linear(a, w, self.qkv.bias), dims, sibling_mask)
+        x = label_rep + self.proj(msg)
+        return x + self.mlp(_ln(x, self.norm2))
+
+
+# --------------------------------------------------------------------------------------------------
+# cross-shaped stripes (CSWinAttention / CSWinNMP, NMP.py:401-600)
+# --------------------------------------------------------------------------------------------------
+class CSWinAttention(nn.Module):
+    """Holds the LePE depthwise 3x3 kernel `get_v`; the attention itself is nmrf_stripe_attn_f32."""
+
+    def __init__(self, dim, idx, split_size=1, num_heads=2):
+        super().__init__()
+        if split_size != 1:
+            raise NotImplementedError("the HIP stripe kernel implements SPLIT_SIZE=1 (every shipped config)")
+        self.dim, self.idx, self.num_heads = dim, idx, num_heads
+        self.get_v = nn.Conv2d(dim, dim, 3, 1, 1, groups=dim, bias=False)
+
+
+class CSWinNMP(nn.Module):
+    def __init__(self, dim, qk_dim, v_dim, num_heads, split_size=1, mlp_ratio=4., normalize_before=True):
+        super().__init__()
+        if not normalize_before:
+            raise NotImplementedError("only NORMALIZE_BEFORE=True (every shipped config) has a HIP path")
+        if v_dim != dim:
+            raise NotImplementedError("v_dim > dim (fourier_grid_embed branch, NMP.py:552-555) is dead in every config")
+        self.dim = dim
+        self.q, self.k, self.v = nn.Linear(qk_dim, dim), nn.Linear(qk_dim, dim), nn.Linear(v_dim, dim)
+        self.norm1 = nn.LayerNorm(dim)
+        self.proj = nn.Linear(dim, dim)
+        self.attns = nn.ModuleList(CSWinAttention(dim // 2, i, split_size, num_heads // 2) for i in range(2))
+        self.mlp = Mlp(dim, int(dim * mlp_ratio), dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self._fused = _FusedCache()
+
+    def _weights(self):
+        def build():
+            kp = (self.q.in_features + 3) // 4 * 4
+            w = torch.cat((_pad_cols(self.q.weight, kp), _pad_cols(self.k.weight, kp), _pad_cols(self.v.weight, kp)), 0)
+            return w.contiguous(), torch.cat((self.q.bias, self.k.bias, self.v.bias)).contiguous(), kp
+        return self._fused.get((self.q.weight, self.k.weight, self.v.weight, self.q.bias, self.k.bias, self.v.bias), build)
+
+    def forward(self, seed_rep, context, dims):
+        """seed_rep [T,C]; context [B*H*W, Cctx] (per pixel, shared by its N labels); dims=(B,H,W,N)."""
+        b, h, wd, n = dims
+        w, bias, kp = self._weights()
+        a = K.ln_concat(seed_rep, self.norm1.weight, self.norm1.bias, context, n, kp, self.norm1.eps)
+        msg = K.stripe_attn(F.linear(a, w, bias), self.attns[0].get_v.weight, self.attns[1].get_v.weight, b, h, wd, n)
+        x = seed_rep + self.proj(msg)
+        return x + self.mlp(_ln(x, self.norm2))
+
+
+class PropagationLayer(nn.Module):
+    def __init__(self, embed_dim, mlp_ratio, context_dim, split_size, n_heads, normalize_before=True, **_unused):
+        super().__init__()
+        self.nmp = CSWinNMP(embed_dim, embed_dim + context_dim, embed_dim, n_heads, split_size, mlp_ratio,
+                            normalize_before)
+
+    def forward(self, tgt, context, dims):
+        return self.nmp(tgt, context, dims)
+
+
+class InferenceLayer(nn.Module):
+    def __init__(self, embed_dim, mlp_ratio, window_size, shift_size, n_heads, normalize_before=True, **_unused):
+        super().__init__()
+        self.window_size, self.shift_size = window_size, shift_size
+        self.self_nmp = BasicAttention(embed_dim, embed_dim + FOURIER_DIM, n_heads, normalize_before)
+        self.nmp = SwinNMP(embed_dim, embed_dim + FOURIER_DIM, n_heads, window_size, shift_size, mlp_ratio,
+                           normalize_before)
+
+    def forward(self, tgt, abs_encoding, dims):
+        tgt = self.self_nmp(tgt, abs_encoding, dims[3])
+        return self.nmp(tgt, abs_encoding, dims, True)
+
+
+class RefinementLayer(nn.Module):
+    def __init__(self, dim, mlp_ratio, window_size, shift_size, n_heads, normalize_before=True, **_unused):
+        super().__init__()
+        self.window_size, self.shift_size = window_size, shift_size
+        self.nmp = SwinNMP(dim, dim + FOURIER_DIM, n_heads, window_size, shift_size, mlp_ratio, normalize_before)
+
+    def forward(self, tgt, abs_encoding, dims):
+        return self.nmp(tgt, abs_encoding, dims, False)
+
+
+# --------------------------------------------------------------------------------------------------
+# stage drivers
+# --------------------------------------------------------------------------------------------------
+class Propagation(nn.Module):
+    """Label-seed propagation (NMP.py:603-667)."""
+
+    def __init__(self, embed_dim, cost_group, layers, norm=None):
+        super().__init__()
+        self.cost_encoder = nn.Sequential(nn.Linear(cost_group * 9, embed_dim), nn.GELU(), nn.Linear(embed_dim, embed_dim))
+        self.proj = nn.Linear(embed_dim + FOURIER_DIM, embed_dim, bias=False)
+        self.embed_dim, self.layers, self.norm = embed_dim, layers, norm
+
+    def forward(self, cost_volume, label_seed, context):
+        """cost_volume [P,G,D]; label_seed [P,N] int64; context [B,H,W,Cctx] -> ([1,P*N,C], seeds.float())"""
+        b, h, wd, cc = context.shape
+        n = label_seed.shape[-1]
+        dims = (b, h, wd, n)
+        cost, enc = K.seed_features(cost_volume, label_seed, 3.14 / 64)
+        x = self.proj(torch.cat((self.cost_encoder(cost), enc), -1))
+        ctx = context.reshape(b * h * wd, cc)
+        for layer in self.layers:
+            x = layer(x, ctx, dims)
+        if self.norm is not None:
+            x = _ln(x, self.norm)
+        return x.unsqueeze(0), label_seed.float()
+
+
+def _pad_grid(x, dims, win):
+    """zero-pad the (H,W) token grid to a multiple of `win`, top = pad//2 (NMP.py:745-762)."""
+    b, h, wd, n = dims
+    ph, pw = (-h) % win, (-wd) % win
+    if ph == 0 and pw == 0:
+        return x, dims, (0, 0)
+    top, left = ph // 2, pw // 2
+    xg = F.pad(x.view(b, h, wd, n, -1), (0, 0, 0, 0, left, pw - left, top, ph - top))
+    return xg.reshape(-1, x.shape[-1]), (b, h + ph, wd + pw, n), (top, left)
+
+
+def _crop_grid(x, pdims, dims, off):
+    if pdims == dims:
+        return x
+    b, hp, wp, n = pdims
+    _, h, wd, _ = dims
+    return x.view(b, hp, wp, n, -1)[:, off[0]:off[0] + h, off[1]:off[1] + wd].reshape(-1, x.shape[-1])
+
+
+class Inference(nn.Module):
+    """Neural MRF inference (NMP.py:670-798)."""
+
+    normalizer = 3.14 / 64
+
+    def __init__(self, cost_group, dim, layers, norm):
+        super().__init__()
+        self.ffn = Mlp(dim + cost_group, dim, dim)
+        self.dim, self.layers, self.norm, self.cost_group = dim, layers, norm, cost_group
+
+    def _run(self, labels_flat, n, fmap1, fmap2, fmap1_gw, fmap2_gw):
+        b, _, h, wd = fmap1.shape
+        dims = (b, h, wd, n)
+        x = self.ffn(K.warp_corr_concat(labels_flat, fmap1, fmap2, fmap1_gw, fmap2_gw, n, self.cost_group))
+        enc = K.fourier_embed(labels_flat, self.normalizer)
+        win = self.layers[0].window_size
+        x, pdims, off = _pad_grid(x, dims, win)
+        enc, _, _ = _pad_grid(enc, dims, win)
+        x, enc = x.contiguous(), enc.contiguous()
+        for layer in self.layers:
+            x = layer(x, enc, pdims)
+        x = _crop_grid(x, pdims, dims, off).contiguous()
+        return _ln(x, self.norm) if self.norm is not None else x
+
+    def forward(self, labels, fmap1, fmap2, fmap1_gw, fmap2_gw):
+        """labels [B*H*W, N] -> [1, B*H*W, N, C]"""
+        n = labels.shape[-1]
+        out = self._run(labels.reshape(-1).contiguous(), n, fmap1, fmap2, fmap1_gw, fmap2_gw)
+        return out.view(1, -1, n, self.dim)
+
+
+class Refinement(Inference):
+    """Refinement at 1/4 resolution, one label per pixel (NMP.py:801-900)."""
+
+    normalizer = 3.14 / 128
+
+    def forward(self, labels, fmap1, fmap2, fmap1_gw, fmap2_gw):
+        """labels [B,H,W] -> [1, B*H*W, C]"""
+        out = self._run(labels.reshape(-1).contiguous(), 1, fmap1, fmap2, fmap1_gw, fmap2_gw)
+        return out.view(1, -1, self.dim)

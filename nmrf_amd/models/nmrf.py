@@ -1,0 +1,137 @@
+"""NMRF top module: same constructor arguments, forward API and state-dict names as
+nmrf/models/NMRF.py:21-262, with the hot path on libnmrf_hip.so.  Inference only: the `Criterion`
+and the aux-loss outputs of the reference are training-side and out of scope.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import kernels as K
+from ..frame_utils import InputPadder
+from .backbone import create_backbone
+from .dpn import DPN
+from .nmp import MLP, Inference, InferenceLayer, Refinement, RefinementLayer
+
+
+def _conv_head(cin, cout):
+    return nn.Sequential(nn.Conv2d(cin, 128, 3, 1, 1, bias=False), nn.InstanceNorm2d(128), nn.ReLU(inplace=True),
+                         nn.Conv2d(128, cout, 1, 1, 0, bias=False))
+
+
+class NMRF(nn.Module):
+    def __init__(self, backbone, dpn=None, num_proposals=4, max_disp=320, num_infer_layers=5, num_refine_layers=5,
+                 infer_embed_dim=128, infer_n_heads=4, mlp_ratio=4, window_size=6, refine_window_size=4,
+                 with_refinement=True, attn_drop=0., proj_drop=0., drop_path=0., dropout=0.,
+                 return_intermediate=False, normalize_before=True, activation="gelu", aux_loss=False,
+                 divis_by=8, compat=True):
+        if dpn is None and hasattr(backbone, "BACKBONE"):       # called as NMRF(cfg)
+            kwargs = self.from_config(backbone)
+            backbone = kwargs.pop("backbone")
+            return self.__init__(backbone, **kwargs)
+        super().__init__()
+        if activation != "gelu" or any(r != 0 for r in (attn_drop, proj_drop, drop_path, dropout)):
+            raise NotImplementedError("inference build: GELU, no dropout (all shipped configs)")
+        if not with_refinement:
+            raise NotImplementedError("refinement is always on in the reference (NMRF.py:131-152)")
+        self.num_proposals, self.max_disp, self.divis_by = num_proposals, max_disp, divis_by
+        self.aux_loss = aux_loss
+        feat_dim = backbone.output_dim
+        self.concatconv = _conv_head(feat_dim, 64)
+        self.gw = _conv_head(feat_dim, 256)
+        infer_layers = nn.ModuleList(
+            InferenceLayer(infer_embed_dim, mlp_ratio, window_size, 0 if i % 2 == 0 else window_size // 2,
+                           infer_n_heads, normalize_before) for i in range(num_infer_layers))
+        self.inference = Inference(32, infer_embed_dim, infer_layers, nn.LayerNorm(infer_embed_dim))
+        self.infer_head = MLP(infer_embed_dim, infer_embed_dim, 8 * 8, 3)
+        self.infer_score_head = nn.Linear(infer_embed_dim, 8 * 8)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=.02)
+                nn.init.zeros_(m.bias)
+        self.with_refinement = True
+        refine_layers = nn.ModuleList(
+            RefinementLayer(infer_embed_dim, mlp_ratio, refine_window_size,
+                            0 if i % 2 == 0 else refine_window_size // 2, infer_n_heads, normalize_before)
+            for i in range(num_refine_layers))
+        self.refinement = Refinement(32, infer_embed_dim, refine_layers, nn.LayerNorm(infer_embed_dim))
+        self.refine_head = MLP(infer_embed_dim, infer_embed_dim, 4 * 4, 3)
+        self.dpn = dpn
+        self.compat = compat
+        if compat:
+            self.backbone = backbone
+        else:
+            self.image_encoder = backbone
+        self.register_buffer("device_indicator_tensor", torch.empty(0))
+
+    @classmethod
+    def from_config(cls, cfg):
+        return dict(backbone=create_backbone(cfg), dpn=DPN.from_config(cfg), num_proposals=cfg.DPN.NUM_PROPOSALS,
+                    max_disp=cfg.DPN.MAX_DISP, aux_loss=cfg.SOLVER.AUX_LOSS, num_infer_layers=cfg.NMP.NUM_INFER_LAYERS,
+                    num_refine_layers=cfg.NMP.NUM_REFINE_LAYERS, infer_embed_dim=cfg.NMP.INFER_EMBED_DIM,
+                    infer_n_heads=cfg.NMP.INFER_N_HEADS, mlp_ratio=cfg.NMP.MLP_RATIO, window_size=cfg.NMP.WINDOW_SIZE,
+                    refine_window_size=cfg.NMP.REFINE_WINDOW_SIZE, attn_drop=cfg.NMP.ATTN_DROP,
+                    proj_drop=cfg.NMP.PROJ_DROP, drop_path=cfg.NMP.DROP_PATH, dropout=cfg.NMP.DROPOUT,
+                    normalize_before=cfg.NMP.NORMALIZE_BEFORE, return_intermediate=cfg.NMP.RETURN_INTERMEDIATE,
+                    divis_by=cfg.DATASETS.DIVIS_BY, compat=cfg.BACKBONE.COMPAT)
+
+    def freeze_bn(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.eval()
+
+    @property
+    def device(self):
+        return self.device_indicator_tensor.device
+
+    def extract_feature(self, img1, img2):
+        """-> (fmap1_list, fmap2_list), each [1/8-res, 1/4-res] (low to high), NMRF.py:172-187"""
+        enc = self.backbone if self.compat else self.image_encoder
+        feats = enc(torch.cat((img1, img2), 0))[::-1]
+        b = img1.shape[0]
+        return [f[:b].contiguous() for f in feats], [f[b:].contiguous() for f in feats]
+
+    def forward(self, sample):
+        if self.training:
+            raise NotImplementedError("nmrf_amd implements the inference path only; call model.eval()")
+        if self.device.type != "cuda":
+            raise RuntimeError("the NMRF hot path runs on an MI355X through libnmrf_hip.so; there is no CPU "
+                               "fallback (move the model with .to('cuda'))")
+        image1 = sample["img1"].to(self.device)
+        image2 = sample["img2"].to(self.device)
+        h0, w0 = image1.shape[-2:]
+        padder = InputPadder(image1.shape, mode="proposal", divis_by=self.divis_by)
+        image1, image2 = padder.pad(image1, image2)
+        fmap1_list, fmap2_list = self.extract_feature(image1, image2)
+        n = self.num_proposals
+
+        # ---- disparity proposals -------------------------------------------------------------------
+        cost_volume = K.cost_volume(fmap1_list[0], fmap2_list[0], self.max_disp // 8, self.dpn.cost_group)
+        _, prob, label_seeds, labels = self.dpn(cost_volume, fmap1_list)
+        labels_curr = labels[-1]                                            # [P, N]
+
+        # ---- neural MRF inference at 1/8 -------------------------------------------------------------
+        fmap1, fmap2 = self.concatconv(fmap1_list[0]), self.concatconv(fmap2_list[0])
+        fmap1_gw, fmap2_gw = self.gw(fmap1_list[0]), self.gw(fmap2_list[0])
+        tgt = self.inference(labels_curr, fmap1, fmap2, fmap1_gw, fmap2_gw).view(-1, self.inference.dim)
+        b, _, h8, w8 = fmap1.shape
+        disp_delta = self.infer_head(tgt)                                   # [T,64]
+        score = self.infer_score_head(tgt)                                  # [T,64]; the reference's 0.25 factor
+        #                                                                     does not change the arg-max
+        disp_curr = K.wta_median(disp_delta, score, labels_curr.reshape(-1).contiguous(), b, h8, w8, n)
+
+        # ---- refinement at 1/4 ---------------------------------------------------------------------------
+        fmap1, fmap2 = self.concatconv(fmap1_list[1]), self.concatconv(fmap2_list[1])
+        fmap1_gw, fmap2_gw = self.gw(fmap1_list[1]), self.gw(fmap2_list[1])
+        tgt = self.refinement(disp_curr, fmap1, fmap2, fmap1_gw, fmap2_gw).view(-1, self.refinement.dim)
+        disp, disp_pred = K.refine_epilogue(self.refine_head(tgt), disp_curr, h0, w0)
+
+        return {"proposal": labels_curr.reshape(b, -1, n), "prob": prob,
+                "initial_proposal": label_seeds.reshape(b, -1, n), "disp": disp, "disp_pred": disp_pred}
+
+
+def build(cfg):
+    """(model, criterion) like nmrf/models/NMRF.py:432-447; the training criterion is not part of this build."""
+    kwargs = NMRF.from_config(cfg)
+    return NMRF(**kwargs), None

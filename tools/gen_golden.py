@@ -1,0 +1,215 @@
+"""Generate the golden parity fixtures under tests/golden/ by running the REAL
+reference (/root/reference, imported read-only through tools/refshim.py) on
+CPU in the build container.  Run:  python tools/gen_golden.py
+
+Nothing of the reference travels: the fixtures hold only inputs (uint8 images,
+crafted logits, MSDA operands) and the reference's outputs.  Weights are never
+stored: they are the closed-form hash fill of nmrf_amd/utils/hashinit.py,
+regenerated from state-dict keys wherever the fixtures are consumed.
+
+Fixtures
+  e2e_a.npz   52x100, MAX_DISP 128 (D=16), B=1: full per-stage captures
+              (layer captures row-subsampled x2) - both pad branches odd
+  e2e_b.npz   96x328, default MAX_DISP 320 (D=40), B=1: small outputs only
+  e2e_c.npz   40x72,  MAX_DISP 128, B=2 (two different pairs): small outputs
+  nms_cases.npz   crafted logits rows (ties, plateaus, NaN, ...) pushed through
+              the reference's DPN.forward NMS+topk (DPN.py:119-125), D in {16,24,32,40,48}
+  msda.npz    ops/test.py known-answer case (seed 3) + model-shaped cases through
+              ms_deform_attn_core_pytorch, fp32 outputs; gradients computed in fp64 autograd, stored fp32
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import refshim  # noqa: E402
+from nmrf_amd.utils.hashinit import apply_hash_weights, synthetic_pair, unit_noise  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def run_e2e(name, shapes_seeds, opts, full):
+    model, cfg = refshim.build_reference_model(opts)
+    apply_hash_weights(model)
+    caps = {}
+
+    def hook(key, with_input=False):
+        def f(m, i, o):
+            caps[key] = o
+            if with_input:
+                caps[key + "_in"] = i
+        return f
+
+    model.inference.register_forward_hook(hook("infer_tgt", True))
+    model.refinement.register_forward_hook(hook("refine_tgt", True))
+    model.dpn.propagation.register_forward_hook(hook("prop", True))
+    model.inference.ffn.register_forward_hook(hook("infer_ffn"))
+    model.refinement.ffn.register_forward_hook(hook("refine_ffn"))
+    model.dpn.proj.register_forward_hook(hook("context"))
+    model.dpn.propagation.proj.register_forward_hook(hook("seed_embed"))
+    for i, l in enumerate(model.dpn.propagation.layers):
+        l.register_forward_hook(hook(f"prop_layer{i}"))
+    for i, l in enumerate(model.inference.layers):
+        l.register_forward_hook(hook(f"infer_layer{i}"))
+        l.self_nmp.register_forward_hook(hook(f"infer_self{i}"))
+    for i, l in enumerate(model.refinement.layers):
+        l.register_forward_hook(hook(f"refine_layer{i}"))
+
+    lefts, rights = [], []
+    for (h, w, seed) in shapes_seeds:
+        l, r, _ = synthetic_pair(h, w, seed=seed)
+        lefts.append(l)
+        rights.append(r)
+    img1, img2 = torch.stack(lefts), torch.stack(rights)
+    with torch.no_grad():
+        out = model({"img1": img1.clone(), "img2": img2.clone()})
+    d = {
+        "img1": _np(img1).astype(np.uint8), "img2": _np(img2).astype(np.uint8),
+        "max_disp": np.int64(cfg.DPN.MAX_DISP),
+        "prob": _np(out["prob"]),
+        "seeds": _np(out["initial_proposal"]).astype(np.int16),
+        "proposal": _np(out["proposal"]),
+        "disp": _np(out["disp"]),
+        "disp_pred": _np(out["disp_pred"]),
+        "disp_curr": _np(caps["refine_tgt_in"][0]),
+    }
+    if full:
+        sub = lambda t: _np(t.reshape(-1, t.shape[-1]))[::2]
+        cv = caps["prop_in"][0]
+        d["cost_volume"] = _np(cv)
+        d["context"] = _np(caps["context"])
+        d["seed_embed_sub2"] = sub(caps["seed_embed"])
+        d["prop_memory"] = _np(caps["prop"][0].reshape(-1, 128))
+        d["infer_ffn_sub2"] = sub(caps["infer_ffn"])
+        d["infer_tgt"] = _np(caps["infer_tgt"].reshape(-1, 128))
+        d["refine_ffn_sub2"] = sub(caps["refine_ffn"])
+        d["refine_tgt"] = _np(caps["refine_tgt"].reshape(-1, 128))
+        for k in ("prop_layer0", "prop_layer1", "infer_self0", "infer_layer0", "infer_layer1",
+                  "refine_layer0", "refine_layer1"):
+            d[k + "_sub2"] = sub(caps[k])
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **d)
+    print(name, {k: v.shape for k, v in d.items() if hasattr(v, "shape")}, os.path.getsize(path) // 1024, "KiB")
+
+
+def crafted_logits(d, rows_per_kind=24):
+    """Rows of logits whose softmax exercises every NMS/top-k branch."""
+    rows = []
+    r = lambda key, n, salt: unit_noise(key, n, salt)
+    for i in range(rows_per_kind):
+        base = r("nms", d, i)
+        rows.append(np.zeros(d, np.float32))                               # all tied
+        rows.append(base.copy())                                           # flat-ish random: many maxima
+        rows.append(base * 12)                                             # peaky: few bins > eps
+        x = np.full(d, -20.0, np.float32); x[(7 * i) % d] = 5.0            # single peak, rest << eps
+        rows.append(x)
+        x = np.full(d, -20.0, np.float32); x[(3 * i) % d] = 4; x[(3 * i + 2) % d] = 4   # two equal peaks
+        rows.append(x)
+        x = base * 6; j = (5 * i) % (d - 3); x[j:j + 3] = x[j:j + 3].max() + 1          # plateau of 3
+        rows.append(x)
+        x = np.round(base * 3) * 2.0                                       # heavy exact ties between peaks
+        rows.append(x.astype(np.float32))
+        x = np.linspace(0, 6 + i * 0.3, d).astype(np.float32)              # monotone up (peak at D-1)
+        rows.append(x)
+        rows.append(x[::-1].copy())                                        # monotone down (peak at 0)
+        x = base * 8; x[::2] = x[::2].max()                                # comb: equal maxima every other bin
+        rows.append(x)
+        x = base * 10; x[: d // 2] = -30                                   # left half dead (x<d zone look-alike)
+        rows.append(x)
+    nan_row = r("nmsn", d, 99) * 4
+    nan_row[3] = np.nan
+    rows.append(nan_row)
+    return np.stack(rows).astype(np.float32)
+
+
+def run_nms():
+    out = {}
+    for dmax in (128, 192, 256, 320, 384):
+        d = dmax // 8
+        model, cfg = refshim.build_reference_model(["DPN.MAX_DISP", dmax])
+        apply_hash_weights(model)
+        logits = torch.from_numpy(crafted_logits(d))
+        rows = logits.shape[0]
+
+        class Fixed(torch.nn.Module):
+            def forward(self, x):
+                return logits[:, None, :]
+
+        model.dpn.mlp = Fixed()
+        cv = torch.zeros(1, 4, d, 1, rows)
+        fmap = torch.from_numpy(unit_noise("f", 256 * rows, 1).reshape(1, 256, 1, rows))
+        with torch.no_grad():
+            _, prob, seeds, _ = model.dpn(cv, [fmap])
+        out[f"logits_{d}"] = logits.numpy()
+        out[f"prob_{d}"] = _np(prob)
+        out[f"seeds_{d}"] = _np(seeds).astype(np.int16)
+    path = os.path.join(OUT, "nms_cases.npz")
+    np.savez_compressed(path, **out)
+    print("nms_cases", {k: v.shape for k, v in out.items()}, os.path.getsize(path) // 1024, "KiB")
+
+
+def run_msda():
+    refshim.install()
+    from ops.functions.ms_deform_attn_func import ms_deform_attn_core_pytorch as core
+    out = {}
+
+    def case(tag, n, m, dch, lq, shapes, p, gen):
+        shapes_t = torch.as_tensor(shapes, dtype=torch.long)
+        s = int(sum(h * w for h, w in shapes))
+        l = len(shapes)
+        value, loc, wgt = gen(n, s, m, dch, lq, l, p)
+        res = core(value, shapes, loc, wgt)
+        v64, l64, w64 = (t.double().requires_grad_(True) for t in (value, loc, wgt))
+        r64 = core(v64, shapes, l64, w64)
+        gout = torch.from_numpy(unit_noise("msda_g" + tag, r64.numel()).reshape(r64.shape)).double()
+        gv, gl, gw = torch.autograd.grad(r64, (v64, l64, w64), gout)
+        out.update({f"{tag}_value": _np(value), f"{tag}_shapes": shapes_t.numpy(), f"{tag}_loc": _np(loc),
+                    f"{tag}_w": _np(wgt), f"{tag}_out": _np(res),
+                    f"{tag}_gout": _np(gout).astype(np.float32),
+                    f"{tag}_gvalue": _np(gv).astype(np.float32), f"{tag}_gloc": _np(gl).astype(np.float32),
+                    f"{tag}_gw": _np(gw).astype(np.float32)})
+
+    def gen_testpy(n, s, m, dch, lq, l, p):          # ops/test.py:14-35 operand recipe
+        torch.manual_seed(3)
+        value = torch.rand(n, s, m, dch) * 0.01
+        loc = torch.rand(n, lq, m, l, p, 2)
+        wgt = torch.rand(n, lq, m, l, p) + 1e-5
+        wgt = wgt / wgt.sum(-1, keepdim=True).sum(-2, keepdim=True)
+        return value, loc, wgt
+
+    def gen_hash(tag):
+        def g(n, s, m, dch, lq, l, p):
+            value = torch.from_numpy(unit_noise(tag + "v", n * s * m * dch).reshape(n, s, m, dch))
+            loc = torch.from_numpy(unit_noise(tag + "l", n * lq * m * l * p * 2).reshape(n, lq, m, l, p, 2)) * 0.6 + 0.5
+            wgt = torch.from_numpy(unit_noise(tag + "w", n * lq * m * l * p).reshape(n, lq, m, l, p)).abs() + 1e-3
+            wgt = wgt / wgt.sum((-1, -2), keepdim=True)
+            return value, loc, wgt
+        return g
+
+    case("kat", 1, 2, 2, 2, [(6, 4), (3, 2)], 2, gen_testpy)
+    case("neck", 2, 8, 8, 8 * 12, [(6, 10)], 4, gen_hash("neck"))          # DeformNeck shape family (1 level, D=8)
+    case("ml", 2, 4, 16, 37, [(9, 7), (5, 4), (3, 2), (2, 1)], 3, gen_hash("ml"))
+    case("odd", 1, 3, 5, 11, [(4, 5), (2, 3)], 2, gen_hash("odd"))
+    path = os.path.join(OUT, "msda.npz")
+    np.savez_compressed(path, **out)
+    print("msda", os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    run_e2e("e2e_a", [(52, 100, 1000)], ["DPN.MAX_DISP", 128], full=True)
+    run_e2e("e2e_b", [(96, 328, 1001)], [], full=False)
+    run_e2e("e2e_c", [(40, 72, 1002), (40, 72, 1003)], ["DPN.MAX_DISP", 128], full=False)
+    run_nms()
+    run_msda()
