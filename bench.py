@@ -1,0 +1,232 @@
+#!/usr/bin/env python
+"""Throughput bench of the NMRF-Stereo inference hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" = one NMRF.forward (backbone + hot path) over one batch of synthetic stereo pairs already
+resident in HBM (BASELINE.json configs[1]: KITTI 1242x375, batch 1 per GPU, CNN backbone, 5/5/5
+layers, fp32).  Prints ONE JSON line on rank 0: whole-job stereo pairs/s + `roofline` of the
+dominant hand-written kernel (horizontal stripe attention, MFMA-bound, timed live with HIP events on
+the launching stream) + `cpu_baseline` (the CPU oracle = a port of the reference path, timed on the
+host cores, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1, help="stereo pairs per GPU per step")
+    ap.add_argument("--height", type=int, default=375)
+    ap.add_argument("--width", type=int, default=1242)
+    ap.add_argument("--infer-layers", type=int, default=5, help="NMP.NUM_INFER_LAYERS (reference default 5)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
+    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL result gather at N>1")
+    return ap.parse_args()
+
+
+class KernelTimer:
+    """HIP-event bracket of one named kernel launch (kernels.kernel_hook)."""
+
+    def __init__(self):
+        self.pairs = []
+        self.enabled = False
+
+    def __call__(self, phase, name):
+        if not self.enabled:
+            return
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        if phase == "begin":
+            self.pairs.append([ev, None])
+        else:
+            self.pairs[-1][1] = ev
+
+    def mean_ms(self):
+        ts = [a.elapsed_time(b) for a, b in self.pairs if b is not None]
+        return sum(ts) / len(ts) if ts else None, len(ts)
+
+
+def cpu_baseline(height, width, infer_layers):
+    """The CPU oracle (a plain-PyTorch port of the reference path, pinned to the reference by
+    tests/test_oracle_golden.py) on all host cores: 1 warm-up at 1/4 size + 2 timed forwards of one pair."""
+    from oracle import nmrf_oracle as O
+    from nmrf_amd.config import get_cfg
+    from nmrf_amd.models import build_model
+    from nmrf_amd.utils.hashinit import hash_state_dict, synthetic_pair
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = get_cfg()
+    cfg.NMP.NUM_INFER_LAYERS = infer_layers
+    w = hash_state_dict(build_model(cfg)[0].state_dict())
+    ocfg = O.OracleCfg(num_infer_layers=infer_layers)
+    l, r, _ = synthetic_pair(height, width, seed=1000)
+    with torch.no_grad():
+        ls, rs, _ = synthetic_pair(max(64, height // 4), max(96, width // 4), seed=1)
+        O.forward(w, ocfg, ls[None], rs[None])
+        reps = 2
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            O.forward(w, ocfg, l[None], r[None])
+        dt = (time.perf_counter() - t0) / reps
+    return {"value": 1.0 / dt, "unit": "stereo pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d forwards of one %dx%d pair (oracle/nmrf_oracle.py, torch CPU fp32, %d threads), %.2f s each"
+                      % (reps, width, height, torch.get_num_threads(), dt)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from nmrf_amd import kernels as K
+    from nmrf_amd.config import get_cfg
+    from nmrf_amd.models import build_model
+    from nmrf_amd.parallel import gather_disparity
+    from nmrf_amd.utils.hashinit import apply_hash_weights, synthetic_pair
+
+    cfg = get_cfg()
+    cfg.NMP.NUM_INFER_LAYERS = args.infer_layers
+    cfg.freeze()
+    model = apply_hash_weights(build_model(cfg)[0]).eval().to(dev)
+    b = args.batch
+    pairs = [synthetic_pair(args.height, args.width, seed=1000 + rank * b + i)[:2] for i in range(b)]
+    sample = {"img1": torch.stack([p[0] for p in pairs]).to(dev), "img2": torch.stack([p[1] for p in pairs]).to(dev)}
+
+    timer = KernelTimer()
+    K.kernel_hook = timer
+
+    def step():
+        out = model(sample)
+        if world > 1 and not args.no_gather:
+            return gather_disparity(out["disp"])
+        return out["disp"]
+
+    graph = None
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 1)):
+            step()
+        torch.cuda.synchronize()
+        if not args.no_graph and world == 1:
+            try:
+                K.kernel_hook = None                      # events cannot be recorded/queried inside a capture
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    static_out = step()
+                graph.replay()
+                torch.cuda.synchronize()
+            except Exception as e:                        # capture unsupported -> eager launches
+                print("[bench] hipGraph capture failed (%s); running eager" % str(e).splitlines()[0], file=sys.stderr)
+                graph = None
+                torch.cuda.synchronize()
+            K.kernel_hook = timer
+
+        run = graph.replay if graph is not None else step
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+
+        # dominant hand-written kernel, timed live with HIP events on its launching stream (eager launches,
+        # same inputs, right after the timed region so clocks/caches are in the same state)
+        timer.enabled = True
+        for _ in range(max(3, min(args.steps, 10))):
+            step()
+        torch.cuda.synchronize()
+        timer.enabled = False
+        k_ms, k_n = timer.mean_ms()
+
+        # hot-path-only time (everything after the backbone)
+        hp_ms = None
+        try:
+            img1, img2 = sample["img1"], sample["img2"]
+            from nmrf_amd.frame_utils import InputPadder
+            padder = InputPadder(img1.shape, mode="proposal", divis_by=model.divis_by)
+            f1l, f2l = model.extract_feature(*padder.pad(img1, img2))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            model.hot_path(f1l, f2l, img1.shape[-2:])
+            e0.record()
+            for _ in range(5):
+                model.hot_path(f1l, f2l, img1.shape[-2:])
+            e1.record()
+            torch.cuda.synchronize()
+            hp_ms = e0.elapsed_time(e1) / 5
+        except Exception:
+            pass
+
+    pairs_total = world * b * args.steps
+    value = pairs_total / elapsed
+    hp, wp = -(-args.height // 8) * 8, -(-args.width // 8) * 8
+    h8, w8, n = hp // 8, wp // 8, cfg.DPN.NUM_PROPOSALS
+    # algorithmic FLOPs of one horizontal-stripe launch: per (row, head) QK^T and PV, 2*T^2*32 each,
+    # T = W8*N tokens, 2 heads per direction  ->  B * H8 * 2 * 4*32*(W8 N)^2     
+    flop = b * h8 * 2 * 4.0 * 32 * (w8 * n) ** 2
+    roof = None
+    if k_ms:
+        ach = flop / (k_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "stripe_attn_kernel<1> (horizontal stripes)", "achieved": round(ach, 3),
+                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                "traffic": None, "launch_ms": round(k_ms, 4), "launches_timed": k_n, "flop_per_launch": flop}
+
+    if rank == 0:
+        res = {
+            "metric": "stereo pairs/sec at 1242x375", "value": round(value, 3), "unit": "stereo pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "KITTI %dx%d stereo pairs, batch %d per GPU, CNN backbone, %d/%d/%d prop/infer/refine "
+                                   "layers, hash-formula weights" % (args.width, args.height, b, cfg.NMP.NUM_PROP_LAYERS,
+                                                                     cfg.NMP.NUM_INFER_LAYERS, cfg.NMP.NUM_REFINE_LAYERS),
+                       "global_batch": world * b, "parallelism": "batch-shard x%d" % world,
+                       "launch": "hipGraph" if graph is not None else "eager",
+                       "result_gather": bool(world > 1 and not args.no_gather)},
+            "hot_path_ms": None if hp_ms is None else round(hp_ms, 3),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(args.height, args.width, args.infer_layers)
+            except Exception as e:
+                res["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

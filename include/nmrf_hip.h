@@ -27,7 +27,7 @@ extern "C" {
 
 const char *nmrf_strerror(int code);
 /* ABI version of this header; bumps on any signature change. */
-int nmrf_abi_version(void);
+int nmrf_abi_version(void);   /* currently 2 */
 
 /* A2  group-wise correlation volume.
  * replaces build_correlation_volume + the permute of DPN.forward
@@ -76,9 +76,11 @@ int nmrf_ln_concat_f32(const float *x, const float *gamma, const float *beta, fl
  * replaces CSWinAttention.forward x2 + cat (nmrf/models/NMP.py:429-505,568-570).
  * qkv [T,3C] token-major (q|k|v, each C=128 = 2 halves x 2 heads x 32); half 0 -> vertical stripes
  * (one per image column), half 1 -> horizontal stripes (one per image row).  q is scaled by 32^-0.5.
- * lepe_v, lepe_h: depthwise 3x3 kernels [C/2,1,3,3] of attns.0 / attns.1.  -> out [T,C]. */
+ * lepe_v, lepe_h: depthwise 3x3 kernels [C/2,1,3,3] of attns.0 / attns.1.  -> out [T,C].
+ * axes: bit 0 = run the vertical stripes (writes out[:, 0:C/2]), bit 1 = the horizontal ones (out[:, C/2:C]);
+ * 3 = both (two kernel launches on `stream`). */
 int nmrf_stripe_attn_f32(const float *qkv, const float *lepe_v, const float *lepe_h, int B, int H, int W, int N,
-                         int C, float *out, void *stream);
+                         int C, int axes, float *out, void *stream);
 
 /* A9  warp right maps at x-label, group correlation, concat.
  * replaces Inference.sample_fmap x2 + corr + cat (nmrf/models/NMP.py:683-741, 839-844).

@@ -167,18 +167,18 @@ __global__ __launch_bounds__(256) void stripe_attn_kernel(const float *__restric
 }
 
 extern "C" int nmrf_stripe_attn_f32(const float *qkv, const float *lepe_v, const float *lepe_h, int B, int H, int W,
-                                    int N, int C, float *out, void *stream) {
+                                    int N, int C, int axes, float *out, void *stream) {
     if (!qkv || !lepe_v || !lepe_h || !out) return NMRF_ENULL;
-    if (B < 1 || H < 1 || W < 1 || N < 1 || C != 128) return NMRF_EINVAL;
+    if (B < 1 || H < 1 || W < 1 || N < 1 || C != 128 || axes < 1 || axes > 3) return NMRF_EINVAL;
     const float scale = 1.0f / sqrtf(32.0f);
     int nshift = -1;
     for (int k = 0; k < 5; ++k) if ((1 << k) == N) nshift = k;
-    {   // vertical stripes: one per column, H*N tokens each, channel half 0
+    if (axes & 1) {   // vertical stripes: one per column, H*N tokens each, channel half 0
         StripeGeom g{H, W, N, C, nshift, H, H * N, (int64_t)W};
         dim3 grid((g.Ts + 4 * SA_TILE - 1) / (4 * SA_TILE), W * 2, B);
         hipLaunchKernelGGL(stripe_attn_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, qkv, lepe_v, g, scale, out);
     }
-    {   // horizontal stripes: one per row, W*N tokens each, channel half 1
+    if (axes & 2) {   // horizontal stripes: one per row, W*N tokens each, channel half 1
         StripeGeom g{H, W, N, C, nshift, W, W * N, (int64_t)1};
         dim3 grid((g.Ts + 4 * SA_TILE - 1) / (4 * SA_TILE), H * 2, B);
         hipLaunchKernelGGL(stripe_attn_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, qkv, lepe_h, g, scale, out);

@@ -104,7 +104,13 @@ class NMRF(nn.Module):
         padder = InputPadder(image1.shape, mode="proposal", divis_by=self.divis_by)
         image1, image2 = padder.pad(image1, image2)
         fmap1_list, fmap2_list = self.extract_feature(image1, image2)
+        return self.hot_path(fmap1_list, fmap2_list, (h0, w0))
+
+    def hot_path(self, fmap1_list, fmap2_list, out_hw):
+        """Everything after the backbone (NMRF.py:207-262): fmap lists are [1/8-res, 1/4-res] NCHW maps of the
+        left / right view; out_hw the un-padded image size.  This is the region the bench's hot-path timer brackets."""
         n = self.num_proposals
+        h0, w0 = out_hw
 
         # ---- disparity proposals -------------------------------------------------------------------
         cost_volume = K.cost_volume(fmap1_list[0], fmap2_list[0], self.max_disp // 8, self.dpn.cost_group)

@@ -1,0 +1,167 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol the header declares
+(no compute without a GPU), config/padder/state-dict mirror the reference interface, the product
+refuses to run without a GPU (no fallback), sharding arithmetic."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from nmrf_amd import _lib
+from nmrf_amd.config import get_cfg
+from nmrf_amd.frame_utils import InputPadder
+from nmrf_amd.models import build_model
+from nmrf_amd.parallel import shard_range
+from tests.util import build_product
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built_library():
+    if not os.path.exists(_lib.LIB_PATH):
+        from nmrf_amd.build import build_library
+        build_library(verbose=False)
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    hdr = open(os.path.join(ROOT, "include", "nmrf_hip.h")).read()
+    declared = set(re.findall(r"\b(nmrf_\w+)\s*\(", hdr))
+    assert len(declared) >= 18
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), f"{name} declared in include/nmrf_hip.h but not exported"
+    assert declared - {"nmrf_strerror"} == set(_lib.PROTOTYPES), "ctypes binding out of sync with the header"
+    lib = _lib.load()
+    assert lib.nmrf_abi_version() == _lib.ABI_VERSION
+    assert lib.nmrf_strerror(-1).decode().startswith("invalid")
+
+
+def test_entry_points_validate_arguments_without_touching_the_gpu():
+    lib = _lib.load()
+    assert lib.nmrf_cost_volume_f32(None, None, 1, 256, 4, 4, 40, 4, None, None) == -3       # NMRF_ENULL
+    one = ctypes.c_void_p(16)
+    assert lib.nmrf_cost_volume_f32(one, one, 1, 255, 4, 4, 40, 4, one, None) == -1           # C % G != 0
+    assert lib.nmrf_nms_topk_f32(one, 10, 300, 4, 1e-3, 1, one, None) == -1                   # D > 64
+    assert lib.nmrf_window_attn_f32(one, one, 1, 13, 12, 4, 128, 4, 6, 0, 1, one, None) == -1 # Hp % win
+    assert lib.nmrf_stripe_attn_f32(one, one, one, 1, 4, 4, 4, 128, 0, one, None) == -1       # axes == 0
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libnmrf_hip.so")
+    with pytest.raises(_lib.NmrfHipError, match="no CPU/PyTorch fallback"):
+        _lib.load()
+
+
+def test_product_has_no_cpu_path():
+    model = build_product(128)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        model({"img1": torch.zeros(1, 3, 32, 64), "img2": torch.zeros(1, 3, 32, 64)})
+    from nmrf_amd import kernels as K
+    with pytest.raises(_lib.NmrfHipError):
+        K.nms_topk(torch.rand(8, 40), 4, 1e-3)
+    with pytest.raises(NotImplementedError):
+        model.train()({"img1": torch.zeros(1, 3, 32, 64), "img2": torch.zeros(1, 3, 32, 64)})
+
+
+def test_config_defaults_and_overrides():
+    cfg = get_cfg()
+    assert (cfg.DPN.MAX_DISP, cfg.DPN.COST_GROUP, cfg.DPN.NUM_PROPOSALS, cfg.DPN.CONTEXT_DIM) == (320, 4, 4, 64)
+    assert (cfg.NMP.WINDOW_SIZE, cfg.NMP.REFINE_WINDOW_SIZE, cfg.NMP.SPLIT_SIZE) == (6, 4, 1)
+    assert (cfg.NMP.NUM_PROP_LAYERS, cfg.NMP.NUM_INFER_LAYERS, cfg.NMP.NUM_REFINE_LAYERS) == (5, 5, 5)
+    cfg.merge_from_list(["NMP.NUM_INFER_LAYERS", "4", "BACKBONE.COMPAT", "False"])
+    assert cfg.NMP.NUM_INFER_LAYERS == 4 and cfg.BACKBONE.COMPAT is False
+    with pytest.raises(KeyError):
+        cfg.merge_from_list(["NMP.NOPE", 1])
+    cfg.freeze()
+    with pytest.raises(AttributeError):
+        cfg.SEED = 1
+    c2 = cfg.clone()
+    c2.defrost()
+    c2.SEED = 7
+    assert cfg.SEED == 326
+
+
+def test_config_yaml_with_base(tmp_path):
+    (tmp_path / "base.yaml").write_text("DATASETS:\n  DIVIS_BY: 32\nBACKBONE:\n  OUT_CHANNELS: 128\n")
+    (tmp_path / "child.yaml").write_text("__BASE__: base.yaml\nBACKBONE:\n  COMPAT: False\n")
+    cfg = get_cfg()
+    cfg.merge_from_file(str(tmp_path / "child.yaml"))
+    assert cfg.DATASETS.DIVIS_BY == 32 and cfg.BACKBONE.OUT_CHANNELS == 128 and cfg.BACKBONE.COMPAT is False
+
+
+def test_input_padder_matches_reference_semantics():
+    x = torch.arange(2 * 3 * 375 * 1242, dtype=torch.float32).view(2, 3, 375, 1242)
+    p = InputPadder(x.shape, mode="proposal", divis_by=8)
+    (y,) = p.pad(x)
+    assert y.shape == (2, 3, 376, 1248)
+    assert torch.equal(y[..., :375, :1242], x) and torch.equal(y[..., 375, :1242], x[..., 374, :])
+    assert torch.equal(y[..., :375, 1242:], x[..., :, 1241:].expand(-1, -1, -1, 6))
+    assert torch.equal(p.unpad(y), x)
+    q = InputPadder((1, 3, 540, 960), mode="sintel", divis_by=32)
+    assert q._pad == [0, 0, 2, 2]
+    assert InputPadder((1, 3, 64, 64), mode="proposal")._pad == [0, 0, 0, 0]
+
+
+def test_state_dict_contract():
+    """Names/shapes the reference checkpoints carry; 351 tensors, 6 113 210 parameters."""
+    model = build_model(get_cfg())[0]
+    sd = model.state_dict()
+    assert len(sd) == 351 and sum(p.numel() for p in model.parameters()) == 6113210
+    expect = {
+        "concatconv.0.weight": (128, 256, 3, 3), "gw.3.weight": (256, 128, 1, 1),
+        "inference.ffn.fc1.weight": (128, 160), "inference.layers.0.self_nmp.q.weight": (128, 159),
+        "inference.layers.4.nmp.qkv.weight": (384, 159),
+        "inference.layers.1.nmp.attn.relative_position_enc_table": (121, 384),
+        "inference.layers.1.nmp.attn.relative_position_index": (36, 36),
+        "refinement.layers.0.nmp.attn.relative_position_enc_table": (49, 384),
+        "refinement.layers.0.nmp.attn.relative_position_index": (16, 16),
+        "infer_head.layers.2.weight": (64, 128), "infer_score_head.weight": (64, 128),
+        "refine_head.layers.2.weight": (16, 128), "dpn.mlp.0.weight": (8, 4, 5), "dpn.mlp.4.weight": (1, 16, 5),
+        "dpn.proj.3.weight": (64, 128, 1, 1), "dpn.propagation.cost_encoder.0.weight": (128, 36),
+        "dpn.propagation.proj.weight": (128, 159), "dpn.propagation.layers.2.nmp.q.weight": (128, 192),
+        "dpn.propagation.layers.2.nmp.attns.1.get_v.weight": (64, 1, 3, 3), "dpn.prop_head.layers.2.weight": (1, 128),
+        "backbone.conv1.weight": (64, 3, 7, 7), "backbone.layer2.0.downsample.0.weight": (96, 64, 1, 1),
+        "backbone.conv2.bias": (256,), "device_indicator_tensor": (0,),
+    }
+    for k, shp in expect.items():
+        assert k in sd and tuple(sd[k].shape) == shp, k
+    assert "dpn.propagation.proj.bias" not in sd
+    cfg = get_cfg()
+    cfg.BACKBONE.COMPAT = False
+    assert any(k.startswith("image_encoder.") for k in build_model(cfg)[0].state_dict())
+    # a state dict round-trips strictly
+    model.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=True)
+
+
+def test_relative_position_index_formula():
+    m = build_model(get_cfg())[0]
+    idx = m.inference.layers[0].nmp.attn.relative_position_index
+    w = 6
+    for (i, j) in ((0, 0), (0, 35), (35, 0), (7, 20)):
+        ai, bi, aj, bj = i // w, i % w, j // w, j % w
+        assert int(idx[i, j]) == (ai - aj + w - 1) * (2 * w - 1) + (bi - bj + w - 1)
+
+
+def test_fused_weight_cache_tracks_parameter_updates():
+    m = build_product(128)
+    blk = m.inference.layers[0].self_nmp
+    w1, b1, kp = blk._weights()
+    assert w1.shape == (384, 160) and kp == 160 and torch.equal(w1[:128, :159], blk.q.weight)
+    assert torch.equal(w1[256:, :128], blk.v.weight) and (w1[256:, 128:] == 0).all() and (w1[:, 159] == 0).all()
+    assert blk._weights()[0] is w1
+    with torch.no_grad():
+        blk.q.weight.add_(1.0)
+    assert blk._weights()[0] is not w1 and torch.equal(blk._weights()[0][:128, :159], blk.q.weight)
+
+
+def test_shard_range_partitions_exactly():
+    for total in (1, 7, 8, 64, 65):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1

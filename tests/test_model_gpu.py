@@ -1,0 +1,154 @@
+"""GPU parity of the assembled hot path (nmrf_amd.models.NMRF on libnmrf_hip.so) against the golden
+vectors of the reference and against the CPU oracle; plus size-independent properties at the full
+BASELINE sizes where the oracle would take too long."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nmrf_oracle as O
+from tests.util import build_product, golden, oracle_cfg, oracle_weights, report, t
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _oracle_features(g):
+    """Backbone features computed by the oracle on CPU (stock convs): the GPU hot path is then fed the
+    exact same activations the reference saw, so seeds can be required bit-exact."""
+    w, cfg = oracle_weights(int(g["max_disp"])), oracle_cfg(int(g["max_disp"]))
+    with torch.no_grad():
+        out = O.forward(w, cfg, t(g["img1"]).float(), t(g["img2"]).float(), return_stages=True)
+    st = out["stages"]
+    return w, cfg, out, ([st["fmap8_l"], st["fmap4_l"]], [st["fmap8_r"], st["fmap4_r"]])
+
+
+@pytest.mark.parametrize("name", ["e2e_a", "e2e_b", "e2e_c"])
+def test_hot_path_from_reference_features(name):
+    g = golden(name)
+    w, cfg, oout, (fl, fr) = _oracle_features(g)
+    model = build_product(int(g["max_disp"]), DEV)
+    with torch.no_grad():
+        out = model.hot_path([f.to(DEV) for f in fl], [f.to(DEV) for f in fr], g["disp"].shape[-2:])
+    report("prob", out["prob"].cpu(), t(g["prob"]), 5e-6)
+    seeds = out["initial_proposal"].cpu().long()
+    assert torch.equal(seeds, t(g["seeds"]).long()), \
+        f"{int((seeds != t(g['seeds']).long()).any(-1).sum())} pixels with different label seeds"
+    report("proposal", out["proposal"].cpu(), t(g["proposal"]), 2e-4)
+    epe = float((out["disp"].cpu() - t(g["disp"])).abs().mean())
+    assert epe < 5e-2, f"EPE vs reference {epe}"
+
+
+def test_stages_from_reference_inputs():
+    """Each stage of the GPU path fed with the reference's own stage inputs (golden e2e_a), so the
+    ~1e3x Fourier amplification of upstream fp32 noise cannot mask or fake an error."""
+    g = golden("e2e_a")
+    w, cfg, oout, (fl, fr) = _oracle_features(g)
+    model = build_product(int(g["max_disp"]), DEV)
+    n = cfg.num_proposals
+    with torch.no_grad():
+        l8, r8, l4, r4 = (x.to(DEV) for x in (fl[0], fr[0], fl[1], fr[1]))
+        # --- propagation from the reference's cost volume
+        cv = t(g["cost_volume"]).to(DEV)
+        _, prob, seeds, labels = model.dpn(cv, [l8])
+        assert torch.equal(seeds.cpu().long(), t(g["seeds"]).long().reshape(-1, n))
+        report("proposal", labels[-1].cpu(), t(g["proposal"]).reshape(-1, n), 1e-4)
+        # --- inference from the reference's proposals
+        lab = t(g["proposal"]).reshape(-1, n).to(DEV)
+        f1, f2, g1, g2 = model.concatconv(l8), model.concatconv(r8), model.gw(l8), model.gw(r8)
+        tgt = model.inference(lab, f1, f2, g1, g2).reshape(-1, 128)
+        report("infer_tgt", tgt.cpu(), t(g["infer_tgt"]), 2e-4)
+        # --- heads + WTA + median from the reference's inference output
+        tg = t(g["infer_tgt"]).to(DEV)
+        from nmrf_amd import kernels as K
+        b, _, h8, w8 = f1.shape
+        dq = K.wta_median(model.infer_head(tg), model.infer_score_head(tg), lab.reshape(-1).contiguous(), b, h8, w8, n)
+        report("disp_curr", dq.cpu(), t(g["disp_curr"]), 2e-5)
+        # --- refinement from the reference's disp_curr
+        f1, f2, g1, g2 = model.concatconv(l4), model.concatconv(r4), model.gw(l4), model.gw(r4)
+        dcur = t(g["disp_curr"]).to(DEV)
+        tgt4 = model.refinement(dcur, f1, f2, g1, g2).reshape(-1, 128)
+        report("refine_tgt", tgt4.cpu(), t(g["refine_tgt"]), 2e-4)
+        disp, pred = K.refine_epilogue(model.refine_head(t(g["refine_tgt"]).to(DEV)), dcur, *g["disp"].shape[-2:])
+        report("disp_pred", pred.cpu(), t(g["disp_pred"]), 2e-5)
+        report("disp", disp.cpu(), t(g["disp"]), 1e-4)
+
+
+def test_individual_layers_vs_oracle():
+    """One propagation / self-edge / window layer at a time on random activations."""
+    from nmrf_amd.utils.hashinit import unit_noise
+    w = oracle_weights(320)
+    model = build_product(320, DEV)
+    b, h, wd, n = 2, 6, 12, 4
+    tkn = b * h * wd * n
+    x = torch.from_numpy(unit_noise("x", tkn * 128).reshape(tkn, 128)) * 2
+    ctx = torch.from_numpy(unit_noise("c", b * h * wd * 64).reshape(b, h, wd, 64))
+    enc = O.fourier_embed(torch.from_numpy(unit_noise("l", tkn)).abs() * 30, 3.14 / 64)
+    with torch.no_grad():
+        for i in (0, 1):
+            got = model.dpn.propagation.layers[i](x.to(DEV), ctx.reshape(-1, 64).to(DEV), (b, h, wd, n)).cpu()
+            report(f"cswin layer {i}", got, O.cswin_layer(x, ctx, w, f"dpn.propagation.layers.{i}.nmp", (b, h, wd, n)), 5e-5)
+            lay = model.inference.layers[i]
+            got = lay.self_nmp(x.to(DEV), enc.to(DEV), n).cpu()
+            report(f"self layer {i}", got, O.self_attention_layer(x, enc, w, f"inference.layers.{i}.self_nmp", n, 4), 5e-5)
+            got = lay.nmp(x.to(DEV), enc.to(DEV), (b, h, wd, n), True).cpu()
+            report(f"swin layer {i}", got, O.swin_layer(x, enc, w, f"inference.layers.{i}.nmp", (b, h, wd, n), 6,
+                                                         lay.shift_size, 4, True), 5e-5)
+        b, h, wd, n = 1, 8, 12, 1
+        tkn = b * h * wd
+        x1, e1 = x[:tkn].contiguous(), enc[:tkn].contiguous()
+        for i in (0, 1):
+            lay = model.refinement.layers[i]
+            got = lay(x1.to(DEV), e1.to(DEV), (b, h, wd, n)).cpu()
+            report(f"refine layer {i}", got, O.swin_layer(x1, e1, w, f"refinement.layers.{i}.nmp", (b, h, wd, n), 4,
+                                                           lay.shift_size, 4, False), 5e-5)
+
+
+def test_full_forward_vs_oracle_mid_size():
+    """Whole model(sample) on the GPU (MIOpen backbone) vs the whole oracle on CPU, 120x264."""
+    from nmrf_amd.utils.hashinit import synthetic_pair
+    l, r, _ = synthetic_pair(120, 264, seed=1234)
+    w, cfg = oracle_weights(320), oracle_cfg(320)
+    with torch.no_grad():
+        want = O.forward(w, cfg, l[None], r[None])
+        got = build_product(320, DEV)({"img1": l[None], "img2": r[None]})
+    report("prob", got["prob"].cpu(), want["prob"], 2e-4)
+    mism = (got["initial_proposal"].cpu() != want["initial_proposal"]).any(-1).float().mean()
+    assert mism < 0.01, f"{float(mism) * 100:.2f}% of pixels got different seeds (MIOpen vs CPU conv noise at exact ties)"
+    epe = float((got["disp"].cpu() - want["disp"]).abs().mean())
+    assert epe < 0.1, f"EPE {epe}"
+    assert got["disp"].shape == (1, 120, 264) and got["disp_pred"].shape == (1, 120, 264)
+
+
+@pytest.mark.parametrize("h,w", [(375, 1242), (540, 960)])
+def test_full_size_properties(h, w):
+    """BASELINE sizes (KITTI, SceneFlow): properties that hold at any size.
+    * per-image independence: a batch of two different pairs == the two pairs run alone (bit-exact,
+      there is no cross-image reduction anywhere on the path), in either order
+    * probabilities sum to 1, seeds are distinct in-range bins sorted by suppressed probability
+    * outputs are finite, non-negative, and of the un-padded size."""
+    from nmrf_amd.utils.hashinit import synthetic_pair
+    model = build_product(320, DEV)
+    pairs = [synthetic_pair(h, w, seed=s)[:2] for s in (1000, 1001)]
+    img1 = torch.stack([p[0] for p in pairs])
+    img2 = torch.stack([p[1] for p in pairs])
+    with torch.no_grad():
+        both = model({"img1": img1, "img2": img2})
+        swapped = model({"img1": img1.flip(0), "img2": img2.flip(0)})
+        solo = model({"img1": img1[:1], "img2": img2[:1]})
+    for k in ("disp", "proposal", "initial_proposal"):
+        assert torch.equal(both[k].flip(0), swapped[k]), k
+        assert torch.equal(both[k][:1], solo[k]), k
+    d = 40
+    prob = both["prob"]
+    assert torch.allclose(prob.sum(-1), torch.ones_like(prob[:, 0]), atol=1e-5)
+    seeds = both["initial_proposal"].long().reshape(-1, 4)
+    assert int(seeds.min()) >= 0 and int(seeds.max()) < d
+    assert (seeds.sort(-1).values.diff(dim=-1) > 0).all(), "seeds of a pixel must be distinct bins"
+    assert both["disp"].shape == (2, h, w)
+    assert torch.isfinite(both["disp"]).all() and (both["disp"] >= 0).all()
+    # NMS invariant: a returned seed whose (suppressed) value exceeds eps is a local maximum of prob
+    p = prob.gather(1, seeds)
+    left = torch.nn.functional.pad(prob, (1, 0), value=-1.0)[:, :-1].gather(1, seeds)
+    right = torch.nn.functional.pad(prob, (0, 1), value=-1.0)[:, 1:].gather(1, seeds)
+    strong = p[:, 0] > 1e-3
+    assert ((p[:, 0] >= left[:, 0]) & (p[:, 0] >= right[:, 0]))[strong].all()
