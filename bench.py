@@ -41,10 +41,10 @@ def parse():
 
 
 class KernelTimer:
-    """HIP-event bracket of one named kernel launch (kernels.kernel_hook)."""
+    """HIP-event brackets of named kernel launches (kernels.kernel_hook), recorded on the launching stream."""
 
     def __init__(self):
-        self.pairs = []
+        self.pairs = {}
         self.enabled = False
 
     def __call__(self, phase, name):
@@ -53,24 +53,30 @@ class KernelTimer:
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.current_stream())
         if phase == "begin":
-            self.pairs.append([ev, None])
+            self.pairs.setdefault(name, []).append([ev, None])
         else:
-            self.pairs[-1][1] = ev
+            self.pairs[name][-1][1] = ev
 
-    def mean_ms(self):
-        ts = [a.elapsed_time(b) for a, b in self.pairs if b is not None]
-        return sum(ts) / len(ts) if ts else None, len(ts)
+    def stats(self):
+        """name -> (mean ms per launch, launches)"""
+        out = {}
+        for name, prs in self.pairs.items():
+            ts = [a.elapsed_time(b) for a, b in prs if b is not None]
+            if ts:
+                out[name] = (sum(ts) / len(ts), len(ts))
+        return out
 
 
 def cpu_baseline(height, width, infer_layers):
     """The CPU oracle (a plain-PyTorch port of the reference path, pinned to the reference by
-    tests/test_oracle_golden.py) on all host cores: 1 warm-up at 1/4 size + 2 timed forwards of one pair."""
+    tests/test_oracle_golden.py) on up to 16 host cores: 1 warm-up at 1/4 size + 1 timed forward of one pair
+    (a bounded sample: one forward is ~5-30 s of CPU work)."""
     from oracle import nmrf_oracle as O
     from nmrf_amd.config import get_cfg
     from nmrf_amd.models import build_model
     from nmrf_amd.utils.hashinit import hash_state_dict, synthetic_pair
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    torch.set_num_threads(min(cores, 16))     # the op-by-op CPU path stops scaling (and collapses) beyond ~16 threads
     cfg = get_cfg()
     cfg.NMP.NUM_INFER_LAYERS = infer_layers
     w = hash_state_dict(build_model(cfg)[0].state_dict())
@@ -79,7 +85,7 @@ def cpu_baseline(height, width, infer_layers):
     with torch.no_grad():
         ls, rs, _ = synthetic_pair(max(64, height // 4), max(96, width // 4), seed=1)
         O.forward(w, ocfg, ls[None], rs[None])
-        reps = 2
+        reps = 1
         t0 = time.perf_counter()
         for _ in range(reps):
             O.forward(w, ocfg, l[None], r[None])
@@ -169,7 +175,7 @@ def main():
             step()
         torch.cuda.synchronize()
         timer.enabled = False
-        k_ms, k_n = timer.mean_ms()
+        kstats = timer.stats()
 
         # hot-path-only time (everything after the backbone)
         hp_ms = None
@@ -193,15 +199,32 @@ def main():
     value = pairs_total / elapsed
     hp, wp = -(-args.height // 8) * 8, -(-args.width // 8) * 8
     h8, w8, n = hp // 8, wp // 8, cfg.DPN.NUM_PROPOSALS
-    # algorithmic FLOPs of one horizontal-stripe launch: per (row, head) QK^T and PV, 2*T^2*32 each,
-    # T = W8*N tokens, 2 heads per direction  ->  B * H8 * 2 * 4*32*(W8 N)^2     
-    flop = b * h8 * 2 * 4.0 * 32 * (w8 * n) ** 2
-    roof = None
-    if k_ms:
-        ach = flop / (k_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "stripe_attn_kernel<1> (horizontal stripes)", "achieved": round(ach, 3),
-                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                "traffic": None, "launch_ms": round(k_ms, 4), "launches_timed": k_n, "flop_per_launch": flop}
+    # ALGORITHMIC FLOPs per launch (SURVEY 8(d) formulas, reference-form contraction counts):
+    #  horizontal stripes: per (row, head) QK^T and PV, 2*T^2*32 each, T = W8*N, 2 heads  -> B*H8*2*4*32*(W8 N)^2
+    #  inference windows : 5 contractions of T^2*32 MACs per (window, head), T = win^2*N, 4 heads, padded grid
+    win = cfg.NMP.WINDOW_SIZE
+    hp8, wp8 = -(-h8 // win) * win, -(-w8 // win) * win
+    tw = win * win * n
+    flops = {
+        "stripe_attn_horizontal": b * h8 * 2 * 4.0 * 32 * (w8 * n) ** 2,
+        "window_attn_w%d_n%d" % (win, n): b * (hp8 // win) * (wp8 // win) * cfg.NMP.INFER_N_HEADS * 5 * 2.0 * tw * tw * 32,
+    }
+    kern_names = {"stripe_attn_horizontal": "stripe_attn_kernel<1> (horizontal stripes, A7)",
+                  "window_attn_w%d_n%d" % (win, n): "window_attn_kernel<%d> (inference windows, A10)" % ((tw + 31) // 32)}
+    roof, others = None, []
+    timed = {k: v for k, v in kstats.items() if k in flops}
+    if timed:
+        per_fwd = {k: v[0] * cfg.NMP.NUM_INFER_LAYERS for k, v in timed.items()}   # both run 5x per forward
+        dom = max(per_fwd, key=per_fwd.get)
+        for k, (ms, cnt) in timed.items():
+            ach = flops[k] / (ms * 1e-3) / 1e12
+            rec = {"bound": "mfma", "kernel": kern_names[k], "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
+                   "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                   "launch_ms": round(ms, 4), "launches_timed": cnt, "flop_per_launch": flops[k]}
+            if k == dom:
+                roof = rec
+            else:
+                others.append(rec)
 
     if rank == 0:
         res = {
@@ -217,6 +240,7 @@ def main():
                        "result_gather": bool(world > 1 and not args.no_gather)},
             "hot_path_ms": None if hp_ms is None else round(hp_ms, 3),
             "roofline": roof,
+            "other_kernels": others,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -148,8 +148,12 @@ def window_attn(qkv, table, b, hp, wp, n, heads, win, shift, sibling_mask):
     c = c3 // 3
     assert t == b * hp * wp * n
     out = torch.empty(t, c, device=qkv.device, dtype=torch.float32)
+    if kernel_hook is not None:
+        kernel_hook("begin", "window_attn_w%d_n%d" % (win, n))
     _lib.check(_lib.load().nmrf_window_attn_f32(_p(qkv), _p(table), b, hp, wp, n, c, heads, win, shift,
                                                 int(bool(sibling_mask)), _p(out), _stream()), "window_attn")
+    if kernel_hook is not None:
+        kernel_hook("end", "window_attn_w%d_n%d" % (win, n))
     return out
 
 

