@@ -26,14 +26,18 @@ struct StripeGeom {
 };
 
 // token row (in units of tokens) of in-stripe token s
-__device__ __forceinline__ int div_n(const StripeGeom &g, int s) { return g.nshift >= 0 ? (s >> g.nshift) : (s / g.N); }
+// NSHIFT >= 0: N == 1<<NSHIFT at compile time (N=4 in every shipped config); NSHIFT < 0: runtime N
+template <int NSHIFT>
+__device__ __forceinline__ int div_n(const StripeGeom &g, int s) { return NSHIFT >= 0 ? (s >> NSHIFT) : (s / g.N); }
 
+template <int NSHIFT>
 __device__ __forceinline__ int64_t stripe_row(const StripeGeom &g, int64_t base_pix, int s) {
-    int l = div_n(g, s), n = s - l * g.N;
-    return (base_pix + (int64_t)l * g.pix_stride) * g.N + n;
+    const int nn = NSHIFT >= 0 ? (1 << NSHIFT) : g.N;
+    int l = div_n<NSHIFT>(g, s), n = s - l * nn;
+    return (base_pix + (int64_t)l * g.pix_stride) * nn + n;
 }
 
-template <int AXIS>
+template <int AXIS, int NSHIFT>
 __global__ __launch_bounds__(256) void stripe_attn_kernel(const float *__restrict__ qkv, const float *__restrict__ lepe,
                                                          StripeGeom g, float scale, float *__restrict__ out) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -51,7 +55,7 @@ __global__ __launch_bounds__(256) void stripe_attn_kernel(const float *__restric
     // ---- Q fragment (B operand): lane (qi,hi) holds Q[q0+qi][16*hi + s], pre-scaled ------------------
     const int qs = q0 + qi;
     const bool q_ok = qs < g.Ts;
-    const int64_t qrow = stripe_row(g, base_pix, q_ok ? qs : g.Ts - 1);
+    const int64_t qrow = stripe_row<NSHIFT>(g, base_pix, q_ok ? qs : g.Ts - 1);
     float qf[16];
     {
         const float *p = qkv + qrow * ld + coff + 16 * hi;
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(256) void stripe_attn_kernel(const float *__restric
             qf[4 * c + 2] = v.z * scale; qf[4 * c + 3] = v.w * scale;
         }
     }
-    const int q_pix = div_n(g, qs);
+    const int q_pix = div_n<NSHIFT>(g, qs);
 
     f32x16 acc_o;
 #pragma unroll
@@ -70,40 +74,47 @@ __global__ __launch_bounds__(256) void stripe_attn_kernel(const float *__restric
     float m_run = -INFINITY, l_run = 0.f;
 
     const int n_kt = (g.Ts + SA_TILE - 1) / SA_TILE;
-    for (int kt = 0; kt < n_kt; ++kt) {
+    // K fragment (A operand): lane (ki=qi, hi) holds K[k0+ki][16*hi + s]
+    // V fragment (A operand of the 2nd product): lane (d=qi, hi), step s: V[k0+mfma_row(s,hi)][d]
+    auto load_k = [&](int kt, float *kd) {
         const int k0 = kt * SA_TILE;
-        // ---- K fragment (A operand): lane (ki=qi, hi) holds K[k0+ki][16*hi + s] ----------------------
-        float kf[16];
-        {
-            int ks = k0 + qi;
-            ks = ks < g.Ts ? ks : g.Ts - 1;
-            const float *p = qkv + stripe_row(g, base_pix, ks) * ld + g.C + coff + 16 * hi;
+        int ks = k0 + qi;
+        ks = ks < g.Ts ? ks : g.Ts - 1;
+        const float *p = qkv + stripe_row<NSHIFT>(g, base_pix, ks) * ld + g.C + coff + 16 * hi;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float4 v = ldg4(p + 4 * c);
-                kf[4 * c + 0] = v.x; kf[4 * c + 1] = v.y; kf[4 * c + 2] = v.z; kf[4 * c + 3] = v.w;
-            }
+        for (int c = 0; c < 4; ++c) {
+            float4 v = ldg4(p + 4 * c);
+            kd[4 * c + 0] = v.x; kd[4 * c + 1] = v.y; kd[4 * c + 2] = v.z; kd[4 * c + 3] = v.w;
         }
-        // ---- V fragment (A operand of the 2nd product): lane (d=qi, hi), step s: V[k0+mfma_row(s,hi)][d]
-        float vf[16];
+    };
+    auto load_v = [&](int kt, float *vd) {
+        const int k0 = kt * SA_TILE;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            int ks = k0 + mfma_row(s, hi);
-            ks = ks < g.Ts ? ks : g.Ts - 1;
-            vf[s] = qkv[stripe_row(g, base_pix, ks) * ld + 2 * g.C + coff + qi];
+            int kv = k0 + mfma_row(s, hi);
+            kv = kv < g.Ts ? kv : g.Ts - 1;
+            vd[s] = qkv[stripe_row<NSHIFT>(g, base_pix, kv) * ld + 2 * g.C + coff + qi];
         }
+    };
+    float kf[16], vf[16];
+    load_k(0, kf);
+    load_v(0, vf);
+#pragma unroll 1
+    for (int kt = 0; kt < n_kt; ++kt) {
+        const int k0 = kt * SA_TILE;
         // ---- S^T = K Q^T -----------------------------------------------------------------------------
         f32x16 st;
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < 16; ++s) st = mfma32(kf[s], qf[s], st);
+        if (kt + 1 < n_kt) load_k(kt + 1, kf);     // K fragment is dead: refill now, in flight during softmax + P.V
         // ---- mask: out-of-stripe keys, and sibling labels of the query's own pixel ---------------------
         float m_tile = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ks = k0 + mfma_row(r, hi);
-            const bool dead = (ks >= g.Ts) || ((div_n(g, ks) == q_pix) && (ks != qs));
+            const bool dead = (ks >= g.Ts) || ((div_n<NSHIFT>(g, ks) == q_pix) && (ks != qs));
             st[r] = dead ? -INFINITY : st[r];
             m_tile = fmaxf(m_tile, st[r]);
         }
@@ -124,6 +135,7 @@ __global__ __launch_bounds__(256) void stripe_attn_kernel(const float *__restric
         // ---- O^T += V^T P^T --------------------------------------------------------------------------
 #pragma unroll
         for (int s = 0; s < 16; ++s) acc_o = mfma32(vf[s], st[s], acc_o);
+        if (kt + 1 < n_kt) load_v(kt + 1, vf);     // V fragment likewise: in flight during the next S^T and softmax
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv_l = 1.0f / l_tot;
@@ -135,8 +147,9 @@ __global__ __launch_bounds__(256) void stripe_attn_kernel(const float *__restric
     // taps = centre column (AXIS 0: kernel[:,1]) or centre row (AXIS 1: kernel[1,:]) of the 3x3 kernel.
     const int tap_m = (AXIS == 0) ? 1 : 3, tap_c = 4, tap_p = (AXIS == 0) ? 7 : 5;
     const bool has_prev = q_pix > 0, has_next = q_pix < g.L - 1;
-    const int64_t prev_row = stripe_row(g, base_pix, (q_pix - 1) * g.N);
-    const int64_t next_row = stripe_row(g, base_pix, (q_pix + 1) * g.N);
+    const int nlab = NSHIFT >= 0 ? (1 << NSHIFT) : g.N;
+    const int64_t prev_row = stripe_row<NSHIFT>(g, base_pix, (q_pix - 1) * nlab);
+    const int64_t next_row = stripe_row<NSHIFT>(g, base_pix, (q_pix + 1) * nlab);
     float *op = out + qrow * g.C + coff;
     const float *vbase = qkv + 2 * g.C + coff;
 #pragma unroll
@@ -145,12 +158,12 @@ __global__ __launch_bounds__(256) void stripe_attn_kernel(const float *__restric
         float4 vq = ldg4(vbase + qrow * ld + d0);
         float4 sp = make_float4(0.f, 0.f, 0.f, 0.f), sn = sp;
         if (has_prev)
-            for (int n = 0; n < g.N; ++n) {
+            for (int n = 0; n < nlab; ++n) {
                 float4 t = ldg4(vbase + (prev_row + n) * ld + d0);
                 sp.x += t.x; sp.y += t.y; sp.z += t.z; sp.w += t.w;
             }
         if (has_next)
-            for (int n = 0; n < g.N; ++n) {
+            for (int n = 0; n < nlab; ++n) {
                 float4 t = ldg4(vbase + (next_row + n) * ld + d0);
                 sn.x += t.x; sn.y += t.y; sn.z += t.z; sn.w += t.w;
             }
@@ -176,12 +189,14 @@ extern "C" int nmrf_stripe_attn_f32(const float *qkv, const float *lepe_v, const
     if (axes & 1) {   // vertical stripes: one per column, H*N tokens each, channel half 0
         StripeGeom g{H, W, N, C, nshift, H, H * N, (int64_t)W};
         dim3 grid((g.Ts + 4 * SA_TILE - 1) / (4 * SA_TILE), W * 2, B);
-        hipLaunchKernelGGL(stripe_attn_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, qkv, lepe_v, g, scale, out);
+        if (N == 4) hipLaunchKernelGGL((stripe_attn_kernel<0, 2>), grid, dim3(256), 0, (hipStream_t)stream, qkv, lepe_v, g, scale, out);
+        else hipLaunchKernelGGL((stripe_attn_kernel<0, -1>), grid, dim3(256), 0, (hipStream_t)stream, qkv, lepe_v, g, scale, out);
     }
     if (axes & 2) {   // horizontal stripes: one per row, W*N tokens each, channel half 1
         StripeGeom g{H, W, N, C, nshift, W, W * N, (int64_t)1};
         dim3 grid((g.Ts + 4 * SA_TILE - 1) / (4 * SA_TILE), H * 2, B);
-        hipLaunchKernelGGL(stripe_attn_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, qkv, lepe_h, g, scale, out);
+        if (N == 4) hipLaunchKernelGGL((stripe_attn_kernel<1, 2>), grid, dim3(256), 0, (hipStream_t)stream, qkv, lepe_h, g, scale, out);
+        else hipLaunchKernelGGL((stripe_attn_kernel<1, -1>), grid, dim3(256), 0, (hipStream_t)stream, qkv, lepe_h, g, scale, out);
     }
     return nmrf_launch_status();
 }

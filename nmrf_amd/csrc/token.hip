@@ -165,46 +165,52 @@ __device__ __forceinline__ float warp_fetch(const float *__restrict__ plane, con
     return r;
 }
 
+// Work split: lane = x (64 consecutive pixels of a row), and the channels of one token are divided over
+// WC_CHUNKS threads (8 feature channels + 4 correlation groups each at the default 64/256/32 sizes), so a KITTI
+// pair launches ~3.7k waves instead of ~460 and every thread issues ~100 independent loads.
+#define WC_CHUNKS 8
 __global__ __launch_bounds__(256) void warp_corr_concat_kernel(const float *__restrict__ labels,
         const float *__restrict__ f1, const float *__restrict__ f2, const float *__restrict__ g1,
         const float *__restrict__ g2, int H, int W, int N, int Cf, int Cg, int groups, float *__restrict__ out, int ld) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int x = blockIdx.x * 64 + lane;
-    const int y = blockIdx.y, b = blockIdx.z;
+    const int y = blockIdx.y / (WC_CHUNKS / 4);
+    const int chunk = (blockIdx.y % (WC_CHUNKS / 4)) * 4 + wv;
+    const int b = blockIdx.z / N, n = blockIdx.z % N;
     if (x >= W) return;
     const size_t plane = (size_t)H * W;
     const int pix = y * W + x;
     const int cpg = Cg / groups;
-    for (int n = wv; n < N; n += 4) {
-        const int64_t t = (((int64_t)b * H + y) * W + x) * N + n;
-        const WarpTaps tp = make_taps(labels[t], x, y, H, W);
-        float *o = out + t * ld;
-        const float *pf1 = f1 + (size_t)b * Cf * plane, *pf2 = f2 + (size_t)b * Cf * plane;
-        for (int c = 0; c < Cf; c += 4) {
-            float a[4], w[4];
+    const int64_t t = (((int64_t)b * H + y) * W + x) * N + n;
+    const WarpTaps tp = make_taps(labels[t], x, y, H, W);
+    float *o = out + t * ld;
+    const float *pf1 = f1 + (size_t)b * Cf * plane, *pf2 = f2 + (size_t)b * Cf * plane;
+    const int fc = Cf / WC_CHUNKS;                          // feature channels per chunk (multiple of 4, host-checked)
+    for (int c = chunk * fc; c < (chunk + 1) * fc; c += 4) {
+        float a[4], w[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                a[k] = pf1[(size_t)(c + k) * plane + pix];
-                w[k] = warp_fetch(pf2 + (size_t)(c + k) * plane, tp);
-            }
-            stg4(o + c, make_float4(a[0], a[1], a[2], a[3]));
-            stg4(o + Cf + c, make_float4(w[0], w[1], w[2], w[3]));
+        for (int k = 0; k < 4; ++k) {
+            a[k] = pf1[(size_t)(c + k) * plane + pix];
+            w[k] = warp_fetch(pf2 + (size_t)(c + k) * plane, tp);
         }
-        const float *pg1 = g1 + (size_t)b * Cg * plane, *pg2 = g2 + (size_t)b * Cg * plane;
-        const float inv = 1.0f / (float)cpg;
-        for (int g = 0; g < groups; g += 4) {
-            float r[4];
+        stg4(o + c, make_float4(a[0], a[1], a[2], a[3]));
+        stg4(o + Cf + c, make_float4(w[0], w[1], w[2], w[3]));
+    }
+    const float *pg1 = g1 + (size_t)b * Cg * plane, *pg2 = g2 + (size_t)b * Cg * plane;
+    const float inv = 1.0f / (float)cpg;
+    const int gc = groups / WC_CHUNKS;                      // correlation groups per chunk (multiple of 4)
+    for (int g = chunk * gc; g < (chunk + 1) * gc; g += 4) {
+        float r[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float s = 0.f;
-                for (int c = 0; c < cpg; ++c) {
-                    size_t ch = (size_t)((g + k) * cpg + c) * plane;
-                    s = fmaf(pg1[ch + pix], warp_fetch(pg2 + ch, tp), s);
-                }
-                r[k] = s * inv;
+        for (int k = 0; k < 4; ++k) {
+            float s = 0.f;
+            for (int c = 0; c < cpg; ++c) {
+                size_t ch = (size_t)((g + k) * cpg + c) * plane;
+                s = fmaf(pg1[ch + pix], warp_fetch(pg2 + ch, tp), s);
             }
-            stg4(o + 2 * Cf + g, make_float4(r[0], r[1], r[2], r[3]));
+            r[k] = s * inv;
         }
+        stg4(o + 2 * Cf + g, make_float4(r[0], r[1], r[2], r[3]));
     }
 }
 
@@ -212,10 +218,10 @@ extern "C" int nmrf_warp_corr_concat_f32(const float *labels, const float *f1, c
                                          const float *g2, int B, int H, int W, int N, int Cf, int Cg, int groups,
                                          float *out, int ld, void *stream) {
     if (!labels || !f1 || !f2 || !g1 || !g2 || !out) return NMRF_ENULL;
-    if (B < 1 || H < 2 || W < 2 || N < 1 || Cf < 4 || (Cf & 3) || groups < 4 || (groups & 3) || Cg % groups ||
-        ld < 2 * Cf + groups || (ld & 3))
+    if (B < 1 || H < 2 || W < 2 || N < 1 || Cf < 4 * WC_CHUNKS || Cf % (4 * WC_CHUNKS) || groups < 4 * WC_CHUNKS ||
+        groups % (4 * WC_CHUNKS) || Cg % groups || ld < 2 * Cf + groups || (ld & 3) || (int64_t)B * N > 65535)
         return NMRF_EINVAL;
-    dim3 grid((W + 63) / 64, H, B);
+    dim3 grid((W + 63) / 64, H * (WC_CHUNKS / 4), B * N);
     hipLaunchKernelGGL(warp_corr_concat_kernel, grid, dim3(256), 0, (hipStream_t)stream, labels, f1, f2, g1, g2, H, W, N,
                        Cf, Cg, groups, out, ld);
     return nmrf_launch_status();

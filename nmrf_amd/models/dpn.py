@@ -47,14 +47,16 @@ class DPN(nn.Module):
         prob = K.dpn_filter_softmax(cost_volume, m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias)
         return prob, K.nms_topk(prob, self.num_proposals, self.eps)
 
-    def forward(self, cost_volume, fmap1_list):
+    def forward(self, cost_volume, fmap1_list, context=None):
         """cost_volume: [B,G,D,H,W] (reference layout) or token-major [B*H*W,G,D].
         Returns (cost_volume [P,G,D], prob [P,D], label_seeds [P,N] float, labels [1,P,N])."""
         if cost_volume.dim() == 5:
             b, g, d, h, w = cost_volume.shape
             cost_volume = cost_volume.permute(0, 3, 4, 1, 2).reshape(b * h * w, g, d).contiguous()
         prob, seeds = self.seeds(cost_volume)
-        context = self.proj(fmap1_list[0]).permute(0, 2, 3, 1).contiguous()
+        if context is None:                                   # [B,Cctx,H,W] may be precomputed by the caller
+            context = self.proj(fmap1_list[0])
+        context = context.permute(0, 2, 3, 1).contiguous()
         memory, seeds_f = self.propagation(cost_volume, seeds, context)
         outputs = self.prop_head(memory).view(-1, *seeds_f.shape)
         labels = F.relu(outputs + seeds_f[None])

@@ -10,7 +10,7 @@ from .. import kernels as K
 from ..frame_utils import InputPadder
 from .backbone import create_backbone
 from .dpn import DPN
-from .nmp import MLP, Inference, InferenceLayer, Refinement, RefinementLayer
+from .nmp import MLP, Inference, InferenceLayer, Refinement, RefinementLayer, _FusedCache
 
 
 def _conv_head(cin, cout):
@@ -64,6 +64,7 @@ class NMRF(nn.Module):
         else:
             self.image_encoder = backbone
         self.register_buffer("device_indicator_tensor", torch.empty(0))
+        self._head_cache8, self._head_cache4 = _FusedCache(), _FusedCache()
 
     @classmethod
     def from_config(cls, cfg):
@@ -106,6 +107,21 @@ class NMRF(nn.Module):
         fmap1_list, fmap2_list = self.extract_feature(image1, image2)
         return self.hot_path(fmap1_list, fmap2_list, (h0, w0))
 
+    def _conv_heads(self, left, right, with_context):
+        """concatconv / gw (/ dpn.proj) on both views as ONE stock 3x3 convolution: the heads share their input,
+        so their first convs are stacked along the output channels and the two views along the batch
+        (conv3x3 -> InstanceNorm -> ReLU are per-(sample, channel) independent, so this is the same arithmetic
+        as NMRF.py:211-214,233-236 and DPN.py:128); then one 1x1 conv per head on its 128-channel slice."""
+        heads = [self.concatconv, self.gw] + ([self.dpn.proj] if with_context else [])
+        cache = self._head_cache8 if with_context else self._head_cache4
+        w3 = cache.get(tuple(h[0].weight for h in heads), lambda: torch.cat([h[0].weight for h in heads], 0).contiguous())
+        b = left.shape[0]
+        y = F.relu(F.instance_norm(F.conv2d(torch.cat((left, right), 0), w3, None, 1, 1), eps=1e-5))
+        f = F.conv2d(y[:, 0:128], self.concatconv[3].weight)
+        g = F.conv2d(y[:, 128:256], self.gw[3].weight)
+        ctx = F.conv2d(y[:b, 256:384], self.dpn.proj[3].weight) if with_context else None
+        return f[:b].contiguous(), f[b:].contiguous(), g[:b].contiguous(), g[b:].contiguous(), ctx
+
     def hot_path(self, fmap1_list, fmap2_list, out_hw):
         """Everything after the backbone (NMRF.py:207-262): fmap lists are [1/8-res, 1/4-res] NCHW maps of the
         left / right view; out_hw the un-padded image size.  This is the region the bench's hot-path timer brackets."""
@@ -114,12 +130,11 @@ class NMRF(nn.Module):
 
         # ---- disparity proposals -------------------------------------------------------------------
         cost_volume = K.cost_volume(fmap1_list[0], fmap2_list[0], self.max_disp // 8, self.dpn.cost_group)
-        _, prob, label_seeds, labels = self.dpn(cost_volume, fmap1_list)
+        fmap1, fmap2, fmap1_gw, fmap2_gw, context = self._conv_heads(fmap1_list[0], fmap2_list[0], True)
+        _, prob, label_seeds, labels = self.dpn(cost_volume, fmap1_list, context=context)
         labels_curr = labels[-1]                                            # [P, N]
 
         # ---- neural MRF inference at 1/8 -------------------------------------------------------------
-        fmap1, fmap2 = self.concatconv(fmap1_list[0]), self.concatconv(fmap2_list[0])
-        fmap1_gw, fmap2_gw = self.gw(fmap1_list[0]), self.gw(fmap2_list[0])
         tgt = self.inference(labels_curr, fmap1, fmap2, fmap1_gw, fmap2_gw).view(-1, self.inference.dim)
         b, _, h8, w8 = fmap1.shape
         disp_delta = self.infer_head(tgt)                                   # [T,64]
@@ -128,8 +143,7 @@ class NMRF(nn.Module):
         disp_curr = K.wta_median(disp_delta, score, labels_curr.reshape(-1).contiguous(), b, h8, w8, n)
 
         # ---- refinement at 1/4 ---------------------------------------------------------------------------
-        fmap1, fmap2 = self.concatconv(fmap1_list[1]), self.concatconv(fmap2_list[1])
-        fmap1_gw, fmap2_gw = self.gw(fmap1_list[1]), self.gw(fmap2_list[1])
+        fmap1, fmap2, fmap1_gw, fmap2_gw, _ = self._conv_heads(fmap1_list[1], fmap2_list[1], False)
         tgt = self.refinement(disp_curr, fmap1, fmap2, fmap1_gw, fmap2_gw).view(-1, self.refinement.dim)
         disp, disp_pred = K.refine_epilogue(self.refine_head(tgt), disp_curr, h0, w0)
 
