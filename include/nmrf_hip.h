@@ -27,7 +27,7 @@ extern "C" {
 
 const char *nmrf_strerror(int code);
 /* ABI version of this header; bumps on any signature change. */
-int nmrf_abi_version(void);   /* currently 2 */
+int nmrf_abi_version(void);   /* currently 3 */
 
 /* A2  group-wise correlation volume.
  * replaces build_correlation_volume + the permute of DPN.forward
@@ -71,6 +71,13 @@ int nmrf_fourier_embed_f32(const float *coord, int64_t T, float normalizer, floa
  * -> out[t, 0:C] = LN(x[t]) (eps), out[t, C:C+E] = extra[t/extra_div], out[t, C+E:ld] = 0.  ld>=C+E, ld%4==0. */
 int nmrf_ln_concat_f32(const float *x, const float *gamma, const float *beta, float eps, const float *extra,
                        int E, int extra_div, int64_t T, int C, float *out, int ld, void *stream);
+
+/* Same with the residual add of the preceding block fused in: x_out = x + y, out = [LN(x_out) | extra | 0].
+ * replaces `shortcut + proj(msg)` / `x + mlp(...)` followed by the next norm (nmrf/models/NMP.py:106,361-362,572-573).
+ * x_out may alias x. */
+int nmrf_add_ln_concat_f32(const float *x, const float *y, float *x_out, const float *gamma, const float *beta,
+                           float eps, const float *extra, int E, int extra_div, int64_t T, int C, float *out, int ld,
+                           void *stream);
 
 /* A7  cross-stripe attention with LePE, both stripe directions in one call (SPLIT_SIZE==1).
  * replaces CSWinAttention.forward x2 + cat (nmrf/models/NMP.py:429-505,568-570).

@@ -5,13 +5,21 @@
 // LayerNorm(x) | extra  -> GEMM operand.  32 lanes per token (C == 128: one float4 per lane),
 // two tokens per wave, statistics by half-wave shuffles.  Two-pass variance like ATen.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ln_concat_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+// Optional fused residual: v = x + y is normalised and also written back to x_out (every residual add of
+// the message-passing blocks is immediately followed by a LayerNorm of its result).
+__global__ __launch_bounds__(256) void ln_concat_kernel(const float *__restrict__ x, const float *__restrict__ y,
+        float *__restrict__ x_out, const float *__restrict__ gamma,
         const float *__restrict__ beta, float eps, const float *__restrict__ extra, int E, int extra_div, int64_t T,
         float *__restrict__ out, int ld) {
     const int sub = threadIdx.x & 31;
     const int64_t t = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 5;
     if (t >= T) return;                                  // whole 32-lane group exits together
     float4 v = ldg4(x + t * 128 + sub * 4);
+    if (y) {
+        const float4 r = ldg4(y + t * 128 + sub * 4);
+        v = make_float4(v.x + r.x, v.y + r.y, v.z + r.z, v.w + r.w);
+        stg4(x_out + t * 128 + sub * 4, v);
+    }
     float s = (v.x + v.y) + (v.z + v.w);
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -35,7 +43,18 @@ extern "C" int nmrf_ln_concat_f32(const float *x, const float *gamma, const floa
     if (!x || !gamma || !beta || !out || (E > 0 && !extra)) return NMRF_ENULL;
     if (C != 128 || T < 1 || E < 0 || extra_div < 1 || ld < C + E || (ld & 3)) return NMRF_EINVAL;
     dim3 grid((unsigned)ceil_div64(T * 32, 256));
-    hipLaunchKernelGGL(ln_concat_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, gamma, beta, eps, extra, E,
+    hipLaunchKernelGGL(ln_concat_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, (const float *)nullptr,
+                       (float *)nullptr, gamma, beta, eps, extra, E, extra_div, T, out, ld);
+    return nmrf_launch_status();
+}
+
+extern "C" int nmrf_add_ln_concat_f32(const float *x, const float *y, float *x_out, const float *gamma, const float *beta,
+                                      float eps, const float *extra, int E, int extra_div, int64_t T, int C, float *out,
+                                      int ld, void *stream) {
+    if (!x || !y || !x_out || !gamma || !beta || !out || (E > 0 && !extra)) return NMRF_ENULL;
+    if (C != 128 || T < 1 || E < 0 || extra_div < 1 || ld < C + E || (ld & 3)) return NMRF_EINVAL;
+    dim3 grid((unsigned)ceil_div64(T * 32, 256));
+    hipLaunchKernelGGL(ln_concat_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, x_out, gamma, beta, eps, extra, E,
                        extra_div, T, out, ld);
     return nmrf_launch_status();
 }

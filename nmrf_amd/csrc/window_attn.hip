@@ -322,6 +322,325 @@ __global__ __launch_bounds__(64 * NKT) void window_attn_kernel(const float *__re
         stg4(op + mfma_row(4 * rb, hi), make_float4(res[4 * rb], res[4 * rb + 1], res[4 * rb + 2], res[4 * rb + 3]));
 }
 
+
+// =================================================================================================
+// Fast path for the shipped configurations (compile-time window size WIN and labels-per-pixel NL,
+// NL in {1,2,4}).  Same algorithm as above, restructured after the round-1 PMC profile
+// (profiles/r01_pmc_attention_kernels.txt: 7.5k VALU instructions and 117k cycles per wave, 1 block/CU
+// because of 256 VGPRs, 52 % of LDS cycles lost to bank conflicts):
+//   * <=168 VGPRs so two 5-wave blocks fit a CU; masks only where they can fire (sibling mask on the
+//     diagonal tile, out-of-window keys on the last tile, shift regions on border windows) behind
+//     wave-uniform branches; KR stored transposed so one ds_read_b128 fetches a key quad; table rows
+//     padded to 36 floats (conflict-free b128 reads); exp2 with log2(e) folded into the q / eq scales.
+// =================================================================================================
+#define WA_TROW 36                         // padded floats per staged table row
+#define WA_LOG2E 1.4426950408889634f
+
+template <int NKT, int WIN, int NL, int OCC>
+__global__ __launch_bounds__(64 * NKT, OCC) void window_attn_fast_kernel(const float *__restrict__ qkv,
+        const float *__restrict__ table, WinGeom g, float scale, float *__restrict__ out) {
+    constexpr int TP = NKT * 32;
+    constexpr int NTHR = 64 * NKT;
+    constexpr int W2 = WIN * WIN;
+    constexpr int SPAN = 2 * WIN - 1;
+    constexpr int R = SPAN * SPAN;
+    constexpr int Tw = W2 * NL;
+    constexpr int TAB_IT = (R * 8 + NTHR - 1) / NTHR;
+    constexpr int PPQ = 4 / NL;                    // pixels per register quad (4 consecutive keys)
+    static_assert(NL == 1 || NL == 2 || NL == 4, "fast path: labels per pixel must divide 4");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *tab_a = smem;                            // ek [R][36]   (later: ev)
+    float *tab_b = tab_a + R * WA_TROW;             // eq*s*log2e [R][36]
+    float *qrt = tab_b + R * WA_TROW;               // [W2][TP]   QR^T : [key pixel][query token]
+    float *krt = qrt + W2 * TP;                     // [W2][TP]   KR^T : [query pixel][key token]
+    unsigned *rowoff = reinterpret_cast<unsigned *>(krt + W2 * TP);   // [TP] element offset of window token i in qkv
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int qi = lane & 31, hi = lane >> 5;
+    const int nwx = g.Wp / WIN;
+    const int wj = blockIdx.x % nwx, wi = blockIdx.x / nwx;
+    const int head = blockIdx.y, bimg = blockIdx.z;
+    const unsigned ld = 3u * g.C;
+    const int tab_ld = 3 * g.C;
+    const int tcol = head * 96;
+    const float sc2 = scale * WA_LOG2E;
+
+    auto token_row = [&](int i) -> unsigned {
+        int ii = i < Tw ? i : Tw - 1;
+        int pt = ii / NL, n = ii - pt * NL;
+        int a = pt / WIN, b = pt - a * WIN;
+        int Y = wi * WIN + a + g.shift, X = wj * WIN + b + g.shift;
+        Y = Y >= g.Hp ? Y - g.Hp : Y;
+        X = X >= g.Wp ? X - g.Wp : X;
+        return (unsigned)((((bimg * g.Hp + Y) * g.Wp) + X) * NL + n);
+    };
+
+    // ---- earliest load: phase-0 operand (q or k of token 32w+qi) ---------------------------------------
+    const int tok = 32 * wv + qi;
+    const bool tok_ok = tok < Tw;
+    const int tokc = tok_ok ? tok : Tw - 1;
+    const unsigned trow = token_row(tokc);
+    float vec[32];
+    {
+        const float *src = qkv + (size_t)trow * ld + (hi ? g.C : 0) + head * 32;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float4 v = ldg4(src + 4 * c);
+            vec[4 * c + 0] = v.x; vec[4 * c + 1] = v.y; vec[4 * c + 2] = v.z; vec[4 * c + 3] = v.w;
+        }
+    }
+    // ---- stage ek / eq (all loads first, then the LDS stores), build the row map ----------------------
+    {
+        float4 te[TAB_IT], tq[TAB_IT];
+#pragma unroll
+        for (int it = 0; it < TAB_IT; ++it) {
+            const int i = tid + it * NTHR;
+            if (i < R * 8) {
+                const int r = i >> 3, c4 = (i & 7) * 4;
+                te[it] = ldg4(table + (size_t)r * tab_ld + tcol + 32 + c4);
+                tq[it] = ldg4(table + (size_t)r * tab_ld + tcol + c4);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < TAB_IT; ++it) {
+            const int i = tid + it * NTHR;
+            if (i < R * 8) {
+                const int r = i >> 3, c4 = (i & 7) * 4;
+                stg4(tab_a + r * WA_TROW + c4, te[it]);
+                stg4(tab_b + r * WA_TROW + c4, make_float4(tq[it].x * sc2, tq[it].y * sc2, tq[it].z * sc2, tq[it].w * sc2));
+            }
+        }
+    }
+    for (int i = tid; i < TP; i += NTHR) rowoff[i] = token_row(i) * ld;
+    __syncthreads();
+
+    // ev goes to registers now (hidden behind phase 0), to LDS once ek is dead
+    float4 tv[TAB_IT];
+#pragma unroll
+    for (int it = 0; it < TAB_IT; ++it) {
+        const int i = tid + it * NTHR;
+        if (i < R * 8) tv[it] = ldg4(table + (size_t)(i >> 3) * tab_ld + tcol + 64 + (i & 7) * 4);
+    }
+
+    // ---- phase 0: relative-position logit terms (log2 domain) -------------------------------------------
+    if (tok_ok) {
+        const float sc = hi ? 1.0f : sc2;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) vec[c] *= sc;
+        const int pt = tok / NL;
+        const int at = pt / WIN, bt = pt - at * WIN;
+        const float *tab = hi ? tab_b : tab_a;
+        float *dst = (hi ? krt : qrt) + tok;
+#pragma unroll 1
+        for (int aj = 0; aj < WIN; ++aj) {
+            const int da = hi ? (aj - at) : (at - aj);
+            const float *erow = tab + ((da + WIN - 1) * SPAN + (WIN - 1)) * WA_TROW;
+#pragma unroll 2
+            for (int bj = 0; bj < WIN; ++bj) {
+                const int db = hi ? (bj - bt) : (bt - bj);
+                const float *e = erow + db * WA_TROW;
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; c += 2) {
+                    float4 t0 = *reinterpret_cast<const float4 *>(e + 4 * c);
+                    float4 t1 = *reinterpret_cast<const float4 *>(e + 4 * c + 4);
+                    s0 = fmaf(vec[4 * c + 0], t0.x, s0); s0 = fmaf(vec[4 * c + 1], t0.y, s0);
+                    s0 = fmaf(vec[4 * c + 2], t0.z, s0); s0 = fmaf(vec[4 * c + 3], t0.w, s0);
+                    s1 = fmaf(vec[4 * c + 4], t1.x, s1); s1 = fmaf(vec[4 * c + 5], t1.y, s1);
+                    s1 = fmaf(vec[4 * c + 6], t1.z, s1); s1 = fmaf(vec[4 * c + 7], t1.w, s1);
+                }
+                dst[(aj * WIN + bj) * TP] = s0 + s1;
+            }
+        }
+    }
+    // Q fragment and the first K / V fragments: their latency overlaps the barrier and the ev stores
+    const float *kbase = qkv + g.C + head * 32 + 16 * hi;
+    const float *vbase = qkv + 2 * g.C + head * 32 + qi;
+    float qf[16], kf[16], vf[16];
+    {
+        const float *p = qkv + (size_t)trow * ld + head * 32 + 16 * hi;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float4 v = ldg4(p + 4 * c);
+            qf[4 * c + 0] = v.x * sc2; qf[4 * c + 1] = v.y * sc2; qf[4 * c + 2] = v.z * sc2; qf[4 * c + 3] = v.w * sc2;
+        }
+    }
+    auto load_k = [&](int kt, float *kd) {
+        const float *p = kbase + rowoff[32 * kt + qi];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float4 v = ldg4(p + 4 * c);
+            kd[4 * c + 0] = v.x; kd[4 * c + 1] = v.y; kd[4 * c + 2] = v.z; kd[4 * c + 3] = v.w;
+        }
+    };
+    auto load_v = [&](int kt, float *vd) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) vd[s] = vbase[rowoff[32 * kt + mfma_row(s, hi)]];
+    };
+    load_k(0, kf);
+    load_v(0, vf);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < TAB_IT; ++it) {
+        const int i = tid + it * NTHR;
+        if (i < R * 8) stg4(tab_a + (i >> 3) * WA_TROW + (i & 7) * 4, tv[it]);
+    }
+    __syncthreads();
+
+    // ---- phase 1 ---------------------------------------------------------------------------------------
+    const int q_pix = tokc / NL;
+    const int qa = q_pix / WIN, qb = q_pix - qa * WIN;
+    auto region = [&](int a, int b) -> int {
+        int Yr = wi * WIN + a, Xr = wj * WIN + b;
+        int fy = Yr < g.Hp - WIN ? 0 : (Yr < g.Hp - g.shift ? 1 : 2);
+        int fx = Xr < g.Wp - WIN ? 0 : (Xr < g.Wp - g.shift ? 1 : 2);
+        return fy * 3 + fx;
+    };
+    const bool need_shift = g.shift && (wi == g.Hp / WIN - 1 || wj == nwx - 1);     // block-uniform
+    const int q_reg = need_shift ? region(qa, qb) : 0;
+    const bool sib = g.sibling && NL > 1;
+
+    f32x16 acc_o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_o[r] = 0.f;
+    float oe[32];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) oe[d] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float *qrt_q = qrt + tokc;
+    const float *krt_q = krt + q_pix * TP;
+    const float *ev_q = tab_a + ((qa + WIN - 1) * SPAN + (qb + WIN - 1)) * WA_TROW;   // ev[rel(pq, pixel 0)]
+
+#pragma unroll 1
+    for (int kt = 0; kt < NKT; ++kt) {
+        const int k0 = 32 * kt;
+        f32x16 st;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) st = mfma32(kf[s], qf[s], st);
+        if (kt + 1 < NKT) load_k(kt + 1, kf);
+        // relative-position terms: one b128 of KR^T per key quad, QR^T per key pixel
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const int keyq = k0 + 8 * rq + 4 * hi;                           // first key of the quad (multiple of 4)
+            const float4 kr4 = *reinterpret_cast<const float4 *>(krt_q + keyq);
+            const float krv[4] = {kr4.x, kr4.y, kr4.z, kr4.w};
+#pragma unroll
+            for (int pp = 0; pp < PPQ; ++pp) {
+                int pk = keyq / NL + pp;
+                pk = pk < W2 ? pk : W2 - 1;
+                const float qv = qrt_q[pk * TP];
+#pragma unroll
+                for (int e = 0; e < NL; ++e) st[4 * rq + pp * NL + e] += qv + krv[pp * NL + e];
+            }
+        }
+        if (kt == NKT - 1 && Tw < TP) {                                      // keys beyond the window (last tile only)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (k0 + mfma_row(r, hi) >= Tw) st[r] = -INFINITY;
+        }
+        if (sib && kt == wv) {                                                // sibling labels of the query's own pixel
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + mfma_row(r, hi);
+                if (key / NL == q_pix && key != tokc) st[r] = -INFINITY;
+            }
+        }
+        if (need_shift) {                                                     // Swin regions (border windows only)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+                for (int pp = 0; pp < PPQ; ++pp) {
+                    int pk = (k0 + 8 * rq + 4 * hi) / NL + pp;
+                    pk = pk < W2 ? pk : W2 - 1;
+                    const bool other = region(pk / WIN, pk % WIN) != q_reg;
+#pragma unroll
+                    for (int e = 0; e < NL; ++e)
+                        if (other) st[4 * rq + pp * NL + e] = -INFINITY;
+                }
+        }
+        float m_tile = st[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) m_tile = fmaxf(m_tile, st[r]);
+        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
+        const float m_new = fmaxf(m_run, m_tile);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            st[r] = __builtin_amdgcn_exp2f(st[r] - m_use);
+            psum += st[r];
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[r] *= alpha;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) oe[d] *= alpha;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc_o = mfma32(vf[s], st[s], acc_o);
+        if (kt + 1 < NKT) load_v(kt + 1, vf);
+        // value-embedding term: sum over key PIXELS of (sum_n p) * ev[rel(pq,pk)]
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            if (kt == NKT - 1 && 32 * (NKT - 1) + 8 * rq >= Tw) continue;     // quad entirely beyond the window
+#pragma unroll
+            for (int pp = 0; pp < PPQ; ++pp) {
+                int pk = (k0 + 8 * rq + 4 * hi) / NL + pp;
+                pk = pk < W2 ? pk : W2 - 1;
+                const int ka = pk / WIN, kb = pk - ka * WIN;
+                float ps = st[4 * rq + pp * NL];
+#pragma unroll
+                for (int e = 1; e < NL; ++e) ps += st[4 * rq + pp * NL + e];
+                const float *e = ev_q - (ka * SPAN + kb) * WA_TROW;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    float4 t = *reinterpret_cast<const float4 *>(e + 4 * c);
+                    oe[4 * c + 0] = fmaf(ps, t.x, oe[4 * c + 0]); oe[4 * c + 1] = fmaf(ps, t.y, oe[4 * c + 1]);
+                    oe[4 * c + 2] = fmaf(ps, t.z, oe[4 * c + 2]); oe[4 * c + 3] = fmaf(ps, t.w, oe[4 * c + 3]);
+                }
+            }
+        }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv_l = 1.0f / l_tot;
+    float res[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float mine = hi ? oe[mfma_row(r, 1)] : oe[mfma_row(r, 0)];
+        const float send = hi ? oe[mfma_row(r, 0)] : oe[mfma_row(r, 1)];
+        const float recv = __shfl_xor(send, 32);
+        res[r] = (acc_o[r] + (mine + recv)) * inv_l;
+    }
+    if (!tok_ok) return;
+    float *op = out + (size_t)trow * g.C + head * 32;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+        stg4(op + mfma_row(4 * rb, hi), make_float4(res[4 * rb], res[4 * rb + 1], res[4 * rb + 2], res[4 * rb + 3]));
+}
+
+template <int NKT, int WIN, int NL, int OCC>
+static int launch_window_fast(const float *qkv, const float *table, const WinGeom &g, int B, float *out, hipStream_t st) {
+    constexpr int TP = NKT * 32, W2 = WIN * WIN, R = (2 * WIN - 1) * (2 * WIN - 1);
+    constexpr size_t smem = (size_t)(2 * R * WA_TROW + 2 * W2 * TP) * sizeof(float) + (size_t)TP * sizeof(unsigned);
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    static bool attr_done = false;      // set once per instantiation, outside any stream capture
+    if (smem > 64 * 1024 && !attr_done) {
+        attr_done = true;
+        if (hipFuncSetAttribute((const void *)window_attn_fast_kernel<NKT, WIN, NL, OCC>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return NMRF_ELAUNCH;
+    }
+    dim3 grid((g.Hp / WIN) * (g.Wp / WIN), g.heads, B);
+    hipLaunchKernelGGL((window_attn_fast_kernel<NKT, WIN, NL, OCC>), grid, dim3(64 * NKT), smem, st, qkv, table, g,
+                       1.0f / sqrtf(32.0f), out);
+    return nmrf_launch_status();
+}
+
 template <int NKT, int WIN, int NL>
 static int launch_window(const float *qkv, const float *table, const WinGeom &g, int B, float *out, hipStream_t st) {
     const int TP = NKT * 32, W2 = g.win * g.win;
@@ -349,8 +668,10 @@ extern "C" int nmrf_window_attn_f32(const float *qkv, const float *table, int B,
     WinGeom g{Hp, Wp, N, C, heads, win, shift, sibling_mask ? 1 : 0, win * win * N, (2 * win - 1) * (2 * win - 1)};
     const int nkt = (g.Tw + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
-    if (win == 6 && N == 4) return launch_window<5, 6, 4>(qkv, table, g, B, out, st);     // inference windows
-    if (win == 4 && N == 1) return launch_window<1, 4, 1>(qkv, table, g, B, out, st);     // refinement windows
+    if ((int64_t)B * Hp * Wp * N * 3 * C < ((int64_t)1 << 32)) {                            // 32-bit element offsets
+        if (win == 6 && N == 4) return launch_window_fast<5, 6, 4, 3>(qkv, table, g, B, out, st);   // inference windows
+        if (win == 4 && N == 1) return launch_window_fast<1, 4, 1, 3>(qkv, table, g, B, out, st);   // refinement windows
+    }
     switch (nkt) {                                                                         // any other configuration
         case 1: return launch_window<1, 0, 0>(qkv, table, g, B, out, st);
         case 2: return launch_window<2, 0, 0>(qkv, table, g, B, out, st);

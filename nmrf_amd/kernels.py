@@ -98,6 +98,20 @@ def ln_concat(x, gamma, beta, extra=None, extra_div=1, ld=None, eps=1e-5):
     return out
 
 
+def add_ln_concat(x, y, gamma, beta, extra=None, extra_div=1, ld=None, eps=1e-5):
+    """x_new = x + y (returned, fresh tensor) and [LN(x_new) | extra | 0-pad] in one pass."""
+    _chk(x, y, gamma, beta, extra)
+    t, c = x.shape
+    e = 0 if extra is None else extra.shape[-1]
+    if ld is None:
+        ld = (c + e + 3) // 4 * 4
+    x_new = torch.empty_like(x)
+    out = torch.empty(t, ld, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_add_ln_concat_f32(_p(x), _p(y), _p(x_new), _p(gamma), _p(beta), float(eps), _p(extra), e,
+                                                  extra_div, t, c, _p(out), ld, _stream()), "add_ln_concat")
+    return x_new, out
+
+
 # optional observer used by bench.py to bracket the dominant kernel with HIP events: called as
 # hook("begin"/"end", name) around that single launch, on the launching stream
 kernel_hook = None

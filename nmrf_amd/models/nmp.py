@@ -72,6 +72,15 @@ def _ln(x, norm):
     return K.ln_concat(x, norm.weight, norm.bias, None, 1, x.shape[1], norm.eps)
 
 
+def _add_ln(x, y, norm, extra=None, extra_div=1, ld=None):
+    """The residual stream travels as a pair (x, y) meaning x + y; the pending add is folded into the next
+    LayerNorm kernel.  Returns (materialised x + y, [LN(x + y) | extra | 0])."""
+    ld = ld or x.shape[1]
+    if y is None:
+        return x, K.ln_concat(x, norm.weight, norm.bias, extra, extra_div, ld, norm.eps)
+    return K.add_ln_concat(x, y, norm.weight, norm.bias, extra, extra_div, ld, norm.eps)
+
+
 # --------------------------------------------------------------------------------------------------
 # self edges (BasicAttention, NMP.py:70-139)
 # --------------------------------------------------------------------------------------------------
@@ -93,12 +102,17 @@ class BasicAttention(nn.Module):
             return w.contiguous(), torch.cat((self.q.bias, self.k.bias, self.v.bias)).contiguous(), kp
         return self._fused.get((self.q.weight, self.k.weight, self.v.weight, self.q.bias, self.k.bias, self.v.bias), build)
 
+    def forward_pair(self, x, y, abs_encoding, n):
+        """(x, y) = residual stream x + y; returns the next pair."""
+        w, b, kp = self._weights()
+        x, a = _add_ln(x, y, self.norm1, abs_encoding, 1, kp)
+        msg = K.self_attn(F.linear(a, w, b), n, self.num_heads)
+        return x, self.proj(msg)
+
     def forward(self, label_rep, abs_encoding, n):
         """label_rep [T,C], abs_encoding [T,31] -> [T,C]; n = labels per pixel."""
-        w, b, kp = self._weights()
-        a = K.ln_concat(label_rep, self.norm1.weight, self.norm1.bias, abs_encoding, 1, kp, self.norm1.eps)
-        msg = K.self_attn(F.linear(a, w, b), n, self.num_heads)
-        return label_rep + self.proj(msg)
+        x, y = self.forward_pair(label_rep, None, abs_encoding, n)
+        return x + y
 
 
 # --------------------------------------------------------------------------------------------------
@@ -144,12 +158,16 @@ class SwinNMP(nn.Module):
             return _pad_cols(self.qkv.weight, kp).contiguous(), kp
         return self._fused.get((self.qkv.weight,), build)
 
-    def forward(self, label_rep, abs_encoding, dims, sibling_mask):
+    def forward_pair(self, x, y, abs_encoding, dims, sibling_mask):
         w, kp = self._weights()
-        a = K.ln_concat(label_rep, self.norm1.weight, self.norm1.bias, abs_encoding, 1, kp, self.norm1.eps)
+        x, a = _add_ln(x, y, self.norm1, abs_encoding, 1, kp)
         msg = self.attn(F.linear(a, w, self.qkv.bias), dims, sibling_mask)
-        x = label_rep + self.proj(msg)
-        return x + self.mlp(_ln(x, self.norm2))
+        x, h = _add_ln(x, self.proj(msg), self.norm2)
+        return x, self.mlp(h)
+
+    def forward(self, label_rep, abs_encoding, dims, sibling_mask):
+        x, y = self.forward_pair(label_rep, None, abs_encoding, dims, sibling_mask)
+        return x + y
 
 
 # --------------------------------------------------------------------------------------------------
@@ -191,12 +209,16 @@ class CSWinNMP(nn.Module):
 
     def forward(self, seed_rep, context, dims):
         """seed_rep [T,C]; context [B*H*W, Cctx] (per pixel, shared by its N labels); dims=(B,H,W,N)."""
+        x, y = self.forward_pair(seed_rep, None, context, dims)
+        return x + y
+
+    def forward_pair(self, x, y, context, dims):
         b, h, wd, n = dims
         w, bias, kp = self._weights()
-        a = K.ln_concat(seed_rep, self.norm1.weight, self.norm1.bias, context, n, kp, self.norm1.eps)
+        x, a = _add_ln(x, y, self.norm1, context, n, kp)
         msg = K.stripe_attn(F.linear(a, w, bias), self.attns[0].get_v.weight, self.attns[1].get_v.weight, b, h, wd, n)
-        x = seed_rep + self.proj(msg)
-        return x + self.mlp(_ln(x, self.norm2))
+        x, hdn = _add_ln(x, self.proj(msg), self.norm2)
+        return x, self.mlp(hdn)
 
 
 class PropagationLayer(nn.Module):
@@ -207,6 +229,9 @@ class PropagationLayer(nn.Module):
 
     def forward(self, tgt, context, dims):
         return self.nmp(tgt, context, dims)
+
+    def forward_pair(self, x, y, context, dims):
+        return self.nmp.forward_pair(x, y, context, dims)
 
 
 class InferenceLayer(nn.Module):
@@ -221,6 +246,10 @@ class InferenceLayer(nn.Module):
         tgt = self.self_nmp(tgt, abs_encoding, dims[3])
         return self.nmp(tgt, abs_encoding, dims, True)
 
+    def forward_pair(self, x, y, abs_encoding, dims):
+        x, y = self.self_nmp.forward_pair(x, y, abs_encoding, dims[3])
+        return self.nmp.forward_pair(x, y, abs_encoding, dims, True)
+
 
 class RefinementLayer(nn.Module):
     def __init__(self, dim, mlp_ratio, window_size, shift_size, n_heads, normalize_before=True, **_unused):
@@ -230,6 +259,9 @@ class RefinementLayer(nn.Module):
 
     def forward(self, tgt, abs_encoding, dims):
         return self.nmp(tgt, abs_encoding, dims, False)
+
+    def forward_pair(self, x, y, abs_encoding, dims):
+        return self.nmp.forward_pair(x, y, abs_encoding, dims, False)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -252,10 +284,13 @@ class Propagation(nn.Module):
         cost, enc = K.seed_features(cost_volume, label_seed, 3.14 / 64)
         x = self.proj(torch.cat((self.cost_encoder(cost), enc), -1))
         ctx = context.reshape(b * h * wd, cc)
+        y = None
         for layer in self.layers:
-            x = layer(x, ctx, dims)
+            x, y = layer.forward_pair(x, y, ctx, dims)
         if self.norm is not None:
-            x = _ln(x, self.norm)
+            x = _add_ln(x, y, self.norm)[1]
+        elif y is not None:
+            x = x + y
         return x.unsqueeze(0), label_seed.float()
 
 
@@ -297,10 +332,15 @@ class Inference(nn.Module):
         x, pdims, off = _pad_grid(x, dims, win)
         enc, _, _ = _pad_grid(enc, dims, win)
         x, enc = x.contiguous(), enc.contiguous()
+        y = None
         for layer in self.layers:
-            x = layer(x, enc, pdims)
+            x, y = layer.forward_pair(x, y, enc, pdims)
         x = _crop_grid(x, pdims, dims, off).contiguous()
-        return _ln(x, self.norm) if self.norm is not None else x
+        if y is not None:
+            y = _crop_grid(y, pdims, dims, off).contiguous()
+        if self.norm is not None:
+            return _add_ln(x, y, self.norm)[1]
+        return x if y is None else x + y
 
     def forward(self, labels, fmap1, fmap2, fmap1_gw, fmap2_gw):
         """labels [B*H*W, N] -> [1, B*H*W, N, C]"""

@@ -119,6 +119,11 @@ def test_ln_concat():
     got = K().ln_concat(x4.to(DEV), gam.to(DEV), bet.to(DEV), ctx.to(DEV), 4, 192).cpu()
     want = torch.cat((F.layer_norm(x4, (128,), gam, bet, 1e-5), ctx.repeat_interleave(4, 0)), 1)
     report("ln|ctx", got, want, 3e-6)
+    # fused residual add
+    y = rnd(1001, 128, seed=13)
+    xn, got = K().add_ln_concat(x.to(DEV), y.to(DEV), gam.to(DEV), bet.to(DEV), e31.to(DEV), 1, 160)
+    assert torch.equal(xn.cpu(), x + y)
+    report("add+ln|enc", got.cpu()[:, :159], torch.cat((F.layer_norm(x + y, (128,), gam, bet, 1e-5), e31), 1), 3e-6)
 
 
 @pytest.mark.parametrize("b,h,w,n", [(2, 7, 13, 4), (1, 47, 20, 4), (1, 5, 40, 1), (1, 9, 6, 2), (1, 3, 5, 3)])

@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""Micro-bench of the hand-written attention kernels at BASELINE sizes (for rocprofv3 --pmc passes).
+    python tools/kernel_bench.py [--iters 10] [--batch 1] [--which window,stripe,refine,warp]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nmrf_amd import kernels as K  # noqa: E402
+from nmrf_amd.utils.hashinit import unit_noise  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--batch", type=int, default=1)
+ap.add_argument("--which", default="window,stripe,refine,warp")
+args = ap.parse_args()
+dev = "cuda"
+b, h, w, n = args.batch, 47, 156, 4
+
+
+def mk(key, *shape):
+    import numpy as np
+    return torch.from_numpy(unit_noise(key, int(np.prod(shape))).reshape(shape)).to(dev)
+
+
+def timeit(name, fn):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    print("%-28s %9.2f us / call" % (name, e0.elapsed_time(e1) * 1e3 / args.iters), flush=True)
+
+
+which = args.which.split(",")
+if "window" in which:
+    hp, wp = 48, 156
+    qkv, table = mk("q", b * hp * wp * n, 384), mk("t", 121, 384)
+    for shift in (0, 3):
+        timeit("window_attn 6x6x4 shift=%d" % shift, lambda: K.window_attn(qkv, table, b, hp, wp, n, 4, 6, shift, True))
+if "stripe" in which:
+    qkv = mk("q2", b * h * w * n, 384)
+    lv, lh = mk("lv", 64, 1, 3, 3), mk("lh", 64, 1, 3, 3)
+    timeit("stripe_attn (both axes)", lambda: K.stripe_attn(qkv, lv, lh, b, h, w, n))
+if "refine" in which:
+    hp, wp = 96, 312
+    qkv, table = mk("q3", b * hp * wp, 384), mk("t3", 49, 384)
+    for shift in (0, 2):
+        timeit("window_attn 4x4x1 shift=%d" % shift, lambda: K.window_attn(qkv, table, b, hp, wp, 1, 4, 4, shift, False))
+if "warp" in which:
+    f1, f2 = mk("f1", b, 64, h, w), mk("f2", b, 64, h, w)
+    g1, g2 = mk("g1", b, 256, h, w), mk("g2", b, 256, h, w)
+    lab = mk("lab", b * h * w * n).abs() * 40
+    timeit("warp_corr_concat 1/8", lambda: K.warp_corr_concat(lab, f1, f2, g1, g2, n))
