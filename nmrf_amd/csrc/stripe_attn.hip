@@ -226,7 +226,8 @@ static void launch_stripe(const float *qkv, const float *lepe, const StripeGeom 
                           float *out, hipStream_t st) {
     // key split: aim for a few thousand waves per launch (256 CUs x 4 SIMDs x ~3), keep >= 2 key tiles per wave
     const int n_qt = (g.Ts + SA_TILE - 1) / SA_TILE;
-    const long waves1 = (long)n_qt * stripes * 2 * B;
+    // (decided per image, NOT per batch, so that results do not depend on the batch size)
+    const long waves1 = (long)n_qt * stripes * 2;
     int ksplit = 1;
     if (waves1 * 2 <= 8192 && n_qt >= 4) ksplit = 2;
     if (waves1 * 4 <= 8192 && n_qt >= 8) ksplit = 4;

@@ -23,6 +23,7 @@
 // WIN/NL template parameters make the index arithmetic compile-time for the shipped configurations
 // (6x6x4 inference windows, 4x4x1 refinement windows); WIN=0 selects the generic runtime path.
 #include "common.h"
+#include <stdlib.h>
 
 struct WinGeom {
     int Hp, Wp, N, C, heads, win, shift, sibling;
@@ -331,9 +332,9 @@ __global__ __launch_bounds__(64 * NKT) void window_attn_kernel(const float *__re
 //   * <=168 VGPRs so two 5-wave blocks fit a CU; masks only where they can fire (sibling mask on the
 //     diagonal tile, out-of-window keys on the last tile, shift regions on border windows) behind
 //     wave-uniform branches; KR stored transposed so one ds_read_b128 fetches a key quad; table rows
-//     padded to 36 floats (conflict-free b128 reads); exp2 with log2(e) folded into the q / eq scales.
+//     XOR-swizzled in 16-byte chunks (conflict-free b128 reads without padding, 73 KB of LDS per block); exp2 with log2(e) folded into the q / eq scales.
 // =================================================================================================
-#define WA_TROW 36                         // padded floats per staged table row
+#define WA_TROW 32                         // floats per staged table row; 16-byte chunks are XOR-swizzled by (row & 7)
 #define WA_LOG2E 1.4426950408889634f
 
 template <int NKT, int WIN, int NL, int OCC>
@@ -346,15 +347,17 @@ __global__ __launch_bounds__(64 * NKT, OCC) void window_attn_fast_kernel(const f
     constexpr int R = SPAN * SPAN;
     constexpr int Tw = W2 * NL;
     constexpr int TAB_IT = (R * 8 + NTHR - 1) / NTHR;
+    constexpr int TS = (Tw + 3) / 4 * 4;          // token stride of the QR^T / KR^T rows (no 32-padding)
     constexpr int PPQ = 4 / NL;                    // pixels per register quad (4 consecutive keys)
     static_assert(NL == 1 || NL == 2 || NL == 4, "fast path: labels per pixel must divide 4");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *tab_a = smem;                            // ek [R][36]   (later: ev)
     float *tab_b = tab_a + R * WA_TROW;             // eq*s*log2e [R][36]
-    float *qrt = tab_b + R * WA_TROW;               // [W2][TP]   QR^T : [key pixel][query token]
-    float *krt = qrt + W2 * TP;                     // [W2][TP]   KR^T : [query pixel][key token]
-    unsigned *rowoff = reinterpret_cast<unsigned *>(krt + W2 * TP);   // [TP] element offset of window token i in qkv
+    float *qrt = tab_b + R * WA_TROW;               // [W2][TS]   QR^T : [key pixel][query token]
+    float *krt = qrt + W2 * TS;                     // [W2][TS+]  KR^T : [query pixel][key token] (+32 floats of slack:
+    //                                                  the last tile's quad reads may run past Tw; those keys are masked)
+    unsigned *rowoff = reinterpret_cast<unsigned *>(krt + W2 * TS + 32);   // [TP] element offset of window token i in qkv
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
@@ -408,8 +411,9 @@ __global__ __launch_bounds__(64 * NKT, OCC) void window_attn_fast_kernel(const f
             const int i = tid + it * NTHR;
             if (i < R * 8) {
                 const int r = i >> 3, c4 = (i & 7) * 4;
-                stg4(tab_a + r * WA_TROW + c4, te[it]);
-                stg4(tab_b + r * WA_TROW + c4, make_float4(tq[it].x * sc2, tq[it].y * sc2, tq[it].z * sc2, tq[it].w * sc2));
+                const int sw = (((i & 7) ^ (r & 7)) << 2);
+                stg4(tab_a + r * WA_TROW + sw, te[it]);
+                stg4(tab_b + r * WA_TROW + sw, make_float4(tq[it].x * sc2, tq[it].y * sc2, tq[it].z * sc2, tq[it].w * sc2));
             }
         }
     }
@@ -436,22 +440,24 @@ __global__ __launch_bounds__(64 * NKT, OCC) void window_attn_fast_kernel(const f
 #pragma unroll 1
         for (int aj = 0; aj < WIN; ++aj) {
             const int da = hi ? (aj - at) : (at - aj);
-            const float *erow = tab + ((da + WIN - 1) * SPAN + (WIN - 1)) * WA_TROW;
+            const int rrow = (da + WIN - 1) * SPAN + (WIN - 1);
 #pragma unroll 2
             for (int bj = 0; bj < WIN; ++bj) {
                 const int db = hi ? (bj - bt) : (bt - bj);
-                const float *e = erow + db * WA_TROW;
+                const int rr = rrow + db;
+                const float *e = tab + rr * WA_TROW;
+                const int sx = rr & 7;
                 float s0 = 0.f, s1 = 0.f;
 #pragma unroll
                 for (int c = 0; c < 8; c += 2) {
-                    float4 t0 = *reinterpret_cast<const float4 *>(e + 4 * c);
-                    float4 t1 = *reinterpret_cast<const float4 *>(e + 4 * c + 4);
+                    float4 t0 = *reinterpret_cast<const float4 *>(e + ((c ^ sx) << 2));
+                    float4 t1 = *reinterpret_cast<const float4 *>(e + (((c + 1) ^ sx) << 2));
                     s0 = fmaf(vec[4 * c + 0], t0.x, s0); s0 = fmaf(vec[4 * c + 1], t0.y, s0);
                     s0 = fmaf(vec[4 * c + 2], t0.z, s0); s0 = fmaf(vec[4 * c + 3], t0.w, s0);
                     s1 = fmaf(vec[4 * c + 4], t1.x, s1); s1 = fmaf(vec[4 * c + 5], t1.y, s1);
                     s1 = fmaf(vec[4 * c + 6], t1.z, s1); s1 = fmaf(vec[4 * c + 7], t1.w, s1);
                 }
-                dst[(aj * WIN + bj) * TP] = s0 + s1;
+                dst[(aj * WIN + bj) * TS] = s0 + s1;
             }
         }
     }
@@ -485,7 +491,7 @@ __global__ __launch_bounds__(64 * NKT, OCC) void window_attn_fast_kernel(const f
 #pragma unroll
     for (int it = 0; it < TAB_IT; ++it) {
         const int i = tid + it * NTHR;
-        if (i < R * 8) stg4(tab_a + (i >> 3) * WA_TROW + (i & 7) * 4, tv[it]);
+        if (i < R * 8) stg4(tab_a + (i >> 3) * WA_TROW + ((((i & 7) ^ ((i >> 3) & 7))) << 2), tv[it]);
     }
     __syncthreads();
 
@@ -510,8 +516,8 @@ __global__ __launch_bounds__(64 * NKT, OCC) void window_attn_fast_kernel(const f
     for (int d = 0; d < 32; ++d) oe[d] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
     const float *qrt_q = qrt + tokc;
-    const float *krt_q = krt + q_pix * TP;
-    const float *ev_q = tab_a + ((qa + WIN - 1) * SPAN + (qb + WIN - 1)) * WA_TROW;   // ev[rel(pq, pixel 0)]
+    const float *krt_q = krt + q_pix * TS;
+    const int ev_r0 = (qa + WIN - 1) * SPAN + (qb + WIN - 1);                          // rel(pq, pixel 0)
 
 #pragma unroll 1
     for (int kt = 0; kt < NKT; ++kt) {
@@ -532,7 +538,7 @@ __global__ __launch_bounds__(64 * NKT, OCC) void window_attn_fast_kernel(const f
             for (int pp = 0; pp < PPQ; ++pp) {
                 int pk = keyq / NL + pp;
                 pk = pk < W2 ? pk : W2 - 1;
-                const float qv = qrt_q[pk * TP];
+                const float qv = qrt_q[pk * TS];
 #pragma unroll
                 for (int e = 0; e < NL; ++e) st[4 * rq + pp * NL + e] += qv + krv[pp * NL + e];
             }
@@ -596,10 +602,12 @@ __global__ __launch_bounds__(64 * NKT, OCC) void window_attn_fast_kernel(const f
                 float ps = st[4 * rq + pp * NL];
 #pragma unroll
                 for (int e = 1; e < NL; ++e) ps += st[4 * rq + pp * NL + e];
-                const float *e = ev_q - (ka * SPAN + kb) * WA_TROW;
+                const int rr = ev_r0 - (ka * SPAN + kb);
+                const float *e = tab_a + rr * WA_TROW;
+                const int sx = rr & 7;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    float4 t = *reinterpret_cast<const float4 *>(e + 4 * c);
+                    float4 t = *reinterpret_cast<const float4 *>(e + ((c ^ sx) << 2));
                     oe[4 * c + 0] = fmaf(ps, t.x, oe[4 * c + 0]); oe[4 * c + 1] = fmaf(ps, t.y, oe[4 * c + 1]);
                     oe[4 * c + 2] = fmaf(ps, t.z, oe[4 * c + 2]); oe[4 * c + 3] = fmaf(ps, t.w, oe[4 * c + 3]);
                 }
@@ -626,8 +634,9 @@ __global__ __launch_bounds__(64 * NKT, OCC) void window_attn_fast_kernel(const f
 template <int NKT, int WIN, int NL, int OCC>
 static int launch_window_fast(const float *qkv, const float *table, const WinGeom &g, int B, float *out, hipStream_t st) {
     constexpr int TP = NKT * 32, W2 = WIN * WIN, R = (2 * WIN - 1) * (2 * WIN - 1);
-    constexpr size_t smem = (size_t)(2 * R * WA_TROW + 2 * W2 * TP) * sizeof(float) + (size_t)TP * sizeof(unsigned);
-    static_assert(smem <= 160 * 1024, "LDS budget");
+    constexpr int TS = (W2 * NL + 3) / 4 * 4;
+    constexpr size_t smem = (size_t)(2 * R * WA_TROW + 2 * W2 * TS + 32) * sizeof(float) + (size_t)TP * sizeof(unsigned);
+    static_assert(smem <= 76 * 1024, "two blocks must fit the 160 KiB LDS of a CU with slack");
     static bool attr_done = false;      // set once per instantiation, outside any stream capture
     if (smem > 64 * 1024 && !attr_done) {
         attr_done = true;
@@ -635,8 +644,9 @@ static int launch_window_fast(const float *qkv, const float *table, const WinGeo
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return NMRF_ELAUNCH;
     }
+    static const size_t extra = getenv("NMRF_WA_EXTRA_LDS") ? (size_t)atoi(getenv("NMRF_WA_EXTRA_LDS")) : 0;   // probe only
     dim3 grid((g.Hp / WIN) * (g.Wp / WIN), g.heads, B);
-    hipLaunchKernelGGL((window_attn_fast_kernel<NKT, WIN, NL, OCC>), grid, dim3(64 * NKT), smem, st, qkv, table, g,
+    hipLaunchKernelGGL((window_attn_fast_kernel<NKT, WIN, NL, OCC>), grid, dim3(64 * NKT), smem + extra, st, qkv, table, g,
                        1.0f / sqrtf(32.0f), out);
     return nmrf_launch_status();
 }
@@ -657,6 +667,17 @@ static int launch_window(const float *qkv, const float *table, const WinGeom &g,
     hipLaunchKernelGGL((window_attn_kernel<NKT, WIN, NL>), grid, dim3(64 * NKT), smem, st, qkv, table, g,
                        1.0f / sqrtf(32.0f), out);
     return nmrf_launch_status();
+}
+
+// Debug helper (not part of the public header): what the HIP runtime thinks the residency of the two fast
+// instantiations is, plus an optional extra dynamic-LDS pad (env NMRF_WA_EXTRA_LDS) to probe residency effects.
+extern "C" int nmrf_debug_window_occupancy(int *blocks_infer, int *blocks_refine) {
+    constexpr size_t s5 = (size_t)(2 * 121 * WA_TROW + 2 * 36 * 144 + 32) * 4 + 160 * 4;
+    constexpr size_t s1 = (size_t)(2 * 49 * WA_TROW + 2 * 16 * 16 + 32) * 4 + 32 * 4;
+    hipFuncSetAttribute((const void *)window_attn_fast_kernel<5, 6, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s5);
+    hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_infer, window_attn_fast_kernel<5, 6, 4, 3>, 320, s5);
+    hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_refine, window_attn_fast_kernel<1, 4, 1, 3>, 64, s1);
+    return (e1 == hipSuccess && e2 == hipSuccess) ? 0 : -2;
 }
 
 extern "C" int nmrf_window_attn_f32(const float *qkv, const float *table, int B, int Hp, int Wp, int N, int C, int heads,

@@ -2,6 +2,8 @@
 nmrf/models/NMRF.py:21-262, with the hot path on libnmrf_hip.so.  Inference only: the `Criterion`
 and the aux-loss outputs of the reference are training-side and out of scope.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -65,6 +67,7 @@ class NMRF(nn.Module):
             self.image_encoder = backbone
         self.register_buffer("device_indicator_tensor", torch.empty(0))
         self._head_cache8, self._head_cache4 = _FusedCache(), _FusedCache()
+        self._side_stream = None
 
     @classmethod
     def from_config(cls, cfg):
@@ -107,20 +110,18 @@ class NMRF(nn.Module):
         fmap1_list, fmap2_list = self.extract_feature(image1, image2)
         return self.hot_path(fmap1_list, fmap2_list, (h0, w0))
 
-    def _conv_heads(self, left, right, with_context):
-        """concatconv / gw (/ dpn.proj) on both views as ONE stock 3x3 convolution: the heads share their input,
-        so their first convs are stacked along the output channels and the two views along the batch
-        (conv3x3 -> InstanceNorm -> ReLU are per-(sample, channel) independent, so this is the same arithmetic
-        as NMRF.py:211-214,233-236 and DPN.py:128); then one 1x1 conv per head on its 128-channel slice."""
-        heads = [self.concatconv, self.gw] + ([self.dpn.proj] if with_context else [])
-        cache = self._head_cache8 if with_context else self._head_cache4
+    def _match_heads(self, left, right, cache):
+        """concatconv / gw on both views as ONE stock 3x3 convolution: the two heads share their input, so their
+        first convs are stacked along the output channels and the two views along the batch (conv3x3 ->
+        InstanceNorm -> ReLU are per-(sample, channel) independent: same arithmetic as NMRF.py:211-214,233-236),
+        then one 1x1 conv per head on its 128-channel slice.  Returns (fmap1, fmap2, fmap1_gw, fmap2_gw)."""
+        heads = (self.concatconv, self.gw)
         w3 = cache.get(tuple(h[0].weight for h in heads), lambda: torch.cat([h[0].weight for h in heads], 0).contiguous())
         b = left.shape[0]
         y = F.relu(F.instance_norm(F.conv2d(torch.cat((left, right), 0), w3, None, 1, 1), eps=1e-5))
         f = F.conv2d(y[:, 0:128], self.concatconv[3].weight)
         g = F.conv2d(y[:, 128:256], self.gw[3].weight)
-        ctx = F.conv2d(y[:b, 256:384], self.dpn.proj[3].weight) if with_context else None
-        return f[:b].contiguous(), f[b:].contiguous(), g[:b].contiguous(), g[b:].contiguous(), ctx
+        return f[:b].contiguous(), f[b:].contiguous(), g[:b].contiguous(), g[b:].contiguous()
 
     def hot_path(self, fmap1_list, fmap2_list, out_hw):
         """Everything after the backbone (NMRF.py:207-262): fmap lists are [1/8-res, 1/4-res] NCHW maps of the
@@ -129,10 +130,30 @@ class NMRF(nn.Module):
         h0, w0 = out_hw
 
         # ---- disparity proposals -------------------------------------------------------------------
+        # The matching heads (stock convs, needed only from the inference stage on) run on a side stream while
+        # the proposal stage -- latency-bound attention kernels that leave most of the chip idle at batch 1 --
+        # runs on the main one; joined before their first consumer.  Captured as parallel branches by hipGraph.
+        main = torch.cuda.current_stream()
+        overlap = os.environ.get("NMRF_OVERLAP", "1") != "0"
+        side = main
+        if overlap:
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=fmap1_list[0].device)
+            side = self._side_stream
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
+            heads8 = self._match_heads(fmap1_list[0], fmap2_list[0], self._head_cache8)
+            heads4 = self._match_heads(fmap1_list[1], fmap2_list[1], self._head_cache4)
+            if overlap:
+                for t in heads8 + heads4:
+                    t.record_stream(main)
+
         cost_volume = K.cost_volume(fmap1_list[0], fmap2_list[0], self.max_disp // 8, self.dpn.cost_group)
-        fmap1, fmap2, fmap1_gw, fmap2_gw, context = self._conv_heads(fmap1_list[0], fmap2_list[0], True)
-        _, prob, label_seeds, labels = self.dpn(cost_volume, fmap1_list, context=context)
+        _, prob, label_seeds, labels = self.dpn(cost_volume, fmap1_list)
         labels_curr = labels[-1]                                            # [P, N]
+        if overlap:
+            main.wait_stream(side)
+        fmap1, fmap2, fmap1_gw, fmap2_gw = heads8
 
         # ---- neural MRF inference at 1/8 -------------------------------------------------------------
         tgt = self.inference(labels_curr, fmap1, fmap2, fmap1_gw, fmap2_gw).view(-1, self.inference.dim)
@@ -143,7 +164,7 @@ class NMRF(nn.Module):
         disp_curr = K.wta_median(disp_delta, score, labels_curr.reshape(-1).contiguous(), b, h8, w8, n)
 
         # ---- refinement at 1/4 ---------------------------------------------------------------------------
-        fmap1, fmap2, fmap1_gw, fmap2_gw, _ = self._conv_heads(fmap1_list[1], fmap2_list[1], False)
+        fmap1, fmap2, fmap1_gw, fmap2_gw = heads4
         tgt = self.refinement(disp_curr, fmap1, fmap2, fmap1_gw, fmap2_gw).view(-1, self.refinement.dim)
         disp, disp_pred = K.refine_epilogue(self.refine_head(tgt), disp_curr, h0, w0)
 

@@ -37,6 +37,12 @@ def timeit(name, fn):
     print("%-28s %9.2f us / call" % (name, e0.elapsed_time(e1) * 1e3 / args.iters), flush=True)
 
 
+import ctypes
+from nmrf_amd import _lib
+_l = _lib.load()
+a, b2 = ctypes.c_int(-1), ctypes.c_int(-1)
+_l.nmrf_debug_window_occupancy(ctypes.byref(a), ctypes.byref(b2))
+print("runtime occupancy (blocks/CU): infer-window", a.value, " refine-window", b2.value, flush=True)
 which = args.which.split(",")
 if "window" in which:
     hp, wp = 48, 156
