@@ -28,6 +28,18 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// Cross-half exchange without touching the LDS crossbar (ds_bpermute queues behind the b128 traffic of the other
+// waves: ~600 cycles per shuffle measured in the window kernel).  v_permlane32_swap exchanges lanes 32-63 of its
+// first operand with lanes 0-31 of its second:  a' = [a.lo, b.lo]  b' = [a.hi, b.hi].
+__device__ __forceinline__ void half_swap(float &a, float &b) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]);
+    b = __uint_as_float(r[1]);
+}
+// combine lane l with lane l^32; both end up with the same value
+__device__ __forceinline__ float half_max(float x) { float a = x, b = x; half_swap(a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float half_sum(float x) { float a = x, b = x; half_swap(a, b); return a + b; }
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));

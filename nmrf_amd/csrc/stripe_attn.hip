@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void stripe_attn_kernel(const float *__restric
             float m_tile = st[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) m_tile = fmaxf(m_tile, st[r]);
-            m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
+            m_tile = half_max(m_tile);
             const float m_new = fmaxf(m_run, m_tile);
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);          // m_run=-inf -> 0
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void stripe_attn_kernel(const float *__restric
             for (int s = 0; s < 16; ++s) acc_o = mfma32(vf[s], st[s], acc_o);
             if (kt + 1 < kt_end) load_v(kt + 1, vf);          // V fragment likewise
         }
-        l_run += __shfl_xor(l_run, 32);                        // both halves now hold the range's full (m, l)
+        l_run = half_sum(l_run);                        // both halves now hold the range's full (m, l)
     }
 
     // ---- merge the KSPLIT key ranges of each query tile through LDS ----------------------------------------

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64 * NKT) void window_attn_kernel(const float *__re
                 m_tile = fmaxf(m_tile, v);
             }
         }
-        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
+        m_tile = half_max(m_tile);
         const float m_new = fmaxf(m_run, m_tile);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
         const float alpha = expf(m_run - m_use);
@@ -302,18 +302,19 @@ __global__ __launch_bounds__(64 * NKT) void window_attn_kernel(const float *__re
             }
         }
     }
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float l_tot = half_sum(l_run);
     const float inv_l = 1.0f / l_tot;
 
     // lane (q,hi) owns output channels d = mfma_row(r,hi); it needs its partner's oe at those channels and
     // owes the partner its own oe at mfma_row(r,1-hi).  Indices are compile-time on both sides of the select.
+    // lane (q,hi) owns channels d = mfma_row(r,hi) = d0 + 4*hi; one permlane swap of (oe[d0], oe[d0+4]) leaves
+    // {own, partner's} value of exactly that channel in the two registers of every lane
     float res[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const float mine = hi ? oe[mfma_row(r, 1)] : oe[mfma_row(r, 0)];
-        const float send = hi ? oe[mfma_row(r, 0)] : oe[mfma_row(r, 1)];
-        const float recv = __shfl_xor(send, 32);
-        res[r] = (acc_o[r] + (mine + recv)) * inv_l;
+        float a = oe[mfma_row(r, 0)], b = oe[mfma_row(r, 1)];
+        half_swap(a, b);
+        res[r] = (acc_o[r] + (a + b)) * inv_l;
     }
     if (!q_ok) return;
     (void)qs;
@@ -337,9 +338,17 @@ __global__ __launch_bounds__(64 * NKT) void window_attn_kernel(const float *__re
 #define WA_TROW 32                         // floats per staged table row; 16-byte chunks are XOR-swizzled by (row & 7)
 #define WA_LOG2E 1.4426950408889634f
 
-template <int NKT, int WIN, int NL, int OCC>
+// TIMED: debug instantiation that writes s_memtime stamps per wave (nmrf_debug_window_timing); never used in production.
+#define WA_STAMP(k) do { if (TIMED && lane == 0 && blockIdx.y == 0 && blockIdx.x < 64) \
+        stamps[((size_t)blockIdx.x * NKT + wv) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+// census record of every block (wave 0): [smid, realtime start, realtime end] after the 64*NKT*16 stamp words
+#define WA_CENSUS(k, v) do { if (TIMED && tid == 0) \
+        stamps[(size_t)64 * NKT * 16 + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 3 + (k)] = (v); } while (0)
+
+template <int NKT, int WIN, int NL, int OCC, bool TIMED = false>
 __global__ __launch_bounds__(64 * NKT, OCC) void window_attn_fast_kernel(const float *__restrict__ qkv,
-        const float *__restrict__ table, WinGeom g, float scale, float *__restrict__ out) {
+        const float *__restrict__ table, WinGeom g, float scale, float *__restrict__ out,
+        unsigned long long *__restrict__ stamps = nullptr) {
     constexpr int TP = NKT * 32;
     constexpr int NTHR = 64 * NKT;
     constexpr int W2 = WIN * WIN;
@@ -380,6 +389,9 @@ __global__ __launch_bounds__(64 * NKT, OCC) void window_attn_fast_kernel(const f
         return (unsigned)((((bimg * g.Hp + Y) * g.Wp) + X) * NL + n);
     };
 
+    WA_STAMP(0);
+    WA_CENSUS(0, (unsigned long long)__smid());
+    WA_CENSUS(1, wall_clock64());
     // ---- earliest load: phase-0 operand (q or k of token 32w+qi) ---------------------------------------
     const int tok = 32 * wv + qi;
     const bool tok_ok = tok < Tw;
@@ -418,7 +430,9 @@ __global__ __launch_bounds__(64 * NKT, OCC) void window_attn_fast_kernel(const f
         }
     }
     for (int i = tid; i < TP; i += NTHR) rowoff[i] = token_row(i) * ld;
+    WA_STAMP(1);
     __syncthreads();
+    WA_STAMP(2);
 
     // ev goes to registers now (hidden behind phase 0), to LDS once ek is dead
     float4 tv[TAB_IT];
@@ -461,6 +475,7 @@ __global__ __launch_bounds__(64 * NKT, OCC) void window_attn_fast_kernel(const f
             }
         }
     }
+    WA_STAMP(3);
     // Q fragment and the first K / V fragments: their latency overlaps the barrier and the ev stores
     const float *kbase = qkv + g.C + head * 32 + 16 * hi;
     const float *vbase = qkv + 2 * g.C + head * 32 + qi;
@@ -488,12 +503,14 @@ __global__ __launch_bounds__(64 * NKT, OCC) void window_attn_fast_kernel(const f
     load_k(0, kf);
     load_v(0, vf);
     __syncthreads();
+    WA_STAMP(4);
 #pragma unroll
     for (int it = 0; it < TAB_IT; ++it) {
         const int i = tid + it * NTHR;
         if (i < R * 8) stg4(tab_a + (i >> 3) * WA_TROW + ((((i & 7) ^ ((i >> 3) & 7))) << 2), tv[it]);
     }
     __syncthreads();
+    WA_STAMP(5);
 
     // ---- phase 1 ---------------------------------------------------------------------------------------
     const int q_pix = tokc / NL;
@@ -571,7 +588,7 @@ __global__ __launch_bounds__(64 * NKT, OCC) void window_attn_fast_kernel(const f
         float m_tile = st[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) m_tile = fmaxf(m_tile, st[r]);
-        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
+        m_tile = half_max(m_tile);
         const float m_new = fmaxf(m_run, m_tile);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
@@ -613,22 +630,28 @@ __global__ __launch_bounds__(64 * NKT, OCC) void window_attn_fast_kernel(const f
                 }
             }
         }
+        WA_STAMP(6 + kt);
     }
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float l_tot = half_sum(l_run);
     const float inv_l = 1.0f / l_tot;
+    // lane (q,hi) owns channels d = mfma_row(r,hi) = d0 + 4*hi; one permlane swap of (oe[d0], oe[d0+4]) leaves
+    // {own, partner's} value of exactly that channel in the two registers of every lane
     float res[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const float mine = hi ? oe[mfma_row(r, 1)] : oe[mfma_row(r, 0)];
-        const float send = hi ? oe[mfma_row(r, 0)] : oe[mfma_row(r, 1)];
-        const float recv = __shfl_xor(send, 32);
-        res[r] = (acc_o[r] + (mine + recv)) * inv_l;
+        float a = oe[mfma_row(r, 0)], b = oe[mfma_row(r, 1)];
+        half_swap(a, b);
+        res[r] = (acc_o[r] + (a + b)) * inv_l;
     }
+    if (TIMED) asm volatile("" :: "v"(res[0]), "v"(res[15]));
+    WA_STAMP(6 + NKT);
     if (!tok_ok) return;
     float *op = out + (size_t)trow * g.C + head * 32;
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
         stg4(op + mfma_row(4 * rb, hi), make_float4(res[4 * rb], res[4 * rb + 1], res[4 * rb + 2], res[4 * rb + 3]));
+    WA_STAMP(7 + NKT);
+    WA_CENSUS(2, wall_clock64());
 }
 
 template <int NKT, int WIN, int NL, int OCC>
@@ -647,7 +670,7 @@ static int launch_window_fast(const float *qkv, const float *table, const WinGeo
     static const size_t extra = getenv("NMRF_WA_EXTRA_LDS") ? (size_t)atoi(getenv("NMRF_WA_EXTRA_LDS")) : 0;   // probe only
     dim3 grid((g.Hp / WIN) * (g.Wp / WIN), g.heads, B);
     hipLaunchKernelGGL((window_attn_fast_kernel<NKT, WIN, NL, OCC>), grid, dim3(64 * NKT), smem + extra, st, qkv, table, g,
-                       1.0f / sqrtf(32.0f), out);
+                       1.0f / sqrtf(32.0f), out, (unsigned long long *)nullptr);
     return nmrf_launch_status();
 }
 
@@ -674,10 +697,22 @@ static int launch_window(const float *qkv, const float *table, const WinGeom &g,
 extern "C" int nmrf_debug_window_occupancy(int *blocks_infer, int *blocks_refine) {
     constexpr size_t s5 = (size_t)(2 * 121 * WA_TROW + 2 * 36 * 144 + 32) * 4 + 160 * 4;
     constexpr size_t s1 = (size_t)(2 * 49 * WA_TROW + 2 * 16 * 16 + 32) * 4 + 32 * 4;
-    hipFuncSetAttribute((const void *)window_attn_fast_kernel<5, 6, 4, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s5);
-    hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_infer, window_attn_fast_kernel<5, 6, 4, 3>, 320, s5);
+    hipFuncSetAttribute((const void *)window_attn_fast_kernel<5, 6, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s5);
+    hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_infer, window_attn_fast_kernel<5, 6, 4, 2>, 320, s5);
     hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_refine, window_attn_fast_kernel<1, 4, 1, 3>, 64, s1);
     return (e1 == hipSuccess && e2 == hipSuccess) ? 0 : -2;
+}
+
+// Debug: instrumented run of the 6x6x4 kernel; stamps [64 blocks][5 waves][16] of s_memtime values (device buffer).
+extern "C" int nmrf_debug_window_timing(const float *qkv, const float *table, int B, int Hp, int Wp, int shift, float *out,
+                                        unsigned long long *stamps, void *stream) {
+    WinGeom g{Hp, Wp, 4, 128, 4, 6, shift, 1, 144, 121};
+    constexpr size_t smem = (size_t)(2 * 121 * WA_TROW + 2 * 36 * 144 + 32) * 4 + 160 * 4;
+    hipFuncSetAttribute((const void *)window_attn_fast_kernel<5, 6, 4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    dim3 grid((Hp / 6) * (Wp / 6), 4, B);
+    hipLaunchKernelGGL((window_attn_fast_kernel<5, 6, 4, 2, true>), grid, dim3(320), smem, (hipStream_t)stream, qkv, table, g,
+                       1.0f / sqrtf(32.0f), out, stamps);
+    return nmrf_launch_status();
 }
 
 extern "C" int nmrf_window_attn_f32(const float *qkv, const float *table, int B, int Hp, int Wp, int N, int C, int heads,
@@ -690,7 +725,7 @@ extern "C" int nmrf_window_attn_f32(const float *qkv, const float *table, int B,
     const int nkt = (g.Tw + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
     if ((int64_t)B * Hp * Wp * N * 3 * C < ((int64_t)1 << 32)) {                            // 32-bit element offsets
-        if (win == 6 && N == 4) return launch_window_fast<5, 6, 4, 3>(qkv, table, g, B, out, st);   // inference windows
+        if (win == 6 && N == 4) return launch_window_fast<5, 6, 4, 2>(qkv, table, g, B, out, st);   // inference windows
         if (win == 4 && N == 1) return launch_window_fast<1, 4, 1, 3>(qkv, table, g, B, out, st);   // refinement windows
     }
     switch (nkt) {                                                                         // any other configuration

@@ -63,3 +63,42 @@ if "warp" in which:
     g1, g2 = mk("g1", b, 256, h, w), mk("g2", b, 256, h, w)
     lab = mk("lab", b * h * w * n).abs() * 40
     timeit("warp_corr_concat 1/8", lambda: K.warp_corr_concat(lab, f1, f2, g1, g2, n))
+
+if "timing" in which:
+    import numpy as np
+    hp, wp = 48, 156
+    qkv, table = mk("q", b * hp * wp * n, 384), mk("t", 121, 384)
+    out = torch.empty(b * hp * wp * n, 128, device=dev)
+    nblk = (hp // 6) * (wp // 6) * 4 * b
+    stamps = torch.zeros(64 * 5 * 16 + nblk * 3, dtype=torch.int64, device=dev)
+    for _ in range(3):
+        _l.nmrf_debug_window_timing(ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(table.data_ptr()), b, hp, wp, 0,
+                                    ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(stamps.data_ptr()), None)
+    torch.cuda.synchronize()
+    allst = stamps.cpu().numpy().astype(np.int64)
+    st = allst[:64 * 5 * 16].reshape(64, 5, 16)
+    cen = allst[64 * 5 * 16:].reshape(nblk, 3)
+    names = ["vec+tables issued", "barrier1 wait", "ev issue+phase0", "q/k/v issue+barrier2", "ev store+barrier3",
+             "tile0", "tile1", "tile2", "tile3", "tile4", "normalise+exchange", "stores"]
+    d = np.diff(st[:, :, :13], axis=2)
+    print("window 6x6x4 per-wave phase durations in shader cycles (mean over 64 blocks), waves 0..4:")
+    for i, nm in enumerate(names):
+        print("  %-20s" % nm, " ".join("%7.0f" % v for v in d[:, :, i].mean(0)))
+    print("  %-20s" % "total", " ".join("%7.0f" % v for v in (st[:, :, 12] - st[:, :, 0]).mean(0)))
+    # census: per-CU concurrency from realtime (100 MHz) block start/end
+    t0 = cen[:, 1].min()
+    dur = (cen[:, 2] - cen[:, 1]) / 100.0
+    print("  blocks %d, distinct smid %d, block duration us: mean %.1f min %.1f max %.1f; kernel span %.1f us"
+          % (nblk, len(set(cen[:, 0].tolist())), dur.mean(), dur.min(), dur.max(), (cen[:, 2].max() - t0) / 100.0))
+    conc = []
+    for sm in set(cen[:, 0].tolist()):
+        rows = cen[cen[:, 0] == sm]
+        ev = sorted([(r[1], 1) for r in rows] + [(r[2], -1) for r in rows])
+        cur = mx = 0
+        for _, dlt in ev:
+            cur += dlt
+            mx = max(mx, cur)
+        conc.append((len(rows), mx))
+    import collections
+    print("  blocks per smid histogram:", dict(collections.Counter(c[0] for c in conc)))
+    print("  max concurrent blocks per smid histogram:", dict(collections.Counter(c[1] for c in conc)))
