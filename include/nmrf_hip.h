@@ -27,7 +27,7 @@ extern "C" {
 
 const char *nmrf_strerror(int code);
 /* ABI version of this header; bumps on any signature change. */
-int nmrf_abi_version(void);   /* currently 3 */
+int nmrf_abi_version(void);   /* currently 4 */
 
 /* A2  group-wise correlation volume.
  * replaces build_correlation_volume + the permute of DPN.forward
@@ -110,6 +110,13 @@ int nmrf_self_attn_f32(const float *qkv, int64_t T, int N, int C, int heads, flo
  * -> out [B,Hp,Wp,N,C] (already un-rolled). heads*32==C. */
 int nmrf_window_attn_f32(const float *qkv, const float *table, int B, int Hp, int Wp, int N, int C, int heads,
                          int win, int shift, int sibling_mask, float *out, void *stream);
+
+/* A8/A11/A14  narrow prediction-head layers: out[T,N] = act(x[T,K] w[N,K]^T + bias), N <= 64, K % 4 == 0, K <= 512
+ * (LDS: 32*(K+4) + 8*npt*K floats <= 64 KiB), act 0 = identity, 1 = ReLU; bias may be NULL.
+ * replaces the last nn.Linear of prop_head / infer_head / refine_head and infer_score_head
+ * (nmrf/models/NMP.py:54-66, nmrf/models/NMRF.py:82-83,105,218-220,238; nmrf/models/DPN.py:65,131). */
+int nmrf_linear_smalln_f32(const float *x, const float *w, const float *bias, int64_t T, int K, int N, int act,
+                           float *out, void *stream);
 
 /* A11/A12  coarse heads epilogue: relu(label+delta), winner-take-all over N by score (first max),
  * x2, 4x4 lower median.  replaces NMRF.forward (nmrf/models/NMRF.py:219-232).

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnmrf_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -29,6 +29,7 @@ PROTOTYPES = {
     "nmrf_warp_corr_concat_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "nmrf_self_attn_f32": [_P, _L, _I, _I, _I, _P, _P],
     "nmrf_window_attn_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    "nmrf_linear_smalln_f32": [_P, _P, _P, _L, _I, _I, _I, _P, _P],
     "nmrf_wta_median_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "nmrf_refine_epilogue_f32": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "nmrf_msda_forward_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],

@@ -43,10 +43,22 @@ __device__ __forceinline__ int64_t stripe_row(const StripeGeom &g, int64_t base_
     return (base_pix + (int64_t)l * g.pix_stride) * nn + n;
 }
 
-template <int AXIS, int NSHIFT, int KSPLIT>
+// CENSUS: debug instantiation recording [smid, realtime start, realtime end] of every block (nmrf_debug_stripe_census)
+template <int AXIS, int NSHIFT, int KSPLIT, bool CENSUS = false>
 __global__ __launch_bounds__(256) void stripe_attn_kernel(const float *__restrict__ qkv, const float *__restrict__ lepe,
-                                                         StripeGeom g, float scale, float *__restrict__ out) {
+                                                         StripeGeom g, float scale, float *__restrict__ out,
+                                                         unsigned long long *__restrict__ census = nullptr) {
     constexpr int QPB = 4 / KSPLIT;                           // query tiles per block
+    struct Scope {
+        unsigned long long *p;
+        __device__ Scope(unsigned long long *c) : p(c) {
+            if (CENSUS && threadIdx.x == 0) {
+                p = c + 3 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+                p[0] = __smid(); p[1] = wall_clock64();
+            }
+        }
+        __device__ ~Scope() { if (CENSUS && threadIdx.x == 0) p[2] = wall_clock64(); }
+    } scope(census);
     __shared__ float s_o[KSPLIT > 1 ? 4 : 1][16][64];          // partial O^T of the non-leading key ranges
     __shared__ float s_ml[KSPLIT > 1 ? 4 : 1][2][64];          // their (m, l)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -233,9 +245,24 @@ static void launch_stripe(const float *qkv, const float *lepe, const StripeGeom 
     if (waves1 * 4 <= 8192 && n_qt >= 8) ksplit = 4;
     const int qpb = 4 / ksplit;
     dim3 grid((n_qt + qpb - 1) / qpb, stripes * 2, B);
-    if (ksplit == 1) hipLaunchKernelGGL((stripe_attn_kernel<AXIS, NSHIFT, 1>), grid, dim3(256), 0, st, qkv, lepe, g, scale, out);
-    else if (ksplit == 2) hipLaunchKernelGGL((stripe_attn_kernel<AXIS, NSHIFT, 2>), grid, dim3(256), 0, st, qkv, lepe, g, scale, out);
-    else hipLaunchKernelGGL((stripe_attn_kernel<AXIS, NSHIFT, 4>), grid, dim3(256), 0, st, qkv, lepe, g, scale, out);
+    if (ksplit == 1) hipLaunchKernelGGL((stripe_attn_kernel<AXIS, NSHIFT, 1>), grid, dim3(256), 0, st, qkv, lepe, g, scale, out,
+                                          (unsigned long long *)nullptr);
+    else if (ksplit == 2) hipLaunchKernelGGL((stripe_attn_kernel<AXIS, NSHIFT, 2>), grid, dim3(256), 0, st, qkv, lepe, g, scale, out,
+                                          (unsigned long long *)nullptr);
+    else hipLaunchKernelGGL((stripe_attn_kernel<AXIS, NSHIFT, 4>), grid, dim3(256), 0, st, qkv, lepe, g, scale, out,
+                                          (unsigned long long *)nullptr);
+}
+
+// Debug: census run of the horizontal N=4 KSPLIT=4 kernel (KITTI batch-1 configuration); census[blocks*3] on device.
+extern "C" int nmrf_debug_stripe_census(const float *qkv, const float *lepe_h, int B, int H, int W, float *out,
+                                        unsigned long long *census, int *grid_out, void *stream) {
+    StripeGeom g{H, W, 4, 128, W, W * 4, (int64_t)1};
+    const int n_qt = (g.Ts + SA_TILE - 1) / SA_TILE;
+    dim3 grid(n_qt, H * 2, B);                                // KSPLIT = 4 -> one query tile per block
+    grid_out[0] = grid.x; grid_out[1] = grid.y; grid_out[2] = grid.z;
+    hipLaunchKernelGGL((stripe_attn_kernel<1, 2, 4, true>), grid, dim3(256), 0, (hipStream_t)stream, qkv, lepe_h, g,
+                       1.0f / sqrtf(32.0f), out, census);
+    return nmrf_launch_status();
 }
 
 extern "C" int nmrf_stripe_attn_f32(const float *qkv, const float *lepe_v, const float *lepe_h, int B, int H, int W,

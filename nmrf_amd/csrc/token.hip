@@ -340,3 +340,74 @@ extern "C" int nmrf_refine_epilogue_f32(const float *delta, const float *disp_cu
                        outW, disp_pred, disp);
     return nmrf_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Narrow-output linear layers (prediction heads: N = 1, 16, 64 outputs from K = 128 features).
+// hipBLASLt picks 64x64 tiles for these and lands at ~70 us (profiles/r01e); they are HBM-bound
+// ([T,128] in, [T,N] out).  One block = 32 tokens x 8 output groups: the x tile and W are staged in LDS (x rows padded
+// to K+4 floats -> conflict-free b128 reads), thread (token, output group) accumulates NPT outputs.
+// ------------------------------------------------------------------------------------------------
+#define SL_TOK 32
+template <int NPT>      // outputs per thread; the block covers 8*NPT outputs
+__global__ __launch_bounds__(256) void linear_smalln_kernel(const float *__restrict__ x, const float *__restrict__ w,
+        const float *__restrict__ bias, int64_t T, int K, int N, int act, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int ldx = K + 4;
+    float *sx = sm;                          // [SL_TOK][K+4]
+    float *sw = sm + SL_TOK * ldx;           // [8*NPT][K]   (rows >= N are zero)
+    const int tid = threadIdx.x;
+    const int64_t t0 = (int64_t)blockIdx.x * SL_TOK;
+    const int k4n = K >> 2;
+    for (int i = tid; i < SL_TOK * k4n; i += 256) {
+        const int r = i / k4n, c = i - r * k4n;
+        const int64_t t = t0 + r;
+        float4 v = t < T ? ldg4(x + t * K + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4 *>(sx + r * ldx + 4 * c) = v;
+    }
+    for (int i = tid; i < 8 * NPT * k4n; i += 256) {
+        const int r = i / k4n, c = i - r * k4n;
+        float4 v = r < N ? ldg4(w + (size_t)r * K + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4 *>(sw + r * K + 4 * c) = v;
+    }
+    __syncthreads();
+    const int tok = tid & 31, og = tid >> 5;                 // half-wave = output group (W addresses broadcast)
+    float acc[NPT];
+#pragma unroll
+    for (int o = 0; o < NPT; ++o) acc[o] = 0.f;
+    const float *xr = sx + tok * ldx;
+    const float *wr = sw + (size_t)og * NPT * K;
+    for (int c = 0; c < k4n; ++c) {
+        const float4 xv = *reinterpret_cast<const float4 *>(xr + 4 * c);
+#pragma unroll
+        for (int o = 0; o < NPT; ++o) {
+            const float4 wv = *reinterpret_cast<const float4 *>(wr + o * K + 4 * c);
+            acc[o] = fmaf(xv.x, wv.x, acc[o]); acc[o] = fmaf(xv.y, wv.y, acc[o]);
+            acc[o] = fmaf(xv.z, wv.z, acc[o]); acc[o] = fmaf(xv.w, wv.w, acc[o]);
+        }
+    }
+    const int64_t t = t0 + tok;
+    if (t >= T) return;
+#pragma unroll
+    for (int o = 0; o < NPT; ++o) {
+        const int n = og * NPT + o;
+        if (n < N) {
+            float v = acc[o] + (bias ? bias[n] : 0.f);
+            out[t * N + n] = act == 1 ? fmaxf(v, 0.f) : v;
+        }
+    }
+}
+
+extern "C" int nmrf_linear_smalln_f32(const float *x, const float *w, const float *bias, int64_t T, int K, int N, int act,
+                                      float *out, void *stream) {
+    if (!x || !w || !out) return NMRF_ENULL;
+    if (T < 1 || K < 4 || (K & 3) || K > 512 || N < 1 || N > 64 || act < 0 || act > 1) return NMRF_EINVAL;
+    const int npt = N <= 8 ? 1 : (N <= 16 ? 2 : 8);
+    const size_t smem = ((size_t)SL_TOK * (K + 4) + (size_t)8 * npt * K) * sizeof(float);
+    dim3 grid((unsigned)ceil_div64(T, SL_TOK));
+    hipStream_t st = (hipStream_t)stream;
+    if (smem > 64 * 1024) return NMRF_EINVAL;
+    if (npt == 1) hipLaunchKernelGGL(linear_smalln_kernel<1>, grid, dim3(256), smem, st, x, w, bias, T, K, N, act, out);
+    else if (npt == 2) hipLaunchKernelGGL(linear_smalln_kernel<2>, grid, dim3(256), smem, st, x, w, bias, T, K, N, act, out);
+    else hipLaunchKernelGGL(linear_smalln_kernel<8>, grid, dim3(256), smem, st, x, w, bias, T, K, N, act, out);
+    return nmrf_launch_status();
+}

