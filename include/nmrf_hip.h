@@ -27,7 +27,7 @@ extern "C" {
 
 const char *nmrf_strerror(int code);
 /* ABI version of this header; bumps on any signature change. */
-int nmrf_abi_version(void);   /* currently 4 */
+int nmrf_abi_version(void);   /* currently 5 */
 
 /* A2  group-wise correlation volume.
  * replaces build_correlation_volume + the permute of DPN.forward
@@ -129,6 +129,14 @@ int nmrf_wta_median_f32(const float *delta, const float *score, const float *lab
  * delta [B*H4*W4,16], disp_curr [B,H4,W4] -> disp_pred [B,4H4,4W4] (1/4-px units), disp [B,outH,outW] = 4*pred cropped. */
 int nmrf_refine_epilogue_f32(const float *delta, const float *disp_curr, int B, int H4, int W4, int outH, int outW,
                              float *disp_pred, float *disp, void *stream);
+
+/* N2 (stock conv band)  InstanceNorm2d without affine, fused with what follows it:
+ *   y = [relu_mid] IN(x) ; y = [relu_out] (y + residual)        residual may be NULL
+ * replaces nn.InstanceNorm2d + ReLU (+ residual add + ReLU) of the reference's conv heads and backbone blocks
+ * (nmrf/models/NMRF.py:56-65, nmrf/models/DPN.py:45-49, nmrf/models/backbone.py:38-46,87-88).
+ * x, residual, y: [planes, HW] (planes = B*C of an NCHW tensor); ws: workspace of 2*planes*ceil(HW/8192) floats. */
+int nmrf_instance_norm_f32(const float *x, const float *residual, int64_t planes, int64_t HW, float eps,
+                           int relu_mid, int relu_out, float *ws, float *y, void *stream);
 
 /* A15  multi-scale deformable attention.
  * replaces ms_deform_attn_forward / ms_deform_attn_backward of the reference extension

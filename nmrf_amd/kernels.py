@@ -200,6 +200,19 @@ def refine_epilogue(delta, disp_curr, out_h, out_w):
     return disp, pred
 
 
+def instance_norm(x, relu=False, residual=None, relu_out=False, eps=1e-5):
+    """InstanceNorm2d (no affine) of an NCHW tensor fused with ReLU / residual add / ReLU:
+    y = [relu] IN(x); y = [relu_out](y + residual)."""
+    _chk(x, residual)
+    b, c, h, w = x.shape
+    hw = h * w
+    ws = torch.empty(2 * b * c * ((hw + 8191) // 8192), device=x.device, dtype=torch.float32)
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().nmrf_instance_norm_f32(_p(x), _p(residual), b * c, hw, float(eps), int(relu), int(relu_out),
+                                                  _p(ws), _p(y), _stream()), "instance_norm")
+    return y
+
+
 def msda_forward(value, shapes, lvl_start, loc, w):
     dt = value.dtype
     if dt not in (torch.float32, torch.float64):

@@ -23,12 +23,20 @@ class ResidualBlock(nn.Module):
         self.relu = nn.ReLU(inplace=True)
         self.norm1 = _norm(norm, cout)
         self.norm2 = _norm(norm, cout)
+        self.fused = norm == "instance"
         self.downsample = None
         if stride != 1 or cin != cout:
             self.norm3 = _norm(norm, cout)
             self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride), self.norm3)
 
     def forward(self, x):
+        if self.fused and x.is_cuda:
+            # InstanceNorm + ReLU (+ residual add + ReLU) in two HIP passes instead of 4-6 torch kernels
+            from .. import kernels as K
+            y = K.instance_norm(self.conv1(x).contiguous(), relu=True)
+            if self.downsample is not None:
+                x = K.instance_norm(self.downsample[0](x).contiguous())
+            return K.instance_norm(self.conv2(y).contiguous(), relu=True, residual=x.contiguous(), relu_out=True)
         y = self.relu(self.norm1(self.conv1(x)))
         y = self.relu(self.norm2(self.conv2(y)))
         if self.downsample is not None:
@@ -50,13 +58,18 @@ class Backbone(nn.Module):
         self.layer3 = nn.Sequential(ResidualBlock(96, 128, norm, 1), ResidualBlock(128, 128, norm, 1))
         self.conv2 = nn.Conv2d(128, output_dim, 1)
         self.output_dim = output_dim
+        self.fused = norm == "instance"
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
     def forward(self, x):
         x = 2 * (x / 255.0) - 1.0
-        x = self.relu1(self.norm1(self.conv1(x)))
+        if self.fused and x.is_cuda:
+            from .. import kernels as K
+            x = K.instance_norm(self.conv1(x).contiguous(), relu=True)
+        else:
+            x = self.relu1(self.norm1(self.conv1(x)))
         x = self.conv2(self.layer3(self.layer2(self.layer1(x))))
         return [x, F.avg_pool2d(x, 2, 2)]
 

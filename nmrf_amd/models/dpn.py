@@ -55,7 +55,8 @@ class DPN(nn.Module):
             cost_volume = cost_volume.permute(0, 3, 4, 1, 2).reshape(b * h * w, g, d).contiguous()
         prob, seeds = self.seeds(cost_volume)
         if context is None:                                   # [B,Cctx,H,W] may be precomputed by the caller
-            context = self.proj(fmap1_list[0])
+            y = K.instance_norm(self.proj[0](fmap1_list[0]).contiguous(), relu=True)     # conv3x3 - IN - ReLU fused
+            context = self.proj[3](y)
         context = context.permute(0, 2, 3, 1).contiguous()
         memory, seeds_f = self.propagation(cost_volume, seeds, context)
         outputs = self.prop_head(memory).view(-1, *seeds_f.shape)

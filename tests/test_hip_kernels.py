@@ -225,6 +225,17 @@ def test_linear_smalln(t_, k, n, relu):
     assert torch.equal(K().linear_smalln(x.to(DEV), w.to(DEV), None, False).cpu() + b, got) or not relu or True
 
 
+@pytest.mark.parametrize("b,c,h,w", [(2, 5, 7, 9), (1, 3, 188, 624), (2, 4, 47, 156)])
+def test_instance_norm_fused(b, c, h, w):
+    x = rnd(b, c, h, w, seed=h, scale=3.0) + 1.5
+    res = rnd(b, c, h, w, seed=h + 1)
+    ref = F.instance_norm(x.double(), eps=1e-5)
+    report("in", K().instance_norm(x.to(DEV)).cpu(), ref, 5e-6)
+    report("in+relu", K().instance_norm(x.to(DEV), relu=True).cpu(), F.relu(ref), 5e-6)
+    got = K().instance_norm(x.to(DEV), relu=True, residual=res.to(DEV), relu_out=True).cpu()
+    report("in+relu+res+relu", got, F.relu(F.relu(ref) + res.double()), 5e-6)
+
+
 def test_kernels_refuse_cpu_tensors():
     from nmrf_amd._lib import NmrfHipError
     with pytest.raises(NmrfHipError):
