@@ -136,6 +136,33 @@ def test_full_forward_vs_oracle_mid_size():
     assert got["disp"].shape == (1, 120, 264) and got["disp_pred"].shape == (1, 120, 264)
 
 
+def test_driver_pipeline_matches_direct_calls():
+    """The double-buffered batched driver (N1) returns, per pair and in order, what model(sample) returns."""
+    from nmrf_amd.driver import StereoStream
+    from nmrf_amd.utils.hashinit import synthetic_pair
+    model = build_product(128, DEV)
+    pairs = [(i,) + synthetic_pair(64, 104, seed=50 + i)[:2] for i in range(5)]
+    got = dict(StereoStream(model, DEV, batch=2).run(iter(pairs)))
+    assert list(got) == [0, 1, 2, 3, 4]
+    with torch.no_grad():
+        for i, l, r in pairs:
+            want = model({"img1": l[None], "img2": r[None]})["disp"][0].cpu()
+            assert float((got[i] - want).abs().mean()) < 1e-2 and got[i].shape == want.shape
+
+
+def test_middlebury_half_res_size_runs():
+    """Largest BASELINE size (config 5 geometry: ~1500x1000, D_max 256 -> D=32, divisible-by-32 padding) on the
+    CNN backbone: shapes, finiteness, seeds in range."""
+    from nmrf_amd.utils.hashinit import synthetic_pair
+    model = build_product(256, DEV, opts=["DATASETS.DIVIS_BY", 32])
+    l, r, _ = synthetic_pair(1000, 1500, seed=77)
+    with torch.no_grad():
+        out = model({"img1": l[None], "img2": r[None]})
+    assert out["disp"].shape == (1, 1000, 1500) and out["disp_pred"].shape == (1, 1024, 1504)
+    assert out["prob"].shape == (128 * 188, 32) and int(out["initial_proposal"].max()) < 32
+    assert torch.isfinite(out["disp"]).all() and (out["disp"] >= 0).all()
+
+
 @pytest.mark.parametrize("h,w", [(375, 1242), (540, 960)])
 def test_full_size_properties(h, w):
     """BASELINE sizes (KITTI, SceneFlow): properties that hold at any size.
