@@ -14,6 +14,7 @@ Fixtures
   e2e_c.npz   40x72,  MAX_DISP 128, B=2 (two different pairs): small outputs
   nms_cases.npz   crafted logits rows (ties, plateaus, NaN, ...) pushed through
               the reference's DPN.forward NMS+topk (DPN.py:119-125), D in {16,24,32,40,48}
+  e2e_swin.npz / state_dict_keys.json   Swin-T + DeformNeck config: encoder features + outputs; key/shape listings
   msda.npz    ops/test.py known-answer case (seed 3) + model-shaped cases through
               ms_deform_attn_core_pytorch, fp32 outputs; gradients computed in fp64 autograd, stored fp32
 """
@@ -100,6 +101,33 @@ def run_e2e(name, shapes_seeds, opts, full):
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **d)
     print(name, {k: v.shape for k, v in d.items() if hasattr(v, "shape")}, os.path.getsize(path) // 1024, "KiB")
+
+
+def run_swin():
+    """Swin-T + deformable neck config (configs/sceneflow_swint.yaml + MAX_DISP 256): encoder features, outputs,
+    and the state-dict key/shape listing of both configs (for the strict-load contract tests)."""
+    import json
+    opts = ["BACKBONE.MODEL_TYPE", "swin", "BACKBONE.OUT_CHANNELS", 128, "DATASETS.DIVIS_BY", 32,
+            "BACKBONE.COMPAT", False, "DPN.MAX_DISP", 256]
+    model, cfg = refshim.build_reference_model(opts)
+    apply_hash_weights(model)
+    caps = {}
+    model.image_encoder.register_forward_hook(lambda m, i, o: caps.__setitem__("enc", o))
+    model.refinement.register_forward_hook(lambda m, i, o: caps.__setitem__("refine_in", i))
+    l, r, _ = synthetic_pair(60, 90, seed=2000)
+    with torch.no_grad():
+        out = model({"img1": l[None].clone(), "img2": r[None].clone()})
+    d = {"img1": _np(l[None]).astype(np.uint8), "img2": _np(r[None]).astype(np.uint8),
+         "feat4": _np(caps["enc"][0]), "prob": _np(out["prob"]), "seeds": _np(out["initial_proposal"]).astype(np.int16),
+         "proposal": _np(out["proposal"]), "disp": _np(out["disp"]), "disp_curr": _np(caps["refine_in"][0])}
+    path = os.path.join(OUT, "e2e_swin.npz")
+    np.savez_compressed(path, **d)
+    print("e2e_swin", {k: v.shape for k, v in d.items()}, os.path.getsize(path) // 1024, "KiB")
+    keys = {"swin": {k: list(v.shape) for k, v in model.state_dict().items()}}
+    model, _ = refshim.build_reference_model([])
+    keys["default"] = {k: list(v.shape) for k, v in model.state_dict().items()}
+    with open(os.path.join(OUT, "state_dict_keys.json"), "w") as f:
+        json.dump(keys, f)
 
 
 def crafted_logits(d, rows_per_kind=24):
@@ -213,3 +241,4 @@ if __name__ == "__main__":
     run_e2e("e2e_c", [(40, 72, 1002), (40, 72, 1003)], ["DPN.MAX_DISP", 128], full=False)
     run_nms()
     run_msda()
+    run_swin()
