@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL result gather at N>1")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find mode)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the result gather even at N=1 (smoke)")
     return ap.parse_args()
 
 
@@ -109,9 +110,12 @@ def main():
         torch.backends.cudnn.benchmark = True
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from nmrf_amd import kernels as K
     from nmrf_amd.config import get_cfg
@@ -132,7 +136,11 @@ def main():
 
     def step():
         out = model(sample)
-        if world > 1 and not args.no_gather:
+        if use_dist and not args.no_gather:
+            if world == 1:                                    # --force-dist smoke: the collective on a 1-rank group
+                g = torch.empty_like(out["disp"])
+                dist.all_gather_into_tensor(g, out["disp"].contiguous())
+                return g
             return gather_disparity(out["disp"])
         return out["disp"]
 
@@ -141,7 +149,7 @@ def main():
         for _ in range(max(args.warmup, 1)):
             step()
         torch.cuda.synchronize()
-        if not args.no_graph and world == 1:
+        if not args.no_graph and not use_dist:
             try:
                 K.kernel_hook = None                      # events cannot be recorded/queried inside a capture
                 graph = torch.cuda.CUDAGraph()
@@ -156,17 +164,17 @@ def main():
             K.kernel_hook = timer
 
         run = graph.replay if graph is not None else step
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             run()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         elapsed = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
@@ -214,6 +222,15 @@ def main():
     }
     kern_names = {"stripe_attn_horizontal": "stripe_attn_kernel<1> (horizontal stripes, A7)",
                   "window_attn_w%d_n%d" % (win, n): "window_attn_kernel<%d> (inference windows, A10)" % ((tw + 31) // 32)}
+    # HBM bytes per launch from the separate rocprofv3 --pmc passes (tools/gpu_pmc.sh -> profiles/pmc_traffic.json)
+    pmc_names = {"stripe_attn_horizontal": "stripe_attn_kernel<1, 2, 4, false>",
+                 "window_attn_w%d_n%d" % (win, n): "window_attn_fast_kernel<5, 6, 4, 2, false>"}
+    pmc = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pmc = json.load(f)
+    except (OSError, ValueError):
+        pass
     roof, others = None, []
     timed = {k: v for k, v in kstats.items() if k in flops}
     if timed:
@@ -222,7 +239,9 @@ def main():
         for k, (ms, cnt) in timed.items():
             ach = flops[k] / (ms * 1e-3) / 1e12
             rec = {"bound": "mfma", "kernel": kern_names[k], "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
-                   "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                   "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                   "traffic": (pmc.get(pmc_names[k], {}).get("hbm_bytes") if (b == 1 and args.height == 375 and
+                                                                              args.width == 1242) else None),
                    "launch_ms": round(ms, 4), "launches_timed": cnt, "flop_per_launch": flops[k]}
             if k == dom:
                 roof = rec
@@ -240,7 +259,7 @@ def main():
                                                                      cfg.NMP.NUM_INFER_LAYERS, cfg.NMP.NUM_REFINE_LAYERS),
                        "global_batch": world * b, "parallelism": "batch-shard x%d" % world,
                        "launch": "hipGraph" if graph is not None else "eager",
-                       "result_gather": bool(world > 1 and not args.no_gather)},
+                       "result_gather": bool(use_dist and not args.no_gather)},
             "hot_path_ms": None if hp_ms is None else round(hp_ms, 3),
             "roofline": roof,
             "other_kernels": others,
@@ -251,7 +270,7 @@ def main():
             except Exception as e:
                 res["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -20,10 +20,9 @@
 // are staged, the ev table into registers before phase 0 (stored to LDS after the barrier that retires
 // ek), Q and the first K/V fragments before that barrier, the K/V fragments of tile t+1 before the
 // MFMAs of tile t.
-// WIN/NL template parameters make the index arithmetic compile-time for the shipped configurations
-// (6x6x4 inference windows, 4x4x1 refinement windows); WIN=0 selects the generic runtime path.
+// This is the generic kernel (runtime window size / labels per pixel) used by non-shipped configurations; the
+// shipped ones (6x6x4 inference windows, 4x4x1 refinement windows) run window_attn_fast_kernel below.
 #include "common.h"
-#include <stdlib.h>
 
 struct WinGeom {
     int Hp, Wp, N, C, heads, win, shift, sibling;
@@ -31,19 +30,17 @@ struct WinGeom {
     int R;               // (2 win - 1)^2
 };
 
-template <int NKT, int WIN, int NL>
+template <int NKT>
 __global__ __launch_bounds__(64 * NKT) void window_attn_kernel(const float *__restrict__ qkv,
         const float *__restrict__ table, WinGeom g, float scale, float *__restrict__ out) {
     constexpr int TP = NKT * 32;                   // padded tokens per window
     constexpr int NTHR = 64 * NKT;
-    const int win = WIN ? WIN : g.win;
-    const int nl = NL ? NL : g.N;
+    const int win = g.win;
+    const int nl = g.N;
     const int W2 = win * win;
     const int span = 2 * win - 1;
     const int R = span * span;
     const int Tw = W2 * nl;
-    // staged-table iterations per thread (compile-time when WIN is)
-    constexpr int TAB_IT = WIN ? ((2 * WIN - 1) * (2 * WIN - 1) * 8 + NTHR - 1) / NTHR : 0;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *tab_a = smem;                            // ek [R][32]   (later: ev)
@@ -88,47 +85,16 @@ __global__ __launch_bounds__(64 * NKT) void window_attn_kernel(const float *__re
     }
 
     // ---- stage ek / eq*s (all loads first, then the LDS stores), build the row map -------------------
-    if (WIN) {
-        float4 te[TAB_IT ? TAB_IT : 1], tq[TAB_IT ? TAB_IT : 1];
-#pragma unroll
-        for (int it = 0; it < TAB_IT; ++it) {
-            const int i = tid + it * NTHR;
-            if (i < R * 8) {
-                const int r = i >> 3, c4 = (i & 7) * 4;
-                te[it] = ldg4(table + (size_t)r * tab_ld + tcol + 32 + c4);
-                tq[it] = ldg4(table + (size_t)r * tab_ld + tcol + c4);
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < TAB_IT; ++it) {
-            const int i = tid + it * NTHR;
-            if (i < R * 8) {
-                const int r = i >> 3, c4 = (i & 7) * 4;
-                stg4(tab_a + r * 32 + c4, te[it]);
-                stg4(tab_b + r * 32 + c4, make_float4(tq[it].x * scale, tq[it].y * scale, tq[it].z * scale, tq[it].w * scale));
-            }
-        }
-    } else {
-        for (int i = tid; i < R * 8; i += NTHR) {
-            const int r = i >> 3, c4 = (i & 7) * 4;
-            float4 ek = ldg4(table + (size_t)r * tab_ld + tcol + 32 + c4);
-            float4 eq = ldg4(table + (size_t)r * tab_ld + tcol + c4);
-            stg4(tab_a + r * 32 + c4, ek);
-            stg4(tab_b + r * 32 + c4, make_float4(eq.x * scale, eq.y * scale, eq.z * scale, eq.w * scale));
-        }
+    for (int i = tid; i < R * 8; i += NTHR) {
+        const int r = i >> 3, c4 = (i & 7) * 4;
+        float4 ek = ldg4(table + (size_t)r * tab_ld + tcol + 32 + c4);
+        float4 eq = ldg4(table + (size_t)r * tab_ld + tcol + c4);
+        stg4(tab_a + r * 32 + c4, ek);
+        stg4(tab_b + r * 32 + c4, make_float4(eq.x * scale, eq.y * scale, eq.z * scale, eq.w * scale));
     }
     for (int i = tid; i < TP; i += NTHR) rowmap[i] = token_row(i);
     __syncthreads();
 
-    // ev goes to registers now (hidden behind phase 0), to LDS once ek is dead
-    float4 tv[TAB_IT ? TAB_IT : 1];
-    if (WIN) {
-#pragma unroll
-        for (int it = 0; it < TAB_IT; ++it) {
-            const int i = tid + it * NTHR;
-            if (i < R * 8) tv[it] = ldg4(table + (size_t)(i >> 3) * tab_ld + tcol + 64 + (i & 7) * 4);
-        }
-    }
     float kf[16], vf[16];
     auto load_k = [&](int kt, float *kd) {
         const float *p = qkv + (size_t)rowmap[32 * kt + qi] * ld + g.C + head * 32 + 16 * hi;
@@ -185,16 +151,8 @@ __global__ __launch_bounds__(64 * NKT) void window_attn_kernel(const float *__re
     load_v(0, vf);
     __syncthreads();
     // ek is dead: overwrite it with ev
-    if (WIN) {
-#pragma unroll
-        for (int it = 0; it < TAB_IT; ++it) {
-            const int i = tid + it * NTHR;
-            if (i < R * 8) stg4(tab_a + (i >> 3) * 32 + (i & 7) * 4, tv[it]);
-        }
-    } else {
-        for (int i = tid; i < R * 8; i += NTHR)
-            stg4(tab_a + (i >> 3) * 32 + (i & 7) * 4, ldg4(table + (size_t)(i >> 3) * tab_ld + tcol + 64 + (i & 7) * 4));
-    }
+    for (int i = tid; i < R * 8; i += NTHR)
+        stg4(tab_a + (i >> 3) * 32 + (i & 7) * 4, ldg4(table + (size_t)(i >> 3) * tab_ld + tcol + 64 + (i & 7) * 4));
     __syncthreads();
 
     // ---- phase 1: streaming softmax over the key tiles (flash style; S never leaves registers) ---------
@@ -667,14 +625,13 @@ static int launch_window_fast(const float *qkv, const float *table, const WinGeo
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return NMRF_ELAUNCH;
     }
-    static const size_t extra = getenv("NMRF_WA_EXTRA_LDS") ? (size_t)atoi(getenv("NMRF_WA_EXTRA_LDS")) : 0;   // probe only
     dim3 grid((g.Hp / WIN) * (g.Wp / WIN), g.heads, B);
-    hipLaunchKernelGGL((window_attn_fast_kernel<NKT, WIN, NL, OCC>), grid, dim3(64 * NKT), smem + extra, st, qkv, table, g,
+    hipLaunchKernelGGL((window_attn_fast_kernel<NKT, WIN, NL, OCC>), grid, dim3(64 * NKT), smem, st, qkv, table, g,
                        1.0f / sqrtf(32.0f), out, (unsigned long long *)nullptr);
     return nmrf_launch_status();
 }
 
-template <int NKT, int WIN, int NL>
+template <int NKT>
 static int launch_window(const float *qkv, const float *table, const WinGeom &g, int B, float *out, hipStream_t st) {
     const int TP = NKT * 32, W2 = g.win * g.win;
     size_t smem = (size_t)(2 * g.R * 32 + 2 * W2 * TP) * sizeof(float) + (size_t)TP * sizeof(int);
@@ -682,18 +639,18 @@ static int launch_window(const float *qkv, const float *table, const WinGeom &g,
     static bool attr_done = false;      // set once per instantiation, outside any stream capture
     if (smem > 64 * 1024 && !attr_done) {
         attr_done = true;
-        if (hipFuncSetAttribute((const void *)window_attn_kernel<NKT, WIN, NL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void *)window_attn_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem) != hipSuccess)
             return NMRF_ELAUNCH;
     }
     dim3 grid((g.Hp / g.win) * (g.Wp / g.win), g.heads, B);
-    hipLaunchKernelGGL((window_attn_kernel<NKT, WIN, NL>), grid, dim3(64 * NKT), smem, st, qkv, table, g,
+    hipLaunchKernelGGL((window_attn_kernel<NKT>), grid, dim3(64 * NKT), smem, st, qkv, table, g,
                        1.0f / sqrtf(32.0f), out);
     return nmrf_launch_status();
 }
 
 // Debug helper (not part of the public header): what the HIP runtime thinks the residency of the two fast
-// instantiations is, plus an optional extra dynamic-LDS pad (env NMRF_WA_EXTRA_LDS) to probe residency effects.
+// instantiations is (the census of nmrf_debug_window_timing shows what the hardware actually does).
 extern "C" int nmrf_debug_window_occupancy(int *blocks_infer, int *blocks_refine) {
     constexpr size_t s5 = (size_t)(2 * 121 * WA_TROW + 2 * 36 * 144 + 32) * 4 + 160 * 4;
     constexpr size_t s1 = (size_t)(2 * 49 * WA_TROW + 2 * 16 * 16 + 32) * 4 + 32 * 4;
@@ -729,12 +686,12 @@ extern "C" int nmrf_window_attn_f32(const float *qkv, const float *table, int B,
         if (win == 4 && N == 1) return launch_window_fast<1, 4, 1, 3>(qkv, table, g, B, out, st);   // refinement windows
     }
     switch (nkt) {                                                                         // any other configuration
-        case 1: return launch_window<1, 0, 0>(qkv, table, g, B, out, st);
-        case 2: return launch_window<2, 0, 0>(qkv, table, g, B, out, st);
-        case 3: return launch_window<3, 0, 0>(qkv, table, g, B, out, st);
-        case 4: return launch_window<4, 0, 0>(qkv, table, g, B, out, st);
-        case 5: return launch_window<5, 0, 0>(qkv, table, g, B, out, st);
-        case 6: return launch_window<6, 0, 0>(qkv, table, g, B, out, st);
+        case 1: return launch_window<1>(qkv, table, g, B, out, st);
+        case 2: return launch_window<2>(qkv, table, g, B, out, st);
+        case 3: return launch_window<3>(qkv, table, g, B, out, st);
+        case 4: return launch_window<4>(qkv, table, g, B, out, st);
+        case 5: return launch_window<5>(qkv, table, g, B, out, st);
+        case 6: return launch_window<6>(qkv, table, g, B, out, st);
         default: return NMRF_EINVAL;
     }
 }
