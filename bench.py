@@ -224,7 +224,7 @@ def main():
                   "window_attn_w%d_n%d" % (win, n): "window_attn_kernel<%d> (inference windows, A10)" % ((tw + 31) // 32)}
     # HBM bytes per launch from the separate rocprofv3 --pmc passes (tools/gpu_pmc.sh -> profiles/pmc_traffic.json)
     pmc_names = {"stripe_attn_horizontal": "stripe_attn_kernel<1, 2, 4, false>",
-                 "window_attn_w%d_n%d" % (win, n): "window_attn_fast_kernel<5, 6, 4, 2, false>"}
+                 "window_attn_w%d_n%d" % (win, n): "window_attn_fast_kernel<5, 6, 4, 2, 3, false>"}
     pmc = {}
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:

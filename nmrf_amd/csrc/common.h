@@ -9,6 +9,10 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// packed FMA (v_pk_fma_f32): a plain v_fma_f32 costs the same issue slot for half the work
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 static inline int nmrf_launch_status() {
     return hipGetLastError() == hipSuccess ? NMRF_OK : NMRF_ELAUNCH;

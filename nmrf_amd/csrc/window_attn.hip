@@ -284,61 +284,84 @@ __global__ __launch_bounds__(64 * NKT) void window_attn_kernel(const float *__re
 
 
 // =================================================================================================
-// Fast path for the shipped configurations (compile-time window size WIN and labels-per-pixel NL,
-// NL in {1,2,4}).  Same algorithm as above, restructured after the round-1 PMC profile
-// (profiles/r01_pmc_attention_kernels.txt: 7.5k VALU instructions and 117k cycles per wave, 1 block/CU
-// because of 256 VGPRs, 52 % of LDS cycles lost to bank conflicts):
-//   * <=168 VGPRs so two 5-wave blocks fit a CU; masks only where they can fire (sibling mask on the
-//     diagonal tile, out-of-window keys on the last tile, shift regions on border windows) behind
-//     wave-uniform branches; KR stored transposed so one ds_read_b128 fetches a key quad; table rows
-//     XOR-swizzled in 16-byte chunks (conflict-free b128 reads without padding, 73 KB of LDS per block); exp2 with log2(e) folded into the q / eq scales.
+// Fast path for the shipped configurations (compile-time window size WIN and labels per pixel NL in
+// {1,2,4}).  Same algorithm as the generic kernel, restructured after the round-1 profiles
+// (profiles/r01_pmc_attention_kernels_*.txt, tools/kernel_bench.py --which timing):
+//   * WPB windows of the same head per block, NKT waves each, sharing the staged tables.  The census showed
+//     that a 5-wave block never shares a CU with a second one (two waves land on one SIMD), so two windows
+//     are put into ONE 10-wave block at <=168 VGPRs (6x6x4), and eight one-wave windows into one 8-wave
+//     block (4x4x1, tables staged once instead of eight times).
+//   * masks only where they can fire (sibling mask on the diagonal tile, out-of-window keys on the last
+//     tile, shift regions on border windows), behind wave-uniform branches;
+//   * KR stored transposed (one ds_read_b128 per key quad); table rows XOR-swizzled in 16-byte chunks
+//     (conflict-free b128 reads, no padding); exp2 with log2(e) folded into the q / eq scales;
+//   * half-wave exchanges by v_permlane32_swap (no ds_bpermute); the value-embedding accumulator is kept
+//     in the O^T register layout (16 channels per lane, both pixels of a quad pair after one swap of the
+//     pixel probabilities), so no cross-half reduction is left at the end;
+//   * the scaled Q fragment lives in LDS when NKT > 1 (16 VGPRs less across the tile loop).
 // =================================================================================================
 #define WA_TROW 32                         // floats per staged table row; 16-byte chunks are XOR-swizzled by (row & 7)
 #define WA_LOG2E 1.4426950408889634f
 
-// TIMED: debug instantiation that writes s_memtime stamps per wave (nmrf_debug_window_timing); never used in production.
-#define WA_STAMP(k) do { if (TIMED && lane == 0 && blockIdx.y == 0 && blockIdx.x < 64) \
-        stamps[((size_t)blockIdx.x * NKT + wv) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-// census record of every block (wave 0): [smid, realtime start, realtime end] after the 64*NKT*16 stamp words
-#define WA_CENSUS(k, v) do { if (TIMED && tid == 0) \
-        stamps[(size_t)64 * NKT * 16 + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 3 + (k)] = (v); } while (0)
+template <int NKT, int WIN, int NL, int WPB>
+struct WinFastLds {
+    static constexpr int W2 = WIN * WIN;
+    static constexpr int R = (2 * WIN - 1) * (2 * WIN - 1);
+    static constexpr int Tw = W2 * NL;
+    static constexpr int TS = (Tw + 3) / 4 * 4;           // token stride of the QR^T / KR^T rows
+    static constexpr int TP = NKT * 32;
+    static constexpr bool QLDS = NKT > 1;
+    static constexpr int SLOT = 2 * W2 * TS + 32 + (QLDS ? NKT * 16 * 64 : 0) + TP;   // floats per window slot
+    static constexpr size_t BYTES = (size_t)(2 * R * WA_TROW + WPB * SLOT) * 4;
+};
 
-template <int NKT, int WIN, int NL, int OCC, bool TIMED = false>
-__global__ __launch_bounds__(64 * NKT, OCC) void window_attn_fast_kernel(const float *__restrict__ qkv,
+// TIMED: debug instantiation writing s_memtime stamps per wave and a per-block census (nmrf_debug_window_timing).
+#define WA_STAMP(k) do { if (TIMED && lane == 0 && blockIdx.y == 0 && blockIdx.x < 64) \
+        stamps[((size_t)blockIdx.x * NKT * WPB + wv) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define WA_CENSUS(k, v) do { if (TIMED && tid == 0) \
+        stamps[(size_t)64 * NKT * WPB * 16 + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 3 + (k)] = (v); } while (0)
+
+template <int NKT, int WIN, int NL, int WPB, int OCC, bool TIMED = false>
+__global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(const float *__restrict__ qkv,
         const float *__restrict__ table, WinGeom g, float scale, float *__restrict__ out,
         unsigned long long *__restrict__ stamps = nullptr) {
-    constexpr int TP = NKT * 32;
-    constexpr int NTHR = 64 * NKT;
-    constexpr int W2 = WIN * WIN;
+    using L = WinFastLds<NKT, WIN, NL, WPB>;
+    constexpr int TP = L::TP, W2 = L::W2, R = L::R, Tw = L::Tw, TS = L::TS;
+    constexpr int NTHR = 64 * NKT * WPB;
     constexpr int SPAN = 2 * WIN - 1;
-    constexpr int R = SPAN * SPAN;
-    constexpr int Tw = W2 * NL;
     constexpr int TAB_IT = (R * 8 + NTHR - 1) / NTHR;
-    constexpr int TS = (Tw + 3) / 4 * 4;          // token stride of the QR^T / KR^T rows (no 32-padding)
     constexpr int PPQ = 4 / NL;                    // pixels per register quad (4 consecutive keys)
+    constexpr bool QLDS = L::QLDS;
     static_assert(NL == 1 || NL == 2 || NL == 4, "fast path: labels per pixel must divide 4");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *tab_a = smem;                            // ek [R][36]   (later: ev)
-    float *tab_b = tab_a + R * WA_TROW;             // eq*s*log2e [R][36]
-    float *qrt = tab_b + R * WA_TROW;               // [W2][TS]   QR^T : [key pixel][query token]
-    float *krt = qrt + W2 * TS;                     // [W2][TS+]  KR^T : [query pixel][key token] (+32 floats of slack:
-    //                                                  the last tile's quad reads may run past Tw; those keys are masked)
-    unsigned *rowoff = reinterpret_cast<unsigned *>(krt + W2 * TS + 32);   // [TP] element offset of window token i in qkv
+    float *tab_a = smem;                            // ek [R][32]   (later: ev), swizzled
+    float *tab_b = tab_a + R * WA_TROW;             // eq*s*log2e [R][32], swizzled
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
+    const int slot = wv / NKT, qt = wv - slot * NKT;   // window slot of the block, query tile inside the window
     const int qi = lane & 31, hi = lane >> 5;
-    const int nwx = g.Wp / WIN;
-    const int wj = blockIdx.x % nwx, wi = blockIdx.x / nwx;
+    float *slot_mem = tab_b + R * WA_TROW + slot * L::SLOT;
+    float *qrt = slot_mem;                          // [W2][TS]   QR^T : [key pixel][query token]
+    float *krt = qrt + W2 * TS;                     // [W2][TS]+32 KR^T : [query pixel][key token]; the last tile's quad
+    //                                                 reads may run past Tw (those keys are masked)
+    float *qsc = krt + W2 * TS + 32;                // [NKT][4][64] float4: scaled Q fragments (QLDS only)
+    unsigned *rowoff = reinterpret_cast<unsigned *>(qsc + (QLDS ? NKT * 16 * 64 : 0));   // [TP]
+
+    const int nwx = g.Wp / WIN, nwin = nwx * (g.Hp / WIN);
+    const int win_raw = blockIdx.x * WPB + slot;
+    const bool win_ok = win_raw < nwin;             // wave-uniform; idle slots keep running (barriers) on window 0
+    const int widx = win_ok ? win_raw : 0;
+    const int wj = widx % nwx, wi = widx / nwx;
     const int head = blockIdx.y, bimg = blockIdx.z;
     const unsigned ld = 3u * g.C;
     const int tab_ld = 3 * g.C;
-    const int tcol = head * 96;
+    const int tcol = head * 96;                     // per head: [eq(32) | ek(32) | ev(32)]  (NMP.py:257-260)
     const float sc2 = scale * WA_LOG2E;
 
     auto token_row = [&](int i) -> unsigned {
-        int ii = i < Tw ? i : Tw - 1;
+        int ii = i < Tw ? i : Tw - 1;               // padded tokens alias the last real one (always masked)
         int pt = ii / NL, n = ii - pt * NL;
         int a = pt / WIN, b = pt - a * WIN;
         int Y = wi * WIN + a + g.shift, X = wj * WIN + b + g.shift;
@@ -350,8 +373,8 @@ __global__ __launch_bounds__(64 * NKT, OCC) void window_attn_fast_kernel(const f
     WA_STAMP(0);
     WA_CENSUS(0, (unsigned long long)__smid());
     WA_CENSUS(1, wall_clock64());
-    // ---- earliest load: phase-0 operand (q or k of token 32w+qi) ---------------------------------------
-    const int tok = 32 * wv + qi;
+    // ---- earliest load: phase-0 operand (q or k of token 32*qt+qi) --------------------------------------
+    const int tok = 32 * qt + qi;
     const bool tok_ok = tok < Tw;
     const int tokc = tok_ok ? tok : Tw - 1;
     const unsigned trow = token_row(tokc);
@@ -380,14 +403,14 @@ __global__ __launch_bounds__(64 * NKT, OCC) void window_attn_fast_kernel(const f
         for (int it = 0; it < TAB_IT; ++it) {
             const int i = tid + it * NTHR;
             if (i < R * 8) {
-                const int r = i >> 3, c4 = (i & 7) * 4;
+                const int r = i >> 3;
                 const int sw = (((i & 7) ^ (r & 7)) << 2);
                 stg4(tab_a + r * WA_TROW + sw, te[it]);
                 stg4(tab_b + r * WA_TROW + sw, make_float4(tq[it].x * sc2, tq[it].y * sc2, tq[it].z * sc2, tq[it].w * sc2));
             }
         }
     }
-    for (int i = tid; i < TP; i += NTHR) rowoff[i] = token_row(i) * ld;
+    for (int i = tid - slot * NKT * 64; i < TP; i += NKT * 64) rowoff[i] = token_row(i) * ld;   // by the slot's own waves
     WA_STAMP(1);
     __syncthreads();
     WA_STAMP(2);
@@ -398,6 +421,17 @@ __global__ __launch_bounds__(64 * NKT, OCC) void window_attn_fast_kernel(const f
     for (int it = 0; it < TAB_IT; ++it) {
         const int i = tid + it * NTHR;
         if (i < R * 8) tv[it] = ldg4(table + (size_t)(i >> 3) * tab_ld + tcol + 64 + (i & 7) * 4);
+    }
+    // scaled Q fragment of this wave: lane (qi,hi) holds Q[tok][16*hi + s] * s * log2(e)
+    float qf[16];
+    {
+        const float *p = qkv + (size_t)trow * ld + head * 32 + 16 * hi;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float4 v = ldg4(p + 4 * c);
+            qf[4 * c + 0] = v.x * sc2; qf[4 * c + 1] = v.y * sc2; qf[4 * c + 2] = v.z * sc2; qf[4 * c + 3] = v.w * sc2;
+            if (QLDS) stg4(qsc + ((qt * 4 + c) * 64 + lane) * 4, make_float4(qf[4 * c], qf[4 * c + 1], qf[4 * c + 2], qf[4 * c + 3]));
+        }
     }
 
     // ---- phase 0: relative-position logit terms (log2 domain) -------------------------------------------
@@ -419,33 +453,22 @@ __global__ __launch_bounds__(64 * NKT, OCC) void window_attn_fast_kernel(const f
                 const int rr = rrow + db;
                 const float *e = tab + rr * WA_TROW;
                 const int sx = rr & 7;
-                float s0 = 0.f, s1 = 0.f;
+                f32x2 s0 = {0.f, 0.f}, s1 = {0.f, 0.f};           // two packed accumulators: 16 v_pk_fma_f32 per dot
 #pragma unroll
-                for (int c = 0; c < 8; c += 2) {
-                    float4 t0 = *reinterpret_cast<const float4 *>(e + ((c ^ sx) << 2));
-                    float4 t1 = *reinterpret_cast<const float4 *>(e + (((c + 1) ^ sx) << 2));
-                    s0 = fmaf(vec[4 * c + 0], t0.x, s0); s0 = fmaf(vec[4 * c + 1], t0.y, s0);
-                    s0 = fmaf(vec[4 * c + 2], t0.z, s0); s0 = fmaf(vec[4 * c + 3], t0.w, s0);
-                    s1 = fmaf(vec[4 * c + 4], t1.x, s1); s1 = fmaf(vec[4 * c + 5], t1.y, s1);
-                    s1 = fmaf(vec[4 * c + 6], t1.z, s1); s1 = fmaf(vec[4 * c + 7], t1.w, s1);
+                for (int c = 0; c < 8; ++c) {
+                    const float4 t = *reinterpret_cast<const float4 *>(e + ((c ^ sx) << 2));
+                    s0 = pk_fma(f32x2{vec[4 * c + 0], vec[4 * c + 1]}, f32x2{t.x, t.y}, s0);
+                    s1 = pk_fma(f32x2{vec[4 * c + 2], vec[4 * c + 3]}, f32x2{t.z, t.w}, s1);
                 }
-                dst[(aj * WIN + bj) * TS] = s0 + s1;
+                dst[(aj * WIN + bj) * TS] = (s0.x + s1.x) + (s0.y + s1.y);
             }
         }
     }
     WA_STAMP(3);
-    // Q fragment and the first K / V fragments: their latency overlaps the barrier and the ev stores
+    // first K fragment: its latency overlaps the barrier and the ev stores
     const float *kbase = qkv + g.C + head * 32 + 16 * hi;
     const float *vbase = qkv + 2 * g.C + head * 32 + qi;
-    float qf[16], kf[16], vf[16];
-    {
-        const float *p = qkv + (size_t)trow * ld + head * 32 + 16 * hi;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float4 v = ldg4(p + 4 * c);
-            qf[4 * c + 0] = v.x * sc2; qf[4 * c + 1] = v.y * sc2; qf[4 * c + 2] = v.z * sc2; qf[4 * c + 3] = v.w * sc2;
-        }
-    }
+    float kf[16], vf[16];
     auto load_k = [&](int kt, float *kd) {
         const float *p = kbase + rowoff[32 * kt + qi];
 #pragma unroll
@@ -459,7 +482,6 @@ __global__ __launch_bounds__(64 * NKT, OCC) void window_attn_fast_kernel(const f
         for (int s = 0; s < 16; ++s) vd[s] = vbase[rowoff[32 * kt + mfma_row(s, hi)]];
     };
     load_k(0, kf);
-    load_v(0, vf);
     __syncthreads();
     WA_STAMP(4);
 #pragma unroll
@@ -473,22 +495,22 @@ __global__ __launch_bounds__(64 * NKT, OCC) void window_attn_fast_kernel(const f
     // ---- phase 1 ---------------------------------------------------------------------------------------
     const int q_pix = tokc / NL;
     const int qa = q_pix / WIN, qb = q_pix - qa * WIN;
-    auto region = [&](int a, int b) -> int {
+    auto region = [&](int a, int b) -> int {       // Swin shift regions on the rolled grid (NMP.py:211-239)
         int Yr = wi * WIN + a, Xr = wj * WIN + b;
         int fy = Yr < g.Hp - WIN ? 0 : (Yr < g.Hp - g.shift ? 1 : 2);
         int fx = Xr < g.Wp - WIN ? 0 : (Xr < g.Wp - g.shift ? 1 : 2);
         return fy * 3 + fx;
     };
-    const bool need_shift = g.shift && (wi == g.Hp / WIN - 1 || wj == nwx - 1);     // block-uniform
+    const bool need_shift = g.shift && (wi == g.Hp / WIN - 1 || wj == nwx - 1);     // wave-uniform
     const int q_reg = need_shift ? region(qa, qb) : 0;
     const bool sib = g.sibling && NL > 1;
 
-    f32x16 acc_o;
+    f32x16 acc_o;                                   // O^T[d = mfma_row(r,hi)][q] from the MFMAs
+    f32x2 oe[8];                                    // value-embedding term in the SAME layout (register pairs)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc_o[r] = 0.f;
-    float oe[32];
 #pragma unroll
-    for (int d = 0; d < 32; ++d) oe[d] = 0.f;
+    for (int r = 0; r < 8; ++r) oe[r] = f32x2{0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
     const float *qrt_q = qrt + tokc;
     const float *krt_q = krt + q_pix * TS;
@@ -497,6 +519,16 @@ __global__ __launch_bounds__(64 * NKT, OCC) void window_attn_fast_kernel(const f
 #pragma unroll 1
     for (int kt = 0; kt < NKT; ++kt) {
         const int k0 = 32 * kt;
+        load_v(kt, vf);                             // needed only after S^T + softmax (~1.5k cycles from here); the K
+        //                                             fragment of the NEXT tile is fetched right after this tile's S^T, so
+        //                                             only one of the two 16-register fragments is live during the ev term
+        if (QLDS) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float4 v = *reinterpret_cast<const float4 *>(qsc + ((qt * 4 + c) * 64 + lane) * 4);
+                qf[4 * c + 0] = v.x; qf[4 * c + 1] = v.y; qf[4 * c + 2] = v.z; qf[4 * c + 3] = v.w;
+            }
+        }
         f32x16 st;
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[r] = 0.f;
@@ -523,7 +555,7 @@ __global__ __launch_bounds__(64 * NKT, OCC) void window_attn_fast_kernel(const f
             for (int r = 0; r < 16; ++r)
                 if (k0 + mfma_row(r, hi) >= Tw) st[r] = -INFINITY;
         }
-        if (sib && kt == wv) {                                                // sibling labels of the query's own pixel
+        if (sib && kt == qt) {                                                // sibling labels of the query's own pixel
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = k0 + mfma_row(r, hi);
@@ -561,49 +593,49 @@ __global__ __launch_bounds__(64 * NKT, OCC) void window_attn_fast_kernel(const f
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc_o[r] *= alpha;
 #pragma unroll
-        for (int d = 0; d < 32; ++d) oe[d] *= alpha;
+        for (int r = 0; r < 8; ++r) oe[r] *= alpha;
 #pragma unroll
         for (int s = 0; s < 16; ++s) acc_o = mfma32(vf[s], st[s], acc_o);
-        if (kt + 1 < NKT) load_v(kt + 1, vf);
-        // value-embedding term: sum over key PIXELS of (sum_n p) * ev[rel(pq,pk)]
+        // value-embedding term: sum over key PIXELS of (sum_n p) * ev[rel(pq,pk)].  The two half-lanes of a query
+        // swap the probabilities of their pixels, then each accumulates BOTH pixels for its own 16 channels.
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
-            if (kt == NKT - 1 && 32 * (NKT - 1) + 8 * rq >= Tw) continue;     // quad entirely beyond the window
+            if (kt == NKT - 1 && 32 * (NKT - 1) + 8 * rq >= Tw) continue;     // quad pair entirely beyond the window
 #pragma unroll
             for (int pp = 0; pp < PPQ; ++pp) {
-                int pk = (k0 + 8 * rq + 4 * hi) / NL + pp;
-                pk = pk < W2 ? pk : W2 - 1;
-                const int ka = pk / WIN, kb = pk - ka * WIN;
-                float ps = st[4 * rq + pp * NL];
+                float p0 = st[4 * rq + pp * NL];
 #pragma unroll
-                for (int e = 1; e < NL; ++e) ps += st[4 * rq + pp * NL + e];
-                const int rr = ev_r0 - (ka * SPAN + kb);
-                const float *e = tab_a + rr * WA_TROW;
-                const int sx = rr & 7;
+                for (int e = 1; e < NL; ++e) p0 += st[4 * rq + pp * NL + e];
+                float p1 = p0;
+                half_swap(p0, p1);                 // p0 = probability mass of the hi=0 lane's pixel, p1 = of the hi=1 lane's
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    float4 t = *reinterpret_cast<const float4 *>(e + ((c ^ sx) << 2));
-                    oe[4 * c + 0] = fmaf(ps, t.x, oe[4 * c + 0]); oe[4 * c + 1] = fmaf(ps, t.y, oe[4 * c + 1]);
-                    oe[4 * c + 2] = fmaf(ps, t.z, oe[4 * c + 2]); oe[4 * c + 3] = fmaf(ps, t.w, oe[4 * c + 3]);
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    int pk = (k0 + 8 * rq + 4 * h2) / NL + pp;
+                    pk = pk < W2 ? pk : W2 - 1;
+                    const int ka = pk / WIN, kb = pk - ka * WIN;
+                    const int rr = ev_r0 - (ka * SPAN + kb);
+                    const float *e = tab_a + rr * WA_TROW;
+                    const int sx = rr & 7;
+                    const float psv = h2 ? p1 : p0;
+                    const f32x2 ps = {psv, psv};
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {               // channels 8*gq + 4*hi .. +3  = O^T registers 4*gq .. 4*gq+3
+                        const float4 t = *reinterpret_cast<const float4 *>(e + (((2 * gq + hi) ^ sx) << 2));
+                        oe[2 * gq + 0] = pk_fma(ps, f32x2{t.x, t.y}, oe[2 * gq + 0]);
+                        oe[2 * gq + 1] = pk_fma(ps, f32x2{t.z, t.w}, oe[2 * gq + 1]);
+                    }
                 }
             }
         }
         WA_STAMP(6 + kt);
     }
-    const float l_tot = half_sum(l_run);
-    const float inv_l = 1.0f / l_tot;
-    // lane (q,hi) owns channels d = mfma_row(r,hi) = d0 + 4*hi; one permlane swap of (oe[d0], oe[d0+4]) leaves
-    // {own, partner's} value of exactly that channel in the two registers of every lane
+    const float inv_l = 1.0f / half_sum(l_run);
     float res[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float a = oe[mfma_row(r, 0)], b = oe[mfma_row(r, 1)];
-        half_swap(a, b);
-        res[r] = (acc_o[r] + (a + b)) * inv_l;
-    }
+    for (int r = 0; r < 16; ++r) res[r] = (acc_o[r] + ((r & 1) ? oe[r >> 1].y : oe[r >> 1].x)) * inv_l;
     if (TIMED) asm volatile("" :: "v"(res[0]), "v"(res[15]));
     WA_STAMP(6 + NKT);
-    if (!tok_ok) return;
+    if (!tok_ok || !win_ok) return;
     float *op = out + (size_t)trow * g.C + head * 32;
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
@@ -612,22 +644,21 @@ __global__ __launch_bounds__(64 * NKT, OCC) void window_attn_fast_kernel(const f
     WA_CENSUS(2, wall_clock64());
 }
 
-template <int NKT, int WIN, int NL, int OCC>
+template <int NKT, int WIN, int NL, int WPB, int OCC>
 static int launch_window_fast(const float *qkv, const float *table, const WinGeom &g, int B, float *out, hipStream_t st) {
-    constexpr int TP = NKT * 32, W2 = WIN * WIN, R = (2 * WIN - 1) * (2 * WIN - 1);
-    constexpr int TS = (W2 * NL + 3) / 4 * 4;
-    constexpr size_t smem = (size_t)(2 * R * WA_TROW + 2 * W2 * TS + 32) * sizeof(float) + (size_t)TP * sizeof(unsigned);
-    static_assert(smem <= 76 * 1024, "two blocks must fit the 160 KiB LDS of a CU with slack");
+    using L = WinFastLds<NKT, WIN, NL, WPB>;
+    static_assert(L::BYTES <= 160 * 1024, "LDS budget of one CU");
     static bool attr_done = false;      // set once per instantiation, outside any stream capture
-    if (smem > 64 * 1024 && !attr_done) {
+    if (L::BYTES > 64 * 1024 && !attr_done) {
         attr_done = true;
-        if (hipFuncSetAttribute((const void *)window_attn_fast_kernel<NKT, WIN, NL, OCC>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)window_attn_fast_kernel<NKT, WIN, NL, WPB, OCC>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES) != hipSuccess)
             return NMRF_ELAUNCH;
     }
-    dim3 grid((g.Hp / WIN) * (g.Wp / WIN), g.heads, B);
-    hipLaunchKernelGGL((window_attn_fast_kernel<NKT, WIN, NL, OCC>), grid, dim3(64 * NKT), smem, st, qkv, table, g,
-                       1.0f / sqrtf(32.0f), out, (unsigned long long *)nullptr);
+    const int nwin = (g.Hp / WIN) * (g.Wp / WIN);
+    dim3 grid((nwin + WPB - 1) / WPB, g.heads, B);
+    hipLaunchKernelGGL((window_attn_fast_kernel<NKT, WIN, NL, WPB, OCC>), grid, dim3(64 * NKT * WPB), L::BYTES, st, qkv, table,
+                       g, 1.0f / sqrtf(32.0f), out, (unsigned long long *)nullptr);
     return nmrf_launch_status();
 }
 
@@ -652,22 +683,24 @@ static int launch_window(const float *qkv, const float *table, const WinGeom &g,
 // Debug helper (not part of the public header): what the HIP runtime thinks the residency of the two fast
 // instantiations is (the census of nmrf_debug_window_timing shows what the hardware actually does).
 extern "C" int nmrf_debug_window_occupancy(int *blocks_infer, int *blocks_refine) {
-    constexpr size_t s5 = (size_t)(2 * 121 * WA_TROW + 2 * 36 * 144 + 32) * 4 + 160 * 4;
-    constexpr size_t s1 = (size_t)(2 * 49 * WA_TROW + 2 * 16 * 16 + 32) * 4 + 32 * 4;
-    hipFuncSetAttribute((const void *)window_attn_fast_kernel<5, 6, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s5);
-    hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_infer, window_attn_fast_kernel<5, 6, 4, 2>, 320, s5);
-    hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_refine, window_attn_fast_kernel<1, 4, 1, 3>, 64, s1);
+    using L5 = WinFastLds<5, 6, 4, 2>;
+    using L1 = WinFastLds<1, 4, 1, 8>;
+    hipFuncSetAttribute((const void *)window_attn_fast_kernel<5, 6, 4, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L5::BYTES);
+    hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_infer, window_attn_fast_kernel<5, 6, 4, 2, 3>, 640, L5::BYTES);
+    hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_refine, window_attn_fast_kernel<1, 4, 1, 8, 2>, 512, L1::BYTES);
     return (e1 == hipSuccess && e2 == hipSuccess) ? 0 : -2;
 }
 
-// Debug: instrumented run of the 6x6x4 kernel; stamps [64 blocks][5 waves][16] of s_memtime values (device buffer).
+// Debug: instrumented run of the 6x6x4 kernel; stamps [64 blocks][10 waves][16] of s_memtime values followed by the
+// census [blocks][3] (device buffer).
 extern "C" int nmrf_debug_window_timing(const float *qkv, const float *table, int B, int Hp, int Wp, int shift, float *out,
                                         unsigned long long *stamps, void *stream) {
+    using L = WinFastLds<5, 6, 4, 2>;
     WinGeom g{Hp, Wp, 4, 128, 4, 6, shift, 1, 144, 121};
-    constexpr size_t smem = (size_t)(2 * 121 * WA_TROW + 2 * 36 * 144 + 32) * 4 + 160 * 4;
-    hipFuncSetAttribute((const void *)window_attn_fast_kernel<5, 6, 4, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    dim3 grid((Hp / 6) * (Wp / 6), 4, B);
-    hipLaunchKernelGGL((window_attn_fast_kernel<5, 6, 4, 2, true>), grid, dim3(320), smem, (hipStream_t)stream, qkv, table, g,
+    hipFuncSetAttribute((const void *)window_attn_fast_kernel<5, 6, 4, 2, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES);
+    const int nwin = (Hp / 6) * (Wp / 6);
+    dim3 grid((nwin + 1) / 2, 4, B);
+    hipLaunchKernelGGL((window_attn_fast_kernel<5, 6, 4, 2, 3, true>), grid, dim3(640), L::BYTES, (hipStream_t)stream, qkv, table, g,
                        1.0f / sqrtf(32.0f), out, stamps);
     return nmrf_launch_status();
 }
@@ -682,8 +715,8 @@ extern "C" int nmrf_window_attn_f32(const float *qkv, const float *table, int B,
     const int nkt = (g.Tw + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
     if ((int64_t)B * Hp * Wp * N * 3 * C < ((int64_t)1 << 32)) {                            // 32-bit element offsets
-        if (win == 6 && N == 4) return launch_window_fast<5, 6, 4, 2>(qkv, table, g, B, out, st);   // inference windows
-        if (win == 4 && N == 1) return launch_window_fast<1, 4, 1, 3>(qkv, table, g, B, out, st);   // refinement windows
+        if (win == 6 && N == 4) return launch_window_fast<5, 6, 4, 2, 3>(qkv, table, g, B, out, st);   // inference windows
+        if (win == 4 && N == 1) return launch_window_fast<1, 4, 1, 8, 2>(qkv, table, g, B, out, st);   // refinement windows
     }
     switch (nkt) {                                                                         // any other configuration
         case 1: return launch_window<1>(qkv, table, g, B, out, st);

@@ -144,12 +144,16 @@ def test_driver_pipeline_matches_direct_calls():
     pairs = [(i,) + synthetic_pair(64, 104, seed=50 + i)[:2] for i in range(5)]
     got = dict(StereoStream(model, DEV, batch=2).run(iter(pairs)))
     assert list(got) == [0, 1, 2, 3, 4]
-    with torch.no_grad():                                   # same batch composition -> identical arithmetic
+    # same batch composition -> same arithmetic in every hand-written kernel (tools/determinism_check.py: bit-identical
+    # run to run); MIOpen's solver for the tiny 8x13 coarse convs is not (1e-6 run-to-run noise on identical inputs,
+    # tools/determinism_trace.py), which the layers above amplify to <1e-3 px.  Different pairs differ by whole pixels.
+    with torch.no_grad():
         for grp in ([0, 1], [2, 3], [4]):
             want = model({"img1": torch.stack([pairs[i][1] for i in grp]),
                           "img2": torch.stack([pairs[i][2] for i in grp])})["disp"].cpu()
             for j, i in enumerate(grp):
-                assert torch.equal(got[i], want[j]), i
+                assert float((got[i] - want[j]).abs().max()) < 5e-3, i
+                assert all(float((got[i] - got[k]).abs().mean()) > 0.1 for k in got if k != i)
 
 
 def test_middlebury_half_res_size_runs():

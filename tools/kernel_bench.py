@@ -70,14 +70,15 @@ if "timing" in which:
     qkv, table = mk("q", b * hp * wp * n, 384), mk("t", 121, 384)
     out = torch.empty(b * hp * wp * n, 128, device=dev)
     nblk = (hp // 6) * (wp // 6) * 4 * b
-    stamps = torch.zeros(64 * 5 * 16 + nblk * 3, dtype=torch.int64, device=dev)
+    nblk = ((hp // 6) * (wp // 6) + 1) // 2 * 4 * b          # two windows per block
+    stamps = torch.zeros(64 * 10 * 16 + nblk * 3, dtype=torch.int64, device=dev)
     for _ in range(3):
         _l.nmrf_debug_window_timing(ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(table.data_ptr()), b, hp, wp, 0,
                                     ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(stamps.data_ptr()), None)
     torch.cuda.synchronize()
     allst = stamps.cpu().numpy().astype(np.int64)
-    st = allst[:64 * 5 * 16].reshape(64, 5, 16)
-    cen = allst[64 * 5 * 16:].reshape(nblk, 3)
+    st = allst[:64 * 10 * 16].reshape(64, 10, 16)[:, :5]
+    cen = allst[64 * 10 * 16:].reshape(nblk, 3)
     names = ["vec+tables issued", "barrier1 wait", "ev issue+phase0", "q/k/v issue+barrier2", "ev store+barrier3",
              "tile0", "tile1", "tile2", "tile3", "tile4", "normalise+exchange", "stores"]
     d = np.diff(st[:, :, :13], axis=2)
