@@ -190,6 +190,116 @@ extern "C" int nmrf_selftest_mfma_f32(const float *A, const float *Bm, int K, fl
     return nmrf_launch_status();
 }
 
+// Debug: attainable v_mfma_f32_32x32x2_f32 rate (tools/kernel_bench.py --which mfma_peak).  CHAINS independent accumulator
+// chains per wave, `iters` x 16 MFMAs each; out receives one value per thread so nothing is optimised away.
+template <int CHAINS>
+__global__ __launch_bounds__(256, 2) void mfma_peak_kernel(int iters, float *__restrict__ out) {
+    f32x16 acc[CHAINS];
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    float a = (float)threadIdx.x * 1e-3f, b = (float)blockIdx.x * 1e-4f + 1.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int c = 0; c < CHAINS; ++c) acc[c] = mfma32(a, b, acc[c]);
+        a += 1e-6f;
+    }
+    float r = 0.f;
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) r += acc[c][0] + acc[c][15];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
+// Debug: the streaming-softmax tile loop of the attention kernels with the operands held in registers (no memory
+// traffic at all) -- the issue-structure ceiling of that loop at a given number of waves per SIMD.
+// VARIANT 0: S chain, softmax, PV chain (as in stripe_attn.hip).  VARIANT 1: two query-independent tiles interleaved
+// (S of tile B issued before the softmax of tile A) so a lone wave has MFMA work in flight during its VALU phase.
+template <int VARIANT>
+__global__ __launch_bounds__(256, 2) void attn_core_peak_kernel(int iters, const float *__restrict__ seed, float *__restrict__ out) {
+    float qf[16], kf[16], vf[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        qf[s] = seed[(threadIdx.x + s) & 255] * 0.1f; kf[s] = seed[(threadIdx.x * 3 + s) & 255]; vf[s] = seed[(threadIdx.x * 7 + s) & 255];
+    }
+    f32x16 acc_o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_o[r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    auto softmax = [&](f32x16 &st) {
+        float m_tile = st[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) m_tile = fmaxf(m_tile, st[r]);
+        m_tile = half_max(m_tile);
+        const float m_new = fmaxf(m_run, m_tile);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[r] = __builtin_amdgcn_exp2f(st[r] - m_new); psum += st[r]; }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_o[r] *= alpha;
+    };
+    if (VARIANT == 0) {
+        for (int it = 0; it < iters; ++it) {
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) st = mfma32(kf[s], qf[s], st);
+            softmax(st);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc_o = mfma32(vf[s], st[s], acc_o);
+            kf[it & 15] += 1e-7f;
+        }
+    } else {
+        f32x16 sa, sb;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sa[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) sa = mfma32(kf[s], qf[s], sa);
+        for (int it = 0; it < iters; it += 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sb[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) sb = mfma32(kf[s], qf[s], sb);       // S(B) in flight ...
+            softmax(sa);                                                       // ... during softmax(A)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc_o = mfma32(vf[s], sa[s], acc_o);
+            kf[it & 15] += 1e-7f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sa[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) sa = mfma32(kf[s], qf[s], sa);
+            softmax(sb);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc_o = mfma32(vf[s], sb[s], acc_o);
+        }
+    }
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = acc_o[0] + acc_o[15] + l_run;
+}
+
+extern "C" int nmrf_debug_attn_core_peak(int variant, int iters, int blocks, const float *seed, float *out, void *stream) {
+    if (!out || !seed) return NMRF_ENULL;
+    hipStream_t st = (hipStream_t)stream;
+    if (variant == 0) hipLaunchKernelGGL((attn_core_peak_kernel<0>), dim3(blocks), dim3(256), 0, st, iters, seed, out);
+    else hipLaunchKernelGGL((attn_core_peak_kernel<1>), dim3(blocks), dim3(256), 0, st, iters, seed, out);
+    return nmrf_launch_status();
+}
+
+extern "C" int nmrf_debug_mfma_peak(int chains, int iters, int blocks, float *out, void *stream) {
+    if (!out) return NMRF_ENULL;
+    hipStream_t st = (hipStream_t)stream;
+    if (chains == 1) hipLaunchKernelGGL((mfma_peak_kernel<1>), dim3(blocks), dim3(256), 0, st, iters, out);
+    else if (chains == 2) hipLaunchKernelGGL((mfma_peak_kernel<2>), dim3(blocks), dim3(256), 0, st, iters, out);
+    else if (chains == 4) hipLaunchKernelGGL((mfma_peak_kernel<4>), dim3(blocks), dim3(256), 0, st, iters, out);
+    else return NMRF_EINVAL;
+    return nmrf_launch_status();
+}
+
 extern "C" const char *nmrf_strerror(int code) {
     switch (code) {
         case NMRF_OK: return "ok";

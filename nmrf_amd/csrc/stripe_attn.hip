@@ -21,6 +21,8 @@
 // can fire (sibling mask on the diagonal tile, tail mask on the last tile); exp2 with log2(e) folded
 // into the q scale; the next K/V fragments are fetched while the current tile computes.
 #include "common.h"
+#include <type_traits>
+#include <stdlib.h>
 
 #define SA_TILE 32
 #define SA_LOG2E 1.4426950408889634f
@@ -30,6 +32,7 @@ struct StripeGeom {
     int L;                 // pixels per stripe
     int Ts;                // tokens per stripe = L*N
     int64_t pix_stride;    // token-pixel stride between consecutive stripe positions (W or 1)
+    int gx, gy, gz;        // logical grid: query-tile groups x (stripe, head) x image
 };
 
 // NSHIFT >= 0: N == 1<<NSHIFT at compile time (N=4 in every shipped config); NSHIFT < 0: runtime N
@@ -44,37 +47,58 @@ __device__ __forceinline__ int64_t stripe_row(const StripeGeom &g, int64_t base_
 }
 
 // CENSUS: debug instantiation recording [smid, realtime start, realtime end] of every block (nmrf_debug_stripe_census)
+//
+// __launch_bounds__(256, 3): with a register budget <= 256 the compiler keeps the MFMA accumulators in VGPRs; without the
+// occupancy hint it parks them in AGPRs and every `acc *= alpha` / softmax pass pays v_accvgpr_read/write round trips
+// (112 of them per key tile in the first version of this kernel).
 template <int AXIS, int NSHIFT, int KSPLIT, bool CENSUS = false>
-__global__ __launch_bounds__(256) void stripe_attn_kernel(const float *__restrict__ qkv, const float *__restrict__ lepe,
+__global__ __launch_bounds__(256, KSPLIT == 1 ? 2 : 3) void stripe_attn_kernel(const float *__restrict__ qkv, const float *__restrict__ lepe,
                                                          StripeGeom g, float scale, float *__restrict__ out,
                                                          unsigned long long *__restrict__ census = nullptr) {
     constexpr int QPB = 4 / KSPLIT;                           // query tiles per block
+    // XCD-aware block order.  Workgroups go round-robin over the 8 XCDs (linear id % 8), each with a private 4 MB L2.
+    // All query tiles of one (stripe, head) read the same K/V rows, so the logical work items are handed out in
+    // contiguous runs per XCD: with the natural order every XCD streamed the whole K/V set (15 MB at KITTI) through
+    // its L2 and the kernel re-fetched it from MALL/HBM (137 MB of traffic for 60 MB of tensors).
+    const int total = g.gx * g.gy * g.gz;
+    const int chunk = gridDim.x >> 3;                          // the launch pads the grid to a multiple of 8
+    const int item = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (item >= total) return;
+    const int bx = item % g.gx, by = (item / g.gx) % g.gy, bz = item / (g.gx * g.gy);
     struct Scope {
         unsigned long long *p;
-        __device__ Scope(unsigned long long *c) : p(c) {
+        __device__ Scope(unsigned long long *c, int item) : p(c) {
             if (CENSUS && threadIdx.x == 0) {
-                p = c + 3 * ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+                p = c + 3 * (size_t)item;
                 p[0] = __smid(); p[1] = wall_clock64();
             }
         }
         __device__ ~Scope() { if (CENSUS && threadIdx.x == 0) p[2] = wall_clock64(); }
-    } scope(census);
+    } scope(census, item);
+    // CENSUS also records s_memtime stamps [64 blocks][4 waves][16] behind the census triples (tools/kernel_bench.py)
+#define SA_STAMP(k) do { if (CENSUS && lane == 0 && by == 0 && bz == 0 && bx < 64) \
+        census[3 * (size_t)total + ((size_t)bx * 4 + wv) * 16 + (k)] = \
+            __builtin_amdgcn_s_memtime(); } while (0)
     __shared__ float s_o[KSPLIT > 1 ? 4 : 1][16][64];          // partial O^T of the non-leading key ranges
     __shared__ float s_ml[KSPLIT > 1 ? 4 : 1][2][64];          // their (m, l)
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int RB_PER = 4 / KSPLIT;                        // LePE channel blocks computed by each key-range wave
+    __shared__ float s_rpe[KSPLIT > 1 ? 4 : 1][4 * RB_PER][64];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: key loop + addresses on the SALU
     const int qi = lane & 31, hi = lane >> 5;
     const int qslot = wv / KSPLIT, ks = wv % KSPLIT;           // which query tile of the block, which key range
-    const int qt = blockIdx.x * QPB + qslot;
+    const int qt = bx * QPB + qslot;
     const int q0 = qt * SA_TILE;
     const bool wave_on = q0 < g.Ts;                            // wave-uniform
-    const int stripe = blockIdx.y >> 1, head = blockIdx.y & 1;
-    const int b = blockIdx.z;
+    const int stripe = by >> 1, head = by & 1;
+    const int b = bz;
     const int64_t base_pix = (AXIS == 0) ? ((int64_t)b * g.H * g.W + stripe)          // column x = stripe
                                          : ((int64_t)b * g.H * g.W + (int64_t)stripe * g.W);  // row y = stripe
-    const size_t ld = (size_t)3 * g.C;
+    constexpr size_t ld = 384;                                // 3*C; the entry point only admits C == 128
     const int coff = AXIS * (g.C / 2) + head * 32;            // channel offset of this (half, head) inside q / k / v
     const int nlab = NSHIFT >= 0 ? (1 << NSHIFT) : g.N;
 
+    SA_STAMP(0);
     const int qs = q0 + qi;
     const bool q_ok = qs < g.Ts;
     const int qsc = q_ok ? qs : g.Ts - 1;
@@ -103,11 +127,40 @@ __global__ __launch_bounds__(256) void stripe_attn_kernel(const float *__restric
         const int kt_begin = ks * per, kt_end = (kt_begin + per < n_kt) ? kt_begin + per : n_kt;
         const float *kbase = qkv + g.C + coff + 16 * hi;
         const float *vbase = qkv + 2 * g.C + coff + qi;
+        // N == 4: a key tile is 8 whole pixels, so the rows of a FULL tile sit at fixed offsets from one per-lane
+        // pointer that advances by `tile_step` per tile (the generic row arithmetic cost 68 v_mul_lo_u32 + 34
+        // v_mad_u64_u32 per tile -- more VALU issue than the softmax).  Only a ragged last tile takes the clamped path.
+        const int64_t ps = (AXIS == 1) ? (int64_t)1 : g.pix_stride;
+        const int64_t tile_step = 32 * ps * (int64_t)ld;        // floats per key tile: 8 pixels x 4 labels
+        const int64_t vj_step = 8 * ps * (int64_t)ld;           // two pixels: key k0 + 4*hi + 8*j + i
+        const float *kfast = kbase + ((base_pix + (int64_t)(qi >> 2) * ps) * 4 + (qi & 3)) * (int64_t)ld;
+        const float *vfast = vbase + ((base_pix + (int64_t)hi * ps) * 4) * (int64_t)ld;
+        auto tile_full = [&](int kt) { return NSHIFT == 2 && (kt + 1) * SA_TILE <= g.Ts; };   // wave-uniform
         // K fragment (A operand): lane (ki=qi, hi) holds K[k0+ki][16*hi + s]
+        auto load_k_fast = [&](int kt, float *kd) {
+            const float *p = kfast + (int64_t)kt * tile_step;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float4 v = ldg4(p + 4 * c);
+                kd[4 * c + 0] = v.x; kd[4 * c + 1] = v.y; kd[4 * c + 2] = v.z; kd[4 * c + 3] = v.w;
+            }
+        };
+        auto load_v_fast = [&](int kt, float *vd) {
+            const float *p = vfast + (int64_t)kt * tile_step;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) vd[4 * j + i] = p[j * vj_step + i * (int64_t)ld];
+        };
         auto load_k = [&](int kt, float *kd) {
-            int kk = kt * SA_TILE + qi;
-            kk = kk < g.Ts ? kk : g.Ts - 1;
-            const float *p = kbase + stripe_row<NSHIFT>(g, base_pix, kk) * ld;
+            const float *p;
+            if (tile_full(kt)) {
+                p = kfast + (int64_t)kt * tile_step;
+            } else {
+                int kk = kt * SA_TILE + qi;
+                kk = kk < g.Ts ? kk : g.Ts - 1;
+                p = kbase + stripe_row<NSHIFT>(g, base_pix, kk) * ld;
+            }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 float4 v = ldg4(p + 4 * c);
@@ -116,25 +169,39 @@ __global__ __launch_bounds__(256) void stripe_attn_kernel(const float *__restric
         };
         // V fragment (A operand of the 2nd product): lane (d=qi, hi), step s: V[k0+mfma_row(s,hi)][d]
         auto load_v = [&](int kt, float *vd) {
+            if (tile_full(kt)) {
+                load_v_fast(kt, vd);
+            } else {
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                int kv = kt * SA_TILE + mfma_row(s, hi);
-                kv = kv < g.Ts ? kv : g.Ts - 1;
-                vd[s] = vbase[stripe_row<NSHIFT>(g, base_pix, kv) * ld];
+                for (int s = 0; s < 16; ++s) {
+                    int kv = kt * SA_TILE + mfma_row(s, hi);
+                    kv = kv < g.Ts ? kv : g.Ts - 1;
+                    vd[s] = vbase[stripe_row<NSHIFT>(g, base_pix, kv) * ld];
+                }
             }
         };
-        float kf[16], vf[16];
-        if (kt_begin < kt_end) { load_k(kt_begin, kf); load_v(kt_begin, vf); }
-#pragma unroll 1
-        for (int kt = kt_begin; kt < kt_end; ++kt) {
+        // Two K/V register sets, each refilled in place for the tile two steps ahead: a fragment is requested ~1.6 tile
+        // times before its MFMAs (one tile time is ~1.3 us for a lone wave, less than a MALL/HBM round trip, so the
+        // single in-place buffer of the first version left every tile waiting on memory).
+        float kf0[16], vf0[16], kf1[16], vf1[16];
+        if (kt_begin < kt_end) { load_k(kt_begin, kf0); load_v(kt_begin, vf0); }
+        if (kt_begin + 1 < kt_end) { load_k(kt_begin + 1, kf1); load_v(kt_begin + 1, vf1); }
+        SA_STAMP(1);
+        // One key tile on register set (kf, vf).  STEADY: the tile two steps ahead is a full tile inside the range, so
+        // the refill is straight-line code (the compiler then emits exact vmcnt waits; with the full/ragged branch in
+        // the loop it fell back to vmcnt(0) and every tile stalled on the fragment it had just requested) and the tail
+        // mask is compiled out.
+        auto tile = [&](int kt, float *kf, float *vf, auto steady_tag) {
+            constexpr bool STEADY = decltype(steady_tag)::value;
             const int k0 = kt * SA_TILE;
             f32x16 st;
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
             for (int s = 0; s < 16; ++s) st = mfma32(kf[s], qf[s], st);
-            if (kt + 1 < kt_end) load_k(kt + 1, kf);          // K fragment is dead: refill now
-            if (kt == n_kt - 1) {                              // keys beyond the stripe (last tile only)
+            if (STEADY) load_k_fast(kt + 2, kf);                // K fragment is dead: refill now
+            else if (kt + 2 < kt_end) load_k(kt + 2, kf);
+            if (!STEADY && kt == n_kt - 1) {                   // keys beyond the stripe (last tile only)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (k0 + mfma_row(r, hi) >= g.Ts) st[r] = -INFINITY;
@@ -166,11 +233,69 @@ __global__ __launch_bounds__(256) void stripe_attn_kernel(const float *__restric
             for (int r = 0; r < 16; ++r) acc_o[r] *= alpha;
 #pragma unroll
             for (int s = 0; s < 16; ++s) acc_o = mfma32(vf[s], st[s], acc_o);
-            if (kt + 1 < kt_end) load_v(kt + 1, vf);          // V fragment likewise
+            if (STEADY) load_v_fast(kt + 2, vf);                // V fragment likewise
+            else if (kt + 2 < kt_end) load_v(kt + 2, vf);
+            if (CENSUS) { asm volatile("" :: "v"(acc_o[0])); if (kt - kt_begin < 6) SA_STAMP(2 + kt - kt_begin); }
+        };
+        int kt = kt_begin;
+        if (NSHIFT == 2) {
+            const int n_full = g.Ts / SA_TILE;
+            const int steady_end = (kt_end < n_full ? kt_end : n_full) - 3;    // kt + 3 is still a full tile of the range
+#pragma unroll 1
+            for (; kt < steady_end; kt += 2) {
+                tile(kt, kf0, vf0, std::true_type{});
+                tile(kt + 1, kf1, vf1, std::true_type{});
+            }
         }
+#pragma unroll 1
+        for (; kt < kt_end; kt += 2) {
+            tile(kt, kf0, vf0, std::false_type{});
+            if (kt + 1 < kt_end) tile(kt + 1, kf1, vf1, std::false_type{});
+        }
+        SA_STAMP(7);
         l_run = half_sum(l_run);                        // both halves now hold the range's full (m, l)
     }
 
+    // ---- LePE for width-1 stripes (NMP.py:433-449 / SURVEY H3), independent of the attention itself:
+    //   rpe_j(p)[c] = w_c v_j(p)[c] + sum_k ( w_- v_k(p-1)[c] + w_+ v_k(p+1)[c] )
+    // taps = centre column (AXIS 0: kernel[:,1]) or centre row (AXIS 1: kernel[1,:]) of the 3x3 kernel.
+    // Lane (q=qi, hi) owns output channels d = mfma_row(r, hi): four blocks rb of 4 consecutive channels.  The KSPLIT
+    // waves of a query tile share the work (wave ks takes blocks ks*RB_PER ..) right after their key loop -- computing it
+    // before the loop keeps 20-36 more VGPRs live and costs the 4th wave per SIMD; the leading wave collects the other
+    // blocks from LDS after the merge barrier (it used to do all 36 float4 + 48 weight loads alone while 3 waves idled).
+    float rpe[4 * RB_PER];
+    {
+        const int tap_m = (AXIS == 0) ? 1 : 3, tap_c = 4, tap_p = (AXIS == 0) ? 7 : 5;
+        const bool has_prev = q_pix > 0, has_next = q_pix < g.L - 1;
+        const int64_t prev_row = stripe_row<NSHIFT>(g, base_pix, (has_prev ? q_pix - 1 : q_pix) * nlab);
+        const int64_t next_row = stripe_row<NSHIFT>(g, base_pix, (has_next ? q_pix + 1 : q_pix) * nlab);
+        const float *vb = qkv + 2 * g.C + coff;
+#pragma unroll
+        for (int j = 0; j < RB_PER; ++j) {
+            const int rb = ks * RB_PER + j;
+            const int d0 = 8 * rb + 4 * hi;                        // == mfma_row(4*rb, hi)
+            float4 vq = ldg4(vb + qrow * ld + d0);
+            float4 sp = make_float4(0.f, 0.f, 0.f, 0.f), sn = sp;
+            if (wave_on)
+                for (int n = 0; n < nlab; ++n) {
+                    float4 t = ldg4(vb + (prev_row + n) * ld + d0);
+                    sp.x += t.x; sp.y += t.y; sp.z += t.z; sp.w += t.w;
+                    float4 u = ldg4(vb + (next_row + n) * ld + d0);
+                    sn.x += u.x; sn.y += u.y; sn.z += u.z; sn.w += u.w;
+                }
+            const float fp = has_prev ? 1.f : 0.f, fn = has_next ? 1.f : 0.f;
+            const float vqa[4] = {vq.x, vq.y, vq.z, vq.w}, spa[4] = {sp.x, sp.y, sp.z, sp.w}, sna[4] = {sn.x, sn.y, sn.z, sn.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float *wk = lepe + (size_t)(head * 32 + d0 + e) * 9;
+                rpe[4 * j + e] = wk[tap_c] * vqa[e] + (wk[tap_m] * fp) * spa[e] + (wk[tap_p] * fn) * sna[e];
+            }
+        }
+    }
+
+
+    if (CENSUS) asm volatile("" :: "v"(rpe[0]));
+    SA_STAMP(8);
     // ---- merge the KSPLIT key ranges of each query tile through LDS ----------------------------------------
     if (KSPLIT > 1) {
         if (ks != 0) {
@@ -178,8 +303,12 @@ __global__ __launch_bounds__(256) void stripe_attn_kernel(const float *__restric
             for (int r = 0; r < 16; ++r) s_o[wv][r][lane] = acc_o[r];
             s_ml[wv][0][lane] = m_run;
             s_ml[wv][1][lane] = l_run;
+#pragma unroll
+            for (int r = 0; r < 4 * RB_PER; ++r) s_rpe[wv][r][lane] = rpe[r];
         }
+        SA_STAMP(9);
         __syncthreads();
+        SA_STAMP(10);
         if (ks != 0) return;
 #pragma unroll
         for (int j = 1; j < KSPLIT; ++j) {
@@ -197,54 +326,41 @@ __global__ __launch_bounds__(256) void stripe_attn_kernel(const float *__restric
     const float inv_l = 1.0f / l_run;
 
     // ---- epilogue: normalise, add LePE, store.  Lane (q=qi, hi) owns channels d = mfma_row(r,hi) --------
-    // LePE for width-1 stripes (NMP.py:433-449 / SURVEY H3):
-    //   rpe_j(p)[c] = w_c v_j(p)[c] + sum_k ( w_- v_k(p-1)[c] + w_+ v_k(p+1)[c] )
-    // taps = centre column (AXIS 0: kernel[:,1]) or centre row (AXIS 1: kernel[1,:]) of the 3x3 kernel.
-    const int tap_m = (AXIS == 0) ? 1 : 3, tap_c = 4, tap_p = (AXIS == 0) ? 7 : 5;
-    const bool has_prev = q_pix > 0, has_next = q_pix < g.L - 1;
-    const int64_t prev_row = stripe_row<NSHIFT>(g, base_pix, (q_pix - 1) * nlab);
-    const int64_t next_row = stripe_row<NSHIFT>(g, base_pix, (q_pix + 1) * nlab);
     float *op = out + qrow * g.C + coff;
-    const float *vb = qkv + 2 * g.C + coff;
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
         const int d0 = mfma_row(4 * rb, hi);                   // 4 consecutive channels d0..d0+3
-        float4 vq = ldg4(vb + qrow * ld + d0);
-        float4 sp = make_float4(0.f, 0.f, 0.f, 0.f), sn = sp;
-        if (has_prev)
-            for (int n = 0; n < nlab; ++n) {
-                float4 t = ldg4(vb + (prev_row + n) * ld + d0);
-                sp.x += t.x; sp.y += t.y; sp.z += t.z; sp.w += t.w;
-            }
-        if (has_next)
-            for (int n = 0; n < nlab; ++n) {
-                float4 t = ldg4(vb + (next_row + n) * ld + d0);
-                sn.x += t.x; sn.y += t.y; sn.z += t.z; sn.w += t.w;
-            }
-        const float vqa[4] = {vq.x, vq.y, vq.z, vq.w}, spa[4] = {sp.x, sp.y, sp.z, sp.w}, sna[4] = {sn.x, sn.y, sn.z, sn.w};
         float res[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float *wk = lepe + (size_t)(head * 32 + d0 + e) * 9;
-            const float rpe = wk[tap_c] * vqa[e] + wk[tap_m] * spa[e] + wk[tap_p] * sna[e];
-            res[e] = acc_o[4 * rb + e] * inv_l + rpe;
+            float r;
+            if (KSPLIT == 1) r = rpe[4 * rb + e];
+            else if (rb / RB_PER == 0) r = rpe[4 * (rb % RB_PER) + e];
+            else r = s_rpe[wv + rb / RB_PER][4 * (rb % RB_PER) + e][lane];
+            res[e] = acc_o[4 * rb + e] * inv_l + r;
         }
         stg4(op + d0, make_float4(res[0], res[1], res[2], res[3]));
     }
+    SA_STAMP(11);
 }
 
 template <int AXIS, int NSHIFT>
-static void launch_stripe(const float *qkv, const float *lepe, const StripeGeom &g, int stripes, int B, float scale,
+static void launch_stripe(const float *qkv, const float *lepe, const StripeGeom &g_in, int stripes, int B, float scale,
                           float *out, hipStream_t st) {
-    // key split: aim for a few thousand waves per launch (256 CUs x 4 SIMDs x ~3), keep >= 2 key tiles per wave
-    const int n_qt = (g.Ts + SA_TILE - 1) / SA_TILE;
-    // (decided per image, NOT per batch, so that results do not depend on the batch size)
-    const long waves1 = (long)n_qt * stripes * 2;
+    // key split, decided per image and NOT per batch so that results do not depend on the batch size.  Measured on MI355X
+    // (tools/kernel_bench.py --which stripe, NMRF_STRIPE_KSPLIT sweep, batch 1 / 4 / 8):
+    //   horizontal KITTI stripes (20 key tiles): 1 -> 64 / 244 / 425 us,  2 -> 72 / 246 / 465,  4 -> 76 / 257 / 475
+    //   vertical   KITTI stripes ( 6 key tiles): 1 -> 37 / 109 / 211 us,  2 -> 33 / 100 / 209,  4 -> 37 / 112 / 220
+    // a wave needs ~3 key tiles to amortise its Q load, LePE and merge; long stripes are best left whole.
+    const int n_qt = (g_in.Ts + SA_TILE - 1) / SA_TILE;
     int ksplit = 1;
-    if (waves1 * 2 <= 8192 && n_qt >= 4) ksplit = 2;
-    if (waves1 * 4 <= 8192 && n_qt >= 8) ksplit = 4;
+    if (n_qt >= 4 && n_qt < 16) ksplit = 2;
+    static const char *force = getenv("NMRF_STRIPE_KSPLIT");   // tuning override (tools/kernel_bench.py)
+    if (force && (force[0] == '1' || force[0] == '2' || force[0] == '4')) ksplit = force[0] - '0';
     const int qpb = 4 / ksplit;
-    dim3 grid((n_qt + qpb - 1) / qpb, stripes * 2, B);
+    StripeGeom g = g_in;
+    g.gx = (n_qt + qpb - 1) / qpb; g.gy = stripes * 2; g.gz = B;
+    dim3 grid((unsigned)(((int64_t)g.gx * g.gy * g.gz + 7) / 8 * 8));
     if (ksplit == 1) hipLaunchKernelGGL((stripe_attn_kernel<AXIS, NSHIFT, 1>), grid, dim3(256), 0, st, qkv, lepe, g, scale, out,
                                           (unsigned long long *)nullptr);
     else if (ksplit == 2) hipLaunchKernelGGL((stripe_attn_kernel<AXIS, NSHIFT, 2>), grid, dim3(256), 0, st, qkv, lepe, g, scale, out,
@@ -253,14 +369,15 @@ static void launch_stripe(const float *qkv, const float *lepe, const StripeGeom 
                                           (unsigned long long *)nullptr);
 }
 
-// Debug: census run of the horizontal N=4 KSPLIT=4 kernel (KITTI batch-1 configuration); census[blocks*3] on device.
+// Debug: census run of the horizontal N=4 KSPLIT=1 kernel (KITTI configuration); census[blocks*3] + stamps on device.
 extern "C" int nmrf_debug_stripe_census(const float *qkv, const float *lepe_h, int B, int H, int W, float *out,
                                         unsigned long long *census, int *grid_out, void *stream) {
-    StripeGeom g{H, W, 4, 128, W, W * 4, (int64_t)1};
+    StripeGeom g{H, W, 4, 128, W, W * 4, (int64_t)1, 0, 0, 0};
     const int n_qt = (g.Ts + SA_TILE - 1) / SA_TILE;
-    dim3 grid(n_qt, H * 2, B);                                // KSPLIT = 4 -> one query tile per block
-    grid_out[0] = grid.x; grid_out[1] = grid.y; grid_out[2] = grid.z;
-    hipLaunchKernelGGL((stripe_attn_kernel<1, 2, 4, true>), grid, dim3(256), 0, (hipStream_t)stream, qkv, lepe_h, g,
+    g.gx = (n_qt + 3) / 4; g.gy = H * 2; g.gz = B;            // KSPLIT = 1 -> four query tiles per block
+    dim3 grid((unsigned)(((int64_t)g.gx * g.gy * g.gz + 7) / 8 * 8));
+    grid_out[0] = g.gx; grid_out[1] = g.gy; grid_out[2] = g.gz;
+    hipLaunchKernelGGL((stripe_attn_kernel<1, 2, 1, true>), grid, dim3(256), 0, (hipStream_t)stream, qkv, lepe_h, g,
                        1.0f / sqrtf(32.0f), out, census);
     return nmrf_launch_status();
 }
@@ -273,12 +390,12 @@ extern "C" int nmrf_stripe_attn_f32(const float *qkv, const float *lepe_v, const
     const float scale = 1.0f / sqrtf(32.0f);
     hipStream_t st = (hipStream_t)stream;
     if (axes & 1) {   // vertical stripes: one per column, H*N tokens each, channel half 0
-        StripeGeom g{H, W, N, C, H, H * N, (int64_t)W};
+        StripeGeom g{H, W, N, C, H, H * N, (int64_t)W, 0, 0, 0};
         if (N == 4) launch_stripe<0, 2>(qkv, lepe_v, g, W, B, scale, out, st);
         else launch_stripe<0, -1>(qkv, lepe_v, g, W, B, scale, out, st);
     }
     if (axes & 2) {   // horizontal stripes: one per row, W*N tokens each, channel half 1
-        StripeGeom g{H, W, N, C, W, W * N, (int64_t)1};
+        StripeGeom g{H, W, N, C, W, W * N, (int64_t)1, 0, 0, 0};
         if (N == 4) launch_stripe<1, 2>(qkv, lepe_h, g, H, B, scale, out, st);
         else launch_stripe<1, -1>(qkv, lepe_h, g, H, B, scale, out, st);
     }

@@ -53,6 +53,11 @@ if "stripe" in which:
     qkv = mk("q2", b * h * w * n, 384)
     lv, lh = mk("lv", 64, 1, 3, 3), mk("lh", 64, 1, 3, 3)
     timeit("stripe_attn (both axes)", lambda: K.stripe_attn(qkv, lv, lh, b, h, w, n))
+    so = torch.empty(b * h * w * n, 128, device=dev)
+    for ax, nm in ((1, "vertical"), (2, "horizontal")):
+        timeit("stripe_attn %s only" % nm, lambda: _l.nmrf_stripe_attn_f32(
+            ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(lv.data_ptr()), ctypes.c_void_p(lh.data_ptr()), b, h, w, n, 128, ax,
+            ctypes.c_void_p(so.data_ptr()), None))
 if "refine" in which:
     hp, wp = 96, 312
     qkv, table = mk("q3", b * hp * wp, 384), mk("t3", 49, 384)
@@ -110,7 +115,7 @@ if "stripe_census" in which:
     lh = mk("lh", 64, 1, 3, 3)
     out = torch.empty(b * h * w * n, 128, device=dev)
     grid = (ctypes.c_int * 3)()
-    cap = 20 * h * 2 * b * 3 + 64
+    cap = 20 * h * 2 * b * 3 + 64 * 4 * 16 + 64
     census = torch.zeros(cap, dtype=torch.int64, device=dev)
     for _ in range(3):
         _l.nmrf_debug_stripe_census(ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(lh.data_ptr()), b, h, w,
@@ -118,9 +123,16 @@ if "stripe_census" in which:
     torch.cuda.synchronize()
     nblk = grid[0] * grid[1] * grid[2]
     cen = census.cpu().numpy()[: nblk * 3].reshape(nblk, 3)
+    st = census.cpu().numpy()[nblk * 3: nblk * 3 + grid[0] * 4 * 16].reshape(grid[0], 4, 16).astype(np.int64)
+    nm = ["setup+q/k/v issue", "tile0", "tile1", "tile2", "tile3", "tile4", "loop exit", "lepe", "o->lds", "barrier", "merge+store(w0)"]
+    d = np.diff(st[:, :, :12], axis=2)
+    print("stripe<1,2,1> per-wave phases in shader cycles (mean over the blocks of stripe 0/head 0), waves 0..3 (first 5 of 20 tiles):")
+    for i, n_ in enumerate(nm):
+        print("  %-20s" % n_, " ".join("%7.0f" % v for v in d[:, :, i].mean(0)[: (1 if i == 10 else 4)]))
+    print("  %-20s" % "start->barrier", " ".join("%7.0f" % v for v in (st[:, :, 9] - st[:, :, 0]).mean(0)))
     t0 = cen[:, 1].min()
     dur = (cen[:, 2] - cen[:, 1]) / 100.0
-    print("stripe<1,2,4>: blocks %d, smids %d, block us mean %.1f min %.1f max %.1f, span %.1f us" %
+    print("stripe<1,2,1>: blocks %d, smids %d, block us mean %.1f min %.1f max %.1f, span %.1f us" %
           (nblk, len(set(cen[:, 0].tolist())), dur.mean(), dur.min(), dur.max(), (cen[:, 2].max() - t0) / 100.0))
     conc = []
     for sm in set(cen[:, 0].tolist()):
@@ -133,3 +145,33 @@ if "stripe_census" in which:
         conc.append((len(rows), mx))
     print("  blocks per smid:", dict(collections.Counter(c[0] for c in conc)))
     print("  max concurrent blocks per smid:", dict(collections.Counter(c[1] for c in conc)))
+
+if "mfma_peak" in which:
+    out = torch.empty(4096 * 256, device=dev)
+    for chains in (1, 2, 4):
+        for blocks in (256, 512, 1024, 2048):
+            iters = 2000
+            fn = lambda: _l.nmrf_debug_mfma_peak(chains, iters, blocks, ctypes.c_void_p(out.data_ptr()), None)
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); fn(); fn(); e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 3
+            fl = blocks * 4 * iters * 16 * chains * 4096.0
+            print("mfma 32x32x2 f32: chains/wave %d, blocks %4d (waves/SIMD %.1f): %.1f TFLOP/s (%.3f ms)"
+                  % (chains, blocks, blocks * 4 / 1024.0, fl / ms / 1e9, ms), flush=True)
+
+if "attn_core" in which:
+    out = torch.empty(4096 * 256, device=dev)
+    seed = mk("seed", 256)
+    for variant in (0, 1):
+        for blocks in (256, 512, 768, 1024):
+            iters = 2000
+            fn = lambda: _l.nmrf_debug_attn_core_peak(variant, iters, blocks, ctypes.c_void_p(seed.data_ptr()),
+                                                      ctypes.c_void_p(out.data_ptr()), None)
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); fn(); fn(); e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 3
+            fl = blocks * 4 * iters * 32 * 4096.0
+            print("attention tile loop, registers only, variant %d, waves/SIMD %.0f: %.1f TFLOP/s, %.0f cycles/tile/wave @2.4GHz"
+                  % (variant, blocks * 4 / 1024.0, fl / ms / 1e9, ms * 1e-3 * 2.4e9 / iters), flush=True)
