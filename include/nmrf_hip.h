@@ -27,7 +27,7 @@ extern "C" {
 
 const char *nmrf_strerror(int code);
 /* ABI version of this header; bumps on any signature change. */
-int nmrf_abi_version(void);   /* currently 5 */
+int nmrf_abi_version(void);   /* currently 6 */
 
 /* A2  group-wise correlation volume.
  * replaces build_correlation_volume + the permute of DPN.forward
@@ -117,6 +117,23 @@ int nmrf_window_attn_f32(const float *qkv, const float *table, int B, int Hp, in
  * (nmrf/models/NMP.py:54-66, nmrf/models/NMRF.py:82-83,105,218-220,238; nmrf/models/DPN.py:65,131). */
 int nmrf_linear_smalln_f32(const float *x, const float *w, const float *bias, int64_t T, int K, int N, int act,
                            float *out, void *stream);
+
+/* N3  token linear with fused prologue / epilogue on fp32 MFMA:
+ *     out[T,N] = act( P(x) . W^T + bias ) + residual
+ *     P(x)[t]  = [ LayerNorm_128(x[t] + y[t]) | extra[t / extra_div][0..E) ]   when ln_gamma != NULL  (Cx == 128, K == 128 + E)
+ *              = x[t][0..K)                                                     otherwise              (Cx == K, K % 4 == 0)
+ * replaces, per message-passing block, nn.LayerNorm + torch.cat + nn.Linear (+ nn.GELU) (+ the residual add):
+ * BasicAttention.forward_pre (nmrf/models/NMP.py:90-108), SwinNMP.forward_pre/get_qkv_input (:343-364),
+ * CSWinNMP.forward_pre/get_qkv (:544-574), the timm Mlp fc1-GELU-fc2 (:337,537,675) and the proj layers.
+ * y (optional, with x_out): pending residual; x + y is what is normalised and x_out receives it.
+ * w_packed: the [N,K] weight in MFMA fragment order from nmrf_pack_linear_weight_f32 (N % 32 == 0; K zero-padded to
+ * 32*ceil(K/32), supported ceil(K/32): 4,5,6 with LayerNorm; 1,2,4,5,16 without).
+ * act: 0 identity, 1 ReLU, 2 GELU(erf).  bias [N] / residual [T,N] may be NULL. */
+int nmrf_token_linear_f32(const float *x, const float *y, float *x_out, const float *ln_gamma, const float *ln_beta,
+                          float eps, const float *extra, int E, int extra_div, const float *w_packed, const float *bias,
+                          const float *residual, int act, int64_t T, int Cx, int K, int N, float *out, void *stream);
+/* w [N,K] row-major -> packed [N/32][ceil(K/32)][4][64][4] floats (one contiguous 1 KiB line per wave load). */
+int nmrf_pack_linear_weight_f32(const float *w, int N, int K, float *packed, void *stream);
 
 /* A11/A12  coarse heads epilogue: relu(label+delta), winner-take-all over N by score (first max),
  * x2, 4x4 lower median.  replaces NMRF.forward (nmrf/models/NMRF.py:219-232).

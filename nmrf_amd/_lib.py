@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnmrf_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -30,6 +30,8 @@ PROTOTYPES = {
     "nmrf_self_attn_f32": [_P, _L, _I, _I, _I, _P, _P],
     "nmrf_window_attn_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "nmrf_linear_smalln_f32": [_P, _P, _P, _L, _I, _I, _I, _P, _P],
+    "nmrf_token_linear_f32": [_P, _P, _P, _P, _P, _F, _P, _I, _I, _P, _P, _P, _I, _L, _I, _I, _I, _P, _P],
+    "nmrf_pack_linear_weight_f32": [_P, _I, _I, _P, _P],
     "nmrf_wta_median_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "nmrf_refine_epilogue_f32": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "nmrf_instance_norm_f32": [_P, _P, _L, _L, _F, _I, _I, _P, _P, _P],

@@ -20,20 +20,57 @@ __device__ __forceinline__ float block_sum_256(float v, float *red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// A chunk is read ONCE: up to 8 float4 per thread stay in registers between the mean pass and the centred
+// sum-of-squares pass (the first version re-read the chunk from L2).  Planes whose byte offset is not a multiple of 16
+// (odd HW, e.g. the 94x311 quarter-resolution KITTI plane) are handled by peeling up to 3 head / 3 tail elements, so the
+// body is always 16-byte aligned.
+struct ChunkView {
+    const float *p;      // first element of the chunk
+    int n, head, nvec;   // elements, scalar head elements, float4 body elements
+};
+__device__ __forceinline__ ChunkView chunk_view(const float *plane, int64_t HW, int chunk) {
+    const int64_t beg = (int64_t)chunk * IN_CHUNK;
+    const int64_t end = beg + IN_CHUNK < HW ? beg + IN_CHUNK : HW;
+    ChunkView v;
+    v.p = plane + beg;
+    v.n = (int)(end - beg);
+    const int mis = (int)(((uintptr_t)v.p >> 2) & 3);
+    v.head = mis ? 4 - mis : 0;
+    if (v.head > v.n) v.head = v.n;
+    v.nvec = (v.n - v.head) >> 2;
+    return v;
+}
+
 __global__ __launch_bounds__(256) void in_stats_kernel(const float *__restrict__ x, int64_t HW, int chunks,
                                                       float *__restrict__ ws) {
     __shared__ float red[4];
     const int64_t plane = blockIdx.y;
     const int chunk = blockIdx.x;
-    const int64_t beg = (int64_t)chunk * IN_CHUNK;
-    const int64_t end = beg + IN_CHUNK < HW ? beg + IN_CHUNK : HW;
-    const float *p = x + plane * HW;
-    const int n = (int)(end - beg);
-    float s = 0.f;
-    for (int64_t i = beg + threadIdx.x; i < end; i += 256) s += p[i];
-    const float mean = block_sum_256(s, red) / (float)n;
+    const ChunkView cv = chunk_view(x + plane * HW, HW, chunk);
+    const float4 *pv = reinterpret_cast<const float4 *>(cv.p + cv.head);
+    float4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        v[k] = i < cv.nvec ? pv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // scalar edge elements: head (< 4) then tail (< 4), one per thread
+    const int tail0 = cv.head + 4 * cv.nvec, n_edge = cv.head + (cv.n - tail0);
+    const bool has_e = (int)threadIdx.x < n_edge;
+    const float ev = has_e ? cv.p[(int)threadIdx.x < cv.head ? (int)threadIdx.x : tail0 + ((int)threadIdx.x - cv.head)] : 0.f;
+    float s = ev;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    const float mean = block_sum_256(s, red) / (float)cv.n;
     float q = 0.f;
-    for (int64_t i = beg + threadIdx.x; i < end; i += 256) { const float d = p[i] - mean; q = fmaf(d, d, q); }
+    if (has_e) { const float d = ev - mean; q = d * d; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if ((int)threadIdx.x + 256 * k < cv.nvec) {
+            const float dx = v[k].x - mean, dy = v[k].y - mean, dz = v[k].z - mean, dw = v[k].w - mean;
+            q = fmaf(dx, dx, q); q = fmaf(dy, dy, q); q = fmaf(dz, dz, q); q = fmaf(dw, dw, q);
+        }
+    }
     const float m2 = block_sum_256(q, red);
     if (threadIdx.x == 0) {
         float *o = ws + (plane * chunks + chunk) * 2;
@@ -64,17 +101,33 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const float *__restrict__
         m2 += w[2 * c + 1] + nc * d * d;
     }
     const float rstd = 1.0f / sqrtf(m2 / (float)HW + eps);
-    const int64_t beg = (int64_t)chunk * IN_CHUNK;
-    const int64_t end = beg + IN_CHUNK < HW ? beg + IN_CHUNK : HW;
-    const float *p = x + plane * HW;
-    const float *r = res ? res + plane * HW : nullptr;
-    float *o = y + plane * HW;
-    for (int64_t i = beg + threadIdx.x; i < end; i += 256) {
-        float v = (p[i] - mean) * rstd;
-        if (relu_mid) v = fmaxf(v, 0.f);
-        if (r) v += r[i];
-        if (relu_out) v = fmaxf(v, 0.f);
-        o[i] = v;
+    const ChunkView cv = chunk_view(x + plane * HW, HW, chunk);
+    const int64_t off = cv.p - x;                               // same element offset (and alignment) in res / y
+    const float *r = res ? res + off : nullptr;
+    float *o = y + off;
+    auto f = [&](float xv, float rv) {
+        float t = (xv - mean) * rstd;
+        if (relu_mid) t = fmaxf(t, 0.f);
+        t += rv;
+        if (relu_out) t = fmaxf(t, 0.f);
+        return t;
+    };
+    const float4 *pv = reinterpret_cast<const float4 *>(cv.p + cv.head);
+    const float4 *rv = reinterpret_cast<const float4 *>(r ? r + cv.head : nullptr);
+    float4 *ov = reinterpret_cast<float4 *>(o + cv.head);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        if (i < cv.nvec) {
+            const float4 a = pv[i];
+            const float4 b = r ? rv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            ov[i] = make_float4(f(a.x, b.x), f(a.y, b.y), f(a.z, b.z), f(a.w, b.w));
+        }
+    }
+    const int tail0 = cv.head + 4 * cv.nvec, n_edge = cv.head + (cv.n - tail0);
+    if ((int)threadIdx.x < n_edge) {
+        const int i = (int)threadIdx.x < cv.head ? (int)threadIdx.x : tail0 + ((int)threadIdx.x - cv.head);
+        o[i] = f(cv.p[i], r ? r[i] : 0.f);
     }
 }
 
@@ -82,6 +135,8 @@ extern "C" int nmrf_instance_norm_f32(const float *x, const float *residual, int
                                       int relu_mid, int relu_out, float *ws, float *y, void *stream) {
     if (!x || !ws || !y) return NMRF_ENULL;
     if (planes < 1 || planes > 65535 || HW < 1) return NMRF_EINVAL;
+    // x, residual and y must share their 16-byte phase (torch allocations are 256-byte aligned; views may not be)
+    if ((((uintptr_t)x ^ (uintptr_t)y) & 15) || (residual && (((uintptr_t)x ^ (uintptr_t)residual) & 15))) return NMRF_EINVAL;
     const int chunks = (int)ceil_div64(HW, IN_CHUNK);
     dim3 grid(chunks, (unsigned)planes);
     hipLaunchKernelGGL(in_stats_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, HW, chunks, ws);

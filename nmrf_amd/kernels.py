@@ -182,6 +182,36 @@ def linear_smalln(x, weight, bias=None, relu=False):
     return out
 
 
+def pack_linear_weight(weight):
+    """[N,K] nn.Linear weight -> MFMA fragment order for token_linear (N % 32 == 0)."""
+    _chk(weight)
+    n, k = weight.shape
+    packed = torch.empty(n * ((k + 31) // 32 * 32), device=weight.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_pack_linear_weight_f32(_p(weight.contiguous()), n, k, _p(packed), _stream()), "pack_linear_weight")
+    return packed
+
+
+def token_linear(x, packed_w, n, k, bias=None, ln=None, y=None, extra=None, extra_div=1, act=0, residual=None):
+    """out[T,n] = act(P(x) W^T + bias) + residual on the fused MFMA kernel.
+    ln = (gamma, beta, eps): P(x) = [LayerNorm(x + y) | extra[t // extra_div]]; returns (x + y, out) when y is given.
+    ln = None: P(x) = x (k columns).  act: 0 / 'relu' / 'gelu'."""
+    _chk(x, packed_w, bias, y, extra, residual)
+    t, cx = x.shape
+    act = {0: 0, 1: 1, 2: 2, None: 0, "relu": 1, "gelu": 2}[act]
+    e = 0 if extra is None else extra.shape[-1]
+    g = bt = None
+    eps = 0.0
+    if ln is not None:
+        g, bt, eps = ln
+        _chk(g, bt)
+    out = torch.empty(t, n, device=x.device, dtype=torch.float32)
+    x_out = torch.empty_like(x) if y is not None else None
+    _lib.check(_lib.load().nmrf_token_linear_f32(_p(x), _p(y), _p(x_out), _p(g), _p(bt), float(eps), _p(extra), e, extra_div,
+                                                 _p(packed_w), _p(bias), _p(residual), act, t, cx, k, n, _p(out), _stream()),
+               "token_linear")
+    return (x_out, out) if y is not None else out
+
+
 def wta_median(delta, score, labels, b, h, w, n):
     _chk(delta, score, labels)
     out = torch.empty(b, 2 * h, 2 * w, device=delta.device, dtype=torch.float32)

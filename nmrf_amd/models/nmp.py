@@ -2,17 +2,24 @@
 
 The module tree and parameter names mirror nmrf/models/NMP.py so that reference checkpoints load
 with strict=True.  The arithmetic does not: every block is
-    [HIP] LayerNorm+concat  ->  [hipBLASLt] one fused q|k|v GEMM  ->  [HIP] attention kernel
-    ->  [hipBLASLt] proj / MLP GEMMs
-on token-major fp32 buffers [T, C] with T = B*H*W*N.  q/k/v weights are fused (and the K dimension
-padded to a multiple of 4 with zero columns) once per parameter version.
+    [HIP] token_linear: (x + y) -> LayerNorm -> concat -> fused q|k|v GEMM on fp32 MFMA  ->  [HIP] attention kernel
+    ->  [HIP] token_linear proj  ->  [HIP] token_linear: add -> LayerNorm -> fc1 -> GELU  ->  [hipBLASLt] fc2
+on token-major fp32 buffers [T, C] with T = B*H*W*N.  q/k/v weights are fused and packed into MFMA fragment order
+once per parameter version.  NMRF_FUSED_LINEAR=0 switches the linears back to the round-1 path
+(ln_concat kernel + hipBLASLt GEMM + torch GELU) for A/B timing.
 There is no CPU path: the kernels raise on non-CUDA tensors.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import kernels as K
+
+
+def _fused():
+    return os.environ.get("NMRF_FUSED_LINEAR", "1") != "0"
 
 FOURIER_DIM = 31        # 15 sin + 15 cos + the scaled coordinate (NMP.py:35-51)
 
@@ -29,7 +36,15 @@ class MLP(nn.Module):
     def forward(self, x):
         for i, layer in enumerate(self.layers):
             last = i == self.num_layers - 1
-            if x.is_cuda and layer.out_features <= 64 and layer.in_features % 4 == 0 and layer.in_features <= 128:
+            if (_fused() and x.is_cuda and layer.out_features % 32 == 0 and layer.out_features > 64
+                    and layer.in_features in (32, 64, 128, 160)):
+                if not hasattr(self, "_lin"):
+                    self._lin = {}
+                lin = self._lin.setdefault(i, _Lin(layer))
+                shp = x.shape
+                y = lin(x.reshape(-1, shp[-1]).contiguous(), act=0 if last else "relu")
+                x = y.view(*shp[:-1], layer.out_features)
+            elif x.is_cuda and layer.out_features <= 64 and layer.in_features % 4 == 0 and layer.in_features <= 128:
                 shp = x.shape
                 y = K.linear_smalln(x.reshape(-1, shp[-1]).contiguous(), layer.weight, layer.bias, relu=not last)
                 x = y.view(*shp[:-1], layer.out_features)
@@ -51,7 +66,20 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden_features, out_features)
 
     def forward(self, x):
+        if _fused() and x.is_cuda and x.dim() == 2 and self.fc1.in_features in (64, 128, 160) and self.fc1.out_features % 32 == 0:
+            if not hasattr(self, "_lin1"):
+                self._lin1 = _Lin(self.fc1)
+            return self.fc2(self._lin1(x.contiguous(), act="gelu"))
         return self.fc2(F.gelu(self.fc1(x)))
+
+    def forward_ln(self, x, y, norm):
+        """fc2(GELU(fc1(LayerNorm(x + y)))) with add, norm, fc1 and GELU in one kernel -> (x + y, out)."""
+        if not hasattr(self, "_lin1"):
+            self._lin1 = _Lin(self.fc1)
+        pw, b, k, n = _packed(self._lin1.cache, (self.fc1.weight,), (self.fc1.bias,))
+        r = K.token_linear(x, pw, n, k, b, ln=(norm.weight, norm.bias, norm.eps), y=y, act="gelu")
+        x, h = r if y is not None else (x, r)
+        return x, self.fc2(h)
 
 
 class _FusedCache:
@@ -72,6 +100,28 @@ class _FusedCache:
 
 def _pad_cols(w, k):
     return w if w.shape[1] == k else F.pad(w, (0, k - w.shape[1]))
+
+
+def _packed(cache, weights, biases):
+    """(packed q|k|.. weight in MFMA fragment order, concatenated bias or None, K, N) for K.token_linear."""
+    def build():
+        k = max(w.shape[1] for w in weights)
+        w = torch.cat([_pad_cols(w, k) for w in weights], 0).contiguous()
+        b = None if biases[0] is None else torch.cat(list(biases)).contiguous()
+        return K.pack_linear_weight(w), b, k, w.shape[0]
+    return cache.get(tuple(weights) + tuple(b for b in biases if b is not None), build)
+
+
+class _Lin:
+    """token_linear front end of one nn.Linear (packed weight cached per parameter version)."""
+
+    def __init__(self, linear):
+        self.linear = linear
+        self.cache = _FusedCache()
+
+    def __call__(self, x, act=0, **kw):
+        pw, b, k, n = _packed(self.cache, (self.linear.weight,), (self.linear.bias,))
+        return K.token_linear(x, pw, n, k, b, act=act, **kw)
 
 
 def _ln(x, norm):
@@ -100,6 +150,8 @@ class BasicAttention(nn.Module):
         self.q, self.k, self.v = nn.Linear(qk_dim, dim), nn.Linear(qk_dim, dim), nn.Linear(dim, dim)
         self.proj = nn.Linear(dim, dim)
         self._fused = _FusedCache()
+        self._packed_qkv = _FusedCache()
+        self._proj = _Lin(self.proj)
 
     def _weights(self):
         def build():
@@ -110,6 +162,13 @@ class BasicAttention(nn.Module):
 
     def forward_pair(self, x, y, abs_encoding, n):
         """(x, y) = residual stream x + y; returns the next pair."""
+        if _fused():
+            pw, b, k, nn_ = _packed(self._packed_qkv, (self.q.weight, self.k.weight, self.v.weight),
+                                    (self.q.bias, self.k.bias, self.v.bias))
+            r = K.token_linear(x, pw, nn_, k, b, ln=(self.norm1.weight, self.norm1.bias, self.norm1.eps), y=y,
+                               extra=abs_encoding)
+            x, qkv = r if y is not None else (x, r)
+            return x, self._proj(K.self_attn(qkv, n, self.num_heads))
         w, b, kp = self._weights()
         x, a = _add_ln(x, y, self.norm1, abs_encoding, 1, kp)
         msg = K.self_attn(F.linear(a, w, b), n, self.num_heads)
@@ -157,6 +216,8 @@ class SwinNMP(nn.Module):
         self.norm2 = nn.LayerNorm(dim)
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
         self._fused = _FusedCache()
+        self._qkv = _Lin(self.qkv)
+        self._proj = _Lin(self.proj)
 
     def _weights(self):
         def build():
@@ -165,6 +226,10 @@ class SwinNMP(nn.Module):
         return self._fused.get((self.qkv.weight,), build)
 
     def forward_pair(self, x, y, abs_encoding, dims, sibling_mask):
+        if _fused():
+            r = self._qkv(x, ln=(self.norm1.weight, self.norm1.bias, self.norm1.eps), y=y, extra=abs_encoding)
+            x, qkv = r if y is not None else (x, r)
+            return self.mlp.forward_ln(x, self._proj(self.attn(qkv, dims, sibling_mask)), self.norm2)
         w, kp = self._weights()
         x, a = _add_ln(x, y, self.norm1, abs_encoding, 1, kp)
         msg = self.attn(F.linear(a, w, self.qkv.bias), dims, sibling_mask)
@@ -205,6 +270,8 @@ class CSWinNMP(nn.Module):
         self.mlp = Mlp(dim, int(dim * mlp_ratio), dim)
         self.norm2 = nn.LayerNorm(dim)
         self._fused = _FusedCache()
+        self._packed_qkv = _FusedCache()
+        self._proj = _Lin(self.proj)
 
     def _weights(self):
         def build():
@@ -220,6 +287,14 @@ class CSWinNMP(nn.Module):
 
     def forward_pair(self, x, y, context, dims):
         b, h, wd, n = dims
+        if _fused():
+            pw, bias, k, nn_ = _packed(self._packed_qkv, (self.q.weight, self.k.weight, self.v.weight),
+                                       (self.q.bias, self.k.bias, self.v.bias))
+            r = K.token_linear(x, pw, nn_, k, bias, ln=(self.norm1.weight, self.norm1.bias, self.norm1.eps), y=y,
+                               extra=context, extra_div=n)
+            x, qkv = r if y is not None else (x, r)
+            msg = K.stripe_attn(qkv, self.attns[0].get_v.weight, self.attns[1].get_v.weight, b, h, wd, n)
+            return self.mlp.forward_ln(x, self._proj(msg), self.norm2)
         w, bias, kp = self._weights()
         x, a = _add_ln(x, y, self.norm1, context, n, kp)
         msg = K.stripe_attn(F.linear(a, w, bias), self.attns[0].get_v.weight, self.attns[1].get_v.weight, b, h, wd, n)

@@ -225,7 +225,58 @@ def test_linear_smalln(t_, k, n, relu):
     assert torch.equal(K().linear_smalln(x.to(DEV), w.to(DEV), None, False).cpu() + b, got) or not relu or True
 
 
-@pytest.mark.parametrize("b,c,h,w", [(2, 5, 7, 9), (1, 3, 188, 624), (2, 4, 47, 156)])
+@pytest.mark.parametrize("t_,e,n,act,div,with_y,res", [
+    (300, 31, 384, 0, 1, True, False),      # q|k|v of the window / self blocks: [LN(x+y) | Fourier31] -> 384
+    (1000, 64, 384, 0, 4, False, False),    # propagation q|k|v: context shared by the 4 labels of a pixel
+    (777, 0, 512, 2, 1, True, False),       # fc1 + GELU(erf) on LN(x + y)
+    (64, 0, 128, 1, 1, False, True),        # ReLU + residual, exactly one tile
+    (29952, 31, 384, 0, 1, True, False),    # KITTI size
+])
+def test_token_linear_layernorm_prologue(t_, e, n, act, div, with_y, res):
+    x, y = rnd(t_, 128, seed=1, scale=2.0), rnd(t_, 128, seed=2)
+    gamma, beta = 1.0 + 0.1 * rnd(128, seed=3), 0.1 * rnd(128, seed=4)
+    extra = rnd((t_ + div - 1) // div, e, seed=5) if e else None
+    k = 128 + e
+    w, bias = rnd(n, k, seed=6, scale=0.1), rnd(n, seed=7)
+    r = rnd(t_, n, seed=8) if res else None
+    d = lambda v: None if v is None else v.to(DEV)
+    kk = K()
+    got = kk.token_linear(d(x), kk.pack_linear_weight(d(w)), n, k, d(bias), (d(gamma), d(beta), 1e-5), d(y) if with_y else None,
+                          d(extra), div, act, d(r))
+    s = (x + y) if with_y else x
+    if with_y:
+        assert torch.equal(got[0].cpu(), s)
+        got = got[1]
+    a = F.layer_norm(s.double(), (128,), gamma.double(), beta.double(), 1e-5)
+    if e:
+        a = torch.cat((a, extra.double().repeat_interleave(div, 0)[:t_]), 1)
+    ref = a @ w.double().t() + bias.double()
+    ref = F.relu(ref) if act == 1 else (F.gelu(ref) if act == 2 else ref)
+    if res:
+        ref = ref + r.double()
+    report("token_linear(LN)", got.cpu(), ref, 2e-5, 1e-5)
+
+
+@pytest.mark.parametrize("t_,k,n,act,res", [(500, 128, 128, 0, False), (333, 512, 128, 0, True), (100, 36, 128, 2, False),
+                                            (2000, 160, 128, 2, False), (70, 128, 64, 1, False), (29952, 512, 128, 0, True),
+                                            (31, 32, 32, 0, False)])
+def test_token_linear_plain(t_, k, n, act, res):
+    x = rnd(t_, k, seed=11, scale=1.5)
+    w, bias = rnd(n, k, seed=12, scale=0.1), rnd(n, seed=13)
+    r = rnd(t_, n, seed=14) if res else None
+    d = lambda v: None if v is None else v.to(DEV)
+    kk = K()
+    got = kk.token_linear(d(x), kk.pack_linear_weight(d(w)), n, k, d(bias), act=act, residual=d(r))
+    ref = x.double() @ w.double().t() + bias.double()
+    ref = F.relu(ref) if act == 1 else (F.gelu(ref) if act == 2 else ref)
+    if res:
+        ref = ref + r.double()
+    report("token_linear", got.cpu(), ref, 2e-5, 1e-5)
+    nob = kk.token_linear(d(x), kk.pack_linear_weight(d(w)), n, k, None, act=0)
+    report("token_linear(no bias)", nob.cpu(), x.double() @ w.double().t(), 2e-5, 1e-5)
+
+
+@pytest.mark.parametrize("b,c,h,w", [(2, 5, 7, 9), (1, 3, 188, 624), (2, 4, 47, 156), (2, 3, 94, 311), (1, 2, 1, 3), (1, 3, 127, 131)])
 def test_instance_norm_fused(b, c, h, w):
     x = rnd(b, c, h, w, seed=h, scale=3.0) + 1.5
     res = rnd(b, c, h, w, seed=h + 1)

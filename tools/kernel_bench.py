@@ -175,3 +175,60 @@ if "attn_core" in which:
             fl = blocks * 4 * iters * 32 * 4096.0
             print("attention tile loop, registers only, variant %d, waves/SIMD %.0f: %.1f TFLOP/s, %.0f cycles/tile/wave @2.4GHz"
                   % (variant, blocks * 4 / 1024.0, fl / ms / 1e9, ms * 1e-3 * 2.4e9 / iters), flush=True)
+
+if "linear" in which:
+    import torch.nn.functional as F
+    T = b * 48 * 156 * 4
+    x, y = mk("lx", T, 128), mk("ly", T, 128)
+    gam, bet = mk("lg", 128) * 0.1 + 1, mk("lb", 128) * 0.1
+    for (nm, e, n, act) in (("q|k|v  [LN(x+y)|F31] -> 384", 31, 384, 0), ("prop q|k|v [LN|ctx64] -> 384", 64, 384, 0),
+                            ("fc1 + GELU  LN(x+y) -> 512", 0, 512, 2)):
+        k = 128 + e
+        extra = mk("le", T, e) if e else None
+        w, bias = mk("lw%d" % n, n, k) * 0.1, mk("lbb", n)
+        kp = (k + 3) // 4 * 4
+        wpad = F.pad(w, (0, kp - k)).contiguous()
+        pw = K.pack_linear_weight(w)
+
+        def base():
+            xn, a = K.add_ln_concat(x, y, gam, bet, extra, 1, kp)
+            o = F.linear(a, wpad, bias)
+            return F.gelu(o) if act == 2 else o
+        timeit("hipBLASLt path : " + nm, base)
+        timeit("token_linear   : " + nm, lambda: K.token_linear(x, pw, n, k, bias, (gam, bet, 1e-5), y, extra, 1, act))
+    for (nm, k, n, res) in (("proj 128 -> 128", 128, 128, False), ("fc2 512 -> 128", 512, 128, False), ("ffn 160 -> 128 (+GELU)", 160, 128, False)):
+        xx = mk("px%d" % k, T, k)
+        w, bias = mk("pw%d" % k, n, k) * 0.1, mk("pb", n)
+        pw = K.pack_linear_weight(w)
+        act = 2 if k == 160 else 0
+        timeit("hipBLASLt path : " + nm, lambda: F.gelu(F.linear(xx, w, bias)) if act else F.linear(xx, w, bias))
+        timeit("token_linear   : " + nm, lambda: K.token_linear(xx, pw, n, k, bias, act=act))
+
+if "linear_timing" in which:
+    import numpy as np
+    import torch.nn.functional as F
+    T = b * 48 * 156 * 4
+    x, y = mk("lx", T, 128), mk("ly", T, 128)
+    gam, bet = mk("lg", 128) * 0.1 + 1, mk("lb", 128) * 0.1
+    extra = mk("le", T, 31)
+    stamps = torch.zeros(64 * 4 * 16, dtype=torch.int64, device=dev)
+    for (nm, fn) in (("q|k|v LN KC=5 N=384", lambda: K.token_linear(x, K.pack_linear_weight(mk("lw", 384, 159)), 384, 159, mk("lb3", 384), (gam, bet, 1e-5), y, extra, 1, 0)),
+                     ("proj KC=4 N=128", lambda: K.token_linear(x, K.pack_linear_weight(mk("pw", 128, 128)), 128, 128, mk("pb", 128))),
+                     ("fc2 KC=16 N=128", lambda: K.token_linear(mk("hx", T, 512), K.pack_linear_weight(mk("hw", 128, 512)), 128, 512, mk("pb", 128)))):
+        fn(); fn()
+        stamps.zero_()
+        _l.nmrf_debug_token_linear_timing(ctypes.c_void_p(stamps.data_ptr()))
+        fn()
+        torch.cuda.synchronize()
+        _l.nmrf_debug_token_linear_timing(None)
+        st = stamps.cpu().numpy().reshape(64, 4, 16).astype(np.int64)
+        marks = [(0, "start"), (1, "prologue (loads, LN, LDS)"), (2, "barrier"), (3, "group 0: MFMAs + LDS staging"),
+                 (4, "barrier"), (5, "group 0: row stores"), (11, "remaining groups")]
+        print(nm, "-- per-wave phases in shader cycles, mean over 64 blocks, waves 0..3")
+        prev = 0
+        for idx, n_ in marks[1:]:
+            if (st[:, :, idx] == 0).all():
+                continue
+            print("  %-26s" % n_, " ".join("%7.0f" % v for v in (st[:, :, idx] - st[:, :, prev]).mean(0)))
+            prev = idx
+        print("  %-26s" % "total", " ".join("%7.0f" % v for v in (st[:, :, 11] - st[:, :, 0]).mean(0)))
