@@ -47,15 +47,18 @@ class KernelTimer:
 
     def __init__(self):
         self.pairs = {}
+        self.flops = {}
         self.enabled = False
 
-    def __call__(self, phase, name):
+    def __call__(self, phase, name, flops=None):
         if not self.enabled:
             return
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.current_stream())
         if phase == "begin":
             self.pairs.setdefault(name, []).append([ev, None])
+            if flops is not None:
+                self.flops.setdefault(name, []).append(flops)
         else:
             self.pairs[name][-1][1] = ev
 
@@ -187,7 +190,8 @@ def main():
         prev_overlap = os.environ.get("NMRF_OVERLAP")
         os.environ["NMRF_OVERLAP"] = "0"
         timer.enabled = True
-        for _ in range(max(3, min(args.steps, 10))):
+        n_timed_fwd = max(3, min(args.steps, 10))
+        for _ in range(n_timed_fwd):
             step()
         torch.cuda.synchronize()
         timer.enabled = False
@@ -232,8 +236,17 @@ def main():
     kern_names = {"stripe_attn_horizontal": "stripe_attn_kernel<1> (horizontal stripes, A7)",
                   "window_attn_w%d_n%d" % (win, n): "window_attn_kernel<%d> (inference windows, A10)" % ((tw + 31) // 32)}
     # HBM bytes per launch from the separate rocprofv3 --pmc passes (tools/gpu_pmc.sh -> profiles/pmc_traffic.json)
-    pmc_names = {"stripe_attn_horizontal": "stripe_attn_kernel<1, 2, 4, false>",
+    pmc_names = {"stripe_attn_horizontal": "stripe_attn_kernel<1, 2, 1, false>",
                  "window_attn_w%d_n%d" % (win, n): "window_attn_fast_kernel<5, 6, 4, 2, 3, false>"}
+    # fused token linears: algorithmic FLOPs 2*T*K*N recorded by the wrapper at each launch
+    for k_, fl in timer.flops.items():
+        ln_, kk, nn_, act_ = (int(v.lstrip("lnkact")) for v in k_.split("_")[2:])
+        flops[k_] = sum(fl) / len(fl)
+        kern_names[k_] = "token_linear_kernel<%d,%s,%s> (%s%d->%d%s, N3)" % (
+            (kk + 31) // 32, "LN" if ln_ else "plain", "GELU" if act_ == 2 else "-", "LayerNorm+" if ln_ else "", kk, nn_,
+            "+GELU" if act_ == 2 else "")
+        pmc_names[k_] = "token_linear_kernel<%d, %s, %s>" % ((kk + 31) // 32, "true" if ln_ else "false",
+                                                            "true" if act_ == 2 else "false")
     pmc = {}
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
@@ -243,7 +256,7 @@ def main():
     roof, others = None, []
     timed = {k: v for k, v in kstats.items() if k in flops}
     if timed:
-        per_fwd = {k: v[0] * cfg.NMP.NUM_INFER_LAYERS for k, v in timed.items()}   # both run 5x per forward
+        per_fwd = {k: v[0] * v[1] / n_timed_fwd for k, v in timed.items()}         # ms per forward spent in each kernel
         dom = max(per_fwd, key=per_fwd.get)
         for k, (ms, cnt) in timed.items():
             ach = flops[k] / (ms * 1e-3) / 1e12
@@ -251,11 +264,14 @@ def main():
                    "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
                    "traffic": (pmc.get(pmc_names[k], {}).get("hbm_bytes") if (b == 1 and args.height == 375 and
                                                                               args.width == 1242) else None),
-                   "launch_ms": round(ms, 4), "launches_timed": cnt, "flop_per_launch": flops[k]}
+                   "launch_ms": round(ms, 4), "launches_timed": cnt, "ms_per_forward": round(per_fwd[k], 4),
+                   "flop_per_launch": flops[k]}
             if k == dom:
                 roof = rec
             else:
                 others.append(rec)
+        others.sort(key=lambda r: -r["ms_per_forward"])
+        others = others[:6]
 
     if rank == 0:
         res = {

@@ -113,7 +113,8 @@ def add_ln_concat(x, y, gamma, beta, extra=None, extra_div=1, ld=None, eps=1e-5)
 
 
 # optional observer used by bench.py to bracket the dominant kernel with HIP events: called as
-# hook("begin"/"end", name) around that single launch, on the launching stream
+# hook("begin"/"end", name[, flops]) around that single launch, on the launching stream (flops: algorithmic FLOPs of the
+# launch where the wrapper knows them)
 kernel_hook = None
 
 
@@ -206,9 +207,15 @@ def token_linear(x, packed_w, n, k, bias=None, ln=None, y=None, extra=None, extr
         _chk(g, bt)
     out = torch.empty(t, n, device=x.device, dtype=torch.float32)
     x_out = torch.empty_like(x) if y is not None else None
+    hook_name = None
+    if kernel_hook is not None:
+        hook_name = "token_linear_ln%d_k%d_n%d_act%d" % (int(ln is not None), k, n, act)
+        kernel_hook("begin", hook_name, 2.0 * t * k * n)
     _lib.check(_lib.load().nmrf_token_linear_f32(_p(x), _p(y), _p(x_out), _p(g), _p(bt), float(eps), _p(extra), e, extra_div,
                                                  _p(packed_w), _p(bias), _p(residual), act, t, cx, k, n, _p(out), _stream()),
                "token_linear")
+    if hook_name is not None:
+        kernel_hook("end", hook_name)
     return (x_out, out) if y is not None else out
 
 

@@ -24,7 +24,7 @@ def main(src, dst_prefix):
     table = {}
     for p in "ABCD":
         for k, cs in load(os.path.join(src, "pass%s_counter_collection.csv" % p)).items():
-            if "attn" in k or "warp" in k:
+            if "attn" in k or "warp" in k or "token_linear" in k:
                 table.setdefault(k, {}).update({c: round(sum(v) / len(v)) for c, v in cs.items()})
     traffic = {}
     for k, c in table.items():
