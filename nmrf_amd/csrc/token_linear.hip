@@ -246,6 +246,162 @@ __global__ __launch_bounds__(256, 2) void token_linear_kernel(TokenLinearArgs a,
     TL_STAMP(11);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Persistent, software-pipelined form of the LayerNorm variants (the q|k|v and fc1 operands: 35 of the 62 linears of a
+// forward).  A block walks tiles blockIdx.x, +gridDim.x, ...: while the MFMAs of tile i run, the rows of tile i+1 are
+// already in flight into registers; they are normalised into the second operand buffer after the last column group,
+// and the row stores of every 128-column group (staged through one of two LDS buffers) are issued right behind its
+// barrier and retire under the next group's MFMAs.  In the one-tile-per-block kernel above every block runs
+// load -> LayerNorm -> MFMA -> store back to back, in step with all its neighbours: 0.9 of the MFMA pipe inside the
+// MFMA phase, 0.4 over the kernel.
+// ------------------------------------------------------------------------------------------------------------------
+template <int KC, bool GELU, int OBUF>
+__global__ __launch_bounds__(256, 2) void token_linear_pipe_kernel(TokenLinearArgs a, int n_tiles) {
+    constexpr int MT = 32, KP = KC * 32, LDA = KP + TL_PAD, GW = 128, LDO = GW + TL_PAD;
+    constexpr int EX = (KP - 128) / 16;                             // extra columns per lane (2 for Fourier31, 4 for context64)
+    extern __shared__ __attribute__((aligned(16))) float sm[];       // A[2][32][LDA] | Ot[OBUF][32][LDO]
+    float *Abuf = sm, *Obuf = sm + 2 * MT * LDA;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i32 = lane & 31, hi = lane >> 5;
+    const int sub = tid & 15, rr = tid >> 4;                        // LayerNorm: 16 lanes per token, 16 tokens per pass
+    const float4 g0 = ldg4(a.gamma + 4 * sub), g1 = ldg4(a.gamma + 64 + 4 * sub);
+    const float4 b0 = ldg4(a.beta + 4 * sub), b1 = ldg4(a.beta + 64 + 4 * sub);
+
+    float4 v0[2], v1[2], w0[2], w1[2];                              // x and y rows of the tile being fetched
+    float ex[2][EX > 0 ? EX : 1];
+    auto fetch = [&](int tile) {                                    // issue the loads, do not wait
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int64_t t = (int64_t)tile * MT + p * 16 + rr;
+            const bool ok = t < a.T;
+            const int64_t tc = ok ? t : a.T - 1;                    // clamped: straight-line loads, masked at use
+            if (EX > 0) {
+                const float *e = a.extra + (tc / a.extra_div) * a.E;
+#pragma unroll
+                for (int j = 0; j < EX; ++j) ex[p][j] = (a.E > 0 && sub + 16 * j < a.E) ? e[sub + 16 * j] : 0.f;
+            }
+            v0[p] = ldg4(a.x + tc * 128 + 4 * sub);
+            v1[p] = ldg4(a.x + tc * 128 + 64 + 4 * sub);
+            if (a.y) {
+                w0[p] = ldg4(a.y + tc * 128 + 4 * sub);
+                w1[p] = ldg4(a.y + tc * 128 + 64 + 4 * sub);
+            }
+        }
+    };
+    auto normalise = [&](int tile, float *At) {                     // (x + y) -> x_out, LayerNorm | extra -> At
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int row = p * 16 + rr;
+            const int64_t t = (int64_t)tile * MT + row;
+            const bool ok = t < a.T;
+            float4 s0 = v0[p], s1 = v1[p];
+            if (a.y) {
+                s0 = make_float4(s0.x + w0[p].x, s0.y + w0[p].y, s0.z + w0[p].z, s0.w + w0[p].w);
+                s1 = make_float4(s1.x + w1[p].x, s1.y + w1[p].y, s1.z + w1[p].z, s1.w + w1[p].w);
+                if (ok) {
+                    stg4(a.x_out + t * 128 + 4 * sub, s0);
+                    stg4(a.x_out + t * 128 + 64 + 4 * sub, s1);
+                }
+            }
+            const float s = ((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w));
+            const float mean = row16_sum(s) * (1.0f / 128.0f);
+            const float4 d0 = make_float4(s0.x - mean, s0.y - mean, s0.z - mean, s0.w - mean);
+            const float4 d1 = make_float4(s1.x - mean, s1.y - mean, s1.z - mean, s1.w - mean);
+            const float q = ((d0.x * d0.x + d0.y * d0.y) + (d0.z * d0.z + d0.w * d0.w)) +
+                            ((d1.x * d1.x + d1.y * d1.y) + (d1.z * d1.z + d1.w * d1.w));
+            const float rstd = 1.0f / sqrtf(row16_sum(q) * (1.0f / 128.0f) + a.eps);
+            float *ar = At + row * LDA;
+            *reinterpret_cast<float4 *>(ar + 4 * sub) = ok ? make_float4(d0.x * rstd * g0.x + b0.x, d0.y * rstd * g0.y + b0.y,
+                                                                         d0.z * rstd * g0.z + b0.z, d0.w * rstd * g0.w + b0.w)
+                                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(ar + 64 + 4 * sub) = ok ? make_float4(d1.x * rstd * g1.x + b1.x, d1.y * rstd * g1.y + b1.y,
+                                                                              d1.z * rstd * g1.z + b1.z, d1.w * rstd * g1.w + b1.w)
+                                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < EX; ++j) ar[128 + sub + 16 * j] = ok ? ex[p][j] : 0.f;
+        }
+    };
+
+    const int n_groups = a.N / GW;                                  // one 32-column strip per wave and group
+    const float4 *wp = reinterpret_cast<const float4 *>(a.w_packed) + lane;
+    auto load_w = [&](int strip, int c, float *wd) {
+        const float4 *p = wp + (size_t)(strip * KC + c) * 256;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 v = p[j * 64];
+            wd[4 * j + 0] = v.x; wd[4 * j + 1] = v.y; wd[4 * j + 2] = v.z; wd[4 * j + 3] = v.w;
+        }
+    };
+    constexpr int NB = KC <= 5 ? KC : (KC == 6 ? 3 : 4);
+    static_assert(KC % NB == 0, "ring size must divide the chunk count");
+    float wbuf[NB][16];
+    auto act_fn = [&](float v) {
+        if (GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        return a.act == 1 ? fmaxf(v, 0.f) : v;
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    fetch(tile);
+    static_for<NB>([&](auto cc) { load_w(wv, decltype(cc)::value, wbuf[decltype(cc)::value]); });
+    normalise(tile, Abuf);
+    __syncthreads();
+    int cur = 0, ob = 0;
+#pragma unroll 1
+    for (;;) {
+        const int next = tile + gridDim.x;
+        const bool has_next = next < n_tiles;
+        if (has_next) fetch(next);
+        const float *a_lane = Abuf + cur * MT * LDA + i32 * LDA + 16 * hi;
+        const int64_t m0 = (int64_t)tile * MT;
+#pragma unroll 1
+        for (int g = 0; g < n_groups; ++g) {
+            const int strip = g * 4 + wv;
+            // the strip after this one: next group, or the first strip of the next tile (same weights)
+            const int next_strip = (g + 1 < n_groups) ? strip + 4 : (has_next ? wv : -1);
+            const float bias_s = a.bias ? a.bias[strip * 32 + i32] : 0.f;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            static_for<KC>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                float af[16];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float4 v = *reinterpret_cast<const float4 *>(a_lane + c * 32 + 4 * jj);
+                    af[4 * jj + 0] = v.x; af[4 * jj + 1] = v.y; af[4 * jj + 2] = v.z; af[4 * jj + 3] = v.w;
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc = mfma32(af[k], wbuf[c % NB][k], acc);
+                if constexpr (c + NB < KC) load_w(strip, c + NB, wbuf[c % NB]);
+                else if (next_strip >= 0) load_w(next_strip, c + NB - KC, wbuf[c % NB]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            float *Ot = Obuf + ob * MT * LDO;
+            float *o = Ot + (4 * hi) * LDO + wv * 32 + i32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2)) * LDO] = act_fn(acc[r] + bias_s);
+            __syncthreads();
+            // 8 rows per wave, 512 B per row: lanes 0-31 one row, lanes 32-63 the next
+#pragma unroll
+            for (int rp = 0; rp < 4; ++rp) {
+                const int row = wv * 8 + 2 * rp + hi;
+                const int64_t t = m0 + row;
+                if (t < a.T) stg4(a.out + (size_t)t * a.N + (size_t)g * GW + 4 * i32,
+                                  *reinterpret_cast<const float4 *>(Ot + row * LDO + 4 * i32));
+            }
+            if (OBUF == 2) ob ^= 1;                                 // the barrier of the next group protects the reuse
+            else __syncthreads();
+        }
+        if (!has_next) break;
+        normalise(next, Abuf + (cur ^ 1) * MT * LDA);
+        __syncthreads();
+        cur ^= 1;
+        tile = next;
+    }
+}
+
 // weights [N, K] row-major -> fragment order [N/32][Kp/32][4][64 lanes][4], zero-padded in K
 __global__ __launch_bounds__(256) void pack_linear_weight_kernel(const float *__restrict__ w, int N, int K, int KC,
                                                                 float *__restrict__ packed) {
@@ -300,6 +456,36 @@ static int launch_token_linear(const TokenLinearArgs &a, hipStream_t st) {
     return a.act == 2 ? launch_token_linear_g<KC, LN, true>(a, st) : launch_token_linear_g<KC, LN, false>(a, st);
 }
 
+template <int KC, bool GELU>
+static int launch_token_linear_pipe_g(const TokenLinearArgs &a, hipStream_t st) {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NMRF_ELAUNCH;
+        n_cu = prop.multiProcessorCount;
+    }
+    constexpr size_t lds_a = (size_t)2 * 32 * (KC * 32 + TL_PAD) * sizeof(float), lds_o1 = (size_t)32 * (128 + TL_PAD) * sizeof(float);
+    constexpr int OBUF = (lds_a + 2 * lds_o1 <= 80 * 1024) ? 2 : 1;          // two blocks per CU must fit in 160 KB
+    constexpr size_t lds = lds_a + OBUF * lds_o1;
+    static bool attr_set = false;
+    if (lds > 65536 && !attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(token_linear_pipe_kernel<KC, GELU, OBUF>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return NMRF_ELAUNCH;
+        attr_set = true;
+    }
+    const int n_tiles = (int)ceil_div64(a.T, 32);
+    const int grid = n_tiles < 2 * n_cu ? n_tiles : 2 * n_cu;
+    hipLaunchKernelGGL((token_linear_pipe_kernel<KC, GELU, OBUF>), dim3(grid), dim3(256), lds, st, a, n_tiles);
+    return nmrf_launch_status();
+}
+
+template <int KC>
+static int launch_token_linear_pipe(const TokenLinearArgs &a, hipStream_t st) {
+    return a.act == 2 ? launch_token_linear_pipe_g<KC, true>(a, st) : launch_token_linear_pipe_g<KC, false>(a, st);
+}
+
 extern "C" int nmrf_token_linear_f32(const float *x, const float *y, float *x_out, const float *ln_gamma,
                                      const float *ln_beta, float eps, const float *extra, int E, int extra_div,
                                      const float *w_packed, const float *bias, const float *residual, int act, int64_t T,
@@ -313,6 +499,14 @@ extern "C" int nmrf_token_linear_f32(const float *x, const float *y, float *x_ou
     TokenLinearArgs a{x, y, x_out, ln_gamma, ln_beta, eps, extra, E, extra_div, w_packed, bias, residual, act, T, Cx, N, out, g_tl_stamps};
     hipStream_t st = (hipStream_t)stream;
     const int KC = (K + 31) / 32;
+    if (ln && !residual && N % 128 == 0 && !g_tl_stamps && !getenv("NMRF_TL_NOPIPE")) {
+        switch (KC) {
+            case 4: return launch_token_linear_pipe<4>(a, st);
+            case 5: return launch_token_linear_pipe<5>(a, st);
+            case 6: return launch_token_linear_pipe<6>(a, st);
+            default: break;
+        }
+    }
     if (ln) {
         switch (KC) {
             case 4: return launch_token_linear<4, true>(a, st);

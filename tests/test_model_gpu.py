@@ -146,15 +146,16 @@ def test_driver_pipeline_matches_direct_calls():
     assert list(got) == [0, 1, 2, 3, 4]
     # same batch composition -> same arithmetic in every hand-written kernel (tools/determinism_check.py: bit-identical
     # run to run); MIOpen's solver for the tiny 8x13 coarse convs is not (1e-6 run-to-run noise on identical inputs,
-    # tools/determinism_trace.py), which the layers above amplify to ~1e-3 px (a few pixels near seed ties more).  Different
-    # pairs differ by whole pixels on average.
+    # tools/determinism_trace.py), which the layers above amplify to ~1e-3 px and, at the odd pixel near a seed tie, to a
+    # good fraction of a pixel -- hence median / outlier-fraction bounds.  Different pairs differ by whole pixels on average.
     with torch.no_grad():
         for grp in ([0, 1], [2, 3], [4]):
             want = model({"img1": torch.stack([pairs[i][1] for i in grp]),
                           "img2": torch.stack([pairs[i][2] for i in grp])})["disp"].cpu()
             for j, i in enumerate(grp):
                 d = (got[i] - want[j]).abs()
-                assert float(d.mean()) < 2e-3 and float(d.max()) < 0.5, (i, float(d.mean()), float(d.max()))
+                assert float(d.median()) < 1e-3 and float((d > 0.1).float().mean()) < 0.01, \
+                    (i, float(d.median()), float(d.mean()), float(d.max()))
                 assert all(float((got[i] - got[k]).abs().mean()) > 0.1 for k in got if k != i)
 
 
