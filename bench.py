@@ -242,17 +242,25 @@ def main():
     for k_, fl in timer.flops.items():
         ln_, kk, nn_, act_ = (int(v.lstrip("lnkact")) for v in k_.split("_")[2:])
         flops[k_] = sum(fl) / len(fl)
-        kern_names[k_] = "token_linear_kernel<%d,%s,%s> (%s%d->%d%s, N3)" % (
+        kern_names[k_] = "token_linear%s_kernel<%d,%s,%s> (%s%d->%d%s, N3)" % ("_pipe" if ln_ else "",
             (kk + 31) // 32, "LN" if ln_ else "plain", "GELU" if act_ == 2 else "-", "LayerNorm+" if ln_ else "", kk, nn_,
             "+GELU" if act_ == 2 else "")
-        pmc_names[k_] = "token_linear_kernel<%d, %s, %s>" % ((kk + 31) // 32, "true" if ln_ else "false",
-                                                            "true" if act_ == 2 else "false")
+        tf = lambda v: "true" if v else "false"
+        pmc_names[k_] = ["token_linear_pipe_kernel<%d, %s, 2>" % ((kk + 31) // 32, tf(act_ == 2)),
+                         "token_linear_pipe_kernel<%d, %s, 1>" % ((kk + 31) // 32, tf(act_ == 2)),
+                         "token_linear_kernel<%d, %s, %s>" % ((kk + 31) // 32, tf(ln_), tf(act_ == 2))][0 if ln_ else 2:]
     pmc = {}
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pmc = json.load(f)
     except (OSError, ValueError):
         pass
+    def pmc_bytes(names):
+        for nm in ([names] if isinstance(names, str) else names):
+            if nm in pmc:
+                return pmc[nm].get("hbm_bytes")
+        return None
+
     roof, others = None, []
     timed = {k: v for k, v in kstats.items() if k in flops}
     if timed:
@@ -262,8 +270,7 @@ def main():
             ach = flops[k] / (ms * 1e-3) / 1e12
             rec = {"bound": "mfma", "kernel": kern_names[k], "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
                    "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                   "traffic": (pmc.get(pmc_names[k], {}).get("hbm_bytes") if (b == 1 and args.height == 375 and
-                                                                              args.width == 1242) else None),
+                   "traffic": (pmc_bytes(pmc_names[k]) if (b == 1 and args.height == 375 and args.width == 1242) else None),
                    "launch_ms": round(ms, 4), "launches_timed": cnt, "ms_per_forward": round(per_fwd[k], 4),
                    "flop_per_launch": flops[k]}
             if k == dom:
