@@ -137,27 +137,32 @@ def main():
     timer = KernelTimer()
     K.kernel_hook = timer
 
-    def step():
-        out = model(sample)
+    def forward():
+        return model(sample)["disp"]
+
+    def gather(disp):
         if use_dist and not args.no_gather:
             if world == 1:                                    # --force-dist smoke: the collective on a 1-rank group
-                g = torch.empty_like(out["disp"])
-                dist.all_gather_into_tensor(g, out["disp"].contiguous())
+                g = torch.empty_like(disp)
+                dist.all_gather_into_tensor(g, disp.contiguous())
                 return g
-            return gather_disparity(out["disp"])
-        return out["disp"]
+            return gather_disparity(disp)
+        return disp
+
+    def step():
+        return gather(forward())
 
     graph = None
     with torch.no_grad():
         for _ in range(max(args.warmup, 1)):
             step()
         torch.cuda.synchronize()
-        if not args.no_graph and not use_dist:
-            try:
+        if not args.no_graph:
+            try:                                          # the forward is captured; the RCCL gather stays an eager launch
                 K.kernel_hook = None                      # events cannot be recorded/queried inside a capture
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
-                    static_out = step()
+                    static_out = forward()
                 graph.replay()
                 torch.cuda.synchronize()
             except Exception as e:                        # capture unsupported -> eager launches
@@ -166,7 +171,12 @@ def main():
                 torch.cuda.synchronize()
             K.kernel_hook = timer
 
-        run = graph.replay if graph is not None else step
+        if graph is not None:
+            def run():
+                graph.replay()
+                return gather(static_out)
+        else:
+            run = step
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()

@@ -230,7 +230,10 @@ def test_linear_smalln(t_, k, n, relu):
     (1000, 64, 384, 0, 4, False, False),    # propagation q|k|v: context shared by the 4 labels of a pixel
     (777, 0, 512, 2, 1, True, False),       # fc1 + GELU(erf) on LN(x + y)
     (64, 0, 128, 1, 1, False, True),        # ReLU + residual, exactly one tile
-    (29952, 31, 384, 0, 1, True, False),    # KITTI size
+    (29952, 31, 384, 0, 1, True, False),    # KITTI size: 936 tiles on 512 persistent blocks
+    (20013, 64, 384, 0, 4, True, False),    # ragged last tile + two tiles per block (pipelined path), shared context rows
+    (16397, 0, 512, 2, 1, True, False),     # same for fc1 + GELU (four 128-column groups per tile)
+    (16397, 0, 512, 2, 1, False, True),     # residual operand -> the one-tile-per-block kernel
 ])
 def test_token_linear_layernorm_prologue(t_, e, n, act, div, with_y, res):
     x, y = rnd(t_, 128, seed=1, scale=2.0), rnd(t_, 128, seed=2)
