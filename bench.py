@@ -292,7 +292,7 @@ def main():
 
     if rank == 0:
         res = {
-            "metric": "stereo pairs/sec at 1242x375", "value": round(value, 3), "unit": "stereo pairs/s",
+            "metric": "stereo pairs/sec at %dx%d" % (args.width, args.height), "value": round(value, 3), "unit": "stereo pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
