@@ -192,10 +192,19 @@ __global__ __launch_bounds__(256) void warp_corr_concat_kernel(const float *__re
         const float *__restrict__ f1, const float *__restrict__ f2, const float *__restrict__ g1,
         const float *__restrict__ g2, int H, int W, int N, int Cf, int Cg, int groups, float *__restrict__ out, int ld) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int x = blockIdx.x * 64 + lane;
-    const int y = blockIdx.y / (WC_CHUNKS / 4);
-    const int chunk = (blockIdx.y % (WC_CHUNKS / 4)) * 4 + wv;
-    const int b = blockIdx.z / N, n = blockIdx.z % N;
+    // XCD-aware block order (workgroups go round-robin over the 8 XCDs): the N labels of a pixel read the same rows of all
+    // four maps, so logical items are numbered label-fastest and every XCD gets a contiguous run of them -- with the
+    // natural (x, y, b*N+n) order the labels of a row were spread over different L2s and each fetched the maps again.
+    const int gx = (W + 63) / 64, gy = H * (WC_CHUNKS / 4);
+    const int per_xcd = gridDim.x >> 3;                             // the launch pads the grid to a multiple of 8
+    const int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (item >= gx * gy * (int)gridDim.y * N) return;
+    const int n = item % N;
+    const int bx = (item / N) % gx, by = (item / (N * gx)) % gy;
+    const int b = blockIdx.y;
+    const int x = bx * 64 + lane;
+    const int y = by / (WC_CHUNKS / 4);
+    const int chunk = (by % (WC_CHUNKS / 4)) * 4 + wv;
     if (x >= W) return;
     const size_t plane = (size_t)H * W;
     const int pix = y * W + x;
@@ -238,9 +247,11 @@ extern "C" int nmrf_warp_corr_concat_f32(const float *labels, const float *f1, c
                                          float *out, int ld, void *stream) {
     if (!labels || !f1 || !f2 || !g1 || !g2 || !out) return NMRF_ENULL;
     if (B < 1 || H < 2 || W < 2 || N < 1 || Cf < 4 * WC_CHUNKS || Cf % (4 * WC_CHUNKS) || groups < 4 * WC_CHUNKS ||
-        groups % (4 * WC_CHUNKS) || Cg % groups || ld < 2 * Cf + groups || (ld & 3) || (int64_t)B * N > 65535)
+        groups % (4 * WC_CHUNKS) || Cg % groups || ld < 2 * Cf + groups || (ld & 3) || B > 65535)
         return NMRF_EINVAL;
-    dim3 grid((W + 63) / 64, H * (WC_CHUNKS / 4), B * N);
+    const int64_t items = (int64_t)((W + 63) / 64) * H * (WC_CHUNKS / 4) * N;      // per image
+    if (items > 0x7ffffff0) return NMRF_EINVAL;
+    dim3 grid((unsigned)((items + 7) / 8 * 8), B);
     hipLaunchKernelGGL(warp_corr_concat_kernel, grid, dim3(256), 0, (hipStream_t)stream, labels, f1, f2, g1, g2, H, W, N,
                        Cf, Cg, groups, out, ld);
     return nmrf_launch_status();
