@@ -27,7 +27,7 @@ extern "C" {
 
 const char *nmrf_strerror(int code);
 /* ABI version of this header; bumps on any signature change. */
-int nmrf_abi_version(void);   /* currently 6 */
+int nmrf_abi_version(void);   /* currently 7 */
 
 /* A2  group-wise correlation volume.
  * replaces build_correlation_volume + the permute of DPN.forward
@@ -134,6 +134,15 @@ int nmrf_token_linear_f32(const float *x, const float *y, float *x_out, const fl
                           const float *residual, int act, int64_t T, int Cx, int K, int N, float *out, void *stream);
 /* w [N,K] row-major -> packed [N/32][ceil(K/32)][4][64][4] floats (one contiguous 1 KiB line per wave load). */
 int nmrf_pack_linear_weight_f32(const float *w, int N, int K, float *packed, void *stream);
+
+/* N2  3x3 / stride 1 / pad 1 / no bias convolution, NCHW fp32, as fused Winograd F(2x2,3x3) on fp32 MFMA.
+ * replaces nn.Conv2d(Ci, Co, 3, 1, 1, bias=False) of the stock conv band: backbone residual blocks
+ * (nmrf/models/backbone.py:38-46), concatconv / gw (nmrf/models/NMRF.py:56-65), dpn.proj (nmrf/models/DPN.py:45-49).
+ * x [B,Ci,H,W]; u_packed from nmrf_wino_pack_filter_f32 (16*Ci*Co floats); Ci % 16 == 0, Co % 32 == 0 -> y [B,Co,H,W]. */
+int nmrf_conv3x3_wino_f32(const float *x, const float *u_packed, int B, int Ci, int H, int W, int Co, float *y,
+                          void *stream);
+/* w [Co,Ci,3,3] -> U = G w G^T in MFMA fragment order [Ci/16][Co/32][4][4][2][64][4]. */
+int nmrf_wino_pack_filter_f32(const float *w, int Co, int Ci, float *packed, void *stream);
 
 /* A11/A12  coarse heads epilogue: relu(label+delta), winner-take-all over N by score (first max),
  * x2, 4x4 lower median.  replaces NMRF.forward (nmrf/models/NMRF.py:219-232).

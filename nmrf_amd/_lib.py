@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnmrf_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -32,6 +32,8 @@ PROTOTYPES = {
     "nmrf_linear_smalln_f32": [_P, _P, _P, _L, _I, _I, _I, _P, _P],
     "nmrf_token_linear_f32": [_P, _P, _P, _P, _P, _F, _P, _I, _I, _P, _P, _P, _I, _L, _I, _I, _I, _P, _P],
     "nmrf_pack_linear_weight_f32": [_P, _I, _I, _P, _P],
+    "nmrf_conv3x3_wino_f32": [_P, _P, _I, _I, _I, _I, _I, _P, _P],
+    "nmrf_wino_pack_filter_f32": [_P, _I, _I, _P, _P],
     "nmrf_wta_median_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "nmrf_refine_epilogue_f32": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "nmrf_instance_norm_f32": [_P, _P, _L, _L, _F, _I, _I, _P, _P, _P],

@@ -219,6 +219,25 @@ def token_linear(x, packed_w, n, k, bias=None, ln=None, y=None, extra=None, extr
     return (x_out, out) if y is not None else out
 
 
+def wino_pack_filter(weight):
+    """[Co,Ci,3,3] conv weight -> Winograd-domain filter in MFMA fragment order for conv3x3_wino."""
+    _chk(weight)
+    co, ci, kh, kw = weight.shape
+    assert kh == 3 and kw == 3
+    packed = torch.empty(16 * co * ci, device=weight.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_wino_pack_filter_f32(_p(weight.contiguous()), co, ci, _p(packed), _stream()), "wino_pack_filter")
+    return packed
+
+
+def conv3x3_wino(x, packed_u, co):
+    """3x3 / stride 1 / pad 1 / no-bias convolution (NCHW fp32) as fused Winograd F(2x2,3x3) on fp32 MFMA."""
+    _chk(x, packed_u)
+    b, ci, h, w = x.shape
+    y = torch.empty(b, co, h, w, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_conv3x3_wino_f32(_p(x), _p(packed_u), b, ci, h, w, co, _p(y), _stream()), "conv3x3_wino")
+    return y
+
+
 def wta_median(delta, score, labels, b, h, w, n):
     _chk(delta, score, labels)
     out = torch.empty(b, 2 * h, 2 * w, device=delta.device, dtype=torch.float32)

@@ -290,6 +290,18 @@ def test_instance_norm_fused(b, c, h, w):
     report("in+relu+res+relu", got, F.relu(F.relu(ref) + res.double()), 5e-6)
 
 
+@pytest.mark.parametrize("b,ci,co,h,w", [(1, 16, 32, 4, 64), (2, 32, 32, 7, 9), (1, 64, 64, 47, 156), (2, 96, 128, 23, 70),
+                                          (1, 256, 128, 12, 33), (1, 16, 32, 1, 1)])
+def test_conv3x3_winograd(b, ci, co, h, w):
+    x = rnd(b, ci, h, w, seed=21, scale=2.0)
+    wt = rnd(co, ci, 3, 3, seed=22, scale=0.2)
+    kk = K()
+    got = kk.conv3x3_wino(x.to(DEV), kk.wino_pack_filter(wt.to(DEV)), co).cpu()
+    ref = F.conv2d(x.double(), wt.double(), None, 1, 1)
+    # F(2x2,3x3) in fp32: a few ulp of the largest partial products (MIOpen's Winograd kernel has the same error profile)
+    report("conv3x3_wino", got, ref, 2e-5 * (ci ** 0.5), 1e-5)
+
+
 def test_kernels_refuse_cpu_tensors():
     from nmrf_amd._lib import NmrfHipError
     with pytest.raises(NmrfHipError):

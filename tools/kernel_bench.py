@@ -232,3 +232,23 @@ if "linear_timing" in which:
             print("  %-26s" % n_, " ".join("%7.0f" % v for v in (st[:, :, idx] - st[:, :, prev]).mean(0)))
             prev = idx
         print("  %-26s" % "total", " ".join("%7.0f" % v for v in (st[:, :, 11] - st[:, :, 0]).mean(0)))
+
+if "conv" in which:
+    import torch.nn.functional as F
+    for (bb, ci, co, hh, ww) in ((2, 64, 64, 188, 624), (2, 96, 96, 94, 312), (2, 128, 128, 94, 312), (2, 128, 256, 94, 312),
+                                 (2, 256, 256, 47, 156), (1, 256, 128, 47, 156)):
+        xx = mk("cx%d" % ci, bb * args.batch, ci, hh, ww)
+        wt = mk("cw%d%d" % (ci, co), co, ci, 3, 3) * 0.05
+        pu = K.wino_pack_filter(wt)
+        fl = 2.0 * bb * args.batch * ci * co * 9 * hh * ww
+        e = []
+        for nm, fn in (("MIOpen", lambda: F.conv2d(xx, wt, None, 1, 1)), ("wino  ", lambda: K.conv3x3_wino(xx, pu, co))):
+            fn(); fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            e.append(e0.elapsed_time(e1) * 1e3 / args.iters)
+        print("conv3x3 %3d->%3d @%dx%dx%d : MIOpen %7.1f us (%5.1f TF/s eff)   wino %7.1f us (%5.1f TF/s eff)  x%.2f"
+              % (ci, co, bb * args.batch, hh, ww, e[0], fl / e[0] / 1e6, e[1], fl / e[1] / 1e6, e[0] / e[1]), flush=True)
