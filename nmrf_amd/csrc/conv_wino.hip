@@ -89,7 +89,10 @@ __global__ __launch_bounds__(512, 4) void conv3x3_wino_kernel(const float *__res
     auto fetch = [&](int kc) {
         const float *src = p_src + (size_t)kc * WN_CK * plane;
 #pragma unroll
-        for (int c = 0; c < WN_CK; ++c) rreg[c] = p_in ? src[(size_t)c * plane] : 0.f;
+        for (int c = 0; c < WN_CK; ++c) {                           // unconditional load of a valid address, masked after
+            const float v = src[(size_t)c * plane];
+            rreg[c] = p_in ? v : 0.f;
+        }
         const float4 *p = reinterpret_cast<const float4 *>(up) + ((size_t)kc * n_cb + cb) * 2048 + tid;
 #pragma unroll
         for (int u = 0; u < 4; ++u) ureg[u] = p[512 * u];

@@ -2,6 +2,8 @@
 pointers and the CURRENT torch stream.  PyTorch is plumbing here (memory + streams); all arithmetic
 of these ops happens in libnmrf_hip.so.  Every wrapper refuses non-CUDA tensors: there is no
 fallback path."""
+import os
+
 import torch
 
 from . import _lib
@@ -236,6 +238,24 @@ def conv3x3_wino(x, packed_u, co):
     y = torch.empty(b, co, h, w, device=x.device, dtype=torch.float32)
     _lib.check(_lib.load().nmrf_conv3x3_wino_f32(_p(x), _p(packed_u), b, ci, h, w, co, _p(y), _stream()), "conv3x3_wino")
     return y
+
+
+def conv3x3_auto(x, weight, cache):
+    """3x3 / stride 1 / pad 1 / no-bias convolution: the fused Winograd MFMA kernel where it has enough blocks to fill
+    the chip (>= 600: measured 1.2-1.3x MIOpen there, 0.6-0.9x below), MIOpen otherwise.  NMRF_WINO=0 forces MIOpen.
+    `cache`: a dict owned by the caller, holds the packed filter per weight version."""
+    co, ci = weight.shape[0], weight.shape[1]
+    b, _, h, w = x.shape
+    blocks = ((w + 1) // 2 + 31) // 32 * (((h + 1) // 2 + 1) // 2) * b * (co // 32)
+    if (not x.is_cuda or ci % 16 or co % 32 or blocks < 600 or os.environ.get("NMRF_WINO", "1") == "0"
+            or x.dtype != torch.float32):
+        return torch.nn.functional.conv2d(x, weight, None, 1, 1)
+    key = (weight.data_ptr(), weight._version)
+    if cache.get("key") != key:
+        with torch.no_grad():
+            cache["packed"] = wino_pack_filter(weight)
+        cache["key"] = key
+    return conv3x3_wino(x.contiguous(), cache["packed"], co)
 
 
 def wta_median(delta, score, labels, b, h, w, n):

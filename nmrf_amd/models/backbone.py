@@ -1,4 +1,5 @@
-"""Stock PyTorch-ROCm CNN feature encoder (OUT OF hot-path scope by north_star: runs on MIOpen).
+"""CNN feature encoder.  Stock PyTorch-ROCm (MIOpen) by north_star, except what SURVEY 8(f) N2 pulled in: InstanceNorm
+(+ReLU / residual) on the fused HIP kernels and the large 3x3 stride-1 convolutions on the Winograd MFMA kernel.
 
 Parameter names follow the reference's `Backbone` (nmrf/models/backbone.py:16-98) so released
 checkpoints load with strict=True: conv1, layer{1,2,3}.{0,1}.{conv1,conv2,downsample.0}, conv2.
@@ -24,6 +25,7 @@ class ResidualBlock(nn.Module):
         self.norm1 = _norm(norm, cout)
         self.norm2 = _norm(norm, cout)
         self.fused = norm == "instance"
+        self._wino1, self._wino2 = {}, {}
         self.downsample = None
         if stride != 1 or cin != cout:
             self.norm3 = _norm(norm, cout)
@@ -33,10 +35,12 @@ class ResidualBlock(nn.Module):
         if self.fused and x.is_cuda:
             # InstanceNorm + ReLU (+ residual add + ReLU) in two HIP passes instead of 4-6 torch kernels
             from .. import kernels as K
-            y = K.instance_norm(self.conv1(x).contiguous(), relu=True)
+            c1 = K.conv3x3_auto(x, self.conv1.weight, self._wino1) if self.conv1.stride == (1, 1) else self.conv1(x)
+            y = K.instance_norm(c1.contiguous(), relu=True)
             if self.downsample is not None:
                 x = K.instance_norm(self.downsample[0](x).contiguous())
-            return K.instance_norm(self.conv2(y).contiguous(), relu=True, residual=x.contiguous(), relu_out=True)
+            c2 = K.conv3x3_auto(y, self.conv2.weight, self._wino2)
+            return K.instance_norm(c2.contiguous(), relu=True, residual=x.contiguous(), relu_out=True)
         y = self.relu(self.norm1(self.conv1(x)))
         y = self.relu(self.norm2(self.conv2(y)))
         if self.downsample is not None:

@@ -118,7 +118,9 @@ class NMRF(nn.Module):
         heads = (self.concatconv, self.gw)
         w3 = cache.get(tuple(h[0].weight for h in heads), lambda: torch.cat([h[0].weight for h in heads], 0).contiguous())
         b = left.shape[0]
-        y = K.instance_norm(F.conv2d(torch.cat((left, right), 0), w3, None, 1, 1).contiguous(), relu=True)
+        if not hasattr(cache, "wino"):
+            cache.wino = {}
+        y = K.instance_norm(K.conv3x3_auto(torch.cat((left, right), 0), w3, cache.wino).contiguous(), relu=True)
         f = F.conv2d(y[:, 0:128], self.concatconv[3].weight)
         g = F.conv2d(y[:, 128:256], self.gw[3].weight)
         return f[:b].contiguous(), f[b:].contiguous(), g[:b].contiguous(), g[b:].contiguous()
