@@ -249,7 +249,16 @@ def main():
     pmc_names = {"stripe_attn_horizontal": "stripe_attn_kernel<1, 2, 1, false>",
                  "window_attn_w%d_n%d" % (win, n): "window_attn_fast_kernel<5, 6, 4, 2, 3, false>"}
     # fused token linears: algorithmic FLOPs 2*T*K*N recorded by the wrapper at each launch
+    notes = {}
     for k_, fl in timer.flops.items():
+        if k_ == "conv3x3_wino":                      # N2: all Winograd conv launches of a forward, FLOPs of the direct form
+            flops[k_] = sum(fl) / len(fl)
+            kern_names[k_] = "conv3x3_wino_kernel (3x3 stride-1 convs of the backbone / conv heads, N2; mean over layers)"
+            pmc_names[k_] = "conv3x3_wino_kernel"
+            notes[k_] = ("flop_per_launch counts direct-convolution FLOPs (SURVEY 8(d) convention for the conv band); the "
+                         "kernel executes 1/2.25 of those multiplies (Winograd F(2x2,3x3)), so frac is an effective rate, "
+                         "not MFMA-pipe utilisation (0.35-0.45, DESIGN.md section 5); MIOpen on the same basis: 0.58-0.66")
+            continue
         ln_, kk, nn_, act_ = (int(v.lstrip("lnkact")) for v in k_.split("_")[2:])
         flops[k_] = sum(fl) / len(fl)
         kern_names[k_] = "token_linear%s_kernel<%d,%s,%s> (%s%d->%d%s, N3)" % ("_pipe" if ln_ else "",
@@ -283,6 +292,8 @@ def main():
                    "traffic": (pmc_bytes(pmc_names[k]) if (b == 1 and args.height == 375 and args.width == 1242) else None),
                    "launch_ms": round(ms, 4), "launches_timed": cnt, "ms_per_forward": round(per_fwd[k], 4),
                    "flop_per_launch": flops[k]}
+            if k in notes:
+                rec["note"] = notes[k]
             if k == dom:
                 roof = rec
             else:

@@ -236,7 +236,11 @@ def conv3x3_wino(x, packed_u, co):
     _chk(x, packed_u)
     b, ci, h, w = x.shape
     y = torch.empty(b, co, h, w, device=x.device, dtype=torch.float32)
+    if kernel_hook is not None:                       # algorithmic work = the direct convolution's FLOPs
+        kernel_hook("begin", "conv3x3_wino", 2.0 * 9 * b * ci * co * h * w)
     _lib.check(_lib.load().nmrf_conv3x3_wino_f32(_p(x), _p(packed_u), b, ci, h, w, co, _p(y), _stream()), "conv3x3_wino")
+    if kernel_hook is not None:
+        kernel_hook("end", "conv3x3_wino")
     return y
 
 
