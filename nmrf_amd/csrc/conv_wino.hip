@@ -61,7 +61,8 @@ extern "C" int nmrf_wino_pack_filter_f32(const float *w, int Co, int Ci, float *
 }
 
 __global__ __launch_bounds__(512, 4) void conv3x3_wino_kernel(const float *__restrict__ x, const float *__restrict__ up,
-                                                              int Ci, int H, int W, int Co, float *__restrict__ y) {
+                                                              int Ci, int H, int W, int Co, float *__restrict__ y,
+                                                              unsigned long long *__restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) float sm[];       // raw[16][6][68] | U slab[8192]  (the output tile reuses it)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -73,6 +74,10 @@ __global__ __launch_bounds__(512, 4) void conv3x3_wino_kernel(const float *__res
     const size_t plane = (size_t)H * W;
     const float *xb = x + (size_t)b * Ci * plane;
     const int n_chunks = Ci / WN_CK;
+    const int lin_blk = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+#define WN_STAMP(k) do { if (stamps && lane == 0 && lin_blk < 64) \
+        stamps[((size_t)lin_blk * 8 + wv) * 32 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+    WN_STAMP(0);
 
     // cooperative fetch of one chunk into registers.  Raw patch: thread t < 396 owns pixel (r, col) = (t / 66, t % 66) of
     // the 6 x 66 patch for all 16 channels -- one address increment per load and per LDS store (the first version divided
@@ -120,9 +125,11 @@ __global__ __launch_bounds__(512, 4) void conv3x3_wino_kernel(const float *__res
     fetch(0);
 #pragma unroll 1
     for (int kc = 0; kc < n_chunks; ++kc) {
+        if (kc < 8) WN_STAMP(1 + 3 * kc);
         if (kc > 0) __syncthreads();                                // every wave is done reading the previous chunk
         commit(sm);
         __syncthreads();
+        if (kc < 8) WN_STAMP(2 + 3 * kc);
         if (kc + 1 < n_chunks) fetch(kc + 1);
         const float *buf = sm;
 #pragma unroll 1
@@ -154,8 +161,11 @@ __global__ __launch_bounds__(512, 4) void conv3x3_wino_kernel(const float *__res
                 acc[4 * pg + 3] = mfma16(v[4 * pg + 3], u.w, acc[4 * pg + 3]);
             }
         }
+        if (stamps) asm volatile("" :: "v"(acc[0][0]), "v"(acc[15][3]));
+        if (kc < 8) WN_STAMP(3 + 3 * kc);
     }
     __syncthreads();
+    WN_STAMP(28);
 
     // ---- inverse transform (wave-local) and output.  Lane (co = 16*cs + l%16, quad q): tiles 4q .. 4q+3 of its segment ----
     // (the loop ended on a barrier) LDS is reused as the output tile [32 co][4 rows][64+4]
@@ -190,7 +200,11 @@ __global__ __launch_bounds__(512, 4) void conv3x3_wino_kernel(const float *__res
         const int yy = 2 * ty0 + r, xx = 2 * tx0 + lane;
         if (yy < H && xx < W) yb[(size_t)co * plane + (size_t)yy * W + xx] = ot[row * OS + lane];
     }
+    WN_STAMP(29);
 }
+
+static unsigned long long *g_wn_stamps = nullptr;   // debug (nmrf_debug_wino_timing): s_memtime stamps of the next launches
+extern "C" int nmrf_debug_wino_timing(unsigned long long *stamps) { g_wn_stamps = stamps; return NMRF_OK; }
 
 extern "C" int nmrf_conv3x3_wino_f32(const float *x, const float *u_packed, int B, int Ci, int H, int W, int Co, float *y,
                                      void *stream) {
@@ -208,6 +222,6 @@ extern "C" int nmrf_conv3x3_wino_f32(const float *x, const float *u_packed, int 
         attr_set = true;
     }
     dim3 grid((tw + 31) / 32, (th + 1) / 2, (unsigned)gz);
-    hipLaunchKernelGGL(conv3x3_wino_kernel, grid, dim3(512), lds, (hipStream_t)stream, x, u_packed, Ci, H, W, Co, y);
+    hipLaunchKernelGGL(conv3x3_wino_kernel, grid, dim3(512), lds, (hipStream_t)stream, x, u_packed, Ci, H, W, Co, y, g_wn_stamps);
     return nmrf_launch_status();
 }

@@ -252,3 +252,23 @@ if "conv" in which:
             e.append(e0.elapsed_time(e1) * 1e3 / args.iters)
         print("conv3x3 %3d->%3d @%dx%dx%d : MIOpen %7.1f us (%5.1f TF/s eff)   wino %7.1f us (%5.1f TF/s eff)  x%.2f"
               % (ci, co, bb * args.batch, hh, ww, e[0], fl / e[0] / 1e6, e[1], fl / e[1] / 1e6, e[0] / e[1]), flush=True)
+
+if "conv_timing" in which:
+    import numpy as np
+    for (bb, ci, co, hh, ww) in ((2, 64, 64, 188, 624), (2, 128, 128, 94, 312)):
+        xx = mk("cx%d" % ci, bb, ci, hh, ww)
+        pu = K.wino_pack_filter(mk("cw%d%d" % (ci, co), co, ci, 3, 3) * 0.05)
+        K.conv3x3_wino(xx, pu, co); K.conv3x3_wino(xx, pu, co)
+        stamps = torch.zeros(64 * 8 * 32, dtype=torch.int64, device=dev)
+        _l.nmrf_debug_wino_timing(ctypes.c_void_p(stamps.data_ptr()))
+        K.conv3x3_wino(xx, pu, co)
+        torch.cuda.synchronize()
+        _l.nmrf_debug_wino_timing(None)
+        st = stamps.cpu().numpy().reshape(64, 8, 32).astype(np.int64)
+        nch = ci // 16
+        print("conv3x3_wino %d->%d @%dx%dx%d: per-wave phases in shader cycles, mean over 64 blocks x 8 waves" % (ci, co, bb, hh, ww))
+        print("  launch -> first chunk ready   %7.0f" % (st[:, :, 2] - st[:, :, 0]).mean())
+        cm = np.mean([(st[:, :, 2 + 3 * k] - st[:, :, 1 + 3 * k]).mean() for k in range(1, min(nch, 8))])
+        cp = np.mean([(st[:, :, 3 + 3 * k] - st[:, :, 2 + 3 * k]).mean() for k in range(0, min(nch, 8))])
+        print("  per chunk: barrier+commit+barrier %7.0f   fetch issue + transforms + MFMAs %7.0f" % (cm, cp))
+        print("  inverse transform + output     %7.0f   total %7.0f" % ((st[:, :, 29] - st[:, :, 28]).mean(), (st[:, :, 29] - st[:, :, 0]).mean()))
