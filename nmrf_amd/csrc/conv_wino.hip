@@ -90,15 +90,21 @@ __global__ __launch_bounds__(512, 4) void conv3x3_wino_kernel(const float *__res
     const float *p_src = xb + (p_in ? (size_t)pyy * W + pxx : 0);
     const int p_dst = pr * WN_RS + pc;
     float rreg[WN_CK];
-    float4 ureg[4];
-    auto fetch = [&](int kc) {
+    f32x4 ureg[4];                                                  // (ext_vector_type: an array of HIP float4 structs is not promoted to registers)
+    auto fetch = [&](int kc) {                                      // raw patch of chunk kc: in flight during the MFMAs
         const float *src = p_src + (size_t)kc * WN_CK * plane;
 #pragma unroll
         for (int c = 0; c < WN_CK; ++c) {                           // unconditional load of a valid address, masked after
             const float v = src[(size_t)c * plane];
             rreg[c] = p_in ? v : 0.f;
         }
-        const float4 *p = reinterpret_cast<const float4 *>(up) + ((size_t)kc * n_cb + cb) * 2048 + tid;
+    };
+    // The filter slab is requested when a wave leaves its MFMAs, i.e. while it waits for the others at the barrier, and
+    // goes to LDS right behind it.  Held in registers across the MFMA phase (as the raw patch is) it did not fit the
+    // 128-VGPR budget of two blocks per CU: the compiler parked it in scratch, 64 B out and back per thread and chunk
+    // (WRITE_SIZE 330 MB per launch for 40 MB of output).
+    auto fetch_u = [&](int kc) {
+        const f32x4 *p = reinterpret_cast<const f32x4 *>(up) + ((size_t)kc * n_cb + cb) * 2048 + tid;
 #pragma unroll
         for (int u = 0; u < 4; ++u) ureg[u] = p[512 * u];
     };
@@ -108,7 +114,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_wino_kernel(const float *__res
             for (int c = 0; c < WN_CK; ++c) buf[c * 6 * WN_RS + p_dst] = rreg[c];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) reinterpret_cast<float4 *>(buf + WN_RAW)[tid + 512 * u] = ureg[u];
+        for (int u = 0; u < 4; ++u) reinterpret_cast<f32x4 *>(buf + WN_RAW)[tid + 512 * u] = ureg[u];
     };
 
     f32x4 acc[16];
@@ -126,6 +132,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_wino_kernel(const float *__res
 #pragma unroll 1
     for (int kc = 0; kc < n_chunks; ++kc) {
         if (kc < 8) WN_STAMP(1 + 3 * kc);
+        fetch_u(kc);
         if (kc > 0) __syncthreads();                                // every wave is done reading the previous chunk
         commit(sm);
         __syncthreads();

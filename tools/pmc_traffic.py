@@ -26,6 +26,11 @@ def main(src, dst_prefix):
         for k, cs in load(os.path.join(src, "pass%s_counter_collection.csv" % p)).items():
             if "attn" in k or "warp" in k or "token_linear" in k:
                 table.setdefault(k, {}).update({c: round(sum(v) / len(v)) for c, v in cs.items()})
+    # model-level passes (bench.py, eager): only the Winograd conv is taken from them (mean over the layers of a forward)
+    for pth in ("passM1", "passM2"):
+        for k, cs in load(os.path.join(src, pth + "_counter_collection.csv")).items():
+            if k.startswith("conv3x3_wino"):
+                table.setdefault(k, {}).update({c: round(sum(v) / len(v)) for c, v in cs.items()})
     traffic = {}
     for k, c in table.items():
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
