@@ -52,7 +52,7 @@ __device__ __forceinline__ int64_t stripe_row(const StripeGeom &g, int64_t base_
 // occupancy hint it parks them in AGPRs and every `acc *= alpha` / softmax pass pays v_accvgpr_read/write round trips
 // (112 of them per key tile in the first version of this kernel).
 template <int AXIS, int NSHIFT, int KSPLIT, bool CENSUS = false>
-__global__ __launch_bounds__(256, KSPLIT == 1 ? 2 : 3) void stripe_attn_kernel(const float *__restrict__ qkv, const float *__restrict__ lepe,
+__global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__restrict__ qkv, const float *__restrict__ lepe,
                                                          StripeGeom g, float scale, float *__restrict__ out,
                                                          unsigned long long *__restrict__ census = nullptr) {
     constexpr int QPB = 4 / KSPLIT;                           // query tiles per block

@@ -246,12 +246,12 @@ def conv3x3_wino(x, packed_u, co):
 
 def conv3x3_auto(x, weight, cache):
     """3x3 / stride 1 / pad 1 / no-bias convolution: the fused Winograd MFMA kernel where it has enough blocks to fill
-    the chip (>= 600: measured 1.2-1.3x MIOpen there, 0.6-0.9x below), MIOpen otherwise.  NMRF_WINO=0 forces MIOpen.
+    the chip (>= 512: measured 1.1-1.66x MIOpen there, 0.8x at 144 blocks), MIOpen otherwise.  NMRF_WINO=0 forces MIOpen.
     `cache`: a dict owned by the caller, holds the packed filter per weight version."""
     co, ci = weight.shape[0], weight.shape[1]
     b, _, h, w = x.shape
     blocks = ((w + 1) // 2 + 31) // 32 * (((h + 1) // 2 + 1) // 2) * b * (co // 32)
-    if (not x.is_cuda or ci % 16 or co % 32 or blocks < 600 or os.environ.get("NMRF_WINO", "1") == "0"
+    if (not x.is_cuda or ci % 16 or co % 32 or blocks < 512 or os.environ.get("NMRF_WINO", "1") == "0"
             or x.dtype != torch.float32):
         return torch.nn.functional.conv2d(x, weight, None, 1, 1)
     key = (weight.data_ptr(), weight._version)
