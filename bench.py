@@ -257,7 +257,7 @@ def main():
             pmc_names[k_] = "conv3x3_wino_kernel"
             notes[k_] = ("flop_per_launch counts direct-convolution FLOPs (SURVEY 8(d) convention for the conv band); the "
                          "kernel executes 1/2.25 of those multiplies (Winograd F(2x2,3x3)), so frac is an effective rate, "
-                         "not MFMA-pipe utilisation (0.35-0.45, DESIGN.md section 5); MIOpen on the same basis: 0.58-0.66")
+                         "not MFMA-pipe utilisation (~0.55, DESIGN.md section 5); MIOpen on the same basis: 0.58-0.66")
             continue
         ln_, kk, nn_, act_ = (int(v.lstrip("lnkact")) for v in k_.split("_")[2:])
         flops[k_] = sum(fl) / len(fl)
