@@ -68,13 +68,22 @@ __global__ __launch_bounds__(512, 4) void conv3x3_wino_kernel(const float *__res
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tg = wv & 3, cs = wv >> 2;                            // tile segment (row tg>>1, columns 16*(tg&1)..), co strip
     const int n_cb = Co >> 5;
-    const int b = blockIdx.z / n_cb, cb = blockIdx.z % n_cb;
-    const int ty0 = blockIdx.y * 2, tx0 = blockIdx.x * 32;          // first tile row / column of the block
+    // XCD-aware block order (workgroups go round-robin over the 8 XCDs, each with its own L2): the Co/32 blocks of one tile
+    // block read the same input patches, so logical items are numbered output-channel-block fastest and every XCD gets a
+    // contiguous run of them (with channel blocks as the slowest grid dimension the patches came from MALL/HBM each time:
+    // 229 MB fetched per launch for ~40 MB of input).
+    const int gx = (((W + 1) >> 1) + 31) >> 5, gy = (((H + 1) >> 1) + 1) >> 1;
+    const int per_xcd = gridDim.x >> 3;                             // the launch pads the grid to a multiple of 8
+    const int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (item >= n_cb * gx * gy) return;
+    const int cb = item % n_cb, bxi = (item / n_cb) % gx, byi = item / (n_cb * gx);
+    const int b = blockIdx.y;
+    const int ty0 = byi * 2, tx0 = bxi * 32;                        // first tile row / column of the block
     const int y0 = 2 * ty0 - 1, x0 = 2 * tx0 - 1;                   // top-left input pixel of the raw patch
     const size_t plane = (size_t)H * W;
     const float *xb = x + (size_t)b * Ci * plane;
     const int n_chunks = Ci / WN_CK;
-    const int lin_blk = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int lin_blk = blockIdx.x + gridDim.x * blockIdx.y;
 #define WN_STAMP(k) do { if (stamps && lane == 0 && lin_blk < 64) \
         stamps[((size_t)lin_blk * 8 + wv) * 32 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     WN_STAMP(0);
@@ -218,8 +227,8 @@ extern "C" int nmrf_conv3x3_wino_f32(const float *x, const float *u_packed, int 
     if (!x || !u_packed || !y) return NMRF_ENULL;
     if (B < 1 || H < 1 || W < 1 || Ci < 16 || (Ci & 15) || Co < 32 || (Co & 31)) return NMRF_EINVAL;
     const int tw = (W + 1) / 2, th = (H + 1) / 2;
-    const long gz = (long)B * (Co / 32);
-    if (gz > 65535 || (th + 1) / 2 > 65535) return NMRF_EINVAL;
+    const long items = (long)((tw + 31) / 32) * ((th + 1) / 2) * (Co / 32);
+    if (B > 65535 || items > 0x7ffffff0L) return NMRF_EINVAL;
     const size_t lds = (size_t)WN_BUF * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
@@ -228,7 +237,7 @@ extern "C" int nmrf_conv3x3_wino_f32(const float *x, const float *u_packed, int 
             return NMRF_ELAUNCH;
         attr_set = true;
     }
-    dim3 grid((tw + 31) / 32, (th + 1) / 2, (unsigned)gz);
+    dim3 grid((unsigned)((items + 7) / 8 * 8), (unsigned)B);
     hipLaunchKernelGGL(conv3x3_wino_kernel, grid, dim3(512), lds, (hipStream_t)stream, x, u_packed, Ci, H, W, Co, y, g_wn_stamps);
     return nmrf_launch_status();
 }
