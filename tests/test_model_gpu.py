@@ -212,6 +212,28 @@ def test_full_size_properties(h, w):
     assert ((p[:, 0] >= left[:, 0]) & (p[:, 0] >= right[:, 0]))[strong].all()
 
 
+def test_library_paths_agree_with_hand_written_paths_at_kitti_size(monkeypatch):
+    """N2 / N3 in the model: the Winograd MFMA convolution and the fused token linears against the stock MIOpen / hipBLASLt
+    paths they replace (NMRF_WINO=0, NMRF_FUSED_LINEAR=0), same weights, one KITTI-size pair.  The two sides differ by
+    fp32 rounding only (different summation orders); seeds must agree on >= 99.5 % of pixels, the disparity to a median
+    of 2e-3 px with < 1 % of the pixels moving by more than 0.1 px (ties in seeds / winner-take-all)."""
+    import os
+    from nmrf_amd.utils.hashinit import synthetic_pair
+    model = build_product(320, DEV)
+    l, r, _ = synthetic_pair(375, 1242, seed=1002)
+    sample = {"img1": l[None], "img2": r[None]}
+    with torch.no_grad():
+        ours = model(sample)
+        monkeypatch.setenv("NMRF_WINO", "0")
+        monkeypatch.setenv("NMRF_FUSED_LINEAR", "0")
+        stock = model(sample)
+    assert os.environ["NMRF_WINO"] == "0"
+    mism = (ours["initial_proposal"] != stock["initial_proposal"]).any(-1).float().mean()
+    assert float(mism) < 5e-3, float(mism)
+    d = (ours["disp"] - stock["disp"]).abs()
+    assert float(d.median()) < 2e-3 and float((d > 0.1).float().mean()) < 0.01, (float(d.median()), float(d.mean()))
+
+
 def test_hip_kernels_are_batch_invariant():
     """At KITTI token counts: every hand-written kernel gives bit-identical per-image results whether the
     image is alone or second in a batch (no cross-image reduction, fixed per-wave summation order)."""
