@@ -27,7 +27,7 @@ extern "C" {
 
 const char *nmrf_strerror(int code);
 /* ABI version of this header; bumps on any signature change. */
-int nmrf_abi_version(void);   /* currently 7 */
+int nmrf_abi_version(void);   /* currently 8 */
 
 /* A2  group-wise correlation volume.
  * replaces build_correlation_volume + the permute of DPN.forward
@@ -143,6 +143,14 @@ int nmrf_conv3x3_wino_f32(const float *x, const float *u_packed, int B, int Ci, 
                           void *stream);
 /* w [Co,Ci,3,3] -> U = G w G^T in MFMA fragment order [Ci/16][Co/32][4][4][2][64][4]. */
 int nmrf_wino_pack_filter_f32(const float *w, int Co, int Ci, float *packed, void *stream);
+
+/* A16  superpixel-guided disparity downsample (evaluation only).  PARITY UNPINNED: the reference announces this operator
+ * (README.md:48) but ships neither its source nor frame_utils.downsample_disp; semantics reconstructed from the call site
+ * nmrf/utils/evaluation.py:361-378 and fixed in oracle/superpixel_oracle.py: per 8x8 cell, one mode per superpixel
+ * segment = mean of its valid (> 0) disparities; modes ordered by pixel count (desc) then label (asc); first K kept, 0 =
+ * empty slot.  disp [B,H,W] f32 (0 = invalid), labels [B,H,W] int32 -> out [B, H/8, W/8, K] (H, W truncated to x8). */
+int nmrf_superpixel_downsample_f32(const float *disp, const int *labels, int B, int H, int W, int K, float *out,
+                                   void *stream);
 
 /* A11/A12  coarse heads epilogue: relu(label+delta), winner-take-all over N by score (first max),
  * x2, 4x4 lower median.  replaces NMRF.forward (nmrf/models/NMRF.py:219-232).

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnmrf_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -34,6 +34,7 @@ PROTOTYPES = {
     "nmrf_pack_linear_weight_f32": [_P, _I, _I, _P, _P],
     "nmrf_conv3x3_wino_f32": [_P, _P, _I, _I, _I, _I, _I, _P, _P],
     "nmrf_wino_pack_filter_f32": [_P, _I, _I, _P, _P],
+    "nmrf_superpixel_downsample_f32": [_P, _P, _I, _I, _I, _I, _P, _P],
     "nmrf_wta_median_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "nmrf_refine_epilogue_f32": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "nmrf_instance_norm_f32": [_P, _P, _L, _L, _F, _I, _I, _P, _P, _P],

@@ -26,3 +26,13 @@ class InputPadder:
         assert x.ndim == 4
         ht, wd = x.shape[-2:]
         return x[..., self._pad[2]:ht - self._pad[3], self._pad[0]:wd - self._pad[1]]
+
+
+def downsample_disp(disp, super_pixel_label, num_modes=4):
+    """Superpixel-guided disparity downsample with the call signature of the reference's evaluator
+    (nmrf/utils/evaluation.py:366: `frame_utils.downsample_disp(disp_gt[None], superpixel_label[None])[0]`).
+    PARITY UNPINNED -- the reference does not ship this function or the operator behind it; see include/nmrf_hip.h.
+    disp [B,H,W] (0 = invalid), super_pixel_label [B,H,W] integer -> [B, H//8, W//8, num_modes]."""
+    import torch
+    from . import kernels as K
+    return K.superpixel_downsample(disp.float().contiguous(), super_pixel_label.to(torch.int32).contiguous(), num_modes)

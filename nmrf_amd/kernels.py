@@ -262,6 +262,17 @@ def conv3x3_auto(x, weight, cache):
     return conv3x3_wino(x.contiguous(), cache["packed"], co)
 
 
+def superpixel_downsample(disp, labels, k=4):
+    """A16 (parity unpinned, see include/nmrf_hip.h): disp [B,H,W] f32 (0 invalid), labels [B,H,W] int32 -> [B,H//8,W//8,k]."""
+    _chk(disp)
+    _chk(labels, dtype=torch.int32)
+    b, h, w = disp.shape
+    out = torch.empty(b, h // 8, w // 8, k, device=disp.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_superpixel_downsample_f32(_p(disp), _p(labels), b, h, w, k, _p(out), _stream()),
+               "superpixel_downsample")
+    return out
+
+
 def wta_median(delta, score, labels, b, h, w, n):
     _chk(delta, score, labels)
     out = torch.empty(b, 2 * h, 2 * w, device=delta.device, dtype=torch.float32)

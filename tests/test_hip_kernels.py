@@ -4,6 +4,7 @@ captured from the reference.  Integer outputs are bit-exact; fp32 tolerances are
 Run on the MI355X box:  python -m pytest tests -m gpu -q
 """
 import numpy as np
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -300,6 +301,26 @@ def test_conv3x3_winograd(b, ci, co, h, w):
     ref = F.conv2d(x.double(), wt.double(), None, 1, 1)
     # F(2x2,3x3) in fp32: a few ulp of the largest partial products (MIOpen's Winograd kernel has the same error profile)
     report("conv3x3_wino", got, ref, 2e-5 * (ci ** 0.5), 1e-5)
+
+
+@pytest.mark.parametrize("b,h,w,k,nlab", [(1, 16, 24, 4, 3), (2, 37, 53, 4, 40), (1, 64, 64, 2, 1000), (1, 8, 8, 8, 2)])
+def test_superpixel_downsample_unpinned(b, h, w, k, nlab):
+    """A16: HIP kernel vs its CPU restatement, bit-exact (the restatement itself is unpinned: no reference source)."""
+    from oracle import superpixel_oracle as SO
+    g = torch.Generator().manual_seed(h * w + k)
+    disp = torch.rand(b, h, w, generator=g) * 100
+    disp[torch.rand(b, h, w, generator=g) < 0.3] = 0                 # invalid pixels
+    disp[:, :8, :8] = 0                                              # one fully invalid cell
+    lab = torch.randint(0, nlab, (b, h, w), generator=g, dtype=torch.int32)
+    from nmrf_amd.frame_utils import downsample_disp
+    got = downsample_disp(disp.to(DEV), lab.to(DEV), k).cpu()
+    want = torch.from_numpy(SO.downsample_disp(disp.numpy(), lab.numpy(), k))
+    assert got.shape == (b, h // 8, w // 8, k)
+    assert torch.equal(got, want)
+    assert (got[:, 0, 0] == 0).all()
+    # the evaluator's use of it (evaluation.py:371-375): zero slots are masked, every cell with a valid pixel has a mode
+    has_valid = (torch.nn.functional.max_pool2d(disp[:, :h // 8 * 8, :w // 8 * 8][:, None], 8) > 0)[:, 0]
+    assert ((got > 0).any(-1) == has_valid).all()
 
 
 def test_kernels_refuse_cpu_tensors():
