@@ -27,7 +27,7 @@ extern "C" {
 
 const char *nmrf_strerror(int code);
 /* ABI version of this header; bumps on any signature change. */
-int nmrf_abi_version(void);   /* currently 8 */
+int nmrf_abi_version(void);   /* currently 9 */
 
 /* A2  group-wise correlation volume.
  * replaces build_correlation_volume + the permute of DPN.forward
@@ -132,7 +132,9 @@ int nmrf_linear_smalln_f32(const float *x, const float *w, const float *bias, in
 int nmrf_token_linear_f32(const float *x, const float *y, float *x_out, const float *ln_gamma, const float *ln_beta,
                           float eps, const float *extra, int E, int extra_div, const float *w_packed, const float *bias,
                           const float *residual, int act, int64_t T, int Cx, int K, int N, float *out, void *stream);
-/* w [N,K] row-major -> packed [N/32][ceil(K/32)][4][64][4] floats (one contiguous 1 KiB line per wave load). */
+/* w [N,K] row-major -> packed [N/32][ceil(K/32)][4][64][4] floats (one contiguous 1 KiB line per wave load) followed by
+ * N/32 int32: per 32-column strip the number of leading 32-wide k chunks holding a non-zero weight (the kernels skip the
+ * rest: the v rows of a fused q|k|v weight are zero on the side-input columns).  Size: N*32*ceil(K/32) + N/32 words. */
 int nmrf_pack_linear_weight_f32(const float *w, int N, int K, float *packed, void *stream);
 
 /* N2  3x3 / stride 1 / pad 1 / no bias convolution, NCHW fp32, as fused Winograd F(2x2,3x3) on fp32 MFMA.

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnmrf_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int

@@ -310,4 +310,4 @@ extern "C" const char *nmrf_strerror(int code) {
     }
 }
 
-extern "C" int nmrf_abi_version(void) { return 8; }
+extern "C" int nmrf_abi_version(void) { return 9; }

@@ -178,6 +178,9 @@ __global__ __launch_bounds__(256, 2) void token_linear_kernel(TokenLinearArgs a,
     const int total = cnt * n_groups;
     auto strip_of = [&](int q) { const int g = q / cnt; return g * gstrips + wv + 4 * (q - g * cnt); };
     const float4 *wp = reinterpret_cast<const float4 *>(a.w_packed) + lane;
+    // per-strip count of leading non-zero k chunks, appended to the packed weight by nmrf_pack_linear_weight_f32 (the v rows
+    // of a fused q|k|v weight are zero on the side-input columns: 7-11 % of that GEMM's MFMAs)
+    const int *strip_chunks = reinterpret_cast<const int *>(a.w_packed + (size_t)a.N * KC * 32);
     auto load_w = [&](int strip, int c, float *wd) {
         const float4 *p = wp + (size_t)(strip * KC + c) * 256;
 #pragma unroll
@@ -208,6 +211,7 @@ __global__ __launch_bounds__(256, 2) void token_linear_kernel(TokenLinearArgs a,
             const int strip = g * gstrips + wv + 4 * j;
             const int next_strip = (q + 1 < total) ? strip_of(q + 1) : -1;
             const float bias_s = a.bias ? a.bias[strip * 32 + i32] : 0.f;   // requested now, needed after the strip
+            const int kc_eff = strip_chunks[strip];
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -219,8 +223,10 @@ __global__ __launch_bounds__(256, 2) void token_linear_kernel(TokenLinearArgs a,
                     const float4 v = *reinterpret_cast<const float4 *>(a_lane + c * 32 + 4 * jj);
                     af[4 * jj + 0] = v.x; af[4 * jj + 1] = v.y; af[4 * jj + 2] = v.z; af[4 * jj + 3] = v.w;
                 }
+                if (c < kc_eff) {                                   // trailing all-zero chunks of this strip are skipped
 #pragma unroll
-                for (int k = 0; k < 16; ++k) acc = mfma32(af[k], wbuf[c % NB][k], acc);
+                    for (int k = 0; k < 16; ++k) acc = mfma32(af[k], wbuf[c % NB][k], acc);
+                }
                 // this buffer's MFMAs are issued: refill it with the fragment NB chunks ahead (possibly of the next strip)
                 if constexpr (c + NB < KC) load_w(strip, c + NB, wbuf[c % NB]);
                 else if (next_strip >= 0) load_w(next_strip, c + NB - KC, wbuf[c % NB]);
@@ -337,6 +343,9 @@ __global__ __launch_bounds__(256, 2) void token_linear_pipe_kernel(TokenLinearAr
 
     const int n_groups = a.N / GW;                                  // one 32-column strip per wave and group
     const float4 *wp = reinterpret_cast<const float4 *>(a.w_packed) + lane;
+    // per-strip count of leading non-zero k chunks, appended to the packed weight by nmrf_pack_linear_weight_f32 (the v rows
+    // of a fused q|k|v weight are zero on the side-input columns: 7-11 % of that GEMM's MFMAs)
+    const int *strip_chunks = reinterpret_cast<const int *>(a.w_packed + (size_t)a.N * KC * 32);
     auto load_w = [&](int strip, int c, float *wd) {
         const float4 *p = wp + (size_t)(strip * KC + c) * 256;
 #pragma unroll
@@ -373,6 +382,7 @@ __global__ __launch_bounds__(256, 2) void token_linear_pipe_kernel(TokenLinearAr
             // the strip after this one: next group, or the first strip of the next tile (same weights)
             const int next_strip = (g + 1 < n_groups) ? strip + 4 : (has_next ? wv : -1);
             const float bias_s = a.bias ? a.bias[strip * 32 + i32] : 0.f;
+            const int kc_eff = strip_chunks[strip];
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -384,8 +394,10 @@ __global__ __launch_bounds__(256, 2) void token_linear_pipe_kernel(TokenLinearAr
                     const float4 v = *reinterpret_cast<const float4 *>(a_lane + c * 32 + 4 * jj);
                     af[4 * jj + 0] = v.x; af[4 * jj + 1] = v.y; af[4 * jj + 2] = v.z; af[4 * jj + 3] = v.w;
                 }
+                if (c < kc_eff) {                                   // trailing all-zero chunks of this strip are skipped
 #pragma unroll
-                for (int k = 0; k < 16; ++k) acc = mfma32(af[k], wbuf[c % NB][k], acc);
+                    for (int k = 0; k < 16; ++k) acc = mfma32(af[k], wbuf[c % NB][k], acc);
+                }
                 if constexpr (c + NB < KC) load_w(strip, c + NB, wbuf[c % NB]);
                 else if (next_strip >= 0) load_w(next_strip, c + NB - KC, wbuf[c % NB]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -414,7 +426,8 @@ __global__ __launch_bounds__(256, 2) void token_linear_pipe_kernel(TokenLinearAr
     }
 }
 
-// weights [N, K] row-major -> fragment order [N/32][Kp/32][4][64 lanes][4], zero-padded in K
+// weights [N, K] row-major -> fragment order [N/32][Kp/32][4][64 lanes][4], zero-padded in K, followed by N/32 ints: the
+// number of leading k chunks of each strip that hold a non-zero weight (strip_chunks_kernel)
 __global__ __launch_bounds__(256) void pack_linear_weight_kernel(const float *__restrict__ w, int N, int K, int KC,
                                                                 float *__restrict__ packed) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;       // one float4 of the packed tensor
@@ -430,6 +443,18 @@ __global__ __launch_bounds__(256) void pack_linear_weight_kernel(const float *__
     stg4(packed + idx * 4, make_float4(v[0], v[1], v[2], v[3]));
 }
 
+// one wave per 32-column strip: number of leading k chunks after which every weight of the strip is exactly zero
+__global__ __launch_bounds__(64) void strip_chunks_kernel(const float *__restrict__ w, int K, int KC, int *__restrict__ out) {
+    const int strip = blockIdx.x, lane = threadIdx.x;
+    int last = 0;                                                   // 1 + index of the last chunk with a non-zero weight
+    for (int n = 0; n < 32; ++n)
+        for (int k = lane; k < K; k += 64)
+            if (w[(size_t)(strip * 32 + n) * K + k] != 0.f) last = max(last, k / 32 + 1);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) last = max(last, __shfl_xor(last, o));
+    if (lane == 0) out[strip] = last < 1 ? 1 : last;
+}
+
 extern "C" int nmrf_pack_linear_weight_f32(const float *w, int N, int K, float *packed, void *stream) {
     if (!w || !packed) return NMRF_ENULL;
     if (N < 32 || (N & 31) || K < 1) return NMRF_EINVAL;
@@ -437,6 +462,8 @@ extern "C" int nmrf_pack_linear_weight_f32(const float *w, int N, int K, float *
     const int64_t total = (int64_t)(N / 32) * KC * 4 * 64;
     hipLaunchKernelGGL(pack_linear_weight_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, w,
                        N, K, KC, packed);
+    hipLaunchKernelGGL(strip_chunks_kernel, dim3(N / 32), dim3(64), 0, (hipStream_t)stream, w, K, KC,
+                       reinterpret_cast<int *>(packed + (size_t)N * KC * 32));
     return nmrf_launch_status();
 }
 

@@ -189,7 +189,7 @@ def pack_linear_weight(weight):
     """[N,K] nn.Linear weight -> MFMA fragment order for token_linear (N % 32 == 0)."""
     _chk(weight)
     n, k = weight.shape
-    packed = torch.empty(n * ((k + 31) // 32 * 32), device=weight.device, dtype=torch.float32)
+    packed = torch.empty(n * ((k + 31) // 32 * 32) + n // 32, device=weight.device, dtype=torch.float32)
     _lib.check(_lib.load().nmrf_pack_linear_weight_f32(_p(weight.contiguous()), n, k, _p(packed), _stream()), "pack_linear_weight")
     return packed
 
