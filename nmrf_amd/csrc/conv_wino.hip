@@ -9,34 +9,34 @@
 //
 // Block = 8 waves = 64 tiles (2 tile rows x 32 tile columns) x 32 output channels.  A wave owns 16 tiles of one tile row
 // and 16 output channels for ALL 16 positions (v_mfma_f32_16x16x4_f32, 16 accumulators of 4 registers), so the inverse
-// transform needs no exchange.  Input channels are walked in chunks of 16: the raw 6 x 66 input patch of the chunk and its
-// 16 x 16 x 32 filter slab sit in LDS (fetched into registers during the previous chunk's MFMAs); each lane transforms its
-// own tile for its 4 channels into the A operands on the fly.
-//   A operand  lane l : V_p[tile = l%16][ci = 16*chunk + 4*(l/16) + m]          (one MFMA per m = 0..3)
+// transform needs no exchange.  Input channels are walked in chunks of 8: the raw 6 x 66 input patch of the chunk and its
+// 16 x 8 x 32 filter slab sit in one of two LDS buffers (fetched into registers during the previous chunks' MFMAs); each
+// lane transforms its own tile for its 2 channels into the A operands on the fly.
+//   A operand  lane l : V_p[tile = l%16][ci = 8*chunk + 2*(l/16) + m]           (one MFMA per m = 0, 1)
 //   B operand  lane l : U_p[ci (same)][co = 16*strip + l%16]
 //   D          lane l, reg r : M_p[tile = 4*(l/16) + r][co = l%16]
 #include "common.h"
 
-#define WN_CK 16                 // input channels per chunk
+#define WN_CK 8                  // input channels per chunk
 #define WN_RS 68                 // raw patch row stride (66 columns used)
 #define WN_RAW (WN_CK * 6 * WN_RS)
-#define WN_U (16 * WN_CK * 32)   // filter slab of a chunk: 16 positions x 16 ci x 32 co
+#define WN_U (16 * WN_CK * 32)   // filter slab of a chunk: 16 positions x 8 ci x 32 co
 #define WN_BUF (WN_RAW + WN_U)    // one LDS buffer (floats)
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// filter [Co, Ci, 3, 3] -> U in fragment order [Ci/16][Co/32][m 4][pg 4][strip 2][lane 64][4 positions]
+// filter [Co, Ci, 3, 3] -> U in fragment order [Ci/8][Co/32][m 2][pg 4][strip 2][lane 64][4 positions]
 __global__ __launch_bounds__(256) void wino_pack_filter_kernel(const float *__restrict__ w, int Co, int Ci,
                                                               float *__restrict__ packed) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;       // one float4 = 4 positions of one (co, ci)
-    const int64_t total = (int64_t)(Ci / 16) * (Co / 32) * 4 * 4 * 2 * 64;
+    const int64_t total = (int64_t)(Ci / 8) * (Co / 32) * 2 * 4 * 2 * 64;
     if (idx >= total) return;
-    const int lane = (int)(idx & 63), cs = (int)((idx >> 6) & 1), pg = (int)((idx >> 7) & 3), m = (int)((idx >> 9) & 3);
-    const int64_t slab = idx >> 11;
+    const int lane = (int)(idx & 63), cs = (int)((idx >> 6) & 1), pg = (int)((idx >> 7) & 3), m = (int)((idx >> 9) & 1);
+    const int64_t slab = idx >> 10;
     const int cb = (int)(slab % (Co / 32)), kc = (int)(slab / (Co / 32));
-    const int co = 32 * cb + 16 * cs + (lane & 15), ci = 16 * kc + 4 * (lane >> 4) + m;
+    const int co = 32 * cb + 16 * cs + (lane & 15), ci = 8 * kc + 2 * (lane >> 4) + m;
     const float *g = w + ((int64_t)co * Ci + ci) * 9;
     // U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]; row i = pg of U
     float t[4][3];
@@ -53,8 +53,8 @@ __global__ __launch_bounds__(256) void wino_pack_filter_kernel(const float *__re
 
 extern "C" int nmrf_wino_pack_filter_f32(const float *w, int Co, int Ci, float *packed, void *stream) {
     if (!w || !packed) return NMRF_ENULL;
-    if (Co < 32 || (Co & 31) || Ci < 16 || (Ci & 15)) return NMRF_EINVAL;
-    const int64_t total = (int64_t)(Ci / 16) * (Co / 32) * 4 * 4 * 2 * 64;
+    if (Co < 32 || (Co & 31) || Ci < 8 || (Ci & 7)) return NMRF_EINVAL;
+    const int64_t total = (int64_t)(Ci / 8) * (Co / 32) * 2 * 4 * 2 * 64;
     hipLaunchKernelGGL(wino_pack_filter_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, w, Co,
                        Ci, packed);
     return nmrf_launch_status();
@@ -99,23 +99,17 @@ __global__ __launch_bounds__(512, 4) void conv3x3_wino_kernel(const float *__res
     const float *p_src = xb + (p_in ? (size_t)pyy * W + pxx : 0);
     const int p_dst = pr * WN_RS + pc;
     float rreg[WN_CK];
-    f32x4 ureg[4];                                                  // (ext_vector_type: an array of HIP float4 structs is not promoted to registers)
-    auto fetch = [&](int kc) {                                      // raw patch of chunk kc: in flight during the MFMAs
+    f32x4 ureg[2];                                                  // (ext_vector_type: an array of HIP float4 structs is not promoted to registers)
+    auto fetch = [&](int kc) {                                      // chunk kc -> registers: in flight during the MFMAs
         const float *src = p_src + (size_t)kc * WN_CK * plane;
 #pragma unroll
         for (int c = 0; c < WN_CK; ++c) {                           // unconditional load of a valid address, masked after
             const float v = src[(size_t)c * plane];
             rreg[c] = p_in ? v : 0.f;
         }
-    };
-    // The filter slab is requested when a wave leaves its MFMAs, i.e. while it waits for the others at the barrier, and
-    // goes to LDS right behind it.  Held in registers across the MFMA phase (as the raw patch is) it did not fit the
-    // 128-VGPR budget of two blocks per CU: the compiler parked it in scratch, 64 B out and back per thread and chunk
-    // (WRITE_SIZE 330 MB per launch for 40 MB of output).
-    auto fetch_u = [&](int kc) {
-        const f32x4 *p = reinterpret_cast<const f32x4 *>(up) + ((size_t)kc * n_cb + cb) * 2048 + tid;
+        const f32x4 *p = reinterpret_cast<const f32x4 *>(up) + ((size_t)kc * n_cb + cb) * 1024 + tid;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) ureg[u] = p[512 * u];
+        for (int u = 0; u < 2; ++u) ureg[u] = p[512 * u];
     };
     auto commit = [&](float *buf) {
         if (p_own) {
@@ -123,7 +117,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_wino_kernel(const float *__res
             for (int c = 0; c < WN_CK; ++c) buf[c * 6 * WN_RS + p_dst] = rreg[c];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) reinterpret_cast<f32x4 *>(buf + WN_RAW)[tid + 512 * u] = ureg[u];
+        for (int u = 0; u < 2; ++u) reinterpret_cast<f32x4 *>(buf + WN_RAW)[tid + 512 * u] = ureg[u];
     };
 
     f32x4 acc[16];
@@ -135,22 +129,20 @@ __global__ __launch_bounds__(512, 4) void conv3x3_wino_kernel(const float *__res
     const int r_off = (2 * trow) * WN_RS + 2 * tcol;                // + (ci*6 + r) * WN_RS
     const int u_off = WN_RAW + (cs * 64 + lane) * 4;                // + (m*4 + pg) * 512 floats
 
-    // one LDS buffer, two blocks per CU (120 VGPRs): while one block refills its buffer between two barriers the other one
-    // computes; the next chunk's global loads are issued before the MFMAs of the current one
+    // 8-channel chunks, two LDS buffers (2 x 29 KB: still two blocks per CU): chunk k+1 is written -- from registers filled
+    // during chunk k-1..k -- by whichever wave has finished its MFMAs of chunk k, while the others still compute; one
+    // barrier per chunk.  (16-channel chunks in a single buffer: 2.8k cycles of barrier + commit + barrier per 8.0k of MFMAs.)
     fetch(0);
+    commit(sm);
+    __syncthreads();
+    if (n_chunks > 1) fetch(1);
 #pragma unroll 1
     for (int kc = 0; kc < n_chunks; ++kc) {
-        if (kc < 8) WN_STAMP(1 + 3 * kc);
-        fetch_u(kc);
-        if (kc > 0) __syncthreads();                                // every wave is done reading the previous chunk
-        commit(sm);
-        __syncthreads();
         if (kc < 8) WN_STAMP(2 + 3 * kc);
-        if (kc + 1 < n_chunks) fetch(kc + 1);
-        const float *buf = sm;
+        const float *buf = sm + (kc & 1) * WN_BUF;
 #pragma unroll 1
-        for (int m = 0; m < 4; ++m) {                               // (unrolled, all four patches are fetched up front: spills)
-            const float *rp = buf + r_off + (4 * q + m) * 6 * WN_RS;
+        for (int m = 0; m < 2; ++m) {                               // (unrolled, both patches are fetched up front: spills)
+            const float *rp = buf + r_off + (2 * q + m) * 6 * WN_RS;
             // patch rows as two packed halves (columns 01 | 23); V = B^T d B with v_pk_add_f32
             f32x2 dl[4], dh[4];
 #pragma unroll
@@ -179,8 +171,13 @@ __global__ __launch_bounds__(512, 4) void conv3x3_wino_kernel(const float *__res
         }
         if (stamps) asm volatile("" :: "v"(acc[0][0]), "v"(acc[15][3]));
         if (kc < 8) WN_STAMP(3 + 3 * kc);
+        if (kc + 1 < n_chunks) {
+            commit(sm + ((kc + 1) & 1) * WN_BUF);
+            if (kc + 2 < n_chunks) fetch(kc + 2);
+        }
+        __syncthreads();
+        if (kc < 7) WN_STAMP(1 + 3 * (kc + 1));
     }
-    __syncthreads();
     WN_STAMP(28);
 
     // ---- inverse transform (wave-local) and output.  Lane (co = 16*cs + l%16, quad q): tiles 4q .. 4q+3 of its segment ----
@@ -225,11 +222,11 @@ extern "C" int nmrf_debug_wino_timing(unsigned long long *stamps) { g_wn_stamps 
 extern "C" int nmrf_conv3x3_wino_f32(const float *x, const float *u_packed, int B, int Ci, int H, int W, int Co, float *y,
                                      void *stream) {
     if (!x || !u_packed || !y) return NMRF_ENULL;
-    if (B < 1 || H < 1 || W < 1 || Ci < 16 || (Ci & 15) || Co < 32 || (Co & 31)) return NMRF_EINVAL;
+    if (B < 1 || H < 1 || W < 1 || Ci < 8 || (Ci & 7) || Co < 32 || (Co & 31)) return NMRF_EINVAL;
     const int tw = (W + 1) / 2, th = (H + 1) / 2;
     const long items = (long)((tw + 31) / 32) * ((th + 1) / 2) * (Co / 32);
     if (B > 65535 || items > 0x7ffffff0L) return NMRF_EINVAL;
-    const size_t lds = (size_t)WN_BUF * sizeof(float);
+    const size_t lds = (size_t)2 * WN_BUF * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -265,10 +265,10 @@ if "conv_timing" in which:
         torch.cuda.synchronize()
         _l.nmrf_debug_wino_timing(None)
         st = stamps.cpu().numpy().reshape(64, 8, 32).astype(np.int64)
-        nch = ci // 16
+        nch = ci // 8
         print("conv3x3_wino %d->%d @%dx%dx%d: per-wave phases in shader cycles, mean over 64 blocks x 8 waves" % (ci, co, bb, hh, ww))
         print("  launch -> first chunk ready   %7.0f" % (st[:, :, 2] - st[:, :, 0]).mean())
-        cm = np.mean([(st[:, :, 2 + 3 * k] - st[:, :, 1 + 3 * k]).mean() for k in range(1, min(nch, 8))])
+        cm = np.mean([(st[:, :, 1 + 3 * (k + 1)] - st[:, :, 3 + 3 * k]).mean() for k in range(0, min(nch, 8) - 1)])
         cp = np.mean([(st[:, :, 3 + 3 * k] - st[:, :, 2 + 3 * k]).mean() for k in range(0, min(nch, 8))])
-        print("  per chunk: barrier+commit+barrier %7.0f   fetch issue + transforms + MFMAs %7.0f" % (cm, cp))
+        print("  per 8-channel chunk: commit + fetch issue + barrier %7.0f   transforms + MFMAs %7.0f" % (cm, cp))
         print("  inverse transform + output     %7.0f   total %7.0f" % ((st[:, :, 29] - st[:, :, 28]).mean(), (st[:, :, 29] - st[:, :, 0]).mean()))
