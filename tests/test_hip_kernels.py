@@ -330,11 +330,10 @@ def test_kernels_refuse_cpu_tensors():
 
 
 def test_ops_functions_api_forward_backward():
-    """The reference-level operator API (ops.functions.MSDeformAttnFunction via the dropin aliases):
+    """The reference-level operator API (ops.functions.MSDeformAttnFunction through the import hook of nmrf_amd/dropin.py):
     autograd forward/backward against the golden fp64 gradients, and the ops/test.py float criterion."""
-    import os
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dropin"))
+    from nmrf_amd import dropin
+    dropin.install()                                  # the import hook the reference drivers run under (INTEGRATION.md)
     from ops.functions import MSDeformAttnFunction, ms_deform_attn_core_pytorch
     import MultiScaleDeformableAttention as MSDA
     g = golden("msda")
