@@ -2,6 +2,7 @@
 
     python -m nmrf_amd.build            # incremental
     python -m nmrf_amd.build --force
+    python -m nmrf_amd.build --debug    # tools-only libnmrf_hip_debug.so (probes, micro-benchmarks)
 """
 import concurrent.futures as cf
 import os
@@ -35,19 +36,24 @@ def _deps_mtime():
     return max(os.path.getmtime(h) for h in hdrs)
 
 
-def build_library(force=False, verbose=True):
+def build_library(force=False, verbose=True, debug=False):
+    """debug=True builds libnmrf_hip_debug.so: the same sources with -DNMRF_DEBUG_PROBES (nmrf_debug_* entry points, peak
+    micro-benchmarks, census / stamp instantiations, tuning getenvs).  Used by tools/ only; the product never loads it."""
     hipcc = _hipcc()
+    lib_path = os.path.join(LIBDIR, "libnmrf_hip_debug.so") if debug else LIB
+    objdir = OBJDIR + ("_debug" if debug else "")
+    flags = FLAGS + (["-DNMRF_DEBUG_PROBES"] if debug else [])
     os.makedirs(LIBDIR, exist_ok=True)
-    os.makedirs(OBJDIR, exist_ok=True)
+    os.makedirs(objdir, exist_ok=True)
     hdr_t = _deps_mtime()
     jobs = []
     objs = []
     for src in _sources():
-        obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t)
         if stale:
-            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
 
     def run(cmd):
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -60,15 +66,15 @@ def build_library(force=False, verbose=True):
                     print("[nmrf_amd.build]", os.path.basename(cmd[-3]), "rc=%d" % rc)
                 if rc != 0:
                     raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), log))
-    if jobs or not os.path.exists(LIB):
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    if jobs or not os.path.exists(lib_path):
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib_path] + objs
         cmd, rc, log = run(cmd)
         if rc != 0:
             raise RuntimeError("link failed: %s\n%s" % (" ".join(cmd), log))
         if verbose:
-            print("[nmrf_amd.build] linked", LIB)
-    return LIB
+            print("[nmrf_amd.build] linked", lib_path)
+    return lib_path
 
 
 if __name__ == "__main__":
-    build_library(force="--force" in sys.argv)
+    build_library(force="--force" in sys.argv, debug="--debug" in sys.argv)

@@ -18,6 +18,14 @@ static inline int nmrf_launch_status() {
     return hipGetLastError() == hipSuccess ? NMRF_OK : NMRF_ELAUNCH;
 }
 
+// per-device one-time state of the launchers (hipFuncSetAttribute opt-ins, CU counts): a process may drive several GPUs
+#define NMRF_MAX_DEV 64
+static inline int nmrf_cur_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NMRF_MAX_DEV) return -1;
+    return dev;
+}
+
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---- v_mfma_f32_32x32x2_f32 lane layout (MI355X guide, cdna_hip_programming.md section 3) -------------

@@ -216,8 +216,12 @@ __global__ __launch_bounds__(512, 4) void conv3x3_wino_kernel(const float *__res
     WN_STAMP(29);
 }
 
+#ifdef NMRF_DEBUG_PROBES
 static unsigned long long *g_wn_stamps = nullptr;   // debug (nmrf_debug_wino_timing): s_memtime stamps of the next launches
 extern "C" int nmrf_debug_wino_timing(unsigned long long *stamps) { g_wn_stamps = stamps; return NMRF_OK; }
+#else
+static unsigned long long *const g_wn_stamps = nullptr;
+#endif
 
 extern "C" int nmrf_conv3x3_wino_f32(const float *x, const float *u_packed, int B, int Ci, int H, int W, int Co, float *y,
                                      void *stream) {
@@ -227,7 +231,10 @@ extern "C" int nmrf_conv3x3_wino_f32(const float *x, const float *u_packed, int 
     const long items = (long)((tw + 31) / 32) * ((th + 1) / 2) * (Co / 32);
     if (B > 65535 || items > 0x7ffffff0L) return NMRF_EINVAL;
     const size_t lds = (size_t)2 * WN_BUF * sizeof(float);
-    static bool attr_set = false;
+    static bool attr_set_dev[NMRF_MAX_DEV] = {};
+    const int cur_dev = nmrf_cur_device();
+    if (cur_dev < 0) return NMRF_ELAUNCH;
+    bool &attr_set = attr_set_dev[cur_dev];
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess)

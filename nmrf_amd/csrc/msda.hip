@@ -190,6 +190,7 @@ extern "C" int nmrf_selftest_mfma_f32(const float *A, const float *Bm, int K, fl
     return nmrf_launch_status();
 }
 
+#ifdef NMRF_DEBUG_PROBES   // tools-only library libnmrf_hip_debug.so (python -m nmrf_amd.build --debug)
 // Debug: attainable v_mfma_f32_32x32x2_f32 rate (tools/kernel_bench.py --which mfma_peak).  CHAINS independent accumulator
 // chains per wave, `iters` x 16 MFMAs each; out receives one value per thread so nothing is optimised away.
 template <int CHAINS>
@@ -299,6 +300,7 @@ extern "C" int nmrf_debug_mfma_peak(int chains, int iters, int blocks, float *ou
     else return NMRF_EINVAL;
     return nmrf_launch_status();
 }
+#endif  // NMRF_DEBUG_PROBES
 
 extern "C" const char *nmrf_strerror(int code) {
     switch (code) {

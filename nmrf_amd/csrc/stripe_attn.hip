@@ -355,8 +355,10 @@ static void launch_stripe(const float *qkv, const float *lepe, const StripeGeom 
     const int n_qt = (g_in.Ts + SA_TILE - 1) / SA_TILE;
     int ksplit = 1;
     if (n_qt >= 4 && n_qt < 16) ksplit = 2;
-    static const char *force = getenv("NMRF_STRIPE_KSPLIT");   // tuning override (tools/kernel_bench.py)
+#ifdef NMRF_DEBUG_PROBES
+    static const char *force = getenv("NMRF_STRIPE_KSPLIT");   // tuning override (tools/kernel_bench.py), debug library only
     if (force && (force[0] == '1' || force[0] == '2' || force[0] == '4')) ksplit = force[0] - '0';
+#endif
     const int qpb = 4 / ksplit;
     StripeGeom g = g_in;
     g.gx = (n_qt + qpb - 1) / qpb; g.gy = stripes * 2; g.gz = B;
@@ -369,6 +371,7 @@ static void launch_stripe(const float *qkv, const float *lepe, const StripeGeom 
                                           (unsigned long long *)nullptr);
 }
 
+#ifdef NMRF_DEBUG_PROBES   // tools-only library libnmrf_hip_debug.so (python -m nmrf_amd.build --debug)
 // Debug: census run of the horizontal N=4 KSPLIT=1 kernel (KITTI configuration); census[blocks*3] + stamps on device.
 extern "C" int nmrf_debug_stripe_census(const float *qkv, const float *lepe_h, int B, int H, int W, float *out,
                                         unsigned long long *census, int *grid_out, void *stream) {
@@ -381,6 +384,7 @@ extern "C" int nmrf_debug_stripe_census(const float *qkv, const float *lepe_h, i
                        1.0f / sqrtf(32.0f), out, census);
     return nmrf_launch_status();
 }
+#endif  // NMRF_DEBUG_PROBES
 
 extern "C" int nmrf_stripe_attn_f32(const float *qkv, const float *lepe_v, const float *lepe_h, int B, int H, int W,
                                     int N, int C, int axes, float *out, void *stream) {

@@ -467,8 +467,14 @@ extern "C" int nmrf_pack_linear_weight_f32(const float *w, int N, int K, float *
     return nmrf_launch_status();
 }
 
+#ifdef NMRF_DEBUG_PROBES
 static unsigned long long *g_tl_stamps = nullptr;   // set by nmrf_debug_token_linear_timing for the next launches
 extern "C" int nmrf_debug_token_linear_timing(unsigned long long *stamps) { g_tl_stamps = stamps; return NMRF_OK; }
+static bool tl_nopipe() { return g_tl_stamps || getenv("NMRF_TL_NOPIPE"); }
+#else
+static unsigned long long *const g_tl_stamps = nullptr;
+static bool tl_nopipe() { return false; }
+#endif
 
 template <int KC, bool LN, bool GELU>
 static int launch_token_linear_g(const TokenLinearArgs &a, hipStream_t st) {
@@ -478,7 +484,10 @@ static int launch_token_linear_g(const TokenLinearArgs &a, hipStream_t st) {
     if (alias_out && gw != 128) return NMRF_EINVAL;                 // (exactly one strip per wave, so the tile is dead by then)
     const size_t lds_a = (size_t)32 * (KC * 32 + TL_PAD) * sizeof(float), lds_o = (size_t)32 * (gw + TL_PAD) * sizeof(float);
     const size_t lds = alias_out ? (lds_a > lds_o ? lds_a : lds_o) : lds_a + lds_o;
-    static bool attr_set = false;                                    // > 64 KB of dynamic LDS needs the opt-in once
+    static bool attr_set_dev[NMRF_MAX_DEV] = {};
+    const int cur_dev = nmrf_cur_device();
+    if (cur_dev < 0) return NMRF_ELAUNCH;
+    bool &attr_set = attr_set_dev[cur_dev];                                    // > 64 KB of dynamic LDS needs the opt-in once
     if (lds > 65536 && !attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(token_linear_kernel<KC, LN, GELU>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -497,17 +506,22 @@ static int launch_token_linear(const TokenLinearArgs &a, hipStream_t st) {
 
 template <int KC, bool GELU>
 static int launch_token_linear_pipe_g(const TokenLinearArgs &a, hipStream_t st) {
-    static int n_cu = 0;
+    static int n_cu_dev[NMRF_MAX_DEV] = {};
+    const int cu_dev = nmrf_cur_device();
+    if (cu_dev < 0) return NMRF_ELAUNCH;
+    int &n_cu = n_cu_dev[cu_dev];
     if (!n_cu) {
-        int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return NMRF_ELAUNCH;
+        if (hipGetDeviceProperties(&prop, cu_dev) != hipSuccess) return NMRF_ELAUNCH;
         n_cu = prop.multiProcessorCount;
     }
     constexpr size_t lds_a = (size_t)2 * 32 * (KC * 32 + TL_PAD) * sizeof(float), lds_o1 = (size_t)32 * (128 + TL_PAD) * sizeof(float);
     constexpr int OBUF = (lds_a + 2 * lds_o1 <= 80 * 1024) ? 2 : 1;          // two blocks per CU must fit in 160 KB
     constexpr size_t lds = lds_a + OBUF * lds_o1;
-    static bool attr_set = false;
+    static bool attr_set_dev[NMRF_MAX_DEV] = {};
+    const int cur_dev = nmrf_cur_device();
+    if (cur_dev < 0) return NMRF_ELAUNCH;
+    bool &attr_set = attr_set_dev[cur_dev];
     if (lds > 65536 && !attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(token_linear_pipe_kernel<KC, GELU, OBUF>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -538,7 +552,7 @@ extern "C" int nmrf_token_linear_f32(const float *x, const float *y, float *x_ou
     TokenLinearArgs a{x, y, x_out, ln_gamma, ln_beta, eps, extra, E, extra_div, w_packed, bias, residual, act, T, Cx, N, out, g_tl_stamps};
     hipStream_t st = (hipStream_t)stream;
     const int KC = (K + 31) / 32;
-    if (ln && !residual && N % 128 == 0 && !g_tl_stamps && !getenv("NMRF_TL_NOPIPE")) {
+    if (ln && !residual && N % 128 == 0 && !tl_nopipe()) {
         switch (KC) {
             case 4: return launch_token_linear_pipe<4>(a, st);
             case 5: return launch_token_linear_pipe<5>(a, st);

@@ -680,6 +680,7 @@ static int launch_window(const float *qkv, const float *table, const WinGeom &g,
     return nmrf_launch_status();
 }
 
+#ifdef NMRF_DEBUG_PROBES   // tools-only library libnmrf_hip_debug.so (python -m nmrf_amd.build --debug)
 // Debug helper (not part of the public header): what the HIP runtime thinks the residency of the two fast
 // instantiations is (the census of nmrf_debug_window_timing shows what the hardware actually does).
 extern "C" int nmrf_debug_window_occupancy(int *blocks_infer, int *blocks_refine) {
@@ -704,6 +705,7 @@ extern "C" int nmrf_debug_window_timing(const float *qkv, const float *table, in
                        1.0f / sqrtf(32.0f), out, stamps);
     return nmrf_launch_status();
 }
+#endif  // NMRF_DEBUG_PROBES
 
 extern "C" int nmrf_window_attn_f32(const float *qkv, const float *table, int B, int Hp, int Wp, int N, int C, int heads,
                                     int win, int shift, int sibling_mask, float *out, void *stream) {

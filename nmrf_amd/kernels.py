@@ -2,6 +2,7 @@
 pointers and the CURRENT torch stream.  PyTorch is plumbing here (memory + streams); all arithmetic
 of these ops happens in libnmrf_hip.so.  Every wrapper refuses non-CUDA tensors: there is no
 fallback path."""
+import functools
 import os
 
 import torch
@@ -14,9 +15,15 @@ def _stream():
 
 
 def _chk(*tensors, dtype=torch.float32):
+    dev = None
     for t in tensors:
         if t is None:
             continue
+        if t.is_cuda:
+            if dev is None:
+                dev = t.device
+            elif t.device != dev:
+                raise _lib.NmrfHipError("tensors of one kernel call live on different devices: %s and %s" % (dev, t.device))
         if not t.is_cuda:
             raise _lib.NmrfHipError("NMRF hot-path kernels run on the MI355X only: got a %s tensor "
                                     "(no CPU fallback exists by design)" % t.device)
@@ -30,6 +37,22 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+def _on_device(fn):
+    """Launch on the device the tensors live on (like the reference's device-guarded ATen ops): the stream handed to the C ABI
+    is that device's current torch stream and the HIP current device is switched for the duration of the call."""
+    @functools.wraps(fn)
+    def wrapper(*args, **kw):
+        for a in args:
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if a.device.index != torch.cuda.current_device():
+                    with torch.cuda.device(a.device):
+                        return fn(*args, **kw)
+                break
+        return fn(*args, **kw)
+    return wrapper
+
+
+@_on_device
 def mfma_selftest(a, bm):
     _chk(a, bm)
     k = a.shape[1]
@@ -38,6 +61,7 @@ def mfma_selftest(a, bm):
     return out
 
 
+@_on_device
 def cost_volume(f1, f2, num_disp, groups):
     """[B,C,H,W] x2 -> [B*H*W, G, D]"""
     _chk(f1, f2)
@@ -48,6 +72,7 @@ def cost_volume(f1, f2, num_disp, groups):
     return vol
 
 
+@_on_device
 def dpn_filter_softmax(vol, w0, b0, w1, b1, w2, b2):
     _chk(vol, w0, b0, w1, b1, w2, b2)
     p, g, d = vol.shape
@@ -57,6 +82,7 @@ def dpn_filter_softmax(vol, w0, b0, w1, b1, w2, b2):
     return prob
 
 
+@_on_device
 def nms_topk(prob, k, eps, do_nms=True):
     _chk(prob)
     p, d = prob.shape
@@ -66,6 +92,7 @@ def nms_topk(prob, k, eps, do_nms=True):
     return seeds
 
 
+@_on_device
 def seed_features(vol, seeds, normalizer):
     _chk(vol)
     _chk(seeds, dtype=torch.int64)
@@ -78,6 +105,7 @@ def seed_features(vol, seeds, normalizer):
     return cost, enc
 
 
+@_on_device
 def fourier_embed(coord, normalizer):
     _chk(coord)
     t = coord.numel()
@@ -87,6 +115,7 @@ def fourier_embed(coord, normalizer):
     return enc
 
 
+@_on_device
 def ln_concat(x, gamma, beta, extra=None, extra_div=1, ld=None, eps=1e-5):
     """-> [T, ld] = [LN(x) | extra[t // extra_div] | 0-pad]"""
     _chk(x, gamma, beta, extra)
@@ -100,6 +129,7 @@ def ln_concat(x, gamma, beta, extra=None, extra_div=1, ld=None, eps=1e-5):
     return out
 
 
+@_on_device
 def add_ln_concat(x, y, gamma, beta, extra=None, extra_div=1, ld=None, eps=1e-5):
     """x_new = x + y (returned, fresh tensor) and [LN(x_new) | extra | 0-pad] in one pass."""
     _chk(x, y, gamma, beta, extra)
@@ -120,6 +150,7 @@ def add_ln_concat(x, y, gamma, beta, extra=None, extra_div=1, ld=None, eps=1e-5)
 kernel_hook = None
 
 
+@_on_device
 def stripe_attn(qkv, lepe_v, lepe_h, b, h, w, n):
     _chk(qkv, lepe_v, lepe_h)
     t, c3 = qkv.shape
@@ -136,6 +167,7 @@ def stripe_attn(qkv, lepe_v, lepe_h, b, h, w, n):
     return out
 
 
+@_on_device
 def warp_corr_concat(labels, f1, f2, g1, g2, n, groups=32, ld=None):
     _chk(labels, f1, f2, g1, g2)
     b, cf, h, w = f1.shape
@@ -150,6 +182,7 @@ def warp_corr_concat(labels, f1, f2, g1, g2, n, groups=32, ld=None):
     return out
 
 
+@_on_device
 def self_attn(qkv, n, heads):
     _chk(qkv)
     t, c3 = qkv.shape
@@ -159,6 +192,7 @@ def self_attn(qkv, n, heads):
     return out
 
 
+@_on_device
 def window_attn(qkv, table, b, hp, wp, n, heads, win, shift, sibling_mask):
     _chk(qkv, table)
     t, c3 = qkv.shape
@@ -174,6 +208,7 @@ def window_attn(qkv, table, b, hp, wp, n, heads, win, shift, sibling_mask):
     return out
 
 
+@_on_device
 def linear_smalln(x, weight, bias=None, relu=False):
     """[T,K] x [N,K]^T (+bias, optional ReLU) for the narrow prediction heads (N <= 64)."""
     _chk(x, weight, bias)
@@ -185,6 +220,7 @@ def linear_smalln(x, weight, bias=None, relu=False):
     return out
 
 
+@_on_device
 def pack_linear_weight(weight):
     """[N,K] nn.Linear weight -> MFMA fragment order for token_linear (N % 32 == 0)."""
     _chk(weight)
@@ -194,6 +230,7 @@ def pack_linear_weight(weight):
     return packed
 
 
+@_on_device
 def token_linear(x, packed_w, n, k, bias=None, ln=None, y=None, extra=None, extra_div=1, act=0, residual=None):
     """out[T,n] = act(P(x) W^T + bias) + residual on the fused MFMA kernel.
     ln = (gamma, beta, eps): P(x) = [LayerNorm(x + y) | extra[t // extra_div]]; returns (x + y, out) when y is given.
@@ -221,6 +258,7 @@ def token_linear(x, packed_w, n, k, bias=None, ln=None, y=None, extra=None, extr
     return (x_out, out) if y is not None else out
 
 
+@_on_device
 def wino_pack_filter(weight):
     """[Co,Ci,3,3] conv weight -> Winograd-domain filter in MFMA fragment order for conv3x3_wino."""
     _chk(weight)
@@ -231,6 +269,7 @@ def wino_pack_filter(weight):
     return packed
 
 
+@_on_device
 def conv3x3_wino(x, packed_u, co):
     """3x3 / stride 1 / pad 1 / no-bias convolution (NCHW fp32) as fused Winograd F(2x2,3x3) on fp32 MFMA."""
     _chk(x, packed_u)
@@ -262,6 +301,7 @@ def conv3x3_auto(x, weight, cache):
     return conv3x3_wino(x.contiguous(), cache["packed"], co)
 
 
+@_on_device
 def superpixel_downsample(disp, labels, k=4):
     """A16 (parity unpinned, see include/nmrf_hip.h): disp [B,H,W] f32 (0 invalid), labels [B,H,W] int32 -> [B,H//8,W//8,k]."""
     _chk(disp)
@@ -273,6 +313,7 @@ def superpixel_downsample(disp, labels, k=4):
     return out
 
 
+@_on_device
 def wta_median(delta, score, labels, b, h, w, n):
     _chk(delta, score, labels)
     out = torch.empty(b, 2 * h, 2 * w, device=delta.device, dtype=torch.float32)
@@ -281,6 +322,7 @@ def wta_median(delta, score, labels, b, h, w, n):
     return out
 
 
+@_on_device
 def refine_epilogue(delta, disp_curr, out_h, out_w):
     _chk(delta, disp_curr)
     b, h4, w4 = disp_curr.shape
@@ -291,6 +333,7 @@ def refine_epilogue(delta, disp_curr, out_h, out_w):
     return disp, pred
 
 
+@_on_device
 def instance_norm(x, relu=False, residual=None, relu_out=False, eps=1e-5):
     """InstanceNorm2d (no affine) of an NCHW tensor fused with ReLU / residual add / ReLU:
     y = [relu] IN(x); y = [relu_out](y + residual)."""
@@ -304,6 +347,7 @@ def instance_norm(x, relu=False, residual=None, relu_out=False, eps=1e-5):
     return y
 
 
+@_on_device
 def msda_forward(value, shapes, lvl_start, loc, w):
     dt = value.dtype
     if dt not in (torch.float32, torch.float64):
@@ -319,6 +363,7 @@ def msda_forward(value, shapes, lvl_start, loc, w):
     return out
 
 
+@_on_device
 def msda_backward(value, shapes, lvl_start, loc, w, grad_out):
     dt = value.dtype
     _chk(value, loc, w, grad_out, dtype=dt)
