@@ -4,8 +4,21 @@
 Parameter names follow the reference's `Backbone` (nmrf/models/backbone.py:16-98) so released
 checkpoints load with strict=True: conv1, layer{1,2,3}.{0,1}.{conv1,conv2,downsample.0}, conv2.
 """
+import logging
+
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+
+def _hip_ok(module, x):
+    """The fused HIP kernels are forward-only (outputs carry no grad_fn): take them only when autograd is not recording
+    through this module; otherwise the stock branch runs (nmrf/models/backbone.py:38-46 arithmetic on MIOpen)."""
+    if not x.is_cuda:
+        return False
+    if not torch.is_grad_enabled():
+        return True
+    return not (x.requires_grad or any(p.requires_grad for p in module.parameters()))
 
 
 def _norm(kind, ch):
@@ -32,7 +45,7 @@ class ResidualBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride), self.norm3)
 
     def forward(self, x):
-        if self.fused and x.is_cuda:
+        if self.fused and _hip_ok(self, x):
             # InstanceNorm + ReLU (+ residual add + ReLU) in two HIP passes instead of 4-6 torch kernels
             from .. import kernels as K
             c1 = K.conv3x3_auto(x, self.conv1.weight, self._wino1) if self.conv1.stride == (1, 1) else self.conv1(x)
@@ -69,7 +82,7 @@ class Backbone(nn.Module):
 
     def forward(self, x):
         x = 2 * (x / 255.0) - 1.0
-        if self.fused and x.is_cuda:
+        if self.fused and _hip_ok(self, x):
             from .. import kernels as K
             x = K.instance_norm(self.conv1(x).contiguous(), relu=True)
         else:
@@ -78,11 +91,27 @@ class Backbone(nn.Module):
         return [x, F.avg_pool2d(x, 2, 2)]
 
 
+def checkpoint_filter_fn(state_dict):
+    """Keys of a released Swin-T classification checkpoint that belong to the trunk (nmrf/models/backbone.py:160-173):
+    unwrap 'model' / 'state_dict', drop the attention-mask buffers and the classifier's final norm / head."""
+    state_dict = state_dict.get("model", state_dict)
+    state_dict = state_dict.get("state_dict", state_dict)
+    return {k: v for k, v in state_dict.items()
+            if "attn_mask" not in k and not k.startswith(("norm", "head"))}
+
+
 def create_backbone(cfg):
     kind = cfg.BACKBONE.MODEL_TYPE
     if kind == "resnet":
         return Backbone(cfg.BACKBONE.OUT_CHANNELS, cfg.BACKBONE.NORM_FN)
     if kind == "swin":
         from .swin_neck import SwinAdaptor
-        return SwinAdaptor(cfg.BACKBONE.OUT_CHANNELS, cfg.BACKBONE.DROP_PATH)
+        if cfg.BACKBONE.DROP_PATH != 0:
+            raise NotImplementedError("inference build: BACKBONE.DROP_PATH must be 0 (stochastic depth is training-only)")
+        backbone = SwinAdaptor(cfg.BACKBONE.OUT_CHANNELS, cfg.BACKBONE.DROP_PATH)
+        if cfg.BACKBONE.WEIGHT_URL:                   # pretrained Swin-T trunk (nmrf/models/backbone.py:188-196)
+            weight = checkpoint_filter_fn(torch.load(cfg.BACKBONE.WEIGHT_URL, map_location="cpu"))
+            backbone.backbone.load_state_dict(weight)
+            logging.getLogger(__name__).info("Load pretrained backbone weights from %s", cfg.BACKBONE.WEIGHT_URL)
+        return backbone
     raise ValueError("Do not find %s" % kind)

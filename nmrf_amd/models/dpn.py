@@ -27,6 +27,8 @@ class DPN(nn.Module):
         for m in self.modules():
             if isinstance(m, (nn.Conv1d, nn.Conv2d)):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                if isinstance(m, nn.Conv1d) and m.bias is not None:           # DPN.py:91-94
+                    nn.init.zeros_(m.bias)
             elif isinstance(m, nn.Linear):
                 nn.init.trunc_normal_(m.weight, std=.02)
                 nn.init.zeros_(m.bias) if m.bias is not None else None
@@ -55,6 +57,8 @@ class DPN(nn.Module):
             cost_volume = cost_volume.permute(0, 3, 4, 1, 2).reshape(b * h * w, g, d).contiguous()
         prob, seeds = self.seeds(cost_volume)
         if context is None:                                   # [B,Cctx,H,W] may be precomputed by the caller
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.proj.parameters()):
+                raise NotImplementedError("nmrf_amd implements the inference path only: call under torch.no_grad()")
             y = K.instance_norm(self.proj[0](fmap1_list[0]).contiguous(), relu=True)     # conv3x3 - IN - ReLU fused
             context = self.proj[3](y)
         context = context.permute(0, 2, 3, 1).contiguous()

@@ -96,7 +96,10 @@ class NMRF(nn.Module):
         b = img1.shape[0]
         return [f[:b].contiguous() for f in feats], [f[b:].contiguous() for f in feats]
 
+    @torch.no_grad()
     def forward(self, sample):
+        """model(sample) of NMRF.py:189-262.  Inference build: always runs under no_grad (the HIP kernels are forward-only),
+        so the returned tensors never carry a grad_fn -- fine-tuning needs the reference's training path."""
         if self.training:
             raise NotImplementedError("nmrf_amd implements the inference path only; call model.eval()")
         if self.device.type != "cuda":
