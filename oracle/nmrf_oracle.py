@@ -646,12 +646,9 @@ def msda_core(value, shapes, loc, wgt):
 # --------------------------------------------------------------------------- #
 # full forward (NMRF.py:189-262), CNN backbone
 # --------------------------------------------------------------------------- #
-def forward(w, cfg, img1, img2, return_stages=False):
-    stages = {} if return_stages else None
-    h0, w0 = img1.shape[-2:]
-    img1, img2, pad_hw = pad_images(img1, img2, cfg.divis_by)
-    b = img1.shape[0]
-    feats4, feats8 = cnn_backbone(torch.cat((img1, img2), 0), w, cfg.backbone_prefix)
+def hot_path(w, cfg, feats8, feats4, pad_hw, out_hw, stages=None):
+    """Everything after the backbone (NMRF.py:207-262).  feats8 / feats4: [2B,C,H,W] maps, left views first."""
+    b = feats8.shape[0] // 2
     l8, r8 = feats8[:b], feats8[b:]
     l4, r4 = feats4[:b], feats4[b:]
     num_disp = cfg.max_disp // 8
@@ -675,7 +672,7 @@ def forward(w, cfg, img1, img2, return_stages=False):
     f1, f2 = conv_head(l4, w, "concatconv"), conv_head(r4, w, "concatconv")
     g1, g2 = conv_head(l4, w, "gw"), conv_head(r4, w, "gw")
     tgt4 = refinement(disp_q, f1, f2, g1, g2, w, cfg, stages)
-    disp, pred = refine_epilogue(tgt4, disp_q, w, pad_hw, (h0, w0))
+    disp, pred = refine_epilogue(tgt4, disp_q, w, pad_hw, out_hw)
 
     out = {
         "proposal": labels.view(b, -1, n),
@@ -684,9 +681,17 @@ def forward(w, cfg, img1, img2, return_stages=False):
         "disp": disp,
         "disp_pred": pred,
     }
-    if return_stages:
+    if stages is not None:
         stages.update(cost_volume=cv, seeds=seeds, context=ctx, prop_memory=mem, infer_tgt=tgt,
                       coarse=coarse, score=score, disp_curr=disp_q, refine_tgt=tgt4,
                       fmap8_l=l8, fmap8_r=r8, fmap4_l=l4, fmap4_r=r4)
         out["stages"] = stages
     return out
+
+
+def forward(w, cfg, img1, img2, return_stages=False):
+    stages = {} if return_stages else None
+    h0, w0 = img1.shape[-2:]
+    img1, img2, pad_hw = pad_images(img1, img2, cfg.divis_by)
+    feats4, feats8 = cnn_backbone(torch.cat((img1, img2), 0), w, cfg.backbone_prefix)
+    return hot_path(w, cfg, feats8, feats4, pad_hw, (h0, w0), stages)

@@ -20,3 +20,37 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+# ---- end-to-end disparity statistics: collected by the parity tests, printed after the run (and appended to
+# gpurun_out/e2e_stats.jsonl on the GPU box) so that the numbers behind every green gate are in the pytest output
+_DISP_STATS = []
+
+
+def record_disp_stats(tag, stats):
+    _DISP_STATS.append((tag, dict(stats)))
+    try:
+        import json
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "e2e_stats.jsonl"), "a") as f:
+            f.write(json.dumps(dict(stats, case=tag)) + "\n")
+    except OSError:
+        pass
+
+
+_NOTES = []
+
+
+def record_note(text):
+    _NOTES.append(text)
+
+
+def pytest_terminal_summary(terminalreporter):
+    for n in _NOTES:
+        terminalreporter.write_line("note: " + n)
+    if not _DISP_STATS:
+        return
+    terminalreporter.write_sep("-", "disparity agreement (px): EPE / median / p99 / frac>0.5px / max")
+    for tag, s in _DISP_STATS:
+        terminalreporter.write_line("%-46s %.2e  %.2e  %.2e  %.2e  %.3f" % (tag, s["epe"], s["median"], s["p99"],
+                                                                              s["frac_gt_0p5"], s["max"]))

@@ -127,7 +127,10 @@ def test_ln_concat():
     report("add+ln|enc", got.cpu()[:, :159], torch.cat((F.layer_norm(x + y, (128,), gam, bet, 1e-5), e31), 1), 3e-6)
 
 
-@pytest.mark.parametrize("b,h,w,n", [(2, 7, 13, 4), (1, 47, 20, 4), (1, 5, 40, 1), (1, 9, 6, 2), (1, 3, 5, 3)])
+# the last three are the 1/8 grids of the BASELINE configs (KITTI 376x1248, SceneFlow 544x960, Middlebury-H 1024x1504):
+# 20 / 15 / 24 key tiles per horizontal stripe, i.e. the KSPLIT-1 long-loop and KSPLIT-2 instantiations that run in the bench
+@pytest.mark.parametrize("b,h,w,n", [(2, 7, 13, 4), (1, 47, 20, 4), (1, 5, 40, 1), (1, 9, 6, 2), (1, 3, 5, 3),
+                                     (1, 47, 156, 4), (1, 68, 120, 4), (1, 128, 188, 4), (2, 47, 156, 4)])
 def test_stripe_attention(b, h, w, n):
     tkn = b * h * w * n
     qkv = rnd(tkn, 384, seed=h * w, scale=1.5)
@@ -142,12 +145,13 @@ def test_stripe_attention(b, h, w, n):
     report("stripe_attn", got, torch.cat(outs, -1).reshape(tkn, 128), 2e-5, 1e-5)
 
 
-def test_self_attention():
+@pytest.mark.parametrize("pixels", [300, 68 * 120])                  # 68x120 = the SceneFlow 1/8 grid (32 640 tokens)
+def test_self_attention(pixels):
     for n in (4, 1, 3):
-        tkn = 300 * n
+        tkn = pixels * n
         qkv = rnd(tkn, 384, seed=n, scale=2.0)
         got = K().self_attn(qkv.to(DEV), n, 4).cpu()
-        q, k, v = (qkv[:, i * 128:(i + 1) * 128].view(300, n, 4, 32).transpose(1, 2) for i in range(3))
+        q, k, v = (qkv[:, i * 128:(i + 1) * 128].view(pixels, n, 4, 32).transpose(1, 2) for i in range(3))
         ref = (torch.softmax(q @ k.transpose(-1, -2) * 32 ** -0.5, -1) @ v).transpose(1, 2).reshape(tkn, 128)
         report(f"self_attn n={n}", got, ref, 1e-5)
 
@@ -155,7 +159,12 @@ def test_self_attention():
 @pytest.mark.parametrize("b,hp,wp,n,win,shift,sib", [
     (1, 12, 18, 4, 6, 0, True), (2, 12, 12, 4, 6, 3, True), (1, 6, 6, 4, 6, 3, True),
     (1, 8, 12, 1, 4, 0, False), (2, 8, 8, 1, 4, 2, False), (1, 16, 28, 1, 4, 2, False),
-    (1, 12, 6, 2, 6, 3, True), (1, 12, 12, 1, 6, 3, False), (1, 8, 8, 4, 4, 1, True)])
+    (1, 12, 6, 2, 6, 3, True), (1, 12, 12, 1, 6, 3, False), (1, 8, 8, 4, 4, 1, True),
+    # padded token grids of the BASELINE configs: KITTI / SceneFlow inference windows (208 / 240 windows of 144 tokens),
+    # KITTI / Middlebury-H refinement windows (1 872 / 6 016 windows of 16 tokens), shifted and not
+    (1, 48, 156, 4, 6, 0, True), (1, 48, 156, 4, 6, 3, True), (1, 72, 120, 4, 6, 0, True), (1, 72, 120, 4, 6, 3, True),
+    (1, 96, 312, 1, 4, 0, False), (1, 96, 312, 1, 4, 2, False), (1, 256, 376, 1, 4, 0, False), (1, 256, 376, 1, 4, 2, False),
+    (2, 48, 156, 4, 6, 3, True)])
 def test_window_attention(b, hp, wp, n, win, shift, sib):
     tkn = b * hp * wp * n
     qkv = rnd(tkn, 384, seed=hp * wp + shift, scale=1.5)
@@ -217,6 +226,21 @@ def test_msda_forward_backward(tag):
         report("msda gw", gw.cpu(), t(g[f"{tag}_gw"]), 5e-6, 1e-4)
 
 
+@pytest.mark.parametrize("lvl", [0, 3])
+def test_msda_forward_at_middlebury_swin_shapes(lvl):
+    """A15 at the config-5 message shapes: 2B = 2 images, Lq = (H/4)(W/4) = 256*376 = 96 256 queries, 8 heads x 8
+    channels, one level of 256x376 (stage 1) or 32x47 (stage 4), 4 points -- against the oracle's grid_sample formulation."""
+    h, w = ((256, 376), (128, 188), (64, 94), (32, 47))[lvl]
+    lq = 256 * 376
+    value = rnd(2, h * w, 8, 8, seed=31 + lvl)
+    loc = rnd(2, lq, 8, 1, 4, 2, seed=33).abs() * 1.04 - 0.02          # a few samples fall outside [0,1]
+    wgt = torch.softmax(rnd(2, lq, 8, 1, 4, seed=34) * 2, -1)
+    shapes = torch.tensor([[h, w]])
+    start = torch.tensor([0])
+    got = K().msda_forward(value.to(DEV), shapes.to(DEV), start.to(DEV), loc.to(DEV), wgt.to(DEV)).cpu()
+    report("msda config-5", got, O.msda_core(value, shapes, loc, wgt), 3e-6, 1e-5)
+
+
 @pytest.mark.parametrize("t_,k,n,relu", [(1000, 128, 64, False), (333, 128, 16, True), (4097, 128, 1, False), (70, 36, 5, True)])
 def test_linear_smalln(t_, k, n, relu):
     x, w, b = rnd(t_, k, seed=1), rnd(n, k, seed=2) * 0.2, rnd(n, seed=3)
@@ -235,6 +259,9 @@ def test_linear_smalln(t_, k, n, relu):
     (20013, 64, 384, 0, 4, True, False),    # ragged last tile + two tiles per block (pipelined path), shared context rows
     (16397, 0, 512, 2, 1, True, False),     # same for fc1 + GELU (four 128-column groups per tile)
     (16397, 0, 512, 2, 1, False, True),     # residual operand -> the one-tile-per-block kernel
+    (34560, 31, 384, 0, 1, True, False),    # SceneFlow padded inference grid 72x120x4
+    (32640, 64, 384, 0, 4, True, False),    # SceneFlow propagation grid 68x120x4
+    (34560, 0, 512, 2, 1, True, False),     # SceneFlow fc1 + GELU
 ])
 def test_token_linear_layernorm_prologue(t_, e, n, act, div, with_y, res):
     x, y = rnd(t_, 128, seed=1, scale=2.0), rnd(t_, 128, seed=2)
@@ -263,7 +290,7 @@ def test_token_linear_layernorm_prologue(t_, e, n, act, div, with_y, res):
 
 @pytest.mark.parametrize("t_,k,n,act,res", [(500, 128, 128, 0, False), (333, 512, 128, 0, True), (100, 36, 128, 2, False),
                                             (2000, 160, 128, 2, False), (70, 128, 64, 1, False), (29952, 512, 128, 0, True),
-                                            (31, 32, 32, 0, False)])
+                                            (31, 32, 32, 0, False), (34560, 128, 128, 0, False), (32640, 160, 128, 2, False)])
 def test_token_linear_plain(t_, k, n, act, res):
     x = rnd(t_, k, seed=11, scale=1.5)
     w, bias = rnd(n, k, seed=12, scale=0.1), rnd(n, seed=13)

@@ -9,13 +9,13 @@ import pytest
 import torch
 
 from oracle import nmrf_oracle as O
-from tests.util import golden, oracle_cfg, oracle_weights, report, t
+from tests.util import disp_stats, golden, golden_images, oracle_cfg, oracle_weights, report, t
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _imgs(g):
-    return t(g["img1"]).float(), t(g["img2"]).float()
+    return golden_images(g)
 
 
 @pytest.fixture(scope="module")
@@ -105,11 +105,12 @@ def test_refinement_stage_from_reference_disparity(run_a):
     report("disp", disp, t(g["disp"]), 1e-4)
 
 
-@pytest.mark.parametrize("name", ["e2e_a", "e2e_b", "e2e_c"])
+@pytest.mark.parametrize("name", ["e2e_a", "e2e_b", "e2e_c", "e2e_d"])
 def test_end_to_end_outputs(name):
-    """Whole forward vs the reference.  Seeds and probabilities are exact / 1e-6; the final disparity
-    is compared by EPE because label noise of 1e-6 is amplified ~1e3x by the top Fourier band before
-    the winner-take-all (measured: see DESIGN.md, 'error amplification')."""
+    """Whole forward vs the reference.  Seeds are bit-exact, probabilities 2e-6, proposals 5e-5; the final disparity is held to
+    the contract of BASELINE.json (EPE within 1e-3 px; measured 3e-5 ... 1.2e-4) plus a median and an outlier bound, because
+    label noise of 1e-6 is amplified ~1e3x by the top Fourier band before the winner-take-all and can flip the odd pixel
+    (e2e_d: one 0.27 px pixel in 280 704; DESIGN.md, 'error amplification')."""
     g = golden(name)
     w, cfg = oracle_weights(int(g["max_disp"])), oracle_cfg(int(g["max_disp"]))
     with torch.no_grad():
@@ -117,8 +118,10 @@ def test_end_to_end_outputs(name):
     report("prob", out["prob"], t(g["prob"]), 2e-6)
     assert torch.equal(out["initial_proposal"].long(), t(g["seeds"]).long())
     report("proposal", out["proposal"], t(g["proposal"]), 5e-5)
-    epe = float((out["disp"] - t(g["disp"])).abs().mean())
-    assert epe < 5e-2, f"EPE vs reference {epe}"
+    st = disp_stats(out["disp"], t(g["disp"]))
+    from tests.conftest import record_disp_stats
+    record_disp_stats("oracle vs reference " + name, st)
+    assert st["epe"] < 1e-3 and st["median"] < 2e-4 and st["frac_gt_0p5"] < 2e-3, st
 
 
 # ------------------------------------------------------------------------------------------------

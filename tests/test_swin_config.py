@@ -65,8 +65,8 @@ def test_swin_model_on_gpu():
                             g["disp"].shape[-2:])
     assert torch.equal(hp["initial_proposal"].cpu().long(), t(g["seeds"]).long())
     report("prob", hp["prob"].cpu(), t(g["prob"]), 5e-6)
-    d = (hp["disp"].cpu() - t(g["disp"])).abs()
-    assert float(d.median()) < 5e-3 and float(d.mean()) < 0.15
+    from tests.util import check_disp
+    check_disp("swin hot path from reference features", hp["disp"].cpu(), t(g["disp"]))
     assert out["disp"].shape == (1, 60, 90) and torch.isfinite(out["disp"]).all()
     mism = (out["initial_proposal"].cpu().long() != t(g["seeds"]).long()).any(-1).float().mean()
     assert mism < 0.05, f"{float(mism)} of the pixels changed seeds through the GPU encoder"

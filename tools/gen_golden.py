@@ -12,6 +12,8 @@ Fixtures
               (layer captures row-subsampled x2) - both pad branches odd
   e2e_b.npz   96x328, default MAX_DISP 320 (D=40), B=1: small outputs only
   e2e_c.npz   40x72,  MAX_DISP 128, B=2 (two different pairs): small outputs
+  e2e_d.npz   136x1032, MAX_DISP 320 (D=40), B=2: small outputs; 1/8 grid 17x129 = 17 key tiles per horizontal stripe
+              (the long-loop stripe kernel of the KITTI bench), images regenerated from (h, w, seed)
   nms_cases.npz   crafted logits rows (ties, plateaus, NaN, ...) pushed through
               the reference's DPN.forward NMS+topk (DPN.py:119-125), D in {16,24,32,40,48}
   e2e_swin.npz / state_dict_keys.json   Swin-T + DeformNeck config: encoder features + outputs; key/shape listings
@@ -39,7 +41,7 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
-def run_e2e(name, shapes_seeds, opts, full):
+def run_e2e(name, shapes_seeds, opts, full, store_images=True):
     model, cfg = refshim.build_reference_model(opts)
     apply_hash_weights(model)
     caps = {}
@@ -74,8 +76,10 @@ def run_e2e(name, shapes_seeds, opts, full):
     img1, img2 = torch.stack(lefts), torch.stack(rights)
     with torch.no_grad():
         out = model({"img1": img1.clone(), "img2": img2.clone()})
-    d = {
-        "img1": _np(img1).astype(np.uint8), "img2": _np(img2).astype(np.uint8),
+    d = {"pair_hws": np.asarray(shapes_seeds, np.int64)}          # (h, w, seed) of nmrf_amd.utils.hashinit.synthetic_pair
+    if store_images:
+        d.update({"img1": _np(img1).astype(np.uint8), "img2": _np(img2).astype(np.uint8)})
+    d.update({
         "max_disp": np.int64(cfg.DPN.MAX_DISP),
         "prob": _np(out["prob"]),
         "seeds": _np(out["initial_proposal"]).astype(np.int16),
@@ -83,7 +87,7 @@ def run_e2e(name, shapes_seeds, opts, full):
         "disp": _np(out["disp"]),
         "disp_pred": _np(out["disp_pred"]),
         "disp_curr": _np(caps["refine_tgt_in"][0]),
-    }
+    })
     if full:
         sub = lambda t: _np(t.reshape(-1, t.shape[-1]))[::2]
         cv = caps["prop_in"][0]
@@ -239,6 +243,9 @@ if __name__ == "__main__":
     run_e2e("e2e_a", [(52, 100, 1000)], ["DPN.MAX_DISP", 128], full=True)
     run_e2e("e2e_b", [(96, 328, 1001)], [], full=False)
     run_e2e("e2e_c", [(40, 72, 1002), (40, 72, 1003)], ["DPN.MAX_DISP", 128], full=False)
+    # mid-size: 17 key tiles per horizontal stripe (129 pixels x 4 labels), both window paddings live; the images are the
+    # closed-form synthetic pairs of these seeds and are regenerated where the fixture is consumed
+    run_e2e("e2e_d", [(136, 1032, 1004), (136, 1032, 1005)], [], full=False, store_images=False)
     run_nms()
     run_msda()
     run_swin()
