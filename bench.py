@@ -7,9 +7,12 @@
 A "step" = one NMRF.forward (backbone + hot path) over one batch of synthetic stereo pairs already
 resident in HBM (BASELINE.json configs[1]: KITTI 1242x375, batch 1 per GPU, CNN backbone, 5/5/5
 layers, fp32).  Prints ONE JSON line on rank 0: whole-job stereo pairs/s + `roofline` of the
-dominant hand-written kernel (horizontal stripe attention, MFMA-bound, timed live with HIP events on
-the launching stream) + `cpu_baseline` (the CPU oracle = a port of the reference path, timed on the
-host cores, rank 0, N=1 only).
+hot-path kernel with the largest time per forward, timed live with HIP events on
+the launching stream, + `other_kernels` (the next ones, incl. the N2 conv band and the HBM-bound
+kernels with their GB/s) + `cpu_baseline` (the CPU oracle = a port of the reference path, timed on
+the host cores, rank 0, N=1 only).  Other BASELINE configs: --height 540 --width 960 --batch 32
+(config 3), --batch 8 (config 4's per-GPU shard), --backbone swin --height 1000 --width 1500
+--max-disp 256 (config 5), --infer-layers 4 (the "4 inference iters" reading).
 """
 import argparse
 import json
@@ -23,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+HBM_PEAK_GBS = 8000.0                # same guide: HBM3E ~8 TB/s
 
 
 def parse():
@@ -34,6 +38,8 @@ def parse():
     ap.add_argument("--height", type=int, default=375)
     ap.add_argument("--width", type=int, default=1242)
     ap.add_argument("--infer-layers", type=int, default=5, help="NMP.NUM_INFER_LAYERS (reference default 5)")
+    ap.add_argument("--backbone", default="resnet", choices=["resnet", "swin"], help="swin = configs/sceneflow_swint.yaml keys")
+    ap.add_argument("--max-disp", type=int, default=320, help="DPN.MAX_DISP (256 for the Middlebury config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL result gather at N>1")
@@ -47,18 +53,17 @@ class KernelTimer:
 
     def __init__(self):
         self.pairs = {}
-        self.flops = {}
+        self.meta = {}
         self.enabled = False
 
-    def __call__(self, phase, name, flops=None):
+    def __call__(self, phase, name, meta=None):
         if not self.enabled:
             return
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.current_stream())
         if phase == "begin":
             self.pairs.setdefault(name, []).append([ev, None])
-            if flops is not None:
-                self.flops.setdefault(name, []).append(flops)
+            self.meta.setdefault(name, []).append(meta or {})
         else:
             self.pairs[name][-1][1] = ev
 
@@ -71,33 +76,46 @@ class KernelTimer:
                 out[name] = (sum(ts) / len(ts), len(ts))
         return out
 
+    def mean_meta(self, name, key):
+        vals = [m[key] for m in self.meta.get(name, []) if m.get(key) is not None]
+        return sum(vals) / len(vals) if vals else None
 
-def cpu_baseline(height, width, infer_layers):
-    """The CPU oracle (a plain-PyTorch port of the reference path, pinned to the reference by
-    tests/test_oracle_golden.py) on up to 16 host cores: 1 warm-up at 1/4 size + 1 timed forward of one pair
-    (a bounded sample: one forward is ~5-30 s of CPU work)."""
+
+def cpu_baseline(height, width, infer_layers, max_disp=320):
+    """The CPU oracle (a plain-PyTorch port of the reference path, pinned to the reference by tests/test_oracle_golden.py) on
+    the host cores, same synthetic pair, batch 1: 1 warm-up + median of 3 forwards on up to 16 threads, and one
+    forward on 1 thread.  A bounded sample: ~10 s + ~25 s of CPU work at KITTI size."""
     from oracle import nmrf_oracle as O
     from nmrf_amd.config import get_cfg
     from nmrf_amd.models import build_model
     from nmrf_amd.utils.hashinit import hash_state_dict, synthetic_pair
     cores = os.cpu_count() or 1
-    torch.set_num_threads(min(cores, 16))     # the op-by-op CPU path stops scaling (and collapses) beyond ~16 threads
+    nthr = min(cores, 16)                     # the op-by-op CPU path stops scaling (and collapses) beyond ~16 threads
+    torch.set_num_threads(nthr)
     cfg = get_cfg()
     cfg.NMP.NUM_INFER_LAYERS = infer_layers
+    cfg.DPN.MAX_DISP = max_disp
     w = hash_state_dict(build_model(cfg)[0].state_dict())
-    ocfg = O.OracleCfg(num_infer_layers=infer_layers)
+    ocfg = O.OracleCfg(num_infer_layers=infer_layers, max_disp=max_disp)
     l, r, _ = synthetic_pair(height, width, seed=1000)
-    with torch.no_grad():
-        ls, rs, _ = synthetic_pair(max(64, height // 4), max(96, width // 4), seed=1)
-        O.forward(w, ocfg, ls[None], rs[None])
-        reps = 1
+
+    def once():
         t0 = time.perf_counter()
-        for _ in range(reps):
-            O.forward(w, ocfg, l[None], r[None])
-        dt = (time.perf_counter() - t0) / reps
-    return {"value": 1.0 / dt, "unit": "stereo pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d forwards of one %dx%d pair (oracle/nmrf_oracle.py, torch CPU fp32, %d threads), %.2f s each"
-                      % (reps, width, height, torch.get_num_threads(), dt)}
+        O.forward(w, ocfg, l[None], r[None])
+        return time.perf_counter() - t0
+
+    with torch.no_grad():
+        once()                                                  # warm-up
+        ts = sorted(once() for _ in range(3))
+        dt = ts[1]
+        torch.set_num_threads(1)
+        dt1 = once()
+        torch.set_num_threads(nthr)
+    return {"value": 1.0 / dt, "unit": "stereo pairs/s", "cores": nthr, "kind": "port",
+            "value_1thread": 1.0 / dt1,
+            "sample": "one %dx%d pair, batch 1 (oracle/nmrf_oracle.py, torch CPU fp32): 1 warm-up + median of 3 forwards on %d "
+                      "threads = %.2f s; one forward on 1 thread = %.2f s; host has %d cores"
+                      % (width, height, nthr, dt, dt1, cores)}
 
 
 def main():
@@ -128,6 +146,10 @@ def main():
 
     cfg = get_cfg()
     cfg.NMP.NUM_INFER_LAYERS = args.infer_layers
+    cfg.DPN.MAX_DISP = args.max_disp
+    if args.backbone == "swin":                                   # configs/sceneflow_swint.yaml
+        cfg.merge_from_list(["BACKBONE.MODEL_TYPE", "swin", "BACKBONE.OUT_CHANNELS", 128, "DATASETS.DIVIS_BY", 32,
+                             "BACKBONE.COMPAT", False])
     cfg.freeze()
     model = apply_hash_weights(build_model(cfg)[0]).eval().to(dev)
     b = args.batch
@@ -231,75 +253,56 @@ def main():
 
     pairs_total = world * b * args.steps
     value = pairs_total / elapsed
-    hp, wp = -(-args.height // 8) * 8, -(-args.width // 8) * 8
-    h8, w8, n = hp // 8, wp // 8, cfg.DPN.NUM_PROPOSALS
-    # ALGORITHMIC FLOPs per launch (SURVEY 8(d) formulas, reference-form contraction counts):
-    #  horizontal stripes: per (row, head) QK^T and PV, 2*T^2*32 each, T = W8*N, 2 heads  -> B*H8*2*4*32*(W8 N)^2
-    #  inference windows : 5 contractions of T^2*32 MACs per (window, head), T = win^2*N, 4 heads, padded grid
-    win = cfg.NMP.WINDOW_SIZE
-    hp8, wp8 = -(-h8 // win) * win, -(-w8 // win) * win
-    tw = win * win * n
-    flops = {
-        "stripe_attn_horizontal": b * h8 * 2 * 4.0 * 32 * (w8 * n) ** 2,
-        "window_attn_w%d_n%d" % (win, n): b * (hp8 // win) * (wp8 // win) * cfg.NMP.INFER_N_HEADS * 5 * 2.0 * tw * tw * 32,
-    }
-    kern_names = {"stripe_attn_horizontal": "stripe_attn_kernel<1> (horizontal stripes, A7)",
-                  "window_attn_w%d_n%d" % (win, n): "window_attn_kernel<%d> (inference windows, A10)" % ((tw + 31) // 32)}
-    # HBM bytes per launch from the separate rocprofv3 --pmc passes (tools/gpu_pmc.sh -> profiles/pmc_traffic.json)
-    pmc_names = {"stripe_attn_horizontal": "stripe_attn_kernel<1, 2, 1, false>",
-                 "window_attn_w%d_n%d" % (win, n): "window_attn_fast_kernel<5, 6, 4, 2, 3, false>"}
-    # fused token linears: algorithmic FLOPs 2*T*K*N recorded by the wrapper at each launch
-    notes = {}
-    for k_, fl in timer.flops.items():
-        if k_ == "conv3x3_wino":                      # N2: all Winograd conv launches of a forward, FLOPs of the direct form
-            flops[k_] = sum(fl) / len(fl)
-            kern_names[k_] = "conv3x3_wino_kernel (3x3 stride-1 convs of the backbone / conv heads, N2; mean over layers)"
-            pmc_names[k_] = "conv3x3_wino_kernel"
-            notes[k_] = ("flop_per_launch counts direct-convolution FLOPs (SURVEY 8(d) convention for the conv band); the "
-                         "kernel executes 1/2.25 of those multiplies (Winograd F(2x2,3x3)), so frac is an effective rate, "
-                         "not MFMA-pipe utilisation (~0.55, DESIGN.md section 5); MIOpen on the same basis: 0.58-0.66")
-            continue
-        ln_, kk, nn_, act_ = (int(v.lstrip("lnkact")) for v in k_.split("_")[2:])
-        flops[k_] = sum(fl) / len(fl)
-        kern_names[k_] = "token_linear%s_kernel<%d,%s,%s> (%s%d->%d%s, N3)" % ("_pipe" if ln_ else "",
-            (kk + 31) // 32, "LN" if ln_ else "plain", "GELU" if act_ == 2 else "-", "LayerNorm+" if ln_ else "", kk, nn_,
-            "+GELU" if act_ == 2 else "")
-        tf = lambda v: "true" if v else "false"
-        pmc_names[k_] = ["token_linear_pipe_kernel<%d, %s, 2>" % ((kk + 31) // 32, tf(act_ == 2)),
-                         "token_linear_pipe_kernel<%d, %s, 1>" % ((kk + 31) // 32, tf(act_ == 2)),
-                         "token_linear_kernel<%d, %s, %s>" % ((kk + 31) // 32, tf(ln_), tf(act_ == 2))][0 if ln_ else 2:]
+    n = cfg.DPN.NUM_PROPOSALS
+    # per-kernel records: ALGORITHMIC work per launch (SURVEY 8(d) formulas, recorded by the wrappers in nmrf_amd/kernels.py)
+    # / mean launch time measured above.  MFMA-bound kernels are priced against the fp32 MFMA peak, HBM-bound ones against
+    # 8 TB/s.  `traffic` / `mfma_busy` / `lds_bank_conflict_ratio` come from separate rocprofv3 --pmc passes (never collected
+    # in this run): profiles/pmc_traffic.json, whose "_source" names the round and run they belong to; they are reported only
+    # for the workload those passes were taken on (KITTI, batch 1).
     pmc = {}
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pmc = json.load(f)
     except (OSError, ValueError):
         pass
-    def pmc_bytes(names):
-        for nm in ([names] if isinstance(names, str) else names):
+    pmc_ok = b == 1 and args.height == 375 and args.width == 1242 and args.backbone == "resnet"
+
+    def pmc_rec(names):
+        for nm in names or []:
             if nm in pmc:
-                return pmc[nm].get("hbm_bytes")
-        return None
+                return pmc[nm]
+        return {}
 
     roof, others = None, []
-    timed = {k: v for k, v in kstats.items() if k in flops}
-    if timed:
-        per_fwd = {k: v[0] * v[1] / n_timed_fwd for k, v in timed.items()}         # ms per forward spent in each kernel
-        dom = max(per_fwd, key=per_fwd.get)
-        for k, (ms, cnt) in timed.items():
-            ach = flops[k] / (ms * 1e-3) / 1e12
-            rec = {"bound": "mfma", "kernel": kern_names[k], "achieved": round(ach, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
-                   "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                   "traffic": (pmc_bytes(pmc_names[k]) if (b == 1 and args.height == 375 and args.width == 1242) else None),
-                   "launch_ms": round(ms, 4), "launches_timed": cnt, "ms_per_forward": round(per_fwd[k], 4),
-                   "flop_per_launch": flops[k]}
-            if k in notes:
-                rec["note"] = notes[k]
-            if k == dom:
-                roof = rec
-            else:
-                others.append(rec)
-        others.sort(key=lambda r: -r["ms_per_forward"])
-        others = others[:6]
+    recs = []
+    for k, (ms, cnt) in kstats.items():
+        meta = timer.meta[k][0]
+        bound = meta.get("bound", "mfma")
+        flops, nbytes = timer.mean_meta(k, "flops"), timer.mean_meta(k, "bytes")
+        if bound == "mfma":
+            ach, peak, unit = flops / (ms * 1e-3) / 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s"
+        else:
+            ach, peak, unit = nbytes / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+        pr = pmc_rec(meta.get("pmc")) if pmc_ok else {}
+        rec = {"bound": bound, "kernel": meta.get("label", k), "row": meta.get("row"), "achieved": round(ach, 3), "peak": peak,
+               "unit": unit, "frac": round(ach / peak, 4), "traffic": pr.get("hbm_bytes"),
+               "launch_ms": round(ms, 4), "launches_timed": cnt, "ms_per_forward": round(ms * cnt / n_timed_fwd, 4),
+               "flop_per_launch": flops, "bytes_per_launch": nbytes}
+        if pr:
+            rec["traffic_source"] = "profiles/pmc_traffic.json: " + str(pmc.get("_source", "?"))
+            for key in ("mfma_busy", "lds_bank_conflict_ratio"):
+                if key in pr:
+                    rec[key] = pr[key]
+        if timer.mean_meta(k, "direct_flops"):
+            df = timer.mean_meta(k, "direct_flops")
+            rec["direct_form"] = {"flop_per_launch": df, "tflops": round(df / (ms * 1e-3) / 1e12, 2),
+                                  "note": "SURVEY 8(d) counts the direct convolution; the kernel executes the Winograd F(2x2,3x3) "
+                                          "form (1/2.25 of the multiplies), which `achieved` / `frac` are priced on"}
+        recs.append(rec)
+    hot = [r for r in recs if str(r["row"]).startswith("A")]
+    if hot:
+        roof = max(hot, key=lambda r: r["ms_per_forward"])
+        others = sorted((r for r in recs if r is not roof), key=lambda r: -r["ms_per_forward"])[:9]
 
     if rank == 0:
         res = {
@@ -307,9 +310,13 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "KITTI %dx%d stereo pairs, batch %d per GPU, CNN backbone, %d/%d/%d prop/infer/refine "
-                                   "layers, hash-formula weights" % (args.width, args.height, b, cfg.NMP.NUM_PROP_LAYERS,
-                                                                     cfg.NMP.NUM_INFER_LAYERS, cfg.NMP.NUM_REFINE_LAYERS),
+            "config": {"workload": "%s %dx%d stereo pairs, batch %d per GPU, %s backbone, D_max %d, %d/%d/%d prop/infer/refine "
+                                   "layers, hash-formula weights" % (
+                                       {(375, 1242): "KITTI", (540, 960): "SceneFlow", (1000, 1500): "Middlebury-H"}.get(
+                                           (args.height, args.width), "synthetic"), args.width, args.height, b,
+                                       "CNN" if args.backbone == "resnet" else "Swin-T + deformable neck (HIP MSDA)",
+                                       args.max_disp, cfg.NMP.NUM_PROP_LAYERS, cfg.NMP.NUM_INFER_LAYERS,
+                                       cfg.NMP.NUM_REFINE_LAYERS),
                        "global_batch": world * b, "parallelism": "batch-shard x%d" % world,
                        "launch": "hipGraph" if graph is not None else "eager",
                        "result_gather": bool(use_dist and not args.no_gather)},
@@ -317,9 +324,9 @@ def main():
             "roofline": roof,
             "other_kernels": others,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.backbone == "resnet":      # the oracle restates the CNN configuration
             try:
-                res["cpu_baseline"] = cpu_baseline(args.height, args.width, args.infer_layers)
+                res["cpu_baseline"] = cpu_baseline(args.height, args.width, args.infer_layers, args.max_disp)
             except Exception as e:
                 res["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)

@@ -27,7 +27,7 @@ extern "C" {
 
 const char *nmrf_strerror(int code);
 /* ABI version of this header; bumps on any signature change. */
-int nmrf_abi_version(void);   /* currently 9 */
+int nmrf_abi_version(void);   /* currently 10 */
 
 /* A2  group-wise correlation volume.
  * replaces build_correlation_volume + the permute of DPN.forward
@@ -196,6 +196,16 @@ int nmrf_msda_backward_f64(const double *value, const int64_t *shapes, const int
  * v_mfma_f32_32x32x2_f32 (A [32,K], B [K,32] row-major, K even <= 64); pins the operand/accumulator
  * lane layout every attention kernel relies on. */
 int nmrf_selftest_mfma_f32(const float *A, const float *Bm, int K, float *out, void *stream);
+
+/* Self-test of the split-operand fp16 MFMA (csrc/split_mfma.h): out[32*32] = A*B from one wave of
+ * v_mfma_f32_32x32x16_f16, A [32,K], B [K,32] row-major fp32, K % 16 == 0.  mode 0: full split product (hi/lo pairs,
+ * three MFMAs per chunk, two accumulators); 1: hi parts only; 2: full split with the k slots in C/D order (the order
+ * chained GEMMs use).  Pins the lane layout and the precision claim of every split-MFMA kernel. */
+int nmrf_selftest_mfma_f16split(const float *A, const float *Bm, int K, int mode, float *out, void *stream);
+
+/* Self-test of the LDS-DMA path (global_load_lds_dwordx4) the weight streams use: dst[t] = src[t ^ 65] within each
+ * 256-float4 block, routed through LDS.  n_float4 % 256 == 0. */
+int nmrf_selftest_lds_dma(const float *src, float *dst, int n_float4, void *stream);
 
 #ifdef __cplusplus
 }

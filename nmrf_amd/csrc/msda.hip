@@ -9,6 +9,7 @@
 // Sampling convention (ms_deform_im2col_cuda.cuh:285-288): h_im = loc_y*H - 0.5, zero outside,
 // identical to grid_sample(align_corners=False).
 #include "common.h"
+#include "split_mfma.h"
 
 template <typename T, int CH>
 __global__ __launch_bounds__(256) void msda_fwd_kernel(const T *__restrict__ value, const int64_t *__restrict__ shapes,
@@ -302,6 +303,60 @@ extern "C" int nmrf_debug_mfma_peak(int chains, int iters, int blocks, float *ou
 }
 #endif  // NMRF_DEBUG_PROBES
 
+// ---- split-operand fp16 MFMA self-test (split_mfma.h): one wave, out = A*B with A [32,K], B [K,32] row-major fp32 -------------
+//   mode 0: the full split product (3 MFMAs per 16-deep chunk, two accumulators) -- accuracy + lane layout
+//   mode 1: hi parts only (plain fp16 product) -- what the split buys, and how fp16 subnormal inputs are treated
+//   mode 2: like 0 with the k slots in C/D order (split_kslot) on BOTH operands -- the order chained GEMMs use
+__global__ __launch_bounds__(64) void selftest_mfma_f16split_kernel(const float *__restrict__ A, const float *__restrict__ Bm,
+                                                                   int K, int mode, float *__restrict__ out) {
+    const int lane = threadIdx.x, i = lane & 31, hi = lane >> 5;
+    f32x16 acc_hh, acc_x;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_hh[r] = acc_x[r] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int k = k0 + (mode == 2 ? split_kslot(jj, hi) : 8 * hi + jj);
+            av[jj] = A[i * K + k];
+            bv[jj] = Bm[k * 32 + i];
+        }
+        h16x8 ah, al, bh, bl;
+        split8(av, ah, al);
+        split8(bv, bh, bl);
+        if (mode == 1) acc_hh = mfma16h(ah, bh, acc_hh);
+        else split_mma(ah, al, bh, bl, acc_hh, acc_x);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[mfma_row(r, hi) * 32 + i] = acc_hh[r] + SPLIT_LO_INV * acc_x[r];
+}
+
+extern "C" int nmrf_selftest_mfma_f16split(const float *A, const float *Bm, int K, int mode, float *out, void *stream) {
+    if (!A || !Bm || !out) return NMRF_ENULL;
+    if (K < 16 || K > 1024 || (K & 15) || mode < 0 || mode > 2) return NMRF_EINVAL;
+    hipLaunchKernelGGL(selftest_mfma_f16split_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, Bm, K, mode, out);
+    return nmrf_launch_status();
+}
+
+// ---- LDS-DMA self-test: global_load_lds_dwordx4 places lane l's 16 bytes at (wave-uniform LDS base) + 16*l ----------------
+__global__ __launch_bounds__(256) void selftest_lds_dma_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst) {
+    __shared__ __attribute__((aligned(16))) float4 buf[256];
+    const int t = threadIdx.x;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + blockIdx.x * 256 + t),
+                                     (__attribute__((address_space(3))) void *)(buf + (t & ~63)), 16, 0, 0);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    dst[blockIdx.x * 256 + t] = buf[t ^ 65];          // read through LDS across waves: dst[t] = src[t ^ 65]
+}
+
+extern "C" int nmrf_selftest_lds_dma(const float *src, float *dst, int n_float4, void *stream) {
+    if (!src || !dst) return NMRF_ENULL;
+    if (n_float4 < 256 || (n_float4 & 255)) return NMRF_EINVAL;
+    hipLaunchKernelGGL(selftest_lds_dma_kernel, dim3(n_float4 / 256), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4 *>(src), reinterpret_cast<float4 *>(dst));
+    return nmrf_launch_status();
+}
+
 extern "C" const char *nmrf_strerror(int code) {
     switch (code) {
         case NMRF_OK: return "ok";
@@ -312,4 +367,4 @@ extern "C" const char *nmrf_strerror(int code) {
     }
 }
 
-extern "C" int nmrf_abi_version(void) { return 9; }
+extern "C" int nmrf_abi_version(void) { return 10; }

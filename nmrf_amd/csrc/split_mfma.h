@@ -1,0 +1,61 @@
+// Split-operand fp16 MFMA: fp32-grade products on the 2.5 PFLOP/s fp16 matrix pipe of gfx950.
+//
+// A fp32 value a is carried as two fp16 numbers
+//     hi  = rn_f16(a)                      (11 significant bits)
+//     lo' = rn_f16((a - hi) * 2^11)        (the next 11 bits, rescaled so that lo' lives in the same exponent range as hi:
+//                                           no fp16 subnormals are needed, whatever the hardware does with them)
+// and a product of two such pairs as   a*b ~= hi_a*hi_b + 2^-11 * (lo'_a*hi_b + hi_a*lo'_b)   (the dropped lo*lo term is
+// 2^-22 relative).  Per 16-deep k chunk: three v_mfma_f32_32x32x16_f16 (32 cycles each) into TWO fp32 accumulators
+// (acc_hh, acc_x) that are combined once at the end of the K loop: acc_hh + 2^-11 * acc_x.  The same contraction on the
+// fp32 MFMA (v_mfma_f32_32x32x2_f32, 64 cycles per 2-deep step) costs 512 cycles: 5.3x more matrix-pipe time.
+// Error per product ~3 * 2^-24 * |a*b| (fp32 FMA: 2^-24): sums of 128...512 terms stay well inside the 2e-5 kernel tolerances
+// against fp64 that the fp32-MFMA kernels are held to (tests/test_hip_kernels.py).
+// Range: |a| must stay below 65504 (fp16 max); activations and weights of this network are O(1..100).
+//
+// v_mfma_f32_32x32x16_f16 lane layout (gfx950; pinned by nmrf_selftest_mfma_f16split):
+//   A operand: lane l holds A[i = l&31][k = 8*(l>>5) + 0..7]    (8 fp16 = 4 VGPRs)
+//   B operand: lane l holds B[k = 8*(l>>5) + 0..7][j = l&31]
+//   C/D      : reg r of lane l is D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]        (same as the fp32 form)
+#pragma once
+#include "common.h"
+
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
+#define SPLIT_LO_SCALE 2048.0f
+#define SPLIT_LO_INV (1.0f / 2048.0f)
+
+__device__ __forceinline__ f32x16 mfma16h(h16x8 a, h16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// two fp32 -> packed (hi, lo') pairs: v_cvt_pk_f16_f32, 2 v_cvt_f32_f16, v_pk_add_f32, v_pk_mul_f32, v_cvt_pk_f16_f32
+__device__ __forceinline__ void split2(f32x2 a, h16x2 &hi, h16x2 &lo) {
+    hi = __builtin_convertvector(a, h16x2);
+    const f32x2 back = __builtin_convertvector(hi, f32x2);
+    lo = __builtin_convertvector((a - back) * SPLIT_LO_SCALE, h16x2);
+}
+
+// eight fp32 (v[0..7]) -> one MFMA operand pair
+__device__ __forceinline__ void split8(const float *v, h16x8 &hi, h16x8 &lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h16x2 h, l;
+        split2(f32x2{v[2 * j], v[2 * j + 1]}, h, l);
+        hi[2 * j] = h[0]; hi[2 * j + 1] = h[1];
+        lo[2 * j] = l[0]; lo[2 * j + 1] = l[1];
+    }
+}
+
+// one k chunk of the split product: acc_hh += Ah*Bh ; acc_x += Al*Bh + Ah*Bl
+__device__ __forceinline__ void split_mma(h16x8 ah, h16x8 al, h16x8 bh, h16x8 bl, f32x16 &acc_hh, f32x16 &acc_x) {
+    acc_hh = mfma16h(ah, bh, acc_hh);
+    acc_x = mfma16h(al, bh, acc_x);
+    acc_x = mfma16h(ah, bl, acc_x);
+}
+
+// k slot order of a B operand that is taken straight from a C/D result (and of every A operand contracted with it):
+// slot jj (0..7) of half hi of k chunk c  <->  k = 16*c + (jj&3) + 8*(jj>>2) + 4*hi.  With this order the 16 registers of
+// a 32-row D strip ARE two consecutive k chunks of the next contraction (regs 0-7 -> chunk 0, regs 8-15 -> chunk 1): no
+// cross-lane movement between chained GEMMs.  Host-side weight packing uses the same map (pack_split_weight_kernel).
+__host__ __device__ __forceinline__ int split_kslot(int jj, int hi) { return (jj & 3) + 8 * (jj >> 2) + 4 * hi; }

@@ -62,13 +62,32 @@ def mfma_selftest(a, bm):
 
 
 @_on_device
+def mfma_f16split_selftest(a, bm, mode=0):
+    _chk(a, bm)
+    out = torch.empty(32, 32, device=a.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_selftest_mfma_f16split(_p(a), _p(bm), a.shape[1], mode, _p(out), _stream()), "mfma f16 split selftest")
+    return out
+
+
+@_on_device
+def lds_dma_selftest(src):
+    _chk(src)
+    dst = torch.empty_like(src)
+    _lib.check(_lib.load().nmrf_selftest_lds_dma(_p(src), _p(dst), src.numel() // 4, _stream()), "lds dma selftest")
+    return dst
+
+
+@_on_device
 def cost_volume(f1, f2, num_disp, groups):
     """[B,C,H,W] x2 -> [B*H*W, G, D]"""
     _chk(f1, f2)
     b, c, h, w = f1.shape
     vol = torch.empty(b * h * w, groups, num_disp, device=f1.device, dtype=torch.float32)
+    _hb("cost_volume", row="A2", bound="hbm", bytes=4.0 * (2 * f1.numel() + vol.numel()), flops=2.0 * b * h * w * num_disp * c,
+        label="cost_volume_kernel (group-wise correlation volume, A2)", pmc=["cost_volume_kernel"])
     _lib.check(_lib.load().nmrf_cost_volume_f32(_p(f1), _p(f2), b, c, h, w, num_disp, groups, _p(vol), _stream()),
                "cost_volume")
+    _he("cost_volume")
     return vol
 
 
@@ -144,10 +163,20 @@ def add_ln_concat(x, y, gamma, beta, extra=None, extra_div=1, ld=None, eps=1e-5)
     return x_new, out
 
 
-# optional observer used by bench.py to bracket the dominant kernel with HIP events: called as
-# hook("begin"/"end", name[, flops]) around that single launch, on the launching stream (flops: algorithmic FLOPs of the
-# launch where the wrapper knows them)
+# optional observer used by bench.py to bracket kernel launches with HIP events: called as hook("begin", name, meta) /
+# hook("end", name, None) around one launch, on the launching stream.  meta: row, bound ("mfma"|"hbm"),
+# flops / bytes (ALGORITHMIC work of the launch, SURVEY 8(d) formulas), label, pmc (kernel name(s) in the rocprofv3 tables)
 kernel_hook = None
+
+
+def _hb(name, **meta):
+    if kernel_hook is not None:
+        kernel_hook("begin", name, meta)
+
+
+def _he(name):
+    if kernel_hook is not None:
+        kernel_hook("end", name, None)
 
 
 @_on_device
@@ -159,11 +188,12 @@ def stripe_attn(qkv, lepe_v, lepe_h, b, h, w, n):
     out = torch.empty(t, c, device=qkv.device, dtype=torch.float32)
     fn = _lib.load().nmrf_stripe_attn_f32
     _lib.check(fn(_p(qkv), _p(lepe_v), _p(lepe_h), b, h, w, n, c, 1, _p(out), _stream()), "stripe_attn(vertical)")
-    if kernel_hook is not None:
-        kernel_hook("begin", "stripe_attn_horizontal")
+    # per (row, head): QK^T and PV, 2*T^2*32 FLOPs each, T = W*N, 2 heads of 32 channels
+    _hb("stripe_attn_horizontal", row="A7", bound="mfma", flops=b * h * 2 * 4.0 * 32 * (w * n) ** 2, bytes=4.0 * (qkv.numel() / 2 + t * c / 2),
+        label="stripe_attn_kernel<1> (horizontal stripes, A7)",
+        pmc=["stripe_attn_kernel<1, 2, 1, false>", "stripe_attn_kernel<1, 2, 2, false>"])
     _lib.check(fn(_p(qkv), _p(lepe_v), _p(lepe_h), b, h, w, n, c, 2, _p(out), _stream()), "stripe_attn(horizontal)")
-    if kernel_hook is not None:
-        kernel_hook("end", "stripe_attn_horizontal")
+    _he("stripe_attn_horizontal")
     return out
 
 
@@ -177,8 +207,13 @@ def warp_corr_concat(labels, f1, f2, g1, g2, n, groups=32, ld=None):
     t = b * h * w * n
     assert labels.numel() == t
     out = torch.empty(t, ld, device=f1.device, dtype=torch.float32)
+    _hb("warp_corr_concat_n%d" % n, row="A9" if n > 1 else "A13", bound="hbm",
+        bytes=4.0 * (2 * f1.numel() + 2 * g1.numel() + t + out.numel()), flops=2.0 * t * (cg + 2 * cf),
+        label="warp_corr_concat_kernel (warp + 32-group correlation + concat, %s)" % ("A9, 1/8" if n > 1 else "A13, 1/4"),
+        pmc=["warp_corr_concat_kernel"])
     _lib.check(_lib.load().nmrf_warp_corr_concat_f32(_p(labels), _p(f1), _p(f2), _p(g1), _p(g2), b, h, w, n, cf, cg,
                                                      groups, _p(out), ld, _stream()), "warp_corr_concat")
+    _he("warp_corr_concat_n%d" % n)
     return out
 
 
@@ -199,12 +234,17 @@ def window_attn(qkv, table, b, hp, wp, n, heads, win, shift, sibling_mask):
     c = c3 // 3
     assert t == b * hp * wp * n
     out = torch.empty(t, c, device=qkv.device, dtype=torch.float32)
-    if kernel_hook is not None:
-        kernel_hook("begin", "window_attn_w%d_n%d" % (win, n))
+    tw = win * win * n                                 # reference form: 5 contractions of tw^2 x 32 MACs per (window, head)
+    fast = {(6, 4): "window_attn_fast_kernel<5, 6, 4, 2, 3, false>", (4, 1): "window_attn_fast_kernel<1, 4, 1, 8, 2, false>"}
+    _hb("window_attn_w%d_n%d" % (win, n), row="A10" if n > 1 else "A13", bound="mfma",
+        flops=b * (hp // win) * (wp // win) * heads * 5 * 2.0 * tw * tw * 32, bytes=4.0 * (qkv.numel() + t * c),
+        label="%s (%s windows, %s)" % (fast.get((win, n), "window_attn_kernel<%d>" % ((tw + 31) // 32)).split("<")[0] +
+                                       "<win %d, N %d>" % (win, n), "inference" if n > 1 else "refinement",
+                                       "A10" if n > 1 else "A13"),
+        pmc=[fast.get((win, n), "window_attn_kernel<%d>" % ((tw + 31) // 32))])
     _lib.check(_lib.load().nmrf_window_attn_f32(_p(qkv), _p(table), b, hp, wp, n, c, heads, win, shift,
                                                 int(bool(sibling_mask)), _p(out), _stream()), "window_attn")
-    if kernel_hook is not None:
-        kernel_hook("end", "window_attn_w%d_n%d" % (win, n))
+    _he("window_attn_w%d_n%d" % (win, n))
     return out
 
 
@@ -249,12 +289,19 @@ def token_linear(x, packed_w, n, k, bias=None, ln=None, y=None, extra=None, extr
     hook_name = None
     if kernel_hook is not None:
         hook_name = "token_linear_ln%d_k%d_n%d_act%d" % (int(ln is not None), k, n, act)
-        kernel_hook("begin", hook_name, 2.0 * t * k * n)
+        kc, tf = (k + 31) // 32, lambda v: "true" if v else "false"
+        pmc = (["token_linear_pipe_kernel<%d, %s, 2>" % (kc, tf(act == 2)), "token_linear_pipe_kernel<%d, %s, 1>" % (kc, tf(act == 2))]
+               if ln is not None and residual is None and n % 128 == 0 else [])
+        pmc.append("token_linear_kernel<%d, %s, %s>" % (kc, tf(ln is not None), tf(act == 2)))
+        _hb(hook_name, row="A7/A10/A13 (N3)", bound="mfma", flops=2.0 * t * k * n, bytes=4.0 * t * (cx * (3 if y is not None else 1) + e + n),
+            label="token_linear%s_kernel<%d,%s,%s> (%s%d->%d%s)" % ("_pipe" if len(pmc) > 1 else "", kc, "LN" if ln is not None else "plain",
+                                                                  "GELU" if act == 2 else "-", "LayerNorm+" if ln is not None else "", k, n,
+                                                                  "+GELU" if act == 2 else ""), pmc=pmc)
     _lib.check(_lib.load().nmrf_token_linear_f32(_p(x), _p(y), _p(x_out), _p(g), _p(bt), float(eps), _p(extra), e, extra_div,
                                                  _p(packed_w), _p(bias), _p(residual), act, t, cx, k, n, _p(out), _stream()),
                "token_linear")
     if hook_name is not None:
-        kernel_hook("end", hook_name)
+        _he(hook_name)
     return (x_out, out) if y is not None else out
 
 
@@ -275,11 +322,13 @@ def conv3x3_wino(x, packed_u, co):
     _chk(x, packed_u)
     b, ci, h, w = x.shape
     y = torch.empty(b, co, h, w, device=x.device, dtype=torch.float32)
-    if kernel_hook is not None:                       # algorithmic work = the direct convolution's FLOPs
-        kernel_hook("begin", "conv3x3_wino", 2.0 * 9 * b * ci * co * h * w)
+    # N2 (stock-conv band, not a north_star hot-path row).  SURVEY 8(d) counts the direct convolution's FLOPs; the kernel
+    # executes the Winograd F(2x2,3x3) form = 1/2.25 of those multiplies, which is what its MFMA roofline is priced on
+    _hb("conv3x3_wino", row="N2", bound="mfma", flops=2.0 * 9 * b * ci * co * h * w / 2.25, direct_flops=2.0 * 9 * b * ci * co * h * w,
+        bytes=4.0 * (x.numel() + y.numel()), label="conv3x3_wino_kernel (3x3 stride-1 convs of the backbone / conv heads, N2; "
+        "mean over layers; Winograd-form FLOPs)", pmc=["conv3x3_wino_kernel"])
     _lib.check(_lib.load().nmrf_conv3x3_wino_f32(_p(x), _p(packed_u), b, ci, h, w, co, _p(y), _stream()), "conv3x3_wino")
-    if kernel_hook is not None:
-        kernel_hook("end", "conv3x3_wino")
+    _he("conv3x3_wino")
     return y
 
 
@@ -358,8 +407,12 @@ def msda_forward(value, shapes, lvl_start, loc, w):
     _, lq, _, l, p, _ = loc.shape
     out = torch.empty(b, lq, m * d, device=value.device, dtype=dt)
     fn = _lib.load().nmrf_msda_forward_f32 if dt == torch.float32 else _lib.load().nmrf_msda_forward_f64
+    _hb("msda_forward", row="A15", bound="hbm", bytes=float(value.element_size()) * (value.numel() + loc.numel() + w.numel() + out.numel()),
+        flops=2.0 * b * lq * m * d * l * p * 5, label="msda_fwd_kernel (multi-scale deformable attention forward, A15)",
+        pmc=["msda_fwd_kernel"])
     _lib.check(fn(_p(value), _p(shapes), _p(lvl_start), _p(loc), _p(w), b, s, m, d, l, lq, p, _p(out), _stream()),
                "msda_forward")
+    _he("msda_forward")
     return out
 
 

@@ -42,6 +42,53 @@ def test_mfma_lane_layout():
         report(f"mfma k={k}", got, a.double() @ b.double(), 1e-5, 1e-6)
 
 
+@pytest.mark.parametrize("mode", [0, 2])
+def test_split_fp16_mfma_layout_and_precision(mode):
+    """csrc/split_mfma.h: A*B on one wave of v_mfma_f32_32x32x16_f16 with (hi, lo') fp16 operand pairs, three MFMAs per
+    16-deep chunk, against fp64 -- asymmetric operands (catches transposes / k-slot permutations), magnitudes from 1e-6 to
+    1e3 in one matrix (no reliance on fp16 subnormals, no overflow), and the same tolerance the fp32-MFMA self-test holds."""
+    for k in (16, 32, 128, 512):
+        a, b = rnd(32, k, seed=k), rnd(k, 32, seed=k + 1)
+        b += torch.arange(32)[None, :] * 0.01 + torch.arange(k)[:, None] * (0.1 / k)
+        a[::3] *= 1e-3
+        a[5] *= 1e-3                                   # rows of ~1e-6 .. 1e-3: hi parts are fp16 subnormals or zero
+        a[7] *= 1e3
+        got = K().mfma_f16split_selftest(a.to(DEV), b.to(DEV), mode).cpu()
+        ref = a.double() @ b.double()
+        # error model: ~3 * 2^-24 per product, random signs -> a few 1e-7 of sum |a||b|
+        bound = 4e-7 * (a.double().abs() @ b.double().abs()) + 1e-12
+        err = (got.double() - ref).abs()
+        assert (err <= bound).all(), (k, float((err / bound).max()), float(err.max()))
+        fp32 = K().mfma_selftest(a.to(DEV), b.to(DEV)).cpu() if k <= 64 else (a @ b)
+        from tests.conftest import record_note
+        record_note("split-fp16 MFMA K=%d mode %d: max err %.2e (fp32 path %.2e) on |ref| <= %.1e" % (
+            k, mode, float(err.max()), float((fp32.double() - ref).abs().max()), float(ref.abs().max())))
+
+
+def test_split_fp16_mfma_hi_only_is_fp16_grade_and_subnormal_probe():
+    """mode 1 = plain fp16 product: ~2^-11 relative (what the lo' parts buy back), plus a probe of how the MFMA treats
+    fp16-subnormal inputs (reported, not asserted: the split format does not depend on it)."""
+    a, b = rnd(32, 64, seed=5), rnd(64, 32, seed=6)
+    got = K().mfma_f16split_selftest(a.to(DEV), b.to(DEV), 1).cpu()
+    ref = a.double() @ b.double()
+    err = float((got.double() - ref).abs().max())
+    assert 1e-5 < err < 2e-2, err
+    a = torch.zeros(32, 16); b = torch.zeros(16, 32)
+    a[:, 0] = 2.0 ** -20                                # fp16 subnormal
+    b[0, :] = 1024.0
+    sub = float(K().mfma_f16split_selftest(a.to(DEV), b.to(DEV), 1).cpu()[0, 0])
+    from tests.conftest import record_note
+    record_note("fp16 MFMA with a subnormal input 2^-20 * 1024: got %.3e (2^-10 = %.3e if subnormals are honoured, 0 if flushed)"
+                % (sub, 2.0 ** -10))
+
+
+def test_lds_dma_selftest():
+    src = rnd(4 * 256 * 4, seed=9)
+    got = K().lds_dma_selftest(src.to(DEV)).cpu().view(4, 256, 4)
+    want = src.view(4, 256, 4)[:, torch.arange(256) ^ 65]
+    assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("b,c,h,w,d,g", [(2, 256, 5, 37, 16, 4), (1, 256, 3, 150, 40, 4), (1, 64, 2, 9, 16, 2),
                                          (1, 128, 2, 70, 48, 4)])
 def test_cost_volume(b, c, h, w, d, g):

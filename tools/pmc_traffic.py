@@ -24,20 +24,26 @@ def main(src, dst_prefix):
     table = {}
     for p in "ABCD":
         for k, cs in load(os.path.join(src, "pass%s_counter_collection.csv" % p)).items():
-            if "attn" in k or "warp" in k or "token_linear" in k:
+            if any(tag in k for tag in ("attn", "warp", "token_linear", "mlp", "seed", "cost_volume", "nms", "msda")):
                 table.setdefault(k, {}).update({c: round(sum(v) / len(v)) for c, v in cs.items()})
     # model-level passes (bench.py, eager): only the Winograd conv is taken from them (mean over the layers of a forward)
     for pth in ("passM1", "passM2"):
         for k, cs in load(os.path.join(src, pth + "_counter_collection.csv")).items():
             if k.startswith("conv3x3_wino"):
                 table.setdefault(k, {}).update({c: round(sum(v) / len(v)) for c, v in cs.items()})
-    traffic = {}
+    traffic = {"_source": os.path.basename(dst_prefix) + " (rocprofv3 --pmc passes of tools/gpu_pmc.sh, mean per dispatch)"}
     for k, c in table.items():
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             # guide (MI355X_MICROARCH.md, HBM): FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 -> doubled;
             # WRITE_SIZE taken as is (uncalibrated); both in KiB
             traffic[k] = {"fetch_kib": c["FETCH_SIZE"], "write_kib": c["WRITE_SIZE"],
                           "hbm_bytes": int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)}
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in c and c.get("GRBM_GUI_ACTIVE"):
+                # MFMA pipe utilisation: busy cycles summed over the 1024 SIMDs / (kernel cycles of one XCD x 1024);
+                # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+                traffic[k]["mfma_busy"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024), 4)
+            if c.get("SQ_LDS_IDX_ACTIVE"):
+                traffic[k]["lds_bank_conflict_ratio"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0) / c["SQ_LDS_IDX_ACTIVE"], 4)
     with open("profiles/pmc_traffic.json", "w") as f:
         json.dump(traffic, f, indent=1)
     with open(dst_prefix + "_counters.txt", "w") as f:
