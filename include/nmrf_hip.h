@@ -192,6 +192,35 @@ int nmrf_msda_backward_f64(const double *value, const int64_t *shapes, const int
                            const double *w, const double *grad_out, int B, int S, int M, int D, int L, int Lq, int P,
                            double *grad_value, double *grad_loc, double *grad_w, void *stream);
 
+/* N3 / A7, A10, A13: one message-passing block's per-token linear algebra fused, on split-operand fp16 MFMA
+ * (fp32-grade products, csrc/split_mfma.h).  Replaces, per block of the reference,
+ *   x = x + proj(attn_out)                       (nmrf/models/NMP.py:100-106, 356-361, 566-571)
+ *   x = x + mlp(norm2(x))      [has_mlp]         (NMP.py:337, 361-362, 537, 572-573; timm Mlp: fc1-GELU(erf)-fc2)
+ *   qkv_next = [norm(x) | extra] . Wq^T + bq     (the NEXT block's q|k|v Linear on cat(norm1(x), side), NMP.py:90-96, 343-350, 544-556)
+ *   ln_out   = norm(x)                           (the stage's final LayerNorm, NMP.py:658-659, 789-790, 891-892)
+ * x, msg [T,128]; x_out [T,128]; q_out [T,NQ] (NQ % 128 == 0); ln_out [T,128]; any of the three outputs may be NULL (not all).
+ * msg NULL: no projection stage (x1 = x).  KQ = operand width of the q stage: 0 (none), 128, 160 (LayerNorm | 32 side columns:
+ * Fourier31 + one zero), 192 (LayerNorm | 64 context columns); side rows extra[t / extra_div, 0..KQ-128) with row stride
+ * extra_ld (multiple of 4, rows 16-byte aligned).
+ * stream_w: the block's weights as split-fp16 MFMA fragments in consumption order -- pairs of nmrf_pack_split_weight_f32
+ *   proj   (msg != NULL): Wp [128,128]   pairs (strip 0..3, chunk 0..7)                                   4 stages of 16 KB
+ *   mlp    (has_mlp)    : W1 [512,128] strips and W2 [128,512] k-slices interleaved
+ *                         W1[0] | W1[1], W2s[0] | W1[2], W2s[1] | ... | W1[15], W2s[14] | W2s[15],   W1[h] = pairs (h, 0..7),
+ *                         W2s[h] = pairs (strip n, chunk 2h + c) for n = 0..3, c = 0..1                   32 stages
+ *   q      (q_out)      : Wq [NQ,KQ] pairs (strip, chunk) in strip-major order                           NQ/128 * KQ/32 stages
+ * total_stages must equal the sum.  Biases / LayerNorm parameters are plain fp32 vectors. */
+int nmrf_nmp_block_f32(const float *x, const float *msg, const void *stream_w, int total_stages, const float *bp,
+                       const float *ln2_g, const float *ln2_b, float eps2, const float *b1, const float *b2,
+                       const float *lnq_g, const float *lnq_b, float epsq, const float *extra, int extra_ld,
+                       int extra_div, const float *bq, int has_mlp, int KQ, int NQ, int64_t T, float *x_out,
+                       float *q_out, float *ln_out, void *stream);
+
+/* Weight packing for nmrf_nmp_block_f32: w [N,K] row-major fp32 (an nn.Linear weight) -> N/32 x Kp/16 pairs of 2 KB in
+ * [strip][chunk] order; a pair = [64 lanes][8 fp16] hi parts then the same for the rescaled lo parts (csrc/split_mfma.h);
+ * lane (i = l & 31, h = l >> 5) slot jj holds w[32*strip + i][16*chunk + (jj&3) + 8*(jj>>2) + 4*h], zero beyond K.
+ * out: N * Kp * 4 bytes.  N % 32 == 0, Kp % 16 == 0, Kp >= K. */
+int nmrf_pack_split_weight_f32(const float *w, int N, int K, int Kp, void *out, void *stream);
+
 /* Self-test: fills out[32*32] with the 32x32 product A*B computed by one wave of
  * v_mfma_f32_32x32x2_f32 (A [32,K], B [K,32] row-major, K even <= 64); pins the operand/accumulator
  * lane layout every attention kernel relies on. */

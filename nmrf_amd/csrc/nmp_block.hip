@@ -1,0 +1,420 @@
+// One message-passing block's per-token linear algebra in ONE kernel:
+//
+//     x1  = x + msg . Wp^T + bp                                  attention output projection + residual      (NMP.py:100-106, 356-361, 566-571)
+//     x2  = x1 + GELU(LN2(x1) . W1^T + b1) . W2^T + b2           timm Mlp, pre-norm                           (NMP.py:337, 361-362, 537, 572-573)
+//     qkv = [LNq(x2) | extra] . Wq^T + bq                        the NEXT block's fused q|k|v operand         (NMP.py:90-96, 343-350, 544-556)
+//     or    ln_out = LNq(x2)                                     the stage's final norm                       (NMP.py:658-659, 789-790, 891-892)
+//
+// replacing, per block, token_linear(proj) + token_linear_pipe(LN+fc1+GELU) + hipBLASLt fc2 + token_linear_pipe(LN+q|k|v) of
+// round 1: the 512-wide hidden tile, x1 and both LayerNorm operands never leave the CU (HBM traffic per token 3.2 KB instead of
+// 10.3 KB) and the four contractions run on the fp16 matrix pipe with split operands (split_mfma.h): 3 x 32 cycles per
+// 16-deep k chunk instead of 8 x 64 on the fp32 MFMA.
+//
+// Formulation: everything is computed TRANSPOSED,  out^T[n, t] = W[n, :] . act^T[:, t]:  weights are the MFMA A operand,
+// activations the B operand with the token on the lane (j = lane & 31).  A wave owns 32 tokens for the whole chain and needs
+// no other wave's data: LayerNorm statistics are sums over a lane's own registers plus one half-wave swap, and the C/D
+// registers of one contraction ARE the B operand of the next (k slot order split_kslot(), same trick as S^T -> P^T in the
+// attention kernels), so activations never move between lanes.  Block = 4 waves = 128 tokens; the only thing the waves share
+// is the WEIGHT STREAM: all A fragments of the kernel in consumption order, 2 KB (hi + lo', 64 lanes x 16 B each) per
+// (32-row strip, 16-deep k chunk) "pair", read once per block from L2 in 16 KB stages through a 3-deep LDS ring
+// (global -> registers one stage ahead, registers -> LDS, one barrier per stage).  Per 128 tokens the stream is 816 KB
+// (K_q = 160): 85 B/clk/CU of LDS reads next to a fully busy matrix pipe.
+//
+// Outputs leave through a wave-private LDS tile as whole 512-byte rows (token-major fp32, same layouts as round 1).
+#include "common.h"
+#include "split_mfma.h"
+#include <type_traits>
+#include <utility>
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));    // (HIP's uint4 is a struct: arrays of it are left in scratch)
+
+#define NB_TOK 128                 // tokens per block (4 waves x 32)
+#define NB_STAGE_U4 1024           // uint4 per stage (16 KB = 8 pairs)
+#define NB_RING 3
+#define NB_OLD 132                 // floats per row of the output staging tile (128 + 4: conflict-free b128 writes)
+
+template <class F, int... I>
+__device__ __forceinline__ void nb_static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void nb_static_for(F &&f) {
+    nb_static_for_impl(static_cast<F &&>(f), std::make_integer_sequence<int, N>{});
+}
+
+struct NmpBlockArgs {
+    const float *x;            // [T,128] residual stream
+    const float *msg;          // [T,128] attention output before its projection, or NULL (x1 = x, no proj stage in the stream)
+    const u32x4 *stream;       // weight fragment stream (nmrf_pack_split_weight_f32 pairs in consumption order)
+    int total_stages;          // 16 KB stages in the stream
+    const float *bp;           // [128] or NULL
+    const float *ln2_g, *ln2_b, *b1, *b2;          // MLP stage (MLP = true)
+    const float *lnq_g, *lnq_b;                    // LayerNorm of the q stage / final norm
+    const float *extra;        // [ceil(T / extra_div), extra_ld] side input rows (Fourier31 padded to 32, or context64)
+    int extra_ld, extra_div;
+    const float *bq;           // [NQ] or NULL
+    float *x_out;              // [T,128] x2 (x1 when MLP = false), or NULL
+    float *q_out;              // [T,NQ] or NULL
+    float *ln_out;             // [T,128] LNq(x2) or NULL
+    int64_t T;
+    int n_tiles;
+    float eps2, epsq;
+    int NQ;
+};
+
+// MLP: run the fc1-GELU-fc2 stage.  KQC: k chunks (of 16) of the q stage's operand [LNq(x2) | extra]: 0 = no q stage,
+// 8 = LayerNorm columns only, 10 = + 32 side columns (Fourier31 + 0), 12 = + 64 side columns (context).
+template <bool MLP, int KQC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void nmp_block_kernel(NmpBlockArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4 *ring = reinterpret_cast<u32x4 *>(smem);                                        // [3][1024] uint4
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, hi = lane >> 5;
+    float *Ot = reinterpret_cast<float *>(smem + NB_RING * NB_STAGE_U4 * 16) + wv * 32 * NB_OLD;   // wave-private [32][132]
+
+    // ---- weight stream: registers hold the stage two ahead of the one being consumed -------------------------------------
+    u32x4 R[4];
+    int src_stage = 0;                          // next stage to fetch from global (wraps: persistent blocks re-read the stream)
+    int wr_slot = 0, rd_slot = 0;               // ring slots of the next commit / of the stage being consumed
+    auto fetch = [&]() {
+        const u32x4 *p = a.stream + (size_t)src_stage * NB_STAGE_U4 + tid;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) R[i] = p[256 * i];
+        src_stage = (src_stage + 1 == a.total_stages) ? 0 : src_stage + 1;
+    };
+    auto commit = [&]() {
+        u32x4 *d = ring + wr_slot * NB_STAGE_U4 + tid;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[256 * i] = R[i];
+        wr_slot = (wr_slot == NB_RING - 1) ? 0 : wr_slot + 1;
+    };
+    const u32x4 *cur = ring;                    // stage being consumed
+    bool first_stage = true;
+    // top of a stage: after the barrier the stage to consume (committed a stage ago) and the one after it are visible and
+    // every wave has left the stage before; the slot that one occupied takes the stage two ahead.
+    auto next_stage = [&]() {
+        __syncthreads();
+        if (!first_stage) rd_slot = (rd_slot == NB_RING - 1) ? 0 : rd_slot + 1;
+        first_stage = false;
+        cur = ring + rd_slot * NB_STAGE_U4;
+        commit();
+        fetch();
+    };
+    auto frag_hi = [&](int p) { return *reinterpret_cast<const h16x8 *>(cur + p * 128 + lane); };
+    auto frag_lo = [&](int p) { return *reinterpret_cast<const h16x8 *>(cur + p * 128 + 64 + lane); };
+
+    fetch(); commit();                          // stage 0 -> slot 0
+    fetch(); commit();                          // stage 1 -> slot 1
+    fetch();                                    // stage 2 in registers (committed at the first stage top)
+
+    // output staging: the 16 C/D registers of a 32-channel strip -> columns [col0, col0+32) of the wave's tile
+    auto stage_strip = [&](const float *v, int col0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4 *>(Ot + j * NB_OLD + col0 + 8 * q + 4 * hi) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    };
+    // whole rows of the tile -> dst[t, col0 .. col0+128): lanes 0-31 one row, lanes 32-63 the next (512 B each)
+    auto flush_rows = [&](float *dst, int ld, int col0, int64_t t0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = 2 * i + hi;
+            const float4 v = *reinterpret_cast<const float4 *>(Ot + row * NB_OLD + 4 * j);
+            if (t0 + row < a.T) stg4(dst + (size_t)(t0 + row) * ld + col0 + 4 * j, v);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    // LayerNorm over the 128 channels of each token: a lane holds 64 of them (C/D layout, 4 strips x 16), lane ^ 32 the rest
+    auto layer_norm = [&](const float (&v)[4][16], const float *g, const float *b, float eps, float (&o)[4][16]) {
+        float s = 0.f;
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += v[st][r];
+        const float mean = half_sum(s) * (1.0f / 128.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float d = v[st][r] - mean; q = fmaf(d, d, q); }
+        const float rstd = 1.0f / sqrtf(half_sum(q) * (1.0f / 128.0f) + eps);
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const float4 gv = ldg4(g + st * 32 + 8 * qd + 4 * hi), bv = ldg4(b + st * 32 + 8 * qd + 4 * hi);
+                o[st][4 * qd + 0] = (v[st][4 * qd + 0] - mean) * rstd * gv.x + bv.x;
+                o[st][4 * qd + 1] = (v[st][4 * qd + 1] - mean) * rstd * gv.y + bv.y;
+                o[st][4 * qd + 2] = (v[st][4 * qd + 2] - mean) * rstd * gv.z + bv.z;
+                o[st][4 * qd + 3] = (v[st][4 * qd + 3] - mean) * rstd * gv.w + bv.w;
+            }
+    };
+
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const int64_t t0 = (int64_t)tile * NB_TOK + wv * 32;                 // first token of this wave
+        const int64_t tq = t0 + j;
+        const int64_t tc = tq < a.T ? tq : a.T - 1;                            // clamped: straight-line loads, masked stores
+        float x1[4][16];                                                       // residual stream, C/D layout: channel = 32*st + mfma_row(r, hi)
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = ldg4(a.x + tc * 128 + st * 32 + 8 * q + 4 * hi);
+                x1[st][4 * q] = v.x; x1[st][4 * q + 1] = v.y; x1[st][4 * q + 2] = v.z; x1[st][4 * q + 3] = v.w;
+            }
+
+        f32x16 acc_h[4], acc_x[4];
+        // ---- stage P: x1 = x + msg . Wp^T + bp ------------------------------------------------------------------------------
+        if (a.msg) {
+            h16x8 bmh[8], bml[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float4 v0 = ldg4(a.msg + tc * 128 + 16 * c + 4 * hi), v1 = ldg4(a.msg + tc * 128 + 16 * c + 8 + 4 * hi);
+                const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                split8(v, bmh[c], bml[c]);
+            }
+            nb_static_for<4>([&](auto ss) {
+                constexpr int st = decltype(ss)::value;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_h[st][r] = acc_x[st][r] = 0.f;
+                next_stage();
+#pragma unroll
+                for (int c = 0; c < 8; ++c) split_mma(frag_hi(c), frag_lo(c), bmh[c], bml[c], acc_h[st], acc_x[st]);
+            });
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (a.bp) bv = ldg4(a.bp + st * 32 + 8 * q + 4 * hi);
+                    const float b4[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        x1[st][4 * q + e] += fmaf(SPLIT_LO_INV, acc_x[st][4 * q + e], acc_h[st][4 * q + e]) + b4[e];
+                }
+        }
+
+        // ---- stage M: x2 = x1 + fc2(GELU(fc1(LN2(x1)))) ------------------------------------------------------------------------
+        if constexpr (MLP) {
+            h16x8 bnh[8], bnl[8];                                              // LN2(x1) as the B operand of fc1 (k = channel)
+            {
+                float ln[4][16];
+                layer_norm(x1, a.ln2_g, a.ln2_b, a.eps2, ln);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) split8(&ln[c >> 1][8 * (c & 1)], bnh[c], bnl[c]);
+            }
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_h[st][r] = acc_x[st][r] = 0.f;
+            // hidden strip hs (32 of the 512 hidden channels): fc1 -> fh/fx, GELU, then its 2 k chunks of fc2 into all 4 output
+            // strips.  Stream order: W1[0] | W1[1], W2s[0] | W1[2], W2s[1] | ... | W1[15], W2s[14] | W2s[15]: the MFMAs of
+            // fc1(hs+1) are issued before GELU(hs) so that the activation's VALU work runs under them.
+            auto fc1 = [&](f32x16 &fh, f32x16 &fx) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) fh[r] = fx[r] = 0.f;
+                next_stage();
+#pragma unroll
+                for (int c = 0; c < 8; ++c) split_mma(frag_hi(c), frag_lo(c), bnh[c], bnl[c], fh, fx);
+            };
+            auto act_fc2 = [&](int hs, const f32x16 &fh, const f32x16 &fx) {
+                float hv[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 bv = ldg4(a.b1 + hs * 32 + 8 * q + 4 * hi);
+                    const float b4[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hv[4 * q + e] = gelu_fast(fmaf(SPLIT_LO_INV, fx[4 * q + e], fh[4 * q + e]) + b4[e]);
+                }
+                h16x8 hh[2], hl[2];
+                split8(hv, hh[0], hl[0]);
+                split8(hv + 8, hh[1], hl[1]);
+                next_stage();
+                nb_static_for<4>([&](auto ss) {
+                    constexpr int st = decltype(ss)::value;
+                    split_mma(frag_hi(2 * st), frag_lo(2 * st), hh[0], hl[0], acc_h[st], acc_x[st]);
+                    split_mma(frag_hi(2 * st + 1), frag_lo(2 * st + 1), hh[1], hl[1], acc_h[st], acc_x[st]);
+                });
+            };
+            f32x16 fa_h, fa_x, fb_h, fb_x;
+            fc1(fa_h, fa_x);
+#pragma unroll 1
+            for (int hs = 0; hs < 16; hs += 2) {
+                fc1(fb_h, fb_x);
+                act_fc2(hs, fa_h, fa_x);
+                if (hs + 2 < 16) fc1(fa_h, fa_x);
+                act_fc2(hs + 1, fb_h, fb_x);
+            }
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 bv = ldg4(a.b2 + st * 32 + 8 * q + 4 * hi);
+                    const float b4[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        x1[st][4 * q + e] += fmaf(SPLIT_LO_INV, acc_x[st][4 * q + e], acc_h[st][4 * q + e]) + b4[e];
+                }
+        }
+        if (a.x_out) {
+#pragma unroll
+            for (int st = 0; st < 4; ++st) stage_strip(x1[st], st * 32);
+            flush_rows(a.x_out, 128, 0, t0);
+        }
+
+        // ---- stage Q: next block's q|k|v (or the final norm) ---------------------------------------------------------------------
+        if constexpr (KQC > 0) {
+            h16x8 bqh[KQC], bql[KQC];
+            {
+                float ln[4][16];
+                layer_norm(x1, a.lnq_g, a.lnq_b, a.epsq, ln);
+                if (a.ln_out) {
+#pragma unroll
+                    for (int st = 0; st < 4; ++st) stage_strip(ln[st], st * 32);
+                    flush_rows(a.ln_out, 128, 0, t0);
+                }
+#pragma unroll
+                for (int c = 0; c < 8; ++c) split8(&ln[c >> 1][8 * (c & 1)], bqh[c], bql[c]);
+            }
+            if constexpr (KQC > 8) {
+                const float *e = a.extra + (tc / a.extra_div) * a.extra_ld;
+#pragma unroll
+                for (int c = 8; c < KQC; ++c) {
+                    const float4 v0 = ldg4(e + 16 * (c - 8) + 4 * hi), v1 = ldg4(e + 16 * (c - 8) + 8 + 4 * hi);
+                    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    split8(v, bqh[c], bql[c]);
+                }
+            }
+            if (a.q_out) {
+                const int n_groups = a.NQ >> 7;                                // 128 output columns = 4 strips per group
+#pragma unroll 1
+                for (int g = 0; g < n_groups; ++g) {
+                    nb_static_for<4>([&](auto ss) {
+                        constexpr int sl = decltype(ss)::value;
+                        f32x16 qh, qx;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) qh[r] = qx[r] = 0.f;
+                        nb_static_for<KQC>([&](auto cc) {
+                            constexpr int c = decltype(cc)::value;
+                            constexpr int pg = sl * KQC + c;                   // pair index within the group: 8 pairs per stage
+                            if constexpr (pg % 8 == 0) next_stage();
+                            split_mma(frag_hi(pg % 8), frag_lo(pg % 8), bqh[c], bql[c], qh, qx);
+                        });
+                        float ov[16];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (a.bq) bv = ldg4(a.bq + g * 128 + sl * 32 + 8 * q + 4 * hi);
+                            const float b4[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                            for (int e2 = 0; e2 < 4; ++e2) ov[4 * q + e2] = fmaf(SPLIT_LO_INV, qx[4 * q + e2], qh[4 * q + e2]) + b4[e2];
+                        }
+                        stage_strip(ov, sl * 32);
+                    });
+                    flush_rows(a.q_out, a.NQ, g * 128, t0);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// weight packing: W [N,K] row-major fp32 -> N/32 x Kp/16 pairs of 2 KB in [strip][chunk] order; pair = [64 lanes][8 fp16] hi
+// then the same for lo'; lane (i = l&31, h = l>>5) slot jj holds W[32*strip + i][16*chunk + split_kslot(jj, h)], 0 beyond K.
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_split_weight_kernel(const float *__restrict__ w, int N, int K, int KC,
+                                                               uint4 *__restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;           // one lane of one pair
+    const int64_t total = (int64_t)(N / 32) * KC * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const int64_t pair = idx >> 6;
+    const int c = (int)(pair % KC), s = (int)(pair / KC);
+    const int n = s * 32 + (lane & 31), h = lane >> 5;
+    float v[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const int k = 16 * c + split_kslot(jj, h);
+        v[jj] = k < K ? w[(int64_t)n * K + k] : 0.f;
+    }
+    h16x8 vh, vl;
+    split8(v, vh, vl);
+    out[pair * 128 + lane] = *reinterpret_cast<const uint4 *>(&vh);
+    out[pair * 128 + 64 + lane] = *reinterpret_cast<const uint4 *>(&vl);
+}
+
+extern "C" int nmrf_pack_split_weight_f32(const float *w, int N, int K, int Kp, void *out, void *stream) {
+    if (!w || !out) return NMRF_ENULL;
+    if (N < 32 || (N & 31) || K < 1 || Kp < K || (Kp & 15)) return NMRF_EINVAL;
+    const int KC = Kp / 16;
+    const int64_t total = (int64_t)(N / 32) * KC * 64;
+    hipLaunchKernelGGL(pack_split_weight_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, w, N, K,
+                       KC, reinterpret_cast<uint4 *>(out));
+    return nmrf_launch_status();
+}
+
+template <bool MLP, int KQC>
+static int launch_nmp_block(const NmpBlockArgs &a, hipStream_t st) {
+    static bool attr_set_dev[NMRF_MAX_DEV] = {};
+    static int n_cu_dev[NMRF_MAX_DEV] = {};
+    const int dev = nmrf_cur_device();
+    if (dev < 0) return NMRF_ELAUNCH;
+    const size_t lds = (size_t)NB_RING * NB_STAGE_U4 * 16 + (size_t)4 * 32 * NB_OLD * sizeof(float);
+    if (!attr_set_dev[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(nmp_block_kernel<MLP, KQC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return NMRF_ELAUNCH;
+        attr_set_dev[dev] = true;
+    }
+    if (!n_cu_dev[dev]) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return NMRF_ELAUNCH;
+        n_cu_dev[dev] = prop.multiProcessorCount;
+    }
+    const int grid = a.n_tiles < n_cu_dev[dev] ? a.n_tiles : n_cu_dev[dev];
+    hipLaunchKernelGGL((nmp_block_kernel<MLP, KQC>), dim3(grid), dim3(256), lds, st, a);
+    return nmrf_launch_status();
+}
+
+extern "C" int nmrf_nmp_block_f32(const float *x, const float *msg, const void *stream_w, int total_stages, const float *bp,
+                                  const float *ln2_g, const float *ln2_b, float eps2, const float *b1, const float *b2,
+                                  const float *lnq_g, const float *lnq_b, float epsq, const float *extra, int extra_ld,
+                                  int extra_div, const float *bq, int has_mlp, int KQ, int NQ, int64_t T, float *x_out,
+                                  float *q_out, float *ln_out, void *stream) {
+    if (!x || !stream_w) return NMRF_ENULL;
+    if (T < 1 || ceil_div64(T, NB_TOK) > 0x7fffffff) return NMRF_EINVAL;
+    if (has_mlp && (!ln2_g || !ln2_b || !b1 || !b2)) return NMRF_ENULL;
+    if (KQ != 0 && KQ != 128 && KQ != 160 && KQ != 192) return NMRF_EINVAL;
+    if (KQ && (!lnq_g || !lnq_b)) return NMRF_ENULL;
+    if (KQ > 128 && (!extra || extra_ld < KQ - 128 || (extra_ld & 3) || extra_div < 1)) return NMRF_EINVAL;
+    if (q_out && (KQ == 0 || NQ < 128 || (NQ & 127))) return NMRF_EINVAL;
+    if (ln_out && KQ == 0) return NMRF_EINVAL;
+    if (!q_out && !ln_out && !x_out) return NMRF_ENULL;
+    // the stream must hold exactly the stages this configuration consumes
+    const int want = (msg ? 4 : 0) + (has_mlp ? 32 : 0) + (q_out ? (NQ / 128) * (KQ / 16) / 2 : 0);
+    if (total_stages != want || total_stages < 1) return NMRF_EINVAL;
+    NmpBlockArgs a{x, msg, reinterpret_cast<const u32x4 *>(stream_w), total_stages, bp, ln2_g, ln2_b, b1, b2, lnq_g, lnq_b, extra,
+                   extra_ld, extra_div, bq, x_out, q_out, ln_out, T, (int)ceil_div64(T, NB_TOK), eps2, epsq, NQ};
+    hipStream_t st = (hipStream_t)stream;
+    const int kqc = KQ / 16;
+    if (has_mlp) {
+        switch (kqc) {
+            case 0: return launch_nmp_block<true, 0>(a, st);
+            case 8: return launch_nmp_block<true, 8>(a, st);
+            case 10: return launch_nmp_block<true, 10>(a, st);
+            case 12: return launch_nmp_block<true, 12>(a, st);
+        }
+    } else {
+        switch (kqc) {
+            case 0: return launch_nmp_block<false, 0>(a, st);
+            case 8: return launch_nmp_block<false, 8>(a, st);
+            case 10: return launch_nmp_block<false, 10>(a, st);
+            case 12: return launch_nmp_block<false, 12>(a, st);
+        }
+    }
+    return NMRF_EINVAL;
+}

@@ -327,6 +327,11 @@ __device__ __forceinline__ void fourier_write(float coord, float normalizer, int
     }
 }
 
+// rows wider than 31 floats (ld = 32: 16-byte aligned rows for the fused block kernel's side input): the pad columns are zero
+__device__ __forceinline__ void fourier_pad(int f, float *row, int ld) {
+    if (f == 15) for (int k = 31; k < ld; ++k) row[k] = 0.f;
+}
+
 __global__ __launch_bounds__(256) void seed_features_kernel(const float *__restrict__ vol, const int64_t *__restrict__ seeds,
         int64_t P, int G, int D, int N, float normalizer, float *__restrict__ cost, float *__restrict__ enc) {
     const int per = G * 9;
@@ -366,6 +371,7 @@ __global__ __launch_bounds__(256) void fourier_embed_kernel(const float *__restr
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         int64_t t = i >> 4;
         fourier_write(coord[t], normalizer, (int)(i & 15), enc + t * ld);
+        fourier_pad((int)(i & 15), enc + t * ld, ld);
     }
 }
 

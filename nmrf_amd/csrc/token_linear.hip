@@ -40,18 +40,6 @@ __device__ __forceinline__ void static_for(F &&f) {
 }
 
 
-// GELU(erf) with erf from Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7 in exact arithmetic): 16 VALU instructions instead of
-// the ~33 of ocml's erff, which at 64 hidden values per thread and tile were as much issue time as the tile's MFMAs.
-// Measured over [-12, 12] in fp32: max |gelu_fast - gelu_fp64| = 4.7e-7 (torch's own fp32 GELU: 1.2e-6).
-__device__ __forceinline__ float gelu_fast(float v) {
-    const float z = v * 0.70710678118654752440f, az = fabsf(z);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
-    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(az * az * -1.4426950408889634f);
-    const float er = copysignf(fmaf(-poly, e, 1.0f), z);
-    return 0.5f * v * (1.0f + er);
-}
-
 // 16-lane all-reduce on the DPP network (no LDS crossbar): quad xor 1, quad xor 2, row_half_mirror, row_mirror
 __device__ __forceinline__ float row16_sum(float v) {
     v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));

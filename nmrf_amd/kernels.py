@@ -125,11 +125,12 @@ def seed_features(vol, seeds, normalizer):
 
 
 @_on_device
-def fourier_embed(coord, normalizer):
+def fourier_embed(coord, normalizer, ld=31):
+    """-> [T, ld]: 31 Fourier columns, the rest (ld = 32: 16-byte rows for the fused block kernel) zero."""
     _chk(coord)
     t = coord.numel()
-    enc = torch.empty(t, 31, device=coord.device, dtype=torch.float32)
-    _lib.check(_lib.load().nmrf_fourier_embed_f32(_p(coord), t, float(normalizer), _p(enc), 31, _stream()),
+    enc = torch.empty(t, ld, device=coord.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_fourier_embed_f32(_p(coord), t, float(normalizer), _p(enc), ld, _stream()),
                "fourier_embed")
     return enc
 
@@ -303,6 +304,81 @@ def token_linear(x, packed_w, n, k, bias=None, ln=None, y=None, extra=None, extr
     if hook_name is not None:
         _he(hook_name)
     return (x_out, out) if y is not None else out
+
+
+@_on_device
+def pack_split_weight(weight, kp=None):
+    """[N,K] nn.Linear weight -> split-fp16 MFMA fragment pairs [N/32, Kp/16, 512] (int32 view of 2 KB pairs) for nmp_block."""
+    _chk(weight)
+    n, k = weight.shape
+    kp = kp or (k + 15) // 16 * 16
+    out = torch.empty(n // 32, kp // 16, 512, device=weight.device, dtype=torch.int32)
+    _lib.check(_lib.load().nmrf_pack_split_weight_f32(_p(weight), n, k, kp, _p(out), _stream()), "pack_split_weight")
+    return out
+
+
+def block_stream(wp=None, w1=None, w2=None, wq=None, kq=0):
+    """Weight stream of one nmp_block launch, in the kernel's consumption order (include/nmrf_hip.h, nmrf_nmp_block_f32):
+    proj pairs | W1 strips interleaved with W2 k-slices | q-stage pairs.  Returns (int32 tensor [stages*8, 512], stages)."""
+    parts = []
+    if wp is not None:
+        parts.append(pack_split_weight(wp, 128).view(-1, 512))
+    if w1 is not None:
+        p1 = pack_split_weight(w1, 128)                                                  # [16 hidden strips][8 chunks]
+        p2 = pack_split_weight(w2, 512).view(4, 16, 2, 512).permute(1, 0, 2, 3).reshape(16, 8, 512)    # [hidden strip][n, c]
+        seq = [p1[0]]
+        for h in range(15):
+            seq += [p1[h + 1], p2[h]]
+        seq.append(p2[15])
+        parts.append(torch.stack(seq).view(-1, 512))
+    if wq is not None:
+        parts.append(pack_split_weight(wq, kq).view(-1, 512))
+    stream = torch.cat(parts).contiguous()
+    assert stream.shape[0] % 8 == 0
+    return stream, stream.shape[0] // 8
+
+
+@_on_device
+def nmp_block(x, stream, stages, msg=None, bp=None, mlp=None, q=None, want_x=True):
+    """One fused message-passing block (nmrf_nmp_block_f32).
+    mlp = (ln2_gamma, ln2_beta, eps, b1, b2) or None;  q = dict(g, b, eps, extra=None, extra_div=1, bias=None, kq=0|128|160|192,
+    nq=0 -> no q_out, ln_out=False) or None.  Returns (x_out | None, q_out | None, ln_out | None)."""
+    _chk(x, msg, bp)
+    _chk(stream, dtype=torch.int32)
+    t = x.shape[0]
+    ln2_g = ln2_b = b1 = b2 = None
+    eps2 = 0.0
+    if mlp is not None:
+        ln2_g, ln2_b, eps2, b1, b2 = mlp
+        _chk(ln2_g, ln2_b, b1, b2)
+    lq_g = lq_b = extra = bq = None
+    epsq, kq, nq, ld, div, want_ln = 0.0, 0, 0, 0, 1, False
+    if q is not None:
+        lq_g, lq_b, epsq = q["g"], q["b"], q["eps"]
+        extra, div, bq, kq, nq = q.get("extra"), q.get("extra_div", 1), q.get("bias"), q["kq"], q.get("nq", 0)
+        want_ln = q.get("ln_out", False)
+        _chk(lq_g, lq_b, extra, bq)
+        if extra is not None:
+            ld = extra.shape[-1]
+    x_out = torch.empty_like(x) if want_x else None
+    q_out = torch.empty(t, nq, device=x.device, dtype=torch.float32) if nq else None
+    ln_out = torch.empty_like(x) if want_ln else None
+    if kernel_hook is not None:
+        flops = 2.0 * t * ((128 * 128 if msg is not None else 0) + (2 * 128 * 512 if mlp is not None else 0) + kq * nq)
+        nbytes = 4.0 * t * (128 * (1 + (msg is not None) + bool(want_x) + bool(want_ln)) + nq) + (4.0 * extra.numel() if extra is not None else 0)
+        name = "nmp_block_p%d_m%d_q%dx%d" % (msg is not None, mlp is not None, kq, nq)
+        _hb(name, row="A7/A10/A13 (N3)", bound="mfma", flops=flops, bytes=nbytes, split=True,
+            label="nmp_block_kernel<%s,%d> (%s%s%s fused, split-fp16 MFMA)" % (
+                "true" if mlp is not None else "false", kq // 16, "proj+residual " if msg is not None else "",
+                "LN+fc1+GELU+fc2 " if mlp is not None else "", ("LN+%d->%d" % (kq, nq)) if nq else ("final LN" if want_ln else "")),
+            pmc=["nmp_block_kernel<%s, %d>" % ("true" if mlp is not None else "false", kq // 16)])
+    _lib.check(_lib.load().nmrf_nmp_block_f32(_p(x), _p(msg), _p(stream), stages, _p(bp), _p(ln2_g), _p(ln2_b), float(eps2), _p(b1),
+                                              _p(b2), _p(lq_g), _p(lq_b), float(epsq), _p(extra), ld, div, _p(bq),
+                                              int(mlp is not None), kq, nq, t, _p(x_out), _p(q_out), _p(ln_out), _stream()),
+               "nmp_block")
+    if kernel_hook is not None:
+        _he(name)
+    return x_out, q_out, ln_out
 
 
 @_on_device

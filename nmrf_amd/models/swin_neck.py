@@ -232,8 +232,15 @@ class DeformNeck(nn.Module):
         b, _, hh, ww = image.shape
         h, w = hh // 4, ww // 4
         dev = image.device
-        shapes = torch.as_tensor([(hh // s, ww // s) for s in (4, 8, 16, 32)], dtype=torch.long, device=dev)
-        start = shapes.new_zeros((1,))
+        # level shapes are built on the host and copied once per (size, device): a pageable H2D copy inside forward would
+        # synchronise every call and cannot be captured into a hipGraph
+        key = (hh, ww, str(dev))
+        if not hasattr(self, "_geom"):
+            self._geom = {}
+        if key not in self._geom:
+            shp = torch.as_tensor([(hh // s, ww // s) for s in (4, 8, 16, 32)], dtype=torch.long, device=dev)
+            self._geom[key] = (shp, shp.new_zeros((1,)))
+        shapes, start = self._geom[key]
         ry = (torch.arange(h, dtype=torch.float32, device=dev) + 0.5) / h
         rx = (torch.arange(w, dtype=torch.float32, device=dev) + 0.5) / w
         ref = torch.stack((rx[None, :].expand(h, w), ry[:, None].expand(h, w)), -1).reshape(1, h * w, 1, 2)

@@ -285,7 +285,10 @@ def test_msda_forward_at_middlebury_swin_shapes(lvl):
     shapes = torch.tensor([[h, w]])
     start = torch.tensor([0])
     got = K().msda_forward(value.to(DEV), shapes.to(DEV), start.to(DEV), loc.to(DEV), wgt.to(DEV)).cpu()
-    report("msda config-5", got, O.msda_core(value, shapes, loc, wgt), 3e-6, 1e-5)
+    # tolerance: the sample position loc*W - 0.5 (ms_deform_im2col_cuda.cuh:285-286, and this kernel) vs the oracle's
+    # grid_sample round trip ((2*loc - 1 + 1) * W - 1) / 2: one fp32 ulp of a coordinate up to 376 = 2e-5 px, times the unit
+    # gradient of a random value map (measured max 2.3e-5 at the 256x376 level, < 3e-6 at the small golden shapes)
+    report("msda config-5", got, O.msda_core(value, shapes, loc, wgt), 6e-5, 1e-5)
 
 
 @pytest.mark.parametrize("t_,k,n,relu", [(1000, 128, 64, False), (333, 128, 16, True), (4097, 128, 1, False), (70, 36, 5, True)])
