@@ -309,7 +309,12 @@ def main():
             "metric": "stereo pairs/sec at %dx%d" % (args.width, args.height), "value": round(value, 3), "unit": "stereo pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": ("f32" if os.environ.get("NMRF_LINEAR", "split") == "fp32" else
+                      "f32 (storage, accumulation, attention, convolutions; the per-token linears multiply fp32 operands as "
+                      "fp16 hi/lo pairs on the fp16 MFMA, 3 products per term, ~2^-22 relative -- csrc/split_mfma.h; "
+                      "NMRF_LINEAR=fp32 runs them on the fp32 MFMA)"),
+            "data": "synthetic",
             "config": {"workload": "%s %dx%d stereo pairs, batch %d per GPU, %s backbone, D_max %d, %d/%d/%d prop/infer/refine "
                                    "layers, hash-formula weights" % (
                                        {(375, 1242): "KITTI", (540, 960): "SceneFlow", (1000, 1500): "Middlebury-H"}.get(

@@ -21,6 +21,12 @@ from .. import kernels as K
 def _fused():
     return os.environ.get("NMRF_FUSED_LINEAR", "1") != "0"
 
+
+def _split():
+    """Default: the per-token linears of a block run in ONE kernel on split-operand fp16 MFMA (csrc/nmp_block.hip, fp32-grade
+    products).  NMRF_LINEAR=fp32 keeps the round-1 chain of fp32-MFMA token_linear kernels + hipBLASLt fc2 for A/B runs."""
+    return _fused() and os.environ.get("NMRF_LINEAR", "split") != "fp32"
+
 FOURIER_DIM = 31        # 15 sin + 15 cos + the scaled coordinate (NMP.py:35-51)
 
 
@@ -122,6 +128,58 @@ class _Lin:
     def __call__(self, x, act=0, **kw):
         pw, b, k, n = _packed(self.cache, (self.linear.weight,), (self.linear.bias,))
         return K.token_linear(x, pw, n, k, b, act=act, **kw)
+
+
+class _BlockLauncher:
+    """One nmp_block launch site of a stage: x1 = x + proj(msg); x2 = x1 + mlp(norm2(x1)); then the NEXT block's q|k|v on
+    [norm(x2) | side] or the stage's final norm.  The weight stream and the fused bias are rebuilt when a parameter changes."""
+
+    def __init__(self, proj=None, mlp=None, nxt_norm=None, nxt_linears=(), kq=0, ln_out=False):
+        self.proj, self.mlp, self.nxt_norm, self.nxt_linears, self.kq, self.ln_out = proj, mlp, nxt_norm, tuple(nxt_linears), kq, ln_out
+        self.cache = _FusedCache()
+
+    def _params(self):
+        ps = []
+        if self.proj is not None:
+            ps += [self.proj.weight, self.proj.bias]
+        if self.mlp is not None:
+            ps += [self.mlp[1].fc1.weight, self.mlp[1].fc2.weight]
+        for l in self.nxt_linears:
+            ps += [l.weight, l.bias]
+        return tuple(ps)
+
+    def _build(self):
+        wq = bq = None
+        if self.nxt_linears:
+            k = max(l.in_features for l in self.nxt_linears)
+            wq = torch.cat([_pad_cols(l.weight, k) for l in self.nxt_linears], 0).contiguous()
+            bq = torch.cat([l.bias for l in self.nxt_linears]).contiguous()
+        stream, stages = K.block_stream(None if self.proj is None else self.proj.weight.contiguous(),
+                                        None if self.mlp is None else self.mlp[1].fc1.weight.contiguous(),
+                                        None if self.mlp is None else self.mlp[1].fc2.weight.contiguous(), wq, self.kq)
+        return stream, stages, bq, (0 if wq is None else wq.shape[0])
+
+    def __call__(self, x, msg=None, extra=None, extra_div=1, want_x=True):
+        stream, stages, bq, nq = self.cache.get(self._params(), self._build)
+        mlp = None
+        if self.mlp is not None:
+            n2, m = self.mlp
+            mlp = (n2.weight, n2.bias, n2.eps, m.fc1.bias, m.fc2.bias)
+        q = None
+        if self.nxt_norm is not None:
+            q = dict(g=self.nxt_norm.weight, b=self.nxt_norm.bias, eps=self.nxt_norm.eps, extra=extra if self.kq > 128 else None,
+                     extra_div=extra_div, bias=bq, kq=self.kq, nq=nq, ln_out=self.ln_out)
+        return K.nmp_block(x, stream, stages, msg, None if self.proj is None else self.proj.bias, mlp, q, want_x=want_x)
+
+
+def _block_ok(*mods):
+    """The fused kernel is built for the dimensions of every shipped config: 128-wide tokens, 512-wide hidden layer."""
+    for m in mods:
+        if isinstance(m, Mlp) and (m.fc1.in_features != 128 or m.fc1.out_features != 512 or m.fc2.out_features != 128):
+            return False
+        if isinstance(m, nn.Linear) and m.out_features != 128:
+            return False
+    return True
 
 
 def _ln(x, norm):
@@ -351,6 +409,26 @@ class RefinementLayer(nn.Module):
 class Propagation(nn.Module):
     """Label-seed propagation (NMP.py:603-667)."""
 
+    def _forward_blocks(self, x, ctx, dims):
+        """5 x [stripe attention -> one fused block kernel]; the block of layer i also produces layer i+1's q|k|v."""
+        b, h, wd, n = dims
+        L = [l.nmp for l in self.layers]
+        if not hasattr(self, "_launch"):
+            self._launch = [_BlockLauncher(nxt_norm=L[0].norm1, nxt_linears=_qkv_of(L[0]), kq=192)]
+            for i, m in enumerate(L):
+                if i + 1 < len(L):
+                    self._launch.append(_BlockLauncher(m.proj, (m.norm2, m.mlp), L[i + 1].norm1, _qkv_of(L[i + 1]), 192))
+                elif self.norm is not None:
+                    self._launch.append(_BlockLauncher(m.proj, (m.norm2, m.mlp), self.norm, (), 128, ln_out=True))
+                else:
+                    self._launch.append(_BlockLauncher(m.proj, (m.norm2, m.mlp)))
+        _, qkv, _ = self._launch[0](x, None, ctx, n, want_x=False)
+        for i, m in enumerate(L):
+            msg = K.stripe_attn(qkv, m.attns[0].get_v.weight, m.attns[1].get_v.weight, b, h, wd, n)
+            last = i + 1 == len(L)
+            x, qkv, ln = self._launch[i + 1](x, msg, ctx, n, want_x=not last or self.norm is None)
+        return ln if self.norm is not None else x
+
     def __init__(self, embed_dim, cost_group, layers, norm=None):
         super().__init__()
         self.cost_encoder = nn.Sequential(nn.Linear(cost_group * 9, embed_dim), nn.GELU(), nn.Linear(embed_dim, embed_dim))
@@ -365,6 +443,8 @@ class Propagation(nn.Module):
         cost, enc = K.seed_features(cost_volume, label_seed, 3.14 / 64)
         x = self.proj(torch.cat((self.cost_encoder(cost), enc), -1))
         ctx = context.reshape(b * h * wd, cc)
+        if _split() and cc == 64 and self.embed_dim == 128 and all(_block_ok(l.nmp.proj, l.nmp.mlp) for l in self.layers):
+            return self._forward_blocks(x.contiguous(), ctx, dims).unsqueeze(0), label_seed.float()
         y = None
         for layer in self.layers:
             x, y = layer.forward_pair(x, y, ctx, dims)
@@ -373,6 +453,10 @@ class Propagation(nn.Module):
         elif y is not None:
             x = x + y
         return x.unsqueeze(0), label_seed.float()
+
+
+def _qkv_of(nmp):
+    return (nmp.q, nmp.k, nmp.v) if hasattr(nmp, "q") else (nmp.qkv,)
 
 
 def _pad_grid(x, dims, win):
@@ -408,11 +492,16 @@ class Inference(nn.Module):
         b, _, h, wd = fmap1.shape
         dims = (b, h, wd, n)
         x = self.ffn(K.warp_corr_concat(labels_flat, fmap1, fmap2, fmap1_gw, fmap2_gw, n, self.cost_group))
-        enc = K.fourier_embed(labels_flat, self.normalizer)
+        split = _split() and self.dim == 128 and all(
+            _block_ok(l.nmp.proj, l.nmp.mlp, *((l.self_nmp.proj,) if hasattr(l, "self_nmp") else ())) for l in self.layers)
+        enc = K.fourier_embed(labels_flat, self.normalizer, 32 if split else 31)
         win = self.layers[0].window_size
         x, pdims, off = _pad_grid(x, dims, win)
         enc, _, _ = _pad_grid(enc, dims, win)
         x, enc = x.contiguous(), enc.contiguous()
+        if split:
+            out = self._run_blocks(x, enc, pdims)
+            return _crop_grid(out, pdims, dims, off).contiguous()
         y = None
         for layer in self.layers:
             x, y = layer.forward_pair(x, y, enc, pdims)
@@ -422,6 +511,39 @@ class Inference(nn.Module):
         if self.norm is not None:
             return _add_ln(x, y, self.norm)[1]
         return x if y is None else x + y
+
+    def _run_blocks(self, x, enc, pdims):
+        """Per layer: [self-edge attention -> fused block (proj + residual -> window q|k|v)] (inference only), then
+        window attention -> fused block (proj + residual + MLP -> the next layer's first q|k|v, or the final norm)."""
+        n = pdims[3]
+        if not hasattr(self, "_launch"):
+            sites = []                                                   # (kind, module) in execution order
+            for l in self.layers:
+                if hasattr(l, "self_nmp"):
+                    sites.append(("self", l.self_nmp))
+                sites.append(("win", l.nmp))
+            self._sites = sites
+            first = sites[0][1]
+            self._launch = [_BlockLauncher(nxt_norm=first.norm1, nxt_linears=_qkv_of(first), kq=160)]
+            for i, (kind, m) in enumerate(sites):
+                mlp = (m.norm2, m.mlp) if kind == "win" else None
+                if i + 1 < len(sites):
+                    nx = sites[i + 1][1]
+                    self._launch.append(_BlockLauncher(m.proj, mlp, nx.norm1, _qkv_of(nx), 160))
+                elif self.norm is not None:
+                    self._launch.append(_BlockLauncher(m.proj, mlp, self.norm, (), 128, ln_out=True))
+                else:
+                    self._launch.append(_BlockLauncher(m.proj, mlp))
+        _, qkv, _ = self._launch[0](x, None, enc, 1, want_x=False)
+        ln = None
+        for i, (kind, m) in enumerate(self._sites):
+            if kind == "self":
+                msg = K.self_attn(qkv, n, m.num_heads)
+            else:
+                msg = m.attn(qkv, pdims, n > 1)                         # sibling mask for N > 1 (inference), none for refinement
+            last = i + 1 == len(self._sites)
+            x, qkv, ln = self._launch[i + 1](x, msg, enc, 1, want_x=not last or self.norm is None)
+        return ln if self.norm is not None else x
 
     def forward(self, labels, fmap1, fmap2, fmap1_gw, fmap2_gw):
         """labels [B*H*W, N] -> [1, B*H*W, N, C]"""

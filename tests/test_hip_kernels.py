@@ -357,6 +357,70 @@ def test_token_linear_plain(t_, k, n, act, res):
     report("token_linear(no bias)", nob.cpu(), x.double() @ w.double().t(), 2e-5, 1e-5)
 
 
+def _block_ref(x, msg, wp, bp, mlp, q):
+    """fp64 statement of nmrf_nmp_block_f32 (include/nmrf_hip.h)."""
+    x = x.double()
+    if msg is not None:
+        x = x + msg.double() @ wp.double().t() + bp.double()
+    if mlp is not None:
+        g2, b2n, w1, b1, w2, b2 = (v.double() for v in mlp)
+        x = x + F.gelu(F.layer_norm(x, (128,), g2, b2n, 1e-5) @ w1.t() + b1) @ w2.t() + b2
+    ln = qv = None
+    if q is not None:
+        ln = F.layer_norm(x, (128,), q["g"].double(), q["b"].double(), 1e-5)
+        if q.get("w") is not None:
+            a = ln if q.get("extra") is None else torch.cat((ln, q["extra"].double().repeat_interleave(q["div"], 0)[:x.shape[0]]), 1)
+            wq = q["w"].double()
+            qv = a @ F.pad(wq, (0, a.shape[1] - wq.shape[1])).t() + q["bias"].double()
+    return x, qv, ln
+
+
+@pytest.mark.parametrize("t_,proj,mlp,kq,nq,div,ln_out", [
+    (300, True, True, 160, 384, 1, False),       # window block -> next self/window q|k|v on [LN | Fourier31 + 0]
+    (517, True, False, 160, 384, 1, False),      # self-edge block (no MLP) -> the window block's q|k|v
+    (1000, False, False, 192, 384, 4, False),    # first propagation layer: q|k|v only, context shared by 4 labels
+    (777, True, True, 192, 384, 4, False),       # propagation block -> next layer's q|k|v
+    (130, True, True, 128, 0, 1, True),          # last block of a stage: final LayerNorm only
+    (64, True, True, 0, 0, 1, False),            # block without a q stage
+    (200, True, False, 0, 0, 1, False),          # projection + residual alone
+    (200, False, True, 0, 0, 1, False),          # MLP alone
+    (200, False, False, 128, 128, 1, True),      # LayerNorm + one 128-column group alone
+    (29952, True, True, 160, 384, 1, False),     # KITTI padded inference grid: 234 tiles
+    (40001, True, True, 160, 384, 1, True),      # more tiles than CUs (persistent blocks re-read the stream), ragged tail
+])
+def test_nmp_block_fused(t_, proj, mlp, kq, nq, div, ln_out):
+    """The fused block kernel (split-fp16 MFMA) against fp64, at the tolerances of the fp32-MFMA linears it replaces."""
+    kk = K()
+    d = lambda v: None if v is None else v.to(DEV)
+    x = rnd(t_, 128, seed=1, scale=2.0)
+    msg = rnd(t_, 128, seed=2, scale=1.5) if proj else None
+    wp, bp = rnd(128, 128, seed=3, scale=0.1), rnd(128, seed=4, scale=0.2)
+    g2, b2n = 1.0 + 0.1 * rnd(128, seed=5), 0.1 * rnd(128, seed=6)
+    w1, b1 = rnd(512, 128, seed=7, scale=0.1), rnd(512, seed=8, scale=0.3)
+    w2, b2 = rnd(128, 512, seed=9, scale=0.05), rnd(128, seed=10, scale=0.2)
+    gq, bqn = 1.0 + 0.1 * rnd(128, seed=11), 0.1 * rnd(128, seed=12)
+    e = kq - 128 if kq > 128 else 0
+    extra = rnd((t_ + div - 1) // div, e, seed=13) if e else None
+    k_true = {160: 159, 192: 192, 128: 128, 0: 0}[kq]
+    wq = rnd(nq, k_true, seed=14, scale=0.1) if nq else None
+    bq = rnd(nq, seed=15) if nq else None
+    if extra is not None and e == 32:
+        extra[:, 31] = 0.0                                        # the pad column of the Fourier rows
+    stream, stages = kk.block_stream(d(wp) if proj else None, d(w1) if mlp else None, d(w2) if mlp else None, d(wq), kq)
+    q = None
+    if kq:
+        q = dict(g=d(gq), b=d(bqn), eps=1e-5, extra=d(extra), extra_div=div, bias=d(bq), kq=kq, nq=nq, ln_out=ln_out)
+    xo, qo, lo = kk.nmp_block(d(x), stream, stages, d(msg), d(bp) if proj else None,
+                              (d(g2), d(b2n), 1e-5, d(b1), d(b2)) if mlp else None, q, want_x=True)
+    rx, rq, rl = _block_ref(x, msg, wp, bp, (g2, b2n, w1, b1, w2, b2) if mlp else None,
+                            dict(g=gq, b=bqn, w=wq, bias=bq, extra=extra, div=div) if kq else None)
+    report("block x_out", xo.cpu(), rx, 2e-5, 1e-5)
+    if nq:
+        report("block q_out", qo.cpu(), rq, 2e-5, 1e-5)
+    if ln_out:
+        report("block ln_out", lo.cpu(), rl, 1e-5, 1e-5)
+
+
 @pytest.mark.parametrize("b,c,h,w", [(2, 5, 7, 9), (1, 3, 188, 624), (2, 4, 47, 156), (2, 3, 94, 311), (1, 2, 1, 3), (1, 3, 127, 131)])
 def test_instance_norm_fused(b, c, h, w):
     x = rnd(b, c, h, w, seed=h, scale=3.0) + 1.5

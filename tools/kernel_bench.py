@@ -52,6 +52,32 @@ a, b2 = ctypes.c_int(-1), ctypes.c_int(-1)
 _l.nmrf_debug_window_occupancy(ctypes.byref(a), ctypes.byref(b2))
 print("runtime occupancy (blocks/CU): infer-window", a.value, " refine-window", b2.value, flush=True)
 which = args.which.split(",")
+if "block" in which:
+    # the fused block kernel against the four launches it replaces (KITTI padded inference grid, batch b)
+    import torch.nn.functional as F
+    T = b * 48 * 156 * 4
+    x, msg, enc = mk("bx", T, 128), mk("bm", T, 128), mk("be", T, 32)
+    wp, w1, w2, wq = mk("wp", 128, 128) * 0.1, mk("w1", 512, 128) * 0.1, mk("w2", 128, 512) * 0.05, mk("wq", 384, 159) * 0.1
+    bp, b1, b2, bq = mk("bp", 128), mk("b1", 512), mk("b2", 128), mk("bq", 384)
+    g, be = mk("g", 128) * 0.1 + 1, mk("bb", 128) * 0.1
+    stream, stages = K.block_stream(wp, w1, w2, wq, 160)
+    qd = dict(g=g, b=be, eps=1e-5, extra=enc, extra_div=1, bias=bq, kq=160, nq=384)
+    timeit("nmp_block proj+mlp+qkv (split fp16)", lambda: K.nmp_block(x, stream, stages, msg, bp, (g, be, 1e-5, b1, b2), qd))
+    s2, st2 = K.block_stream(wp, None, None, wq, 160)
+    timeit("nmp_block proj+qkv (self block)", lambda: K.nmp_block(x, s2, st2, msg, bp, None, qd))
+    s3, st3 = K.block_stream(None, None, None, wq, 160)
+    timeit("nmp_block qkv only", lambda: K.nmp_block(x, s3, st3, None, None, None, qd, want_x=False))
+    s4, st4 = K.block_stream(wp, w1, w2, None, 0)
+    timeit("nmp_block proj+mlp", lambda: K.nmp_block(x, s4, st4, msg, bp, (g, be, 1e-5, b1, b2), None))
+    pwp, pw1, pwq = (K.pack_linear_weight(v.contiguous()) for v in (wp, w1, wq))
+    enc31 = enc[:, :31].contiguous()
+
+    def old():
+        y = K.token_linear(msg, pwp, 128, 128, bp)
+        x1, h = K.token_linear(x, pw1, 512, 128, b1, ln=(g, be, 1e-5), y=y, act="gelu")
+        y2 = F.linear(h, w2, b2)
+        return K.token_linear(x1, pwq, 384, 159, bq, ln=(g, be, 1e-5), y=y2, extra=enc31)
+    timeit("round-1 sequence (4 launches, fp32)", old)
 if "window" in which:
     hp, wp = 48, 156
     qkv, table = mk("q", b * hp * wp * n, 384), mk("t", 121, 384)
