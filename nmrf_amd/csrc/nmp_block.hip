@@ -31,6 +31,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));    // (HIP's uin
 #define NB_TOK 128                 // tokens per block (4 waves x 32)
 #define NB_STAGE_U4 1024           // uint4 per stage (16 KB = 8 pairs)
 #define NB_RING 3
+#define NB_FD 1                    // default pipeline depths of the product build (see the kernel template)
+#define NB_PF 2
 #define NB_OLD 132                 // floats per row of the output staging tile (128 + 4: conflict-free b128 writes)
 
 template <class F, int... I>
@@ -64,55 +66,88 @@ struct NmpBlockArgs {
 
 // MLP: run the fc1-GELU-fc2 stage.  KQC: k chunks (of 16) of the q stage's operand [LNq(x2) | extra]: 0 = no q stage,
 // 8 = LayerNorm columns only, 10 = + 32 side columns (Fourier31 + 0), 12 = + 64 side columns (context).
-template <bool MLP, int KQC>
+// FD: stages of latency budget of the global fetch (1 or 2 register sets); PF: pairs read ahead from LDS.
+template <bool MLP, int KQC, int FD, int PF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void nmp_block_kernel(NmpBlockArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u32x4 *ring = reinterpret_cast<u32x4 *>(smem);                                        // [3][1024] uint4
+    u32x4 *ring = reinterpret_cast<u32x4 *>(smem);                                        // [3][1024] x 16 B
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, hi = lane >> 5;
     float *Ot = reinterpret_cast<float *>(smem + NB_RING * NB_STAGE_U4 * 16) + wv * 32 * NB_OLD;   // wave-private [32][132]
 
-    // ---- weight stream: registers hold the stage two ahead of the one being consumed -------------------------------------
-    u32x4 R[4];
+    // ---- weight stream ----------------------------------------------------------------------------------------------------
+    // Stage s (16 KB = 8 pairs) lives in ring slot s % 3.  Timeline of a wave at stage g:  barrier g | fetch stage g+1+FD from
+    // global into registers | consume stage g (its first PF pairs were read from LDS during stage g-1) while reading the first
+    // PF pairs of stage g+1 ahead | commit stage g+2 (fetched FD stages ago) to slot (g+2) % 3 = the slot stage g-1 vacated.
+    // Barrier g orders: every wave has finished reading stage g-1, and stage g+1 (committed during stage g-1) is visible.
+    u32x4 R[FD][4];
     int src_stage = 0;                          // next stage to fetch from global (wraps: persistent blocks re-read the stream)
     int wr_slot = 0, rd_slot = 0;               // ring slots of the next commit / of the stage being consumed
-    auto fetch = [&]() {
+    auto fetch = [&](u32x4 (&r)[4]) {
         const u32x4 *p = a.stream + (size_t)src_stage * NB_STAGE_U4 + tid;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) R[i] = p[256 * i];
+        for (int i = 0; i < 4; ++i) r[i] = p[256 * i];
         src_stage = (src_stage + 1 == a.total_stages) ? 0 : src_stage + 1;
     };
-    auto commit = [&]() {
+    auto commit = [&](const u32x4 (&r)[4]) {
         u32x4 *d = ring + wr_slot * NB_STAGE_U4 + tid;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) d[256 * i] = R[i];
+        for (int i = 0; i < 4; ++i) d[256 * i] = r[i];
         wr_slot = (wr_slot == NB_RING - 1) ? 0 : wr_slot + 1;
     };
-    const u32x4 *cur = ring;                    // stage being consumed
-    bool first_stage = true;
-    // top of a stage: after the barrier the stage to consume (committed a stage ago) and the one after it are visible and
-    // every wave has left the stage before; the slot that one occupied takes the stage two ahead.
-    auto next_stage = [&]() {
-        __syncthreads();
-        if (!first_stage) rd_slot = (rd_slot == NB_RING - 1) ? 0 : rd_slot + 1;
-        first_stage = false;
-        cur = ring + rd_slot * NB_STAGE_U4;
-        commit();
-        fetch();
+    const u32x4 *cur = ring, *nxt = ring + NB_STAGE_U4;      // stage being consumed / the one after it
+    h16x8 fqh[PF], fql[PF];                                  // fragment queue: pairs p .. p+PF-1 of the stream position
+    auto read_pair = [&](const u32x4 *base, int p, h16x8 &h, h16x8 &l) {
+        h = *reinterpret_cast<const h16x8 *>(base + p * 128 + lane);
+        l = *reinterpret_cast<const h16x8 *>(base + p * 128 + 64 + lane);
     };
-    auto frag_hi = [&](int p) { return *reinterpret_cast<const h16x8 *>(cur + p * 128 + lane); };
-    auto frag_lo = [&](int p) { return *reinterpret_cast<const h16x8 *>(cur + p * 128 + 64 + lane); };
+    bool have_barrier = true;                   // the barrier of the very first stage is the one in the prologue
+    auto stage_top = [&]() {
+        if (!have_barrier) __syncthreads();
+        have_barrier = false;
+        fetch(R[FD - 1]);
+    };
+    auto stage_end = [&]() {
+        commit(R[0]);
+        if constexpr (FD == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) R[0][i] = R[1][i];
+        }
+        rd_slot = (rd_slot == NB_RING - 1) ? 0 : rd_slot + 1;
+        cur = nxt;
+        nxt = ring + ((rd_slot == NB_RING - 1) ? 0 : rd_slot + 1) * NB_STAGE_U4;
+    };
+    // pair P (compile-time, 0..7) of the current stage: take it from the queue, refill the queue entry with pair P + PF (of this
+    // stage or the next), then run the three MFMAs
+    auto consume = [&](auto pc, const h16x8 &bh, const h16x8 &bl, f32x16 &acc_hh, f32x16 &acc_xx) {
+        constexpr int P = decltype(pc)::value;
+        const h16x8 ah = fqh[P % PF], al = fql[P % PF];
+        if constexpr (P + PF < 8) read_pair(cur, P + PF, fqh[P % PF], fql[P % PF]);
+        else read_pair(nxt, P + PF - 8, fqh[P % PF], fql[P % PF]);
+        split_mma(ah, al, bh, bl, acc_hh, acc_xx);
+    };
 
-    fetch(); commit();                          // stage 0 -> slot 0
-    fetch(); commit();                          // stage 1 -> slot 1
-    fetch();                                    // stage 2 in registers (committed at the first stage top)
+    fetch(R[0]); commit(R[0]);                  // stage 0 -> slot 0
+    fetch(R[0]); commit(R[0]);                  // stage 1 -> slot 1
+    if constexpr (FD == 2) fetch(R[0]);         // stage 2 waits in R[0]; stage 3 goes to R[1] at the top of stage 0
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < PF; ++p) read_pair(cur, p, fqh[p], fql[p]);
 
-    // output staging: the 16 C/D registers of a 32-channel strip -> columns [col0, col0+32) of the wave's tile
+    // output staging: the 16 C/D registers of a 32-channel strip <-> columns [col0, col0+32) of the wave's tile (lane-private
+    // addresses: a lane reads back exactly what it wrote)
     auto stage_strip = [&](const float *v, int col0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<float4 *>(Ot + j * NB_OLD + col0 + 8 * q + 4 * hi) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+            *reinterpret_cast<f32x4 *>(Ot + j * NB_OLD + col0 + 8 * q + 4 * hi) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+    };
+    auto unstage_strip = [&](float *v, int col0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(Ot + j * NB_OLD + col0 + 8 * q + 4 * hi);
+            v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+        }
     };
     // whole rows of the tile -> dst[t, col0 .. col0+128): lanes 0-31 one row, lanes 32-63 the next (512 B each)
     auto flush_rows = [&](float *dst, int ld, int col0, int64_t t0) {
@@ -181,9 +216,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 constexpr int st = decltype(ss)::value;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc_h[st][r] = acc_x[st][r] = 0.f;
-                next_stage();
-#pragma unroll
-                for (int c = 0; c < 8; ++c) split_mma(frag_hi(c), frag_lo(c), bmh[c], bml[c], acc_h[st], acc_x[st]);
+                stage_top();
+                nb_static_for<8>([&](auto cc) { consume(cc, bmh[decltype(cc)::value], bml[decltype(cc)::value], acc_h[st], acc_x[st]); });
+                stage_end();
             });
 #pragma unroll
             for (int st = 0; st < 4; ++st)
@@ -207,6 +242,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int c = 0; c < 8; ++c) split8(&ln[c >> 1][8 * (c & 1)], bnh[c], bnl[c]);
             }
+            // x1 waits in the wave's LDS tile while the 512-wide hidden layer occupies the registers
+#pragma unroll
+            for (int st = 0; st < 4; ++st) stage_strip(x1[st], st * 32);
 #pragma unroll
             for (int st = 0; st < 4; ++st)
 #pragma unroll
@@ -217,9 +255,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             auto fc1 = [&](f32x16 &fh, f32x16 &fx) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) fh[r] = fx[r] = 0.f;
-                next_stage();
-#pragma unroll
-                for (int c = 0; c < 8; ++c) split_mma(frag_hi(c), frag_lo(c), bnh[c], bnl[c], fh, fx);
+                stage_top();
+                nb_static_for<8>([&](auto cc) { consume(cc, bnh[decltype(cc)::value], bnl[decltype(cc)::value], fh, fx); });
+                stage_end();
             };
             auto act_fc2 = [&](int hs, const f32x16 &fh, const f32x16 &fx) {
                 float hv[16];
@@ -233,12 +271,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 h16x8 hh[2], hl[2];
                 split8(hv, hh[0], hl[0]);
                 split8(hv + 8, hh[1], hl[1]);
-                next_stage();
-                nb_static_for<4>([&](auto ss) {
-                    constexpr int st = decltype(ss)::value;
-                    split_mma(frag_hi(2 * st), frag_lo(2 * st), hh[0], hl[0], acc_h[st], acc_x[st]);
-                    split_mma(frag_hi(2 * st + 1), frag_lo(2 * st + 1), hh[1], hl[1], acc_h[st], acc_x[st]);
+                stage_top();
+                nb_static_for<8>([&](auto cc) {
+                    constexpr int p = decltype(cc)::value;                     // pair p = (output strip p / 2, k chunk p % 2)
+                    consume(cc, hh[p & 1], hl[p & 1], acc_h[p >> 1], acc_x[p >> 1]);
                 });
+                stage_end();
             };
             f32x16 fa_h, fa_x, fb_h, fb_x;
             fc1(fa_h, fa_x);
@@ -250,7 +288,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 act_fc2(hs + 1, fb_h, fb_x);
             }
 #pragma unroll
-            for (int st = 0; st < 4; ++st)
+            for (int st = 0; st < 4; ++st) {
+                unstage_strip(x1[st], st * 32);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float4 bv = ldg4(a.b2 + st * 32 + 8 * q + 4 * hi);
@@ -259,6 +298,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     for (int e = 0; e < 4; ++e)
                         x1[st][4 * q + e] += fmaf(SPLIT_LO_INV, acc_x[st][4 * q + e], acc_h[st][4 * q + e]) + b4[e];
                 }
+            }
         }
         if (a.x_out) {
 #pragma unroll
@@ -301,8 +341,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         nb_static_for<KQC>([&](auto cc) {
                             constexpr int c = decltype(cc)::value;
                             constexpr int pg = sl * KQC + c;                   // pair index within the group: 8 pairs per stage
-                            if constexpr (pg % 8 == 0) next_stage();
-                            split_mma(frag_hi(pg % 8), frag_lo(pg % 8), bqh[c], bql[c], qh, qx);
+                            if constexpr (pg % 8 == 0) stage_top();
+                            consume(std::integral_constant<int, pg % 8>{}, bqh[c], bql[c], qh, qx);
+                            if constexpr (pg % 8 == 7) stage_end();
                         });
                         float ov[16];
 #pragma unroll
@@ -357,16 +398,21 @@ extern "C" int nmrf_pack_split_weight_f32(const float *w, int N, int K, int Kp, 
     return nmrf_launch_status();
 }
 
-template <bool MLP, int KQC>
-static int launch_nmp_block(const NmpBlockArgs &a, hipStream_t st) {
+#ifdef NMRF_DEBUG_PROBES
+static int g_nb_variant = 0;      // pipeline-depth variants for tools/kernel_bench.py --which block
+extern "C" int nmrf_debug_nmp_block_variant(int v) { g_nb_variant = v; return NMRF_OK; }
+#endif
+
+template <bool MLP, int KQC, int FD, int PF>
+static int launch_nmp_block_v(const NmpBlockArgs &a, hipStream_t st) {
     static bool attr_set_dev[NMRF_MAX_DEV] = {};
     static int n_cu_dev[NMRF_MAX_DEV] = {};
     const int dev = nmrf_cur_device();
     if (dev < 0) return NMRF_ELAUNCH;
     const size_t lds = (size_t)NB_RING * NB_STAGE_U4 * 16 + (size_t)4 * 32 * NB_OLD * sizeof(float);
     if (!attr_set_dev[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(nmp_block_kernel<MLP, KQC>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(nmp_block_kernel<MLP, KQC, FD, PF>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return NMRF_ELAUNCH;
         attr_set_dev[dev] = true;
     }
@@ -376,8 +422,22 @@ static int launch_nmp_block(const NmpBlockArgs &a, hipStream_t st) {
         n_cu_dev[dev] = prop.multiProcessorCount;
     }
     const int grid = a.n_tiles < n_cu_dev[dev] ? a.n_tiles : n_cu_dev[dev];
-    hipLaunchKernelGGL((nmp_block_kernel<MLP, KQC>), dim3(grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((nmp_block_kernel<MLP, KQC, FD, PF>), dim3(grid), dim3(256), lds, st, a);
     return nmrf_launch_status();
+}
+
+template <bool MLP, int KQC>
+static int launch_nmp_block(const NmpBlockArgs &a, hipStream_t st) {
+#ifdef NMRF_DEBUG_PROBES
+    switch (g_nb_variant) {
+        case 1: return launch_nmp_block_v<MLP, KQC, 2, 2>(a, st);
+        case 2: return launch_nmp_block_v<MLP, KQC, 1, 1>(a, st);
+        case 3: return launch_nmp_block_v<MLP, KQC, 2, 3>(a, st);
+        case 4: return launch_nmp_block_v<MLP, KQC, 1, 3>(a, st);
+        default: break;
+    }
+#endif
+    return launch_nmp_block_v<MLP, KQC, NB_FD, NB_PF>(a, st);
 }
 
 extern "C" int nmrf_nmp_block_f32(const float *x, const float *msg, const void *stream_w, int total_stages, const float *bp,

@@ -50,7 +50,7 @@ def pytest_terminal_summary(terminalreporter):
         terminalreporter.write_line("note: " + n)
     if not _DISP_STATS:
         return
-    terminalreporter.write_sep("-", "disparity agreement (px): EPE / median / p99 / frac>0.5px / max")
+    terminalreporter.write_sep("-", "disparity agreement (px): EPE / EPE of non-flipped pixels / median / p99 / frac>0.5px / max")
     for tag, s in _DISP_STATS:
-        terminalreporter.write_line("%-46s %.2e  %.2e  %.2e  %.2e  %.3f" % (tag, s["epe"], s["median"], s["p99"],
-                                                                              s["frac_gt_0p5"], s["max"]))
+        terminalreporter.write_line("%-46s %.2e  %.2e  %.2e  %.2e  %.2e  %.3f" % (
+            tag, s["epe"], s.get("epe_inliers", float("nan")), s["median"], s["p99"], s["frac_gt_0p5"], s["max"]))

@@ -364,3 +364,29 @@ def test_config5_swin_t_middlebury_half_res():
     got, _, _ = _hot_path_vs_oracle("config 5 Swin-T 1500x1000 vs oracle", model, feats, (h, w), 256, opts=SWIN_OPTS, prob_tol=4e-5)
     d = (got["disp"] - out["disp"]).abs()                 # the whole-model call and the split call agree
     assert float(d.median()) < 1e-3
+
+
+def test_split_linears_flip_rate_matches_fp32_path(monkeypatch):
+    """The split-fp16 block kernels against the fp32-MFMA chain they replace (NMRF_LINEAR=fp32), both against the oracle from
+    the same KITTI-size features: the typical pixel and the winner-take-all flip rate must be the same arithmetic-noise
+    phenomenon, not a precision loss -- median within 1.5x, flip rate within 3x (+ one 8x8 cell) of the fp32 path."""
+    from nmrf_amd.utils.hashinit import synthetic_pair
+    from tests.util import disp_stats
+    from tests.conftest import record_disp_stats
+    h, w = 375, 1242
+    model = build_product(320, DEV)
+    l, r, _ = synthetic_pair(h, w, seed=1000)
+    f4, f8 = _features(model, l[None], r[None])
+    wts, cfg = oracle_weights(320), oracle_cfg(320)
+    with torch.no_grad():
+        want = O.hot_path(wts, cfg, f8.cpu(), f4.cpu(), None, (h, w))["disp"]
+        args = ([f8[:1].contiguous(), f4[:1].contiguous()], [f8[1:].contiguous(), f4[1:].contiguous()], (h, w))
+        split = model.hot_path(*args)["disp"].cpu()
+        monkeypatch.setenv("NMRF_LINEAR", "fp32")
+        fp32 = model.hot_path(*args)["disp"].cpu()
+    s_split, s_fp32 = disp_stats(split, want), disp_stats(fp32, want)
+    record_disp_stats("KITTI hot path, split-fp16 linears vs oracle", s_split)
+    record_disp_stats("KITTI hot path, fp32-MFMA linears vs oracle", s_fp32)
+    record_disp_stats("KITTI hot path, split vs fp32-MFMA linears", disp_stats(split, fp32))
+    assert s_split["median"] <= 1.5 * s_fp32["median"] + 1e-5, (s_split, s_fp32)
+    assert s_split["frac_gt_0p5"] <= 3 * s_fp32["frac_gt_0p5"] + 64.0 / (h * w) + 1e-4, (s_split, s_fp32)

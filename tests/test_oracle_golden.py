@@ -121,7 +121,7 @@ def test_end_to_end_outputs(name):
     st = disp_stats(out["disp"], t(g["disp"]))
     from tests.conftest import record_disp_stats
     record_disp_stats("oracle vs reference " + name, st)
-    assert st["epe"] < 1e-3 and st["median"] < 2e-4 and st["frac_gt_0p5"] < 2e-3, st
+    assert st["epe"] < 1e-3 and st["median"] < 2e-4 and st["frac_gt_0p5"] < 2e-3, st       # the CPU oracle meets the raw contract
 
 
 # ------------------------------------------------------------------------------------------------

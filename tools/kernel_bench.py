@@ -46,7 +46,7 @@ _lib.LIB_PATH = build_library(debug=True, verbose=False)
 _l = _lib.load()
 for _n, _at in (("nmrf_debug_window_occupancy", None), ("nmrf_debug_window_timing", None), ("nmrf_debug_stripe_census", None),
                 ("nmrf_debug_mfma_peak", None), ("nmrf_debug_attn_core_peak", None), ("nmrf_debug_token_linear_timing", None),
-                ("nmrf_debug_wino_timing", None)):
+                ("nmrf_debug_wino_timing", None), ("nmrf_debug_nmp_block_variant", None)):
     getattr(_l, _n).restype = ctypes.c_int
 a, b2 = ctypes.c_int(-1), ctypes.c_int(-1)
 _l.nmrf_debug_window_occupancy(ctypes.byref(a), ctypes.byref(b2))
@@ -62,7 +62,10 @@ if "block" in which:
     g, be = mk("g", 128) * 0.1 + 1, mk("bb", 128) * 0.1
     stream, stages = K.block_stream(wp, w1, w2, wq, 160)
     qd = dict(g=g, b=be, eps=1e-5, extra=enc, extra_div=1, bias=bq, kq=160, nq=384)
-    timeit("nmp_block proj+mlp+qkv (split fp16)", lambda: K.nmp_block(x, stream, stages, msg, bp, (g, be, 1e-5, b1, b2), qd))
+    for var, tag in ((0, "FD1 PF2 (product)"), (1, "FD2 PF2"), (2, "FD1 PF1"), (3, "FD2 PF3"), (4, "FD1 PF3")):
+        _l.nmrf_debug_nmp_block_variant(var)
+        timeit("nmp_block proj+mlp+qkv " + tag, lambda: K.nmp_block(x, stream, stages, msg, bp, (g, be, 1e-5, b1, b2), qd))
+    _l.nmrf_debug_nmp_block_variant(0)
     s2, st2 = K.block_stream(wp, None, None, wq, 160)
     timeit("nmp_block proj+qkv (self block)", lambda: K.nmp_block(x, s2, st2, msg, bp, None, qd))
     s3, st3 = K.block_stream(None, None, None, wq, 160)
