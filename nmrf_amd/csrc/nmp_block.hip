@@ -62,6 +62,7 @@ struct NmpBlockArgs {
     int n_tiles;
     float eps2, epsq;
     int NQ;
+    unsigned long long *stamps;   // debug build (nmrf_debug_nmp_block_timing): s_memtime per wave and phase of the first 64 blocks
 };
 
 // MLP: run the fc1-GELU-fc2 stage.  KQC: k chunks (of 16) of the q stage's operand [LNq(x2) | extra]: 0 = no q stage,
@@ -75,6 +76,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, hi = lane >> 5;
     float *Ot = reinterpret_cast<float *>(smem + NB_RING * NB_STAGE_U4 * 16) + wv * 32 * NB_OLD;   // wave-private [32][132]
+#ifdef NMRF_DEBUG_PROBES
+#define NB_STAMP(k) do { if (a.stamps && lane == 0 && blockIdx.x < 64) \
+        a.stamps[((size_t)blockIdx.x * 4 + wv) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define NB_STAMP(k) do { } while (0)
+#endif
+    NB_STAMP(0);
 
     // ---- weight stream ----------------------------------------------------------------------------------------------------
     // Stage s (16 KB = 8 pairs) lives in ring slot s % 3.  Timeline of a wave at stage g:  barrier g | fetch stage g+1+FD from
@@ -202,6 +210,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 x1[st][4 * q] = v.x; x1[st][4 * q + 1] = v.y; x1[st][4 * q + 2] = v.z; x1[st][4 * q + 3] = v.w;
             }
 
+        NB_STAMP(1);
         f32x16 acc_h[4], acc_x[4];
         // ---- stage P: x1 = x + msg . Wp^T + bp ------------------------------------------------------------------------------
         if (a.msg) {
@@ -233,6 +242,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
         }
 
+        NB_STAMP(2);
         // ---- stage M: x2 = x1 + fc2(GELU(fc1(LN2(x1)))) ------------------------------------------------------------------------
         if constexpr (MLP) {
             h16x8 bnh[8], bnl[8];                                              // LN2(x1) as the B operand of fc1 (k = channel)
@@ -279,6 +289,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 stage_end();
             };
             f32x16 fa_h, fa_x, fb_h, fb_x;
+            NB_STAMP(3);
             fc1(fa_h, fa_x);
 #pragma unroll 1
             for (int hs = 0; hs < 16; hs += 2) {
@@ -300,11 +311,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
             }
         }
+        NB_STAMP(4);
         if (a.x_out) {
 #pragma unroll
             for (int st = 0; st < 4; ++st) stage_strip(x1[st], st * 32);
             flush_rows(a.x_out, 128, 0, t0);
         }
+        NB_STAMP(5);
 
         // ---- stage Q: next block's q|k|v (or the final norm) ---------------------------------------------------------------------
         if constexpr (KQC > 0) {
@@ -329,6 +342,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     split8(v, bqh[c], bql[c]);
                 }
             }
+            NB_STAMP(6);
             if (a.q_out) {
                 const int n_groups = a.NQ >> 7;                                // 128 output columns = 4 strips per group
 #pragma unroll 1
@@ -357,10 +371,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         stage_strip(ov, sl * 32);
                     });
                     flush_rows(a.q_out, a.NQ, g * 128, t0);
+                    NB_STAMP(7 + g);
                 }
             }
         }
     }
+    NB_STAMP(15);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -401,6 +417,10 @@ extern "C" int nmrf_pack_split_weight_f32(const float *w, int N, int K, int Kp, 
 #ifdef NMRF_DEBUG_PROBES
 static int g_nb_variant = 0;      // pipeline-depth variants for tools/kernel_bench.py --which block
 extern "C" int nmrf_debug_nmp_block_variant(int v) { g_nb_variant = v; return NMRF_OK; }
+static unsigned long long *g_nb_stamps = nullptr;
+extern "C" int nmrf_debug_nmp_block_timing(unsigned long long *stamps) { g_nb_stamps = stamps; return NMRF_OK; }
+#else
+static unsigned long long *const g_nb_stamps = nullptr;
 #endif
 
 template <bool MLP, int KQC, int FD, int PF>
@@ -458,7 +478,7 @@ extern "C" int nmrf_nmp_block_f32(const float *x, const float *msg, const void *
     const int want = (msg ? 4 : 0) + (has_mlp ? 32 : 0) + (q_out ? (NQ / 128) * (KQ / 16) / 2 : 0);
     if (total_stages != want || total_stages < 1) return NMRF_EINVAL;
     NmpBlockArgs a{x, msg, reinterpret_cast<const u32x4 *>(stream_w), total_stages, bp, ln2_g, ln2_b, b1, b2, lnq_g, lnq_b, extra,
-                   extra_ld, extra_div, bq, x_out, q_out, ln_out, T, (int)ceil_div64(T, NB_TOK), eps2, epsq, NQ};
+                   extra_ld, extra_div, bq, x_out, q_out, ln_out, T, (int)ceil_div64(T, NB_TOK), eps2, epsq, NQ, g_nb_stamps};
     hipStream_t st = (hipStream_t)stream;
     const int kqc = KQ / 16;
     if (has_mlp) {

@@ -66,6 +66,25 @@ if "block" in which:
         _l.nmrf_debug_nmp_block_variant(var)
         timeit("nmp_block proj+mlp+qkv " + tag, lambda: K.nmp_block(x, stream, stages, msg, bp, (g, be, 1e-5, b1, b2), qd))
     _l.nmrf_debug_nmp_block_variant(0)
+    import numpy as np
+    stamps = torch.zeros(64 * 4 * 16, dtype=torch.int64, device=dev)
+    _l.nmrf_debug_nmp_block_timing.restype = ctypes.c_int
+    _l.nmrf_debug_nmp_block_timing(ctypes.c_void_p(stamps.data_ptr()))
+    K.nmp_block(x, stream, stages, msg, bp, (g, be, 1e-5, b1, b2), qd)
+    torch.cuda.synchronize()
+    _l.nmrf_debug_nmp_block_timing(None)
+    st = stamps.cpu().numpy().reshape(64, 4, 16).astype(np.int64)
+    names = {1: "prologue (2 stages to LDS, barrier)", 2: "x/msg loads + split + proj stage (4 stages, 96 MFMAs)",
+             3: "LN2 + split + park x1", 4: "MLP (32 stages, 768 MFMAs)", 5: "x_out staging + row stores",
+             6: "LNq + extra loads + split", 7: "q group 0 (5 stages, 120 MFMAs)", 8: "q group 1", 9: "q group 2", 15: "tail"}
+    prev = 0
+    print("nmp_block phases, s_memtime ticks (100 MHz = 10 ns), median over 64 blocks x 4 waves:")
+    for k in (1, 2, 3, 4, 5, 6, 7, 8, 9, 15):
+        d = (st[:, :, k] - st[:, :, prev]).reshape(-1)
+        print("   %-52s median %7.0f  min %7.0f  max %7.0f ticks" % (names[k], np.median(d), d.min(), d.max()))
+        prev = k
+    tot = (st[:, :, 15] - st[:, :, 0]).reshape(-1)
+    print("   total per wave: median %.0f ticks; first-start to last-end over blocks: %.0f ticks" % (np.median(tot), st[:, :, 15].max() - st[:, :, 0].min()))
     s2, st2 = K.block_stream(wp, None, None, wq, 160)
     timeit("nmp_block proj+qkv (self block)", lambda: K.nmp_block(x, s2, st2, msg, bp, None, qd))
     s3, st3 = K.block_stream(None, None, None, wq, 160)
