@@ -27,7 +27,7 @@ extern "C" {
 
 const char *nmrf_strerror(int code);
 /* ABI version of this header; bumps on any signature change. */
-int nmrf_abi_version(void);   /* currently 10 */
+int nmrf_abi_version(void);   /* currently 11 */
 
 /* A2  group-wise correlation volume.
  * replaces build_correlation_volume + the permute of DPN.forward
@@ -208,18 +208,21 @@ int nmrf_msda_backward_f64(const double *value, const int64_t *shapes, const int
  *                         W1[0] | W1[1], W2s[0] | W1[2], W2s[1] | ... | W1[15], W2s[14] | W2s[15],   W1[h] = pairs (h, 0..7),
  *                         W2s[h] = pairs (strip n, chunk 2h + c) for n = 0..3, c = 0..1                   32 stages
  *   q      (q_out)      : Wq [NQ,KQ] pairs (strip, chunk) in strip-major order                           NQ/128 * KQ/32 stages
- * total_stages must equal the sum.  Biases / LayerNorm parameters are plain fp32 vectors. */
+ * total_stages must equal the sum.  Biases / LayerNorm parameters are plain fp32 vectors.  inv_scales: HOST array of 4 floats,
+ * 1 / scale the proj, fc1, fc2 and q weights were packed with (nmrf_pack_split_weight_f32; unused entries ignored). */
 int nmrf_nmp_block_f32(const float *x, const float *msg, const void *stream_w, int total_stages, const float *bp,
                        const float *ln2_g, const float *ln2_b, float eps2, const float *b1, const float *b2,
                        const float *lnq_g, const float *lnq_b, float epsq, const float *extra, int extra_ld,
-                       int extra_div, const float *bq, int has_mlp, int KQ, int NQ, int64_t T, float *x_out,
-                       float *q_out, float *ln_out, void *stream);
+                       int extra_div, const float *bq, int has_mlp, int KQ, int NQ, int64_t T, const float *inv_scales,
+                       float *x_out, float *q_out, float *ln_out, void *stream);
 
 /* Weight packing for nmrf_nmp_block_f32: w [N,K] row-major fp32 (an nn.Linear weight) -> N/32 x Kp/16 pairs of 2 KB in
- * [strip][chunk] order; a pair = [64 lanes][8 fp16] hi parts then the same for the rescaled lo parts (csrc/split_mfma.h);
- * lane (i = l & 31, h = l >> 5) slot jj holds w[32*strip + i][16*chunk + (jj&3) + 8*(jj>>2) + 4*h], zero beyond K.
+ * [strip][chunk] order; a pair = [64 lanes][8 fp16] hi parts then the same for the lo parts (lo = fp16(w - hi), csrc/split_mfma.h);
+ * lane (i = l & 31, h = l >> 5) slot jj holds scale * w[32*strip + i][16*chunk + (jj&3) + 8*(jj>>2) + 4*h], zero beyond K.
+ * scale: a power of two that brings the largest |w| into [2^13, 2^14) (exact; the kernel multiplies the contraction by 1/scale):
+ * the low parts of every weight are then normal fp16 numbers.
  * out: N * Kp * 4 bytes.  N % 32 == 0, Kp % 16 == 0, Kp >= K. */
-int nmrf_pack_split_weight_f32(const float *w, int N, int K, int Kp, void *out, void *stream);
+int nmrf_pack_split_weight_f32(const float *w, int N, int K, int Kp, float scale, void *out, void *stream);
 
 /* Self-test: fills out[32*32] with the 32x32 product A*B computed by one wave of
  * v_mfma_f32_32x32x2_f32 (A [32,K], B [K,32] row-major, K even <= 64); pins the operand/accumulator

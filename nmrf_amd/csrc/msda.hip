@@ -307,6 +307,7 @@ extern "C" int nmrf_debug_mfma_peak(int chains, int iters, int blocks, float *ou
 //   mode 0: the full split product (3 MFMAs per 16-deep chunk, two accumulators) -- accuracy + lane layout
 //   mode 1: hi parts only (plain fp16 product) -- what the split buys, and how fp16 subnormal inputs are treated
 //   mode 2: like 0 with the k slots in C/D order (split_kslot) on BOTH operands -- the order chained GEMMs use
+//   mode 3: single-accumulator form (split8u / split_mma1): unscaled low parts, A multiplied by 2^10 like a packed weight
 __global__ __launch_bounds__(64) void selftest_mfma_f16split_kernel(const float *__restrict__ A, const float *__restrict__ Bm,
                                                                    int K, int mode, float *__restrict__ out) {
     const int lane = threadIdx.x, i = lane & 31, hi = lane >> 5;
@@ -322,18 +323,27 @@ __global__ __launch_bounds__(64) void selftest_mfma_f16split_kernel(const float 
             bv[jj] = Bm[k * 32 + i];
         }
         h16x8 ah, al, bh, bl;
+        if (mode == 3) {
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) av[jj] *= 1024.0f;
+            split8u(av, ah, al);
+            split8u(bv, bh, bl);
+            split_mma1(ah, al, bh, bl, acc_hh);
+            continue;
+        }
         split8(av, ah, al);
         split8(bv, bh, bl);
         if (mode == 1) acc_hh = mfma16h(ah, bh, acc_hh);
         else split_mma(ah, al, bh, bl, acc_hh, acc_x);
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) out[mfma_row(r, hi) * 32 + i] = acc_hh[r] + SPLIT_LO_INV * acc_x[r];
+    for (int r = 0; r < 16; ++r)
+        out[mfma_row(r, hi) * 32 + i] = mode == 3 ? acc_hh[r] * (1.0f / 1024.0f) : acc_hh[r] + SPLIT_LO_INV * acc_x[r];
 }
 
 extern "C" int nmrf_selftest_mfma_f16split(const float *A, const float *Bm, int K, int mode, float *out, void *stream) {
     if (!A || !Bm || !out) return NMRF_ENULL;
-    if (K < 16 || K > 1024 || (K & 15) || mode < 0 || mode > 2) return NMRF_EINVAL;
+    if (K < 16 || K > 1024 || (K & 15) || mode < 0 || mode > 3) return NMRF_EINVAL;
     hipLaunchKernelGGL(selftest_mfma_f16split_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, Bm, K, mode, out);
     return nmrf_launch_status();
 }
@@ -367,4 +377,4 @@ extern "C" const char *nmrf_strerror(int code) {
     }
 }
 
-extern "C" int nmrf_abi_version(void) { return 10; }
+extern "C" int nmrf_abi_version(void) { return 11; }

@@ -33,6 +33,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));    // (HIP's uin
 #define NB_RING 3
 #define NB_FD 1                    // default pipeline depths of the product build (see the kernel template)
 #define NB_PF 2
+#define NB_TOUCH_AHEAD 4           // stages between the L2 touch and the real fetch of a stage
+#define NB_DUMP_OFF (NB_RING * NB_STAGE_U4 * 16 + 4 * 32 * NB_OLD * 4)     // 1 KB of LDS the touch loads land in (never read)
 #define NB_OLD 132                 // floats per row of the output staging tile (128 + 4: conflict-free b128 writes)
 
 template <class F, int... I>
@@ -62,13 +64,14 @@ struct NmpBlockArgs {
     int n_tiles;
     float eps2, epsq;
     int NQ;
+    float inv_p, inv_1, inv_2, inv_q;   // 1 / (power-of-two scale the proj / fc1 / fc2 / q weights were packed with)
     unsigned long long *stamps;   // debug build (nmrf_debug_nmp_block_timing): s_memtime per wave and phase of the first 64 blocks
 };
 
 // MLP: run the fc1-GELU-fc2 stage.  KQC: k chunks (of 16) of the q stage's operand [LNq(x2) | extra]: 0 = no q stage,
 // 8 = LayerNorm columns only, 10 = + 32 side columns (Fourier31 + 0), 12 = + 64 side columns (context).
-// FD: stages of latency budget of the global fetch (1 or 2 register sets); PF: pairs read ahead from LDS.
-template <bool MLP, int KQC, int FD, int PF>
+// FD: stages of latency budget of the global fetch (1 or 2 register sets); PF: pairs read ahead from LDS; TOUCH: L2 warming.
+template <bool MLP, int KQC, int FD, int PF, bool TOUCH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void nmp_block_kernel(NmpBlockArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4 *ring = reinterpret_cast<u32x4 *>(smem);                                        // [3][1024] x 16 B
@@ -85,13 +88,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     NB_STAMP(0);
 
     // ---- weight stream ----------------------------------------------------------------------------------------------------
-    // Stage s (16 KB = 8 pairs) lives in ring slot s % 3.  Timeline of a wave at stage g:  barrier g | fetch stage g+1+FD from
-    // global into registers | consume stage g (its first PF pairs were read from LDS during stage g-1) while reading the first
-    // PF pairs of stage g+1 ahead | commit stage g+2 (fetched FD stages ago) to slot (g+2) % 3 = the slot stage g-1 vacated.
+    // Stage s (16 KB = 8 pairs) lives in ring slot s % 3.  Timeline of a wave at stage g:  barrier g | consume stage g (its
+    // first PF pairs were read from LDS during stage g-1) while reading the first PF pairs of stage g+1 ahead | commit stage g+2
+    // (in registers since the end of stage g-FD) to slot (g+2) % 3 = the slot stage g-1 vacated | fetch stage g+2+FD.
     // Barrier g orders: every wave has finished reading stage g-1, and stage g+1 (committed during stage g-1) is visible.
+    // All blocks walk the stream in step, so without help every stage would be an L2 miss for everybody (measured: ~2.4k
+    // cycles per stage whatever the work in it).  TOUCH: wave 0 of each block pulls 1 KB of the stage TOUCH_AHEAD stages
+    // further on into L2 with an LDS-DMA load nobody reads (no register, no wait); blocks on the same XCD (blockIdx % 8) touch
+    // different sixteenths, so the stage is in their shared L2 when the real fetch comes.
     u32x4 R[FD][4];
     int src_stage = 0;                          // next stage to fetch from global (wraps: persistent blocks re-read the stream)
     int wr_slot = 0, rd_slot = 0;               // ring slots of the next commit / of the stage being consumed
+    int par = 0;                                // register set of the next commit (FD == 2)
     auto fetch = [&](u32x4 (&r)[4]) {
         const u32x4 *p = a.stream + (size_t)src_stage * NB_STAGE_U4 + tid;
 #pragma unroll
@@ -110,17 +118,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         h = *reinterpret_cast<const h16x8 *>(base + p * 128 + lane);
         l = *reinterpret_cast<const h16x8 *>(base + p * 128 + 64 + lane);
     };
+    const int touch_slice = (blockIdx.x >> 3) & 15;
+    auto touch = [&]() {
+        if constexpr (TOUCH) {
+            if (wv == 0) {
+                int ts = src_stage + NB_TOUCH_AHEAD;
+                if (ts >= a.total_stages) ts -= a.total_stages;
+                if (ts >= a.total_stages) ts -= a.total_stages;
+                const u32x4 *p = a.stream + (size_t)ts * NB_STAGE_U4 + touch_slice * 64 + lane;
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(p), "s"(NB_DUMP_OFF) : "memory", "m0");
+            }
+        }
+    };
     bool have_barrier = true;                   // the barrier of the very first stage is the one in the prologue
     auto stage_top = [&]() {
         if (!have_barrier) __syncthreads();
         have_barrier = false;
-        fetch(R[FD - 1]);
+        touch();
     };
     auto stage_end = [&]() {
-        commit(R[0]);
         if constexpr (FD == 2) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) R[0][i] = R[1][i];
+            if (par) { commit(R[1]); fetch(R[1]); } else { commit(R[0]); fetch(R[0]); }
+            par ^= 1;
+        } else {
+            commit(R[0]);
+            fetch(R[0]);
         }
         rd_slot = (rd_slot == NB_RING - 1) ? 0 : rd_slot + 1;
         cur = nxt;
@@ -128,17 +150,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
     // pair P (compile-time, 0..7) of the current stage: take it from the queue, refill the queue entry with pair P + PF (of this
     // stage or the next), then run the three MFMAs
-    auto consume = [&](auto pc, const h16x8 &bh, const h16x8 &bl, f32x16 &acc_hh, f32x16 &acc_xx) {
+    auto consume = [&](auto pc, const h16x8 &bh, const h16x8 &bl, f32x16 &acc) {
         constexpr int P = decltype(pc)::value;
         const h16x8 ah = fqh[P % PF], al = fql[P % PF];
         if constexpr (P + PF < 8) read_pair(cur, P + PF, fqh[P % PF], fql[P % PF]);
         else read_pair(nxt, P + PF - 8, fqh[P % PF], fql[P % PF]);
-        split_mma(ah, al, bh, bl, acc_hh, acc_xx);
+        split_mma1(ah, al, bh, bl, acc);
     };
 
     fetch(R[0]); commit(R[0]);                  // stage 0 -> slot 0
     fetch(R[0]); commit(R[0]);                  // stage 1 -> slot 1
-    if constexpr (FD == 2) fetch(R[0]);         // stage 2 waits in R[0]; stage 3 goes to R[1] at the top of stage 0
+    fetch(R[0]);                                // stage 2, committed at the end of stage 0
+    if constexpr (FD == 2) fetch(R[1]);         // stage 3, committed at the end of stage 1
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < PF; ++p) read_pair(cur, p, fqh[p], fql[p]);
@@ -211,7 +234,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
 
         NB_STAMP(1);
-        f32x16 acc_h[4], acc_x[4];
+        f32x16 acc[4];
         // ---- stage P: x1 = x + msg . Wp^T + bp ------------------------------------------------------------------------------
         if (a.msg) {
             h16x8 bmh[8], bml[8];
@@ -219,14 +242,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int c = 0; c < 8; ++c) {
                 const float4 v0 = ldg4(a.msg + tc * 128 + 16 * c + 4 * hi), v1 = ldg4(a.msg + tc * 128 + 16 * c + 8 + 4 * hi);
                 const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                split8(v, bmh[c], bml[c]);
+                split8u(v, bmh[c], bml[c]);
             }
             nb_static_for<4>([&](auto ss) {
                 constexpr int st = decltype(ss)::value;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc_h[st][r] = acc_x[st][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[st][r] = 0.f;
                 stage_top();
-                nb_static_for<8>([&](auto cc) { consume(cc, bmh[decltype(cc)::value], bml[decltype(cc)::value], acc_h[st], acc_x[st]); });
+                nb_static_for<8>([&](auto cc) { consume(cc, bmh[decltype(cc)::value], bml[decltype(cc)::value], acc[st]); });
                 stage_end();
             });
 #pragma unroll
@@ -237,8 +260,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     if (a.bp) bv = ldg4(a.bp + st * 32 + 8 * q + 4 * hi);
                     const float b4[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        x1[st][4 * q + e] += fmaf(SPLIT_LO_INV, acc_x[st][4 * q + e], acc_h[st][4 * q + e]) + b4[e];
+                    for (int e = 0; e < 4; ++e) x1[st][4 * q + e] += fmaf(acc[st][4 * q + e], a.inv_p, b4[e]);
                 }
         }
 
@@ -250,7 +272,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 float ln[4][16];
                 layer_norm(x1, a.ln2_g, a.ln2_b, a.eps2, ln);
 #pragma unroll
-                for (int c = 0; c < 8; ++c) split8(&ln[c >> 1][8 * (c & 1)], bnh[c], bnl[c]);
+                for (int c = 0; c < 8; ++c) split8u(&ln[c >> 1][8 * (c & 1)], bnh[c], bnl[c]);
             }
             // x1 waits in the wave's LDS tile while the 512-wide hidden layer occupies the registers
 #pragma unroll
@@ -258,45 +280,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int st = 0; st < 4; ++st)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc_h[st][r] = acc_x[st][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[st][r] = 0.f;
             // hidden strip hs (32 of the 512 hidden channels): fc1 -> fh/fx, GELU, then its 2 k chunks of fc2 into all 4 output
             // strips.  Stream order: W1[0] | W1[1], W2s[0] | W1[2], W2s[1] | ... | W1[15], W2s[14] | W2s[15]: the MFMAs of
             // fc1(hs+1) are issued before GELU(hs) so that the activation's VALU work runs under them.
-            auto fc1 = [&](f32x16 &fh, f32x16 &fx) {
+            auto fc1 = [&](f32x16 &fh) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) fh[r] = fx[r] = 0.f;
+                for (int r = 0; r < 16; ++r) fh[r] = 0.f;
                 stage_top();
-                nb_static_for<8>([&](auto cc) { consume(cc, bnh[decltype(cc)::value], bnl[decltype(cc)::value], fh, fx); });
+                nb_static_for<8>([&](auto cc) { consume(cc, bnh[decltype(cc)::value], bnl[decltype(cc)::value], fh); });
                 stage_end();
             };
-            auto act_fc2 = [&](int hs, const f32x16 &fh, const f32x16 &fx) {
+            auto act_fc2 = [&](int hs, const f32x16 &fh) {
                 float hv[16];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float4 bv = ldg4(a.b1 + hs * 32 + 8 * q + 4 * hi);
                     const float b4[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) hv[4 * q + e] = gelu_fast(fmaf(SPLIT_LO_INV, fx[4 * q + e], fh[4 * q + e]) + b4[e]);
+                    for (int e = 0; e < 4; ++e) hv[4 * q + e] = gelu_fast(fmaf(fh[4 * q + e], a.inv_1, b4[e]));
                 }
                 h16x8 hh[2], hl[2];
-                split8(hv, hh[0], hl[0]);
-                split8(hv + 8, hh[1], hl[1]);
+                split8u(hv, hh[0], hl[0]);
+                split8u(hv + 8, hh[1], hl[1]);
                 stage_top();
                 nb_static_for<8>([&](auto cc) {
                     constexpr int p = decltype(cc)::value;                     // pair p = (output strip p / 2, k chunk p % 2)
-                    consume(cc, hh[p & 1], hl[p & 1], acc_h[p >> 1], acc_x[p >> 1]);
+                    consume(cc, hh[p & 1], hl[p & 1], acc[p >> 1]);
                 });
                 stage_end();
             };
-            f32x16 fa_h, fa_x, fb_h, fb_x;
+            f32x16 fa, fb;
             NB_STAMP(3);
-            fc1(fa_h, fa_x);
+            fc1(fa);
 #pragma unroll 1
             for (int hs = 0; hs < 16; hs += 2) {
-                fc1(fb_h, fb_x);
-                act_fc2(hs, fa_h, fa_x);
-                if (hs + 2 < 16) fc1(fa_h, fa_x);
-                act_fc2(hs + 1, fb_h, fb_x);
+                fc1(fb);
+                act_fc2(hs, fa);
+                if (hs + 2 < 16) fc1(fa);
+                act_fc2(hs + 1, fb);
             }
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
@@ -306,8 +328,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     const float4 bv = ldg4(a.b2 + st * 32 + 8 * q + 4 * hi);
                     const float b4[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        x1[st][4 * q + e] += fmaf(SPLIT_LO_INV, acc_x[st][4 * q + e], acc_h[st][4 * q + e]) + b4[e];
+                    for (int e = 0; e < 4; ++e) x1[st][4 * q + e] += fmaf(acc[st][4 * q + e], a.inv_2, b4[e]);
                 }
             }
         }
@@ -331,7 +352,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     flush_rows(a.ln_out, 128, 0, t0);
                 }
 #pragma unroll
-                for (int c = 0; c < 8; ++c) split8(&ln[c >> 1][8 * (c & 1)], bqh[c], bql[c]);
+                for (int c = 0; c < 8; ++c) split8u(&ln[c >> 1][8 * (c & 1)], bqh[c], bql[c]);
             }
             if constexpr (KQC > 8) {
                 const float *e = a.extra + (tc / a.extra_div) * a.extra_ld;
@@ -339,7 +360,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int c = 8; c < KQC; ++c) {
                     const float4 v0 = ldg4(e + 16 * (c - 8) + 4 * hi), v1 = ldg4(e + 16 * (c - 8) + 8 + 4 * hi);
                     const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                    split8(v, bqh[c], bql[c]);
+                    split8u(v, bqh[c], bql[c]);
                 }
             }
             NB_STAMP(6);
@@ -349,14 +370,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int g = 0; g < n_groups; ++g) {
                     nb_static_for<4>([&](auto ss) {
                         constexpr int sl = decltype(ss)::value;
-                        f32x16 qh, qx;
+                        f32x16 qh;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) qh[r] = qx[r] = 0.f;
+                        for (int r = 0; r < 16; ++r) qh[r] = 0.f;
                         nb_static_for<KQC>([&](auto cc) {
                             constexpr int c = decltype(cc)::value;
                             constexpr int pg = sl * KQC + c;                   // pair index within the group: 8 pairs per stage
                             if constexpr (pg % 8 == 0) stage_top();
-                            consume(std::integral_constant<int, pg % 8>{}, bqh[c], bql[c], qh, qx);
+                            consume(std::integral_constant<int, pg % 8>{}, bqh[c], bql[c], qh);
                             if constexpr (pg % 8 == 7) stage_end();
                         });
                         float ov[16];
@@ -366,7 +387,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                             if (a.bq) bv = ldg4(a.bq + g * 128 + sl * 32 + 8 * q + 4 * hi);
                             const float b4[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
-                            for (int e2 = 0; e2 < 4; ++e2) ov[4 * q + e2] = fmaf(SPLIT_LO_INV, qx[4 * q + e2], qh[4 * q + e2]) + b4[e2];
+                            for (int e2 = 0; e2 < 4; ++e2) ov[4 * q + e2] = fmaf(qh[4 * q + e2], a.inv_q, b4[e2]);
                         }
                         stage_strip(ov, sl * 32);
                     });
@@ -383,7 +404,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // weight packing: W [N,K] row-major fp32 -> N/32 x Kp/16 pairs of 2 KB in [strip][chunk] order; pair = [64 lanes][8 fp16] hi
 // then the same for lo'; lane (i = l&31, h = l>>5) slot jj holds W[32*strip + i][16*chunk + split_kslot(jj, h)], 0 beyond K.
 // ------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_split_weight_kernel(const float *__restrict__ w, int N, int K, int KC,
+__global__ __launch_bounds__(256) void pack_split_weight_kernel(const float *__restrict__ w, int N, int K, int KC, float scale,
                                                                uint4 *__restrict__ out) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;           // one lane of one pair
     const int64_t total = (int64_t)(N / 32) * KC * 64;
@@ -396,21 +417,21 @@ __global__ __launch_bounds__(256) void pack_split_weight_kernel(const float *__r
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) {
         const int k = 16 * c + split_kslot(jj, h);
-        v[jj] = k < K ? w[(int64_t)n * K + k] : 0.f;
+        v[jj] = k < K ? w[(int64_t)n * K + k] * scale : 0.f;
     }
     h16x8 vh, vl;
-    split8(v, vh, vl);
+    split8u(v, vh, vl);
     out[pair * 128 + lane] = *reinterpret_cast<const uint4 *>(&vh);
     out[pair * 128 + 64 + lane] = *reinterpret_cast<const uint4 *>(&vl);
 }
 
-extern "C" int nmrf_pack_split_weight_f32(const float *w, int N, int K, int Kp, void *out, void *stream) {
+extern "C" int nmrf_pack_split_weight_f32(const float *w, int N, int K, int Kp, float scale, void *out, void *stream) {
     if (!w || !out) return NMRF_ENULL;
-    if (N < 32 || (N & 31) || K < 1 || Kp < K || (Kp & 15)) return NMRF_EINVAL;
+    if (N < 32 || (N & 31) || K < 1 || Kp < K || (Kp & 15) || !(scale > 0.f)) return NMRF_EINVAL;
     const int KC = Kp / 16;
     const int64_t total = (int64_t)(N / 32) * KC * 64;
     hipLaunchKernelGGL(pack_split_weight_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, w, N, K,
-                       KC, reinterpret_cast<uint4 *>(out));
+                       KC, scale, reinterpret_cast<uint4 *>(out));
     return nmrf_launch_status();
 }
 
@@ -423,15 +444,15 @@ extern "C" int nmrf_debug_nmp_block_timing(unsigned long long *stamps) { g_nb_st
 static unsigned long long *const g_nb_stamps = nullptr;
 #endif
 
-template <bool MLP, int KQC, int FD, int PF>
+template <bool MLP, int KQC, int FD, int PF, bool TOUCH>
 static int launch_nmp_block_v(const NmpBlockArgs &a, hipStream_t st) {
     static bool attr_set_dev[NMRF_MAX_DEV] = {};
     static int n_cu_dev[NMRF_MAX_DEV] = {};
     const int dev = nmrf_cur_device();
     if (dev < 0) return NMRF_ELAUNCH;
-    const size_t lds = (size_t)NB_RING * NB_STAGE_U4 * 16 + (size_t)4 * 32 * NB_OLD * sizeof(float);
+    const size_t lds = (size_t)NB_DUMP_OFF + 1024;
     if (!attr_set_dev[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(nmp_block_kernel<MLP, KQC, FD, PF>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(nmp_block_kernel<MLP, KQC, FD, PF, TOUCH>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return NMRF_ELAUNCH;
         attr_set_dev[dev] = true;
@@ -442,7 +463,7 @@ static int launch_nmp_block_v(const NmpBlockArgs &a, hipStream_t st) {
         n_cu_dev[dev] = prop.multiProcessorCount;
     }
     const int grid = a.n_tiles < n_cu_dev[dev] ? a.n_tiles : n_cu_dev[dev];
-    hipLaunchKernelGGL((nmp_block_kernel<MLP, KQC, FD, PF>), dim3(grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((nmp_block_kernel<MLP, KQC, FD, PF, TOUCH>), dim3(grid), dim3(256), lds, st, a);
     return nmrf_launch_status();
 }
 
@@ -450,22 +471,21 @@ template <bool MLP, int KQC>
 static int launch_nmp_block(const NmpBlockArgs &a, hipStream_t st) {
 #ifdef NMRF_DEBUG_PROBES
     switch (g_nb_variant) {
-        case 1: return launch_nmp_block_v<MLP, KQC, 2, 2>(a, st);
-        case 2: return launch_nmp_block_v<MLP, KQC, 1, 1>(a, st);
-        case 3: return launch_nmp_block_v<MLP, KQC, 2, 3>(a, st);
-        case 4: return launch_nmp_block_v<MLP, KQC, 1, 3>(a, st);
+        case 1: return launch_nmp_block_v<MLP, KQC, 1, 2, false>(a, st);
+        case 2: return launch_nmp_block_v<MLP, KQC, 2, 2, true>(a, st);
+        case 3: return launch_nmp_block_v<MLP, KQC, 2, 2, false>(a, st);
         default: break;
     }
 #endif
-    return launch_nmp_block_v<MLP, KQC, NB_FD, NB_PF>(a, st);
+    return launch_nmp_block_v<MLP, KQC, NB_FD, NB_PF, true>(a, st);
 }
 
 extern "C" int nmrf_nmp_block_f32(const float *x, const float *msg, const void *stream_w, int total_stages, const float *bp,
                                   const float *ln2_g, const float *ln2_b, float eps2, const float *b1, const float *b2,
                                   const float *lnq_g, const float *lnq_b, float epsq, const float *extra, int extra_ld,
-                                  int extra_div, const float *bq, int has_mlp, int KQ, int NQ, int64_t T, float *x_out,
-                                  float *q_out, float *ln_out, void *stream) {
-    if (!x || !stream_w) return NMRF_ENULL;
+                                  int extra_div, const float *bq, int has_mlp, int KQ, int NQ, int64_t T, const float *inv_scales,
+                                  float *x_out, float *q_out, float *ln_out, void *stream) {
+    if (!x || !stream_w || !inv_scales) return NMRF_ENULL;
     if (T < 1 || ceil_div64(T, NB_TOK) > 0x7fffffff) return NMRF_EINVAL;
     if (has_mlp && (!ln2_g || !ln2_b || !b1 || !b2)) return NMRF_ENULL;
     if (KQ != 0 && KQ != 128 && KQ != 160 && KQ != 192) return NMRF_EINVAL;
@@ -478,7 +498,7 @@ extern "C" int nmrf_nmp_block_f32(const float *x, const float *msg, const void *
     const int want = (msg ? 4 : 0) + (has_mlp ? 32 : 0) + (q_out ? (NQ / 128) * (KQ / 16) / 2 : 0);
     if (total_stages != want || total_stages < 1) return NMRF_EINVAL;
     NmpBlockArgs a{x, msg, reinterpret_cast<const u32x4 *>(stream_w), total_stages, bp, ln2_g, ln2_b, b1, b2, lnq_g, lnq_b, extra,
-                   extra_ld, extra_div, bq, x_out, q_out, ln_out, T, (int)ceil_div64(T, NB_TOK), eps2, epsq, NQ, g_nb_stamps};
+                   extra_ld, extra_div, bq, x_out, q_out, ln_out, T, (int)ceil_div64(T, NB_TOK), eps2, epsq, NQ, inv_scales[0], inv_scales[1], inv_scales[2], inv_scales[3], g_nb_stamps};
     hipStream_t st = (hipStream_t)stream;
     const int kqc = KQ / 16;
     if (has_mlp) {

@@ -54,6 +54,33 @@ __device__ __forceinline__ void split_mma(h16x8 ah, h16x8 al, h16x8 bh, h16x8 bl
     acc_x = mfma16h(ah, bl, acc_x);
 }
 
+// ---- single-accumulator form ------------------------------------------------------------------------------------------------
+// gfx950's fp16 MFMA honours subnormal inputs (probed by nmrf_selftest_mfma_f16split mode 1: 2^-20 * 2^10 = 2^-10 exactly), so
+// the low part may stay unscaled, lo = rn_f16(a - hi), and all three products of a chunk go into ONE accumulator.  lo is a
+// normal fp16 number while |a| >= 2^-3 (22 significant bits in hi + lo); below that it is subnormal with spacing 2^-24, i.e. an
+// ABSOLUTE error <= 2^-25 = 3e-8 per element -- the size of one fp32 rounding of an O(1) accumulator.  Weights are multiplied
+// by a power of two at pack time (largest entry in [2^13, 2^14), exact, undone in the epilogue), so their low parts are normal
+// whatever their magnitude; activations are used as they are.  Half the accumulator registers, no combine step.
+__device__ __forceinline__ void split2u(f32x2 a, h16x2 &hi, h16x2 &lo) {
+    hi = __builtin_convertvector(a, h16x2);
+    lo = __builtin_convertvector(a - __builtin_convertvector(hi, f32x2), h16x2);
+}
+__device__ __forceinline__ void split8u(const float *v, h16x8 &hi, h16x8 &lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h16x2 h, l;
+        split2u(f32x2{v[2 * j], v[2 * j + 1]}, h, l);
+        hi[2 * j] = h[0]; hi[2 * j + 1] = h[1];
+        lo[2 * j] = l[0]; lo[2 * j + 1] = l[1];
+    }
+}
+// acc += Al*Bh + Ah*Bl + Ah*Bh (small terms first)
+__device__ __forceinline__ void split_mma1(h16x8 ah, h16x8 al, h16x8 bh, h16x8 bl, f32x16 &acc) {
+    acc = mfma16h(al, bh, acc);
+    acc = mfma16h(ah, bl, acc);
+    acc = mfma16h(ah, bh, acc);
+}
+
 // k slot order of a B operand that is taken straight from a C/D result (and of every A operand contracted with it):
 // slot jj (0..7) of half hi of k chunk c  <->  k = 16*c + (jj&3) + 8*(jj>>2) + 4*hi.  With this order the 16 registers of
 // a 32-row D strip ARE two consecutive k chunks of the next contraction (regs 0-7 -> chunk 0, regs 8-15 -> chunk 1): no

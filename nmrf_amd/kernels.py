@@ -308,38 +308,48 @@ def token_linear(x, packed_w, n, k, bias=None, ln=None, y=None, extra=None, extr
 
 @_on_device
 def pack_split_weight(weight, kp=None):
-    """[N,K] nn.Linear weight -> split-fp16 MFMA fragment pairs [N/32, Kp/16, 512] (int32 view of 2 KB pairs) for nmp_block."""
+    """[N,K] nn.Linear weight -> (split-fp16 MFMA fragment pairs [N/32, Kp/16, 512] (int32 view of 2 KB pairs), 1/scale) for
+    nmp_block.  scale = the power of two that brings max|w| into [2^13, 2^14) (host-side, once per parameter version)."""
+    import math
     _chk(weight)
     n, k = weight.shape
     kp = kp or (k + 15) // 16 * 16
+    amax = float(weight.abs().max())
+    scale = 1.0 if not (amax > 0 and math.isfinite(amax)) else 2.0 ** min(40, max(-40, math.floor(math.log2(16383.0 / amax))))
     out = torch.empty(n // 32, kp // 16, 512, device=weight.device, dtype=torch.int32)
-    _lib.check(_lib.load().nmrf_pack_split_weight_f32(_p(weight), n, k, kp, _p(out), _stream()), "pack_split_weight")
-    return out
+    _lib.check(_lib.load().nmrf_pack_split_weight_f32(_p(weight), n, k, kp, scale, _p(out), _stream()), "pack_split_weight")
+    return out, 1.0 / scale
 
 
 def block_stream(wp=None, w1=None, w2=None, wq=None, kq=0):
     """Weight stream of one nmp_block launch, in the kernel's consumption order (include/nmrf_hip.h, nmrf_nmp_block_f32):
-    proj pairs | W1 strips interleaved with W2 k-slices | q-stage pairs.  Returns (int32 tensor [stages*8, 512], stages)."""
+    proj pairs | W1 strips interleaved with W2 k-slices | q-stage pairs.
+    Returns (int32 tensor [stages*8, 512], stages, (1/scale of proj, fc1, fc2, q))."""
+    import ctypes
     parts = []
+    inv = [1.0, 1.0, 1.0, 1.0]
     if wp is not None:
-        parts.append(pack_split_weight(wp, 128).view(-1, 512))
+        pk, inv[0] = pack_split_weight(wp, 128)
+        parts.append(pk.view(-1, 512))
     if w1 is not None:
-        p1 = pack_split_weight(w1, 128)                                                  # [16 hidden strips][8 chunks]
-        p2 = pack_split_weight(w2, 512).view(4, 16, 2, 512).permute(1, 0, 2, 3).reshape(16, 8, 512)    # [hidden strip][n, c]
+        p1, inv[1] = pack_split_weight(w1, 128)                                          # [16 hidden strips][8 chunks]
+        p2, inv[2] = pack_split_weight(w2, 512)
+        p2 = p2.view(4, 16, 2, 512).permute(1, 0, 2, 3).reshape(16, 8, 512)             # [hidden strip][n, c]
         seq = [p1[0]]
         for h in range(15):
             seq += [p1[h + 1], p2[h]]
         seq.append(p2[15])
         parts.append(torch.stack(seq).view(-1, 512))
     if wq is not None:
-        parts.append(pack_split_weight(wq, kq).view(-1, 512))
+        pk, inv[3] = pack_split_weight(wq, kq)
+        parts.append(pk.view(-1, 512))
     stream = torch.cat(parts).contiguous()
     assert stream.shape[0] % 8 == 0
-    return stream, stream.shape[0] // 8
+    return stream, stream.shape[0] // 8, (ctypes.c_float * 4)(*inv)
 
 
 @_on_device
-def nmp_block(x, stream, stages, msg=None, bp=None, mlp=None, q=None, want_x=True):
+def nmp_block(x, stream, stages, inv_scales, msg=None, bp=None, mlp=None, q=None, want_x=True):
     """One fused message-passing block (nmrf_nmp_block_f32).
     mlp = (ln2_gamma, ln2_beta, eps, b1, b2) or None;  q = dict(g, b, eps, extra=None, extra_div=1, bias=None, kq=0|128|160|192,
     nq=0 -> no q_out, ln_out=False) or None.  Returns (x_out | None, q_out | None, ln_out | None)."""
@@ -374,7 +384,8 @@ def nmp_block(x, stream, stages, msg=None, bp=None, mlp=None, q=None, want_x=Tru
             pmc=["nmp_block_kernel<%s, %d>" % ("true" if mlp is not None else "false", kq // 16)])
     _lib.check(_lib.load().nmrf_nmp_block_f32(_p(x), _p(msg), _p(stream), stages, _p(bp), _p(ln2_g), _p(ln2_b), float(eps2), _p(b1),
                                               _p(b2), _p(lq_g), _p(lq_b), float(epsq), _p(extra), ld, div, _p(bq),
-                                              int(mlp is not None), kq, nq, t, _p(x_out), _p(q_out), _p(ln_out), _stream()),
+                                              int(mlp is not None), kq, nq, t, inv_scales, _p(x_out), _p(q_out), _p(ln_out),
+                                              _stream()),
                "nmp_block")
     if kernel_hook is not None:
         _he(name)

@@ -154,13 +154,13 @@ class _BlockLauncher:
             k = max(l.in_features for l in self.nxt_linears)
             wq = torch.cat([_pad_cols(l.weight, k) for l in self.nxt_linears], 0).contiguous()
             bq = torch.cat([l.bias for l in self.nxt_linears]).contiguous()
-        stream, stages = K.block_stream(None if self.proj is None else self.proj.weight.contiguous(),
-                                        None if self.mlp is None else self.mlp[1].fc1.weight.contiguous(),
-                                        None if self.mlp is None else self.mlp[1].fc2.weight.contiguous(), wq, self.kq)
-        return stream, stages, bq, (0 if wq is None else wq.shape[0])
+        stream, stages, inv = K.block_stream(None if self.proj is None else self.proj.weight.contiguous(),
+                                             None if self.mlp is None else self.mlp[1].fc1.weight.contiguous(),
+                                             None if self.mlp is None else self.mlp[1].fc2.weight.contiguous(), wq, self.kq)
+        return stream, stages, inv, bq, (0 if wq is None else wq.shape[0])
 
     def __call__(self, x, msg=None, extra=None, extra_div=1, want_x=True):
-        stream, stages, bq, nq = self.cache.get(self._params(), self._build)
+        stream, stages, inv, bq, nq = self.cache.get(self._params(), self._build)
         mlp = None
         if self.mlp is not None:
             n2, m = self.mlp
@@ -169,7 +169,7 @@ class _BlockLauncher:
         if self.nxt_norm is not None:
             q = dict(g=self.nxt_norm.weight, b=self.nxt_norm.bias, eps=self.nxt_norm.eps, extra=extra if self.kq > 128 else None,
                      extra_div=extra_div, bias=bq, kq=self.kq, nq=nq, ln_out=self.ln_out)
-        return K.nmp_block(x, stream, stages, msg, None if self.proj is None else self.proj.bias, mlp, q, want_x=want_x)
+        return K.nmp_block(x, stream, stages, inv, msg, None if self.proj is None else self.proj.bias, mlp, q, want_x=want_x)
 
 
 def _block_ok(*mods):

@@ -60,17 +60,17 @@ if "block" in which:
     wp, w1, w2, wq = mk("wp", 128, 128) * 0.1, mk("w1", 512, 128) * 0.1, mk("w2", 128, 512) * 0.05, mk("wq", 384, 159) * 0.1
     bp, b1, b2, bq = mk("bp", 128), mk("b1", 512), mk("b2", 128), mk("bq", 384)
     g, be = mk("g", 128) * 0.1 + 1, mk("bb", 128) * 0.1
-    stream, stages = K.block_stream(wp, w1, w2, wq, 160)
+    stream, stages, inv = K.block_stream(wp, w1, w2, wq, 160)
     qd = dict(g=g, b=be, eps=1e-5, extra=enc, extra_div=1, bias=bq, kq=160, nq=384)
-    for var, tag in ((0, "FD1 PF2 (product)"), (1, "FD2 PF2"), (2, "FD1 PF1"), (3, "FD2 PF3"), (4, "FD1 PF3")):
+    for var, tag in ((0, "FD1 touch (product)"), (1, "FD1 no touch"), (2, "FD2 touch"), (3, "FD2 no touch")):
         _l.nmrf_debug_nmp_block_variant(var)
-        timeit("nmp_block proj+mlp+qkv " + tag, lambda: K.nmp_block(x, stream, stages, msg, bp, (g, be, 1e-5, b1, b2), qd))
+        timeit("nmp_block proj+mlp+qkv " + tag, lambda: K.nmp_block(x, stream, stages, inv, msg, bp, (g, be, 1e-5, b1, b2), qd))
     _l.nmrf_debug_nmp_block_variant(0)
     import numpy as np
     stamps = torch.zeros(64 * 4 * 16, dtype=torch.int64, device=dev)
     _l.nmrf_debug_nmp_block_timing.restype = ctypes.c_int
     _l.nmrf_debug_nmp_block_timing(ctypes.c_void_p(stamps.data_ptr()))
-    K.nmp_block(x, stream, stages, msg, bp, (g, be, 1e-5, b1, b2), qd)
+    K.nmp_block(x, stream, stages, inv, msg, bp, (g, be, 1e-5, b1, b2), qd)
     torch.cuda.synchronize()
     _l.nmrf_debug_nmp_block_timing(None)
     st = stamps.cpu().numpy().reshape(64, 4, 16).astype(np.int64)
@@ -85,12 +85,12 @@ if "block" in which:
         prev = k
     tot = (st[:, :, 15] - st[:, :, 0]).reshape(-1)
     print("   total per wave: median %.0f ticks; first-start to last-end over blocks: %.0f ticks" % (np.median(tot), st[:, :, 15].max() - st[:, :, 0].min()))
-    s2, st2 = K.block_stream(wp, None, None, wq, 160)
-    timeit("nmp_block proj+qkv (self block)", lambda: K.nmp_block(x, s2, st2, msg, bp, None, qd))
-    s3, st3 = K.block_stream(None, None, None, wq, 160)
-    timeit("nmp_block qkv only", lambda: K.nmp_block(x, s3, st3, None, None, None, qd, want_x=False))
-    s4, st4 = K.block_stream(wp, w1, w2, None, 0)
-    timeit("nmp_block proj+mlp", lambda: K.nmp_block(x, s4, st4, msg, bp, (g, be, 1e-5, b1, b2), None))
+    s2, st2, i2 = K.block_stream(wp, None, None, wq, 160)
+    timeit("nmp_block proj+qkv (self block)", lambda: K.nmp_block(x, s2, st2, i2, msg, bp, None, qd))
+    s3, st3, i3 = K.block_stream(None, None, None, wq, 160)
+    timeit("nmp_block qkv only", lambda: K.nmp_block(x, s3, st3, i3, None, None, None, qd, want_x=False))
+    s4, st4, i4 = K.block_stream(wp, w1, w2, None, 0)
+    timeit("nmp_block proj+mlp", lambda: K.nmp_block(x, s4, st4, i4, msg, bp, (g, be, 1e-5, b1, b2), None))
     pwp, pw1, pwq = (K.pack_linear_weight(v.contiguous()) for v in (wp, w1, wq))
     enc31 = enc[:, :31].contiguous()
 
