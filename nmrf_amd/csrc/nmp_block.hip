@@ -32,9 +32,20 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));    // (HIP's uin
 #define NB_STAGE_U4 1024           // uint4 per stage (16 KB = 8 pairs)
 #define NB_RING 3
 #define NB_FD 1                    // default pipeline depths of the product build (see the kernel template)
-#define NB_PF 2
+#define NB_PF 4
 #define NB_TOUCH_AHEAD 4           // stages between the L2 touch and the real fetch of a stage
 #define NB_DUMP_OFF (NB_RING * NB_STAGE_U4 * 16 + 4 * 32 * NB_OLD * 4)     // 1 KB of LDS the touch loads land in (never read)
+#define NB_PAR_OFF (NB_DUMP_OFF + 1024)                                    // bias / LayerNorm vectors, staged once per block
+// float offsets inside the parameter area
+#define NBP_BP 0
+#define NBP_G2 128
+#define NBP_B2N 256
+#define NBP_B1 384
+#define NBP_B2 896
+#define NBP_GQ 1024
+#define NBP_BQN 1152
+#define NBP_BQ 1280
+#define NBP_FLOATS (1280 + 512)
 #define NB_OLD 132                 // floats per row of the output staging tile (128 + 4: conflict-free b128 writes)
 
 template <class F, int... I>
@@ -71,7 +82,7 @@ struct NmpBlockArgs {
 // MLP: run the fc1-GELU-fc2 stage.  KQC: k chunks (of 16) of the q stage's operand [LNq(x2) | extra]: 0 = no q stage,
 // 8 = LayerNorm columns only, 10 = + 32 side columns (Fourier31 + 0), 12 = + 64 side columns (context).
 // FD: stages of latency budget of the global fetch (1 or 2 register sets); PF: pairs read ahead from LDS; TOUCH: L2 warming.
-template <bool MLP, int KQC, int FD, int PF, bool TOUCH>
+template <bool MLP, int KQC, int FD, int PF, bool TOUCH, int DBG = 0>      // DBG: timing experiments of the debug build (wrong results)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void nmp_block_kernel(NmpBlockArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     u32x4 *ring = reinterpret_cast<u32x4 *>(smem);                                        // [3][1024] x 16 B
@@ -79,6 +90,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, hi = lane >> 5;
     float *Ot = reinterpret_cast<float *>(smem + NB_RING * NB_STAGE_U4 * 16) + wv * 32 * NB_OLD;   // wave-private [32][132]
+    // Biases and LayerNorm vectors live in LDS: read from global inside the stage loop they would queue behind the weight-stream
+    // fetches on the in-order vmcnt counter, and every bias wait would expose a full L2 round trip (measured: the stage loop
+    // ran at 60 cycles per MFMA with the loads in it).
+    float *Par = reinterpret_cast<float *>(smem + NB_PAR_OFF);
+    {
+        auto put = [&](int off, const float *src, int n) {
+            for (int i = tid; i < n; i += 256) Par[off + i] = src ? src[i] : 0.f;
+        };
+        put(NBP_BP, a.bp, 128); put(NBP_G2, a.ln2_g, 128); put(NBP_B2N, a.ln2_b, 128); put(NBP_B1, a.b1, 512);
+        put(NBP_B2, a.b2, 128); put(NBP_GQ, a.lnq_g, 128); put(NBP_BQN, a.lnq_b, 128); put(NBP_BQ, a.bq, a.bq ? a.NQ : 512);
+    }
+    auto par4 = [&](int off) { return *reinterpret_cast<const f32x4 *>(Par + off); };
 #ifdef NMRF_DEBUG_PROBES
 #define NB_STAMP(k) do { if (a.stamps && lane == 0 && blockIdx.x < 64) \
         a.stamps[((size_t)blockIdx.x * 4 + wv) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -92,10 +115,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // first PF pairs were read from LDS during stage g-1) while reading the first PF pairs of stage g+1 ahead | commit stage g+2
     // (in registers since the end of stage g-FD) to slot (g+2) % 3 = the slot stage g-1 vacated | fetch stage g+2+FD.
     // Barrier g orders: every wave has finished reading stage g-1, and stage g+1 (committed during stage g-1) is visible.
-    // All blocks walk the stream in step, so without help every stage would be an L2 miss for everybody (measured: ~2.4k
-    // cycles per stage whatever the work in it).  TOUCH: wave 0 of each block pulls 1 KB of the stage TOUCH_AHEAD stages
-    // further on into L2 with an LDS-DMA load nobody reads (no register, no wait); blocks on the same XCD (blockIdx % 8) touch
-    // different sixteenths, so the stage is in their shared L2 when the real fetch comes.
+    // TOUCH (experiment, off in the product build: no measurable effect, 72.3 vs 72.2 us): wave 0 of each block pulls 1 KB of the
+    // stage TOUCH_AHEAD stages further on into L2 with an LDS-DMA load nobody reads; blocks on the same XCD (blockIdx % 8) touch
+    // different sixteenths.
     u32x4 R[FD][4];
     int src_stage = 0;                          // next stage to fetch from global (wraps: persistent blocks re-read the stream)
     int wr_slot = 0, rd_slot = 0;               // ring slots of the next commit / of the stage being consumed
@@ -131,19 +153,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     };
     bool have_barrier = true;                   // the barrier of the very first stage is the one in the prologue
+#ifdef NMRF_DEBUG_PROBES
+    unsigned long long tk_bar = 0, tk_use = 0, tk_commit = 0, tk0 = 0, tk1 = 0;     // per-wave totals: barrier wait / consume / commit+fetch
+#define NB_TICK(v) do { if (a.stamps) v = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define NB_TICK(v) do { } while (0)
+#endif
     auto stage_top = [&]() {
-        if (!have_barrier) __syncthreads();
+#ifdef NMRF_DEBUG_PROBES
+        NB_TICK(tk0);
+#endif
+        if (!have_barrier && !(DBG & 1)) __syncthreads();
         have_barrier = false;
         touch();
+#ifdef NMRF_DEBUG_PROBES
+        NB_TICK(tk1);
+        tk_bar += tk1 - tk0;
+#endif
     };
     auto stage_end = [&]() {
-        if constexpr (FD == 2) {
-            if (par) { commit(R[1]); fetch(R[1]); } else { commit(R[0]); fetch(R[0]); }
-            par ^= 1;
-        } else {
-            commit(R[0]);
-            fetch(R[0]);
+#ifdef NMRF_DEBUG_PROBES
+        NB_TICK(tk0);
+        tk_use += tk0 - tk1;
+#endif
+        if constexpr (!(DBG & 2)) {
+            if constexpr (FD == 2) {
+                if (par) { commit(R[1]); fetch(R[1]); } else { commit(R[0]); fetch(R[0]); }
+                par ^= 1;
+            } else {
+                commit(R[0]);
+                fetch(R[0]);
+            }
         }
+#ifdef NMRF_DEBUG_PROBES
+        NB_TICK(tk1);
+        tk_commit += tk1 - tk0;
+#endif
         rd_slot = (rd_slot == NB_RING - 1) ? 0 : rd_slot + 1;
         cur = nxt;
         nxt = ring + ((rd_slot == NB_RING - 1) ? 0 : rd_slot + 1) * NB_STAGE_U4;
@@ -153,9 +198,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto consume = [&](auto pc, const h16x8 &bh, const h16x8 &bl, f32x16 &acc) {
         constexpr int P = decltype(pc)::value;
         const h16x8 ah = fqh[P % PF], al = fql[P % PF];
-        if constexpr (P + PF < 8) read_pair(cur, P + PF, fqh[P % PF], fql[P % PF]);
-        else read_pair(nxt, P + PF - 8, fqh[P % PF], fql[P % PF]);
-        split_mma1(ah, al, bh, bl, acc);
+        if constexpr (!(DBG & 4)) {
+            if constexpr (P + PF < 8) read_pair(cur, P + PF, fqh[P % PF], fql[P % PF]);
+            else read_pair(nxt, P + PF - 8, fqh[P % PF], fql[P % PF]);
+        }
+        // Pin the read-ahead: LDS reads may not sink below this point and MFMAs may not rise above it (VALU / SALU / VMEM /
+        // transcendental instructions may still cross, so the compiler keeps interleaving the GELU with the MFMAs).  Without it
+        // the scheduler moved every fragment read down to just before its MFMAs and each pair paid the LDS latency:
+        // ~2.5k cycles per 24-MFMA stage whatever else the stage did (s_memtime census, profiles/r02d_block_phases.txt).
+        __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x10 | 0x400);
+        if constexpr (!(DBG & 8)) split_mma1(ah, al, bh, bl, acc);
+        else acc[P] += (float)ah[0] + (float)bl[1];
     };
 
     fetch(R[0]); commit(R[0]);                  // stage 0 -> slot 0
@@ -194,7 +247,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __builtin_amdgcn_wave_barrier();
     };
     // LayerNorm over the 128 channels of each token: a lane holds 64 of them (C/D layout, 4 strips x 16), lane ^ 32 the rest
-    auto layer_norm = [&](const float (&v)[4][16], const float *g, const float *b, float eps, float (&o)[4][16]) {
+    auto layer_norm = [&](const float (&v)[4][16], int g_off, int b_off, float eps, float (&o)[4][16]) {
         float s = 0.f;
 #pragma unroll
         for (int st = 0; st < 4; ++st)
@@ -211,11 +264,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int st = 0; st < 4; ++st)
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
-                const float4 gv = ldg4(g + st * 32 + 8 * qd + 4 * hi), bv = ldg4(b + st * 32 + 8 * qd + 4 * hi);
-                o[st][4 * qd + 0] = (v[st][4 * qd + 0] - mean) * rstd * gv.x + bv.x;
-                o[st][4 * qd + 1] = (v[st][4 * qd + 1] - mean) * rstd * gv.y + bv.y;
-                o[st][4 * qd + 2] = (v[st][4 * qd + 2] - mean) * rstd * gv.z + bv.z;
-                o[st][4 * qd + 3] = (v[st][4 * qd + 3] - mean) * rstd * gv.w + bv.w;
+                const f32x4 gv = par4(g_off + st * 32 + 8 * qd + 4 * hi), bv = par4(b_off + st * 32 + 8 * qd + 4 * hi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[st][4 * qd + e] = (v[st][4 * qd + e] - mean) * rstd * gv[e] + bv[e];
             }
     };
 
@@ -256,9 +307,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int st = 0; st < 4; ++st)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (a.bp) bv = ldg4(a.bp + st * 32 + 8 * q + 4 * hi);
-                    const float b4[4] = {bv.x, bv.y, bv.z, bv.w};
+                    const f32x4 b4 = par4(NBP_BP + st * 32 + 8 * q + 4 * hi);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) x1[st][4 * q + e] += fmaf(acc[st][4 * q + e], a.inv_p, b4[e]);
                 }
@@ -270,7 +319,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             h16x8 bnh[8], bnl[8];                                              // LN2(x1) as the B operand of fc1 (k = channel)
             {
                 float ln[4][16];
-                layer_norm(x1, a.ln2_g, a.ln2_b, a.eps2, ln);
+                layer_norm(x1, NBP_G2, NBP_B2N, a.eps2, ln);
 #pragma unroll
                 for (int c = 0; c < 8; ++c) split8u(&ln[c >> 1][8 * (c & 1)], bnh[c], bnl[c]);
             }
@@ -295,8 +344,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 float hv[16];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float4 bv = ldg4(a.b1 + hs * 32 + 8 * q + 4 * hi);
-                    const float b4[4] = {bv.x, bv.y, bv.z, bv.w};
+                    const f32x4 b4 = par4(NBP_B1 + hs * 32 + 8 * q + 4 * hi);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) hv[4 * q + e] = gelu_fast(fmaf(fh[4 * q + e], a.inv_1, b4[e]));
                 }
@@ -325,8 +373,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 unstage_strip(x1[st], st * 32);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float4 bv = ldg4(a.b2 + st * 32 + 8 * q + 4 * hi);
-                    const float b4[4] = {bv.x, bv.y, bv.z, bv.w};
+                    const f32x4 b4 = par4(NBP_B2 + st * 32 + 8 * q + 4 * hi);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) x1[st][4 * q + e] += fmaf(acc[st][4 * q + e], a.inv_2, b4[e]);
                 }
@@ -345,7 +392,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             h16x8 bqh[KQC], bql[KQC];
             {
                 float ln[4][16];
-                layer_norm(x1, a.lnq_g, a.lnq_b, a.epsq, ln);
+                layer_norm(x1, NBP_GQ, NBP_BQN, a.epsq, ln);
                 if (a.ln_out) {
 #pragma unroll
                     for (int st = 0; st < 4; ++st) stage_strip(ln[st], st * 32);
@@ -383,9 +430,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         float ov[16];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if (a.bq) bv = ldg4(a.bq + g * 128 + sl * 32 + 8 * q + 4 * hi);
-                            const float b4[4] = {bv.x, bv.y, bv.z, bv.w};
+                            const f32x4 b4 = par4(NBP_BQ + g * 128 + sl * 32 + 8 * q + 4 * hi);
 #pragma unroll
                             for (int e2 = 0; e2 < 4; ++e2) ov[4 * q + e2] = fmaf(qh[4 * q + e2], a.inv_q, b4[e2]);
                         }
@@ -398,6 +443,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     }
     NB_STAMP(15);
+#ifdef NMRF_DEBUG_PROBES
+    if (a.stamps && lane == 0 && blockIdx.x < 64) {
+        unsigned long long *o = a.stamps + ((size_t)blockIdx.x * 4 + wv) * 16;
+        o[10] = tk_bar; o[11] = tk_use; o[12] = tk_commit;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -436,6 +487,38 @@ extern "C" int nmrf_pack_split_weight_f32(const float *w, int N, int K, int Kp, 
 }
 
 #ifdef NMRF_DEBUG_PROBES
+// attainable v_mfma_f32_32x32x16_f16 rate: CHAINS independent accumulators per wave, iters x 24 MFMAs each, operands constant
+template <int CHAINS>
+__global__ __launch_bounds__(256) void mfma16_peak_kernel(int iters, float *__restrict__ out) {
+    f32x16 acc[CHAINS];
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    h16x8 a, b;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { a[k] = (_Float16)(0.001f * (threadIdx.x + k)); b[k] = (_Float16)(0.002f * (threadIdx.x ^ k)); }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 24 / CHAINS; ++k)
+#pragma unroll
+            for (int c = 0; c < CHAINS; ++c) acc[c] = mfma16h(a, b, acc[c]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) sum += acc[c][0] + acc[c][15];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = sum;
+}
+extern "C" int nmrf_debug_mfma16_peak(int chains, int iters, int blocks, float *out, void *stream) {
+    if (!out) return NMRF_ENULL;
+    hipStream_t st = (hipStream_t)stream;
+    if (chains == 1) hipLaunchKernelGGL((mfma16_peak_kernel<1>), dim3(blocks), dim3(256), 0, st, iters, out);
+    else if (chains == 2) hipLaunchKernelGGL((mfma16_peak_kernel<2>), dim3(blocks), dim3(256), 0, st, iters, out);
+    else if (chains == 3) hipLaunchKernelGGL((mfma16_peak_kernel<3>), dim3(blocks), dim3(256), 0, st, iters, out);
+    else return NMRF_EINVAL;
+    return nmrf_launch_status();
+}
+
 static int g_nb_variant = 0;      // pipeline-depth variants for tools/kernel_bench.py --which block
 extern "C" int nmrf_debug_nmp_block_variant(int v) { g_nb_variant = v; return NMRF_OK; }
 static unsigned long long *g_nb_stamps = nullptr;
@@ -444,15 +527,15 @@ extern "C" int nmrf_debug_nmp_block_timing(unsigned long long *stamps) { g_nb_st
 static unsigned long long *const g_nb_stamps = nullptr;
 #endif
 
-template <bool MLP, int KQC, int FD, int PF, bool TOUCH>
+template <bool MLP, int KQC, int FD, int PF, bool TOUCH, int DBG = 0>
 static int launch_nmp_block_v(const NmpBlockArgs &a, hipStream_t st) {
     static bool attr_set_dev[NMRF_MAX_DEV] = {};
     static int n_cu_dev[NMRF_MAX_DEV] = {};
     const int dev = nmrf_cur_device();
     if (dev < 0) return NMRF_ELAUNCH;
-    const size_t lds = (size_t)NB_DUMP_OFF + 1024;
+    const size_t lds = (size_t)NB_PAR_OFF + NBP_FLOATS * sizeof(float);
     if (!attr_set_dev[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(nmp_block_kernel<MLP, KQC, FD, PF, TOUCH>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(nmp_block_kernel<MLP, KQC, FD, PF, TOUCH, DBG>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return NMRF_ELAUNCH;
         attr_set_dev[dev] = true;
@@ -463,7 +546,7 @@ static int launch_nmp_block_v(const NmpBlockArgs &a, hipStream_t st) {
         n_cu_dev[dev] = prop.multiProcessorCount;
     }
     const int grid = a.n_tiles < n_cu_dev[dev] ? a.n_tiles : n_cu_dev[dev];
-    hipLaunchKernelGGL((nmp_block_kernel<MLP, KQC, FD, PF, TOUCH>), dim3(grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((nmp_block_kernel<MLP, KQC, FD, PF, TOUCH, DBG>), dim3(grid), dim3(256), lds, st, a);
     return nmrf_launch_status();
 }
 
@@ -474,10 +557,17 @@ static int launch_nmp_block(const NmpBlockArgs &a, hipStream_t st) {
         case 1: return launch_nmp_block_v<MLP, KQC, 1, 2, false>(a, st);
         case 2: return launch_nmp_block_v<MLP, KQC, 2, 2, true>(a, st);
         case 3: return launch_nmp_block_v<MLP, KQC, 2, 2, false>(a, st);
+        case 4: return launch_nmp_block_v<MLP, KQC, 1, 4, true>(a, st);
+        case 10: return launch_nmp_block_v<MLP, KQC, 1, 2, true, 1>(a, st);
+        case 11: return launch_nmp_block_v<MLP, KQC, 1, 2, true, 2>(a, st);
+        case 12: return launch_nmp_block_v<MLP, KQC, 1, 2, true, 4>(a, st);
+        case 13: return launch_nmp_block_v<MLP, KQC, 1, 2, true, 8>(a, st);
+        case 14: return launch_nmp_block_v<MLP, KQC, 1, 2, true, 3>(a, st);
+        case 15: return launch_nmp_block_v<MLP, KQC, 1, 2, true, 7>(a, st);
         default: break;
     }
 #endif
-    return launch_nmp_block_v<MLP, KQC, NB_FD, NB_PF, true>(a, st);
+    return launch_nmp_block_v<MLP, KQC, NB_FD, NB_PF, false>(a, st);
 }
 
 extern "C" int nmrf_nmp_block_f32(const float *x, const float *msg, const void *stream_w, int total_stages, const float *bp,
@@ -491,7 +581,7 @@ extern "C" int nmrf_nmp_block_f32(const float *x, const float *msg, const void *
     if (KQ != 0 && KQ != 128 && KQ != 160 && KQ != 192) return NMRF_EINVAL;
     if (KQ && (!lnq_g || !lnq_b)) return NMRF_ENULL;
     if (KQ > 128 && (!extra || extra_ld < KQ - 128 || (extra_ld & 3) || extra_div < 1)) return NMRF_EINVAL;
-    if (q_out && (KQ == 0 || NQ < 128 || (NQ & 127))) return NMRF_EINVAL;
+    if (q_out && (KQ == 0 || NQ < 128 || (NQ & 127) || NQ > 512)) return NMRF_EINVAL;
     if (ln_out && KQ == 0) return NMRF_EINVAL;
     if (!q_out && !ln_out && !x_out) return NMRF_ENULL;
     // the stream must hold exactly the stages this configuration consumes

@@ -52,6 +52,19 @@ a, b2 = ctypes.c_int(-1), ctypes.c_int(-1)
 _l.nmrf_debug_window_occupancy(ctypes.byref(a), ctypes.byref(b2))
 print("runtime occupancy (blocks/CU): infer-window", a.value, " refine-window", b2.value, flush=True)
 which = args.which.split(",")
+if "mfma16" in which:
+    out = torch.empty(256 * 256, device=dev)
+    _l.nmrf_debug_mfma16_peak.restype = ctypes.c_int
+    for chains in (1, 2, 3):
+        iters = 2000
+        fn = lambda: _l.nmrf_debug_mfma16_peak(chains, iters, 256, ctypes.c_void_p(out.data_ptr()), None)
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        n_mfma = 256 * 4 * iters * (24 // chains) * chains
+        print("mfma 32x32x16 f16, %d chain(s) per wave, 1 wave/SIMD: %.1f TFLOP/s, %.1f cycles/MFMA at 2.4 GHz" % (
+            chains, n_mfma * 32768 / ms / 1e9, ms * 1e-3 * 2.4e9 / (iters * (24 // chains) * chains)), flush=True)
 if "block" in which:
     # the fused block kernel against the four launches it replaces (KITTI padded inference grid, batch b)
     import torch.nn.functional as F
@@ -62,7 +75,9 @@ if "block" in which:
     g, be = mk("g", 128) * 0.1 + 1, mk("bb", 128) * 0.1
     stream, stages, inv = K.block_stream(wp, w1, w2, wq, 160)
     qd = dict(g=g, b=be, eps=1e-5, extra=enc, extra_div=1, bias=bq, kq=160, nq=384)
-    for var, tag in ((0, "FD1 touch (product)"), (1, "FD1 no touch"), (2, "FD2 touch"), (3, "FD2 no touch")):
+    for var, tag in ((0, "FD1 touch (product)"), (1, "FD1 no touch"), (2, "FD2 touch"), (3, "FD2 no touch"), (4, "FD1 PF4 touch"),
+                     (10, "DBG no barrier"), (11, "DBG no commit/fetch"), (12, "DBG no LDS fragment reads"), (13, "DBG no MFMA"),
+                     (14, "DBG no barrier, no commit/fetch"), (15, "DBG no barrier/commit/fetch/fragment reads")):
         _l.nmrf_debug_nmp_block_variant(var)
         timeit("nmp_block proj+mlp+qkv " + tag, lambda: K.nmp_block(x, stream, stages, inv, msg, bp, (g, be, 1e-5, b1, b2), qd))
     _l.nmrf_debug_nmp_block_variant(0)
@@ -83,6 +98,9 @@ if "block" in which:
         d = (st[:, :, k] - st[:, :, prev]).reshape(-1)
         print("   %-52s median %7.0f  min %7.0f  max %7.0f ticks" % (names[k], np.median(d), d.min(), d.max()))
         prev = k
+    for k, nm in ((10, "sum over stages: barrier wait"), (11, "sum over stages: consume (LDS reads + MFMAs + VALU)"), (12, "sum over stages: commit + fetch")):
+        d = st[:, :, k].reshape(-1)
+        print("   %-52s median %7.0f  min %7.0f  max %7.0f ticks" % (nm, np.median(d), d.min(), d.max()))
     tot = (st[:, :, 15] - st[:, :, 0]).reshape(-1)
     print("   total per wave: median %.0f ticks; first-start to last-end over blocks: %.0f ticks" % (np.median(tot), st[:, :, 15].max() - st[:, :, 0].min()))
     s2, st2, i2 = K.block_stream(wp, None, None, wq, 160)
