@@ -27,7 +27,7 @@ extern "C" {
 
 const char *nmrf_strerror(int code);
 /* ABI version of this header; bumps on any signature change. */
-int nmrf_abi_version(void);   /* currently 11 */
+int nmrf_abi_version(void);   /* currently 12 */
 
 /* A2  group-wise correlation volume.
  * replaces build_correlation_volume + the permute of DPN.forward
@@ -55,14 +55,16 @@ int nmrf_nms_topk_f32(const float *prob, int64_t P, int D, int K, float eps, int
 /* A6  seed features: 9-tap x G-group cost gather + Fourier(31) of the seed.
  * replaces Propagation.sample_cost and fourier_coord_embed (nmrf/models/NMP.py:619-634,35-51,646-647).
  * vol [P,G,D], seeds [P,N] int64 -> cost [P*N, G*9] (group-major, tap-minor, taps clamped to [0,D-1]),
- * enc [P*N, 31] = [sin(c*2^i) i<15 | cos(c*2^i) | c], c = seed*normalizer.  enc may be NULL. */
+ * enc rows of enc_ld >= 31 floats = [sin(c*2^i) i<15 | cos(c*2^i) | c | 0 ...], c = seed*normalizer.  enc may be NULL. */
 int nmrf_seed_features_f32(const float *vol, const int64_t *seeds, int64_t P, int G, int D, int N,
-                           float normalizer, float *cost, float *enc, void *stream);
+                           float normalizer, float *cost, float *enc, int enc_ld, void *stream);
 
 /* Fourier(31) of arbitrary fp32 coordinates (labels / refined disparity).
  * replaces fourier_coord_embed call sites nmrf/models/NMP.py:743,846.
- * coord [T] -> enc rows of 31 floats written at enc + t*ld (ld >= 31). */
-int nmrf_fourier_embed_f32(const float *coord, int64_t T, float normalizer, float *enc, int ld, void *stream);
+ * coord [T] -> enc rows of 31 floats (+ zeros up to ld) written at enc + row*ld, row = out_map ? out_map[t] : t (negative:
+ * skipped; the zero-padded token grids of NMP.py:745-762 are filled in place). */
+int nmrf_fourier_embed_f32(const float *coord, int64_t T, float normalizer, float *enc, int ld, const int *out_map,
+                           void *stream);
 
 /* LayerNorm(x) concatenated with a per-token (extra_div=1) or per-pixel (extra_div=N) side vector;
  * builds the q/k(/v) GEMM operand of every message-passing layer in one pass.
@@ -209,12 +211,28 @@ int nmrf_msda_backward_f64(const double *value, const int64_t *shapes, const int
  *                         W2s[h] = pairs (strip n, chunk 2h + c) for n = 0..3, c = 0..1                   32 stages
  *   q      (q_out)      : Wq [NQ,KQ] pairs (strip, chunk) in strip-major order                           NQ/128 * KQ/32 stages
  * total_stages must equal the sum.  Biases / LayerNorm parameters are plain fp32 vectors.  inv_scales: HOST array of 4 floats,
- * 1 / scale the proj, fc1, fc2 and q weights were packed with (nmrf_pack_split_weight_f32; unused entries ignored). */
+ * 1 / scale the proj, fc1, fc2 and q weights were packed with (nmrf_pack_split_weight_f32; unused entries ignored).
+ * ln_out_map (optional, device int32 [T]): row of ln_out that token t is written to, negative = dropped (the crop of the padded
+ * token grid, NMP.py:786-788, 888-890). */
 int nmrf_nmp_block_f32(const float *x, const float *msg, const void *stream_w, int total_stages, const float *bp,
                        const float *ln2_g, const float *ln2_b, float eps2, const float *b1, const float *b2,
                        const float *lnq_g, const float *lnq_b, float epsq, const float *extra, int extra_ld,
                        int extra_div, const float *bq, int has_mlp, int KQ, int NQ, int64_t T, const float *inv_scales,
-                       float *x_out, float *q_out, float *ln_out, void *stream);
+                       float *x_out, float *q_out, float *ln_out, const int *ln_out_map, void *stream);
+
+/* Per-token MLP chains of the hot path, one launch each (csrc/mlp_chain.hip), split-operand fp16 MFMA:
+ *   kind 0  Inference.ffn / Refinement.ffn: timm Mlp(160,128,128), GELU             (NMP.py:675, 735-741, 839-844)
+ *   kind 1  Propagation.cost_encoder + proj: Linear(36,128)-GELU-Linear(128,128); [. | Fourier31+0] -> Linear(159,128)   (NMP.py:607-612, 643-649)
+ *   kind 2  prop_head / infer_head / refine_head: MLP(128,128,n_out <= 64, 3 layers, ReLU)   (DPN.py:65; NMRF.py:82,105; NMP.py:54-66)
+ *   kind 3  infer_score_head: Linear(128, n_out <= 64)                              (NMRF.py:83)
+ * in [T, in_ld] rows with K1 live columns (K1, in_ld multiples of 4); extra [T, extra_ld] (kind 1: the 32-float Fourier rows);
+ * out rows of out_ld floats, n_out stored, at row out_map ? out_map[t] : t (negative: dropped).
+ * stream_w: nmrf_pack_split_weight_f32 pairs of layer 1 [strip][chunk] (Kp = 16*ceil(K1/16); last layer rows zero-padded to a
+ * multiple of 32), layer 2, layer 3, then zero pairs up to a multiple of 8 pairs; total_stages = pairs / 8.
+ * b1/b2/b3 may be NULL.  inv_scales: HOST array of 3 floats. */
+int nmrf_mlp_chain_f32(int kind, const float *in, int in_ld, int K1, const void *stream_w, int total_stages,
+                       const float *b1, const float *b2, const float *b3, const float *extra, int extra_ld,
+                       const float *inv_scales, int64_t T, float *out, int out_ld, int n_out, const int *out_map, void *stream);
 
 /* Weight packing for nmrf_nmp_block_f32: w [N,K] row-major fp32 (an nn.Linear weight) -> N/32 x Kp/16 pairs of 2 KB in
  * [strip][chunk] order; a pair = [64 lanes][8 fp16] hi parts then the same for the lo parts (lo = fp16(w - hi), csrc/split_mfma.h);

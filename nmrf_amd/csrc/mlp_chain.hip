@@ -1,0 +1,241 @@
+// Per-token MLP chains of the hot path in one kernel each, on split-operand fp16 MFMA (split_mfma.h, split_stream.h):
+//
+//     h1  = act1( in[t, 0:K1] . W1^T + b1 )                          K1 <= 160, N1 = 32 * N1S <= 128
+//     h2  = act2( h1 . W2^T + b2 )                [L2]               128 -> 128
+//     out = [h2 | extra[t, 0:32]] . W3^T + b3     [K3C > 0]          N3 = 32 * N3S <= 128
+//
+//   Inference.ffn / Refinement.ffn   timm Mlp(160 -> 128 -> 128, GELU)                              NMP.py:675, 735-741, 839-844
+//   Propagation.cost_encoder + proj  Linear(36,128)-GELU-Linear(128,128); cat Fourier31; Linear(159,128)   NMP.py:607-612, 643-649
+//   prop_head / infer_head / refine_head   MLP(128 -> 128 -> 128 -> 1 | 64 | 16, ReLU)               DPN.py:65, NMRF.py:82, 105; NMP.py:54-66
+//   infer_score_head                 Linear(128, 64)                                                 NMRF.py:83
+//
+// replacing chains of token_linear (fp32 MFMA) / hipBLASLt / linear_smalln launches with their intermediates in HBM.  Same
+// formulation as nmp_block.hip: transposed GEMMs (weights = A operand from the shared LDS stream, activations = B operand with
+// the token on the lane), a layer's C/D registers are the next layer's B operand.  Rows leave through a wave-private LDS tile;
+// `out_map` (optional) sends token t to output row out_map[t] (< 0: dropped): the zero-padded token grids of the window stages
+// (NMP.py:745-762, 848-865) are written in place instead of F.pad'ing a dense result.
+#include "split_stream.h"
+
+#define MC_TOK 128
+#define MC_OLD 132
+#define MC_PF 4
+
+struct ChainArgs {
+    const float *in;
+    int in_ld, K1;
+    const void *stream;
+    int total_stages;
+    const float *b1, *b2, *b3;
+    const float *extra;          // [T, extra_ld] side columns of layer 3 (first 32 used) or NULL
+    int extra_ld;
+    float *out;
+    int out_ld, n_out;           // row stride and number of columns actually stored (<= 32 * last layer's strips)
+    const int *out_map;
+    int64_t T;
+    int n_tiles;
+    float inv1, inv2, inv3;
+};
+
+template <int ACT>
+__device__ __forceinline__ float mc_act(float v) {
+    if constexpr (ACT == 2) return gelu_fast(v);
+    if constexpr (ACT == 1) return fmaxf(v, 0.f);
+    return v;
+}
+
+// K1C: k chunks of layer 1; N1S: its output strips; L2: 128 -> 128 layer present; K3C: k chunks of layer 3 (0 = absent, 8 =
+// h2 only, 10 = h2 | 32 side columns); N3S: its output strips.
+template <int K1C, int N1S, int ACT1, bool L2, int ACT2, int K3C, int N3S>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void mlp_chain_kernel(ChainArgs a) {
+    static_assert(!L2 || N1S == 4, "layer 2 consumes a 128-wide layer 1");
+    static_assert(K3C == 0 || (L2 ? true : N1S == 4), "layer 3 consumes a 128-wide activation");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, hi = lane >> 5;
+    float *Ot = reinterpret_cast<float *>(smem + SS_RING_BYTES) + wv * 32 * MC_OLD;          // wave-private [32][132]
+    float *Par = reinterpret_cast<float *>(smem + SS_RING_BYTES + 4 * 32 * MC_OLD * 4);      // b1 | b2 | b3, 128 floats each
+    constexpr bool LAST_IS_L1 = !L2 && K3C == 0;                       // then b1 has n_out entries, not 32 * N1S
+    for (int i = tid; i < 128; i += 256) {
+        Par[i] = (a.b1 && i < (LAST_IS_L1 ? a.n_out : 32 * N1S)) ? a.b1[i] : 0.f;
+        Par[128 + i] = (L2 && a.b2) ? a.b2[i] : 0.f;
+        Par[256 + i] = (K3C > 0 && a.b3 && i < a.n_out) ? a.b3[i] : 0.f;
+    }
+    auto par4 = [&](int off) { return *reinterpret_cast<const f32x4 *>(Par + off); };
+    SplitStream<MC_PF> ss;
+    ss.init(a.stream, smem, a.total_stages, tid);
+
+    constexpr int P1 = K1C * N1S, P2 = L2 ? 32 : 0, P3 = K3C * N3S;
+    constexpr int PAIRS = P1 + P2 + P3, PADDED = (PAIRS + 7) / 8 * 8;
+    constexpr int NLAST = K3C > 0 ? N3S : (L2 ? 4 : N1S);
+
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const int64_t t0 = (int64_t)tile * MC_TOK + wv * 32;
+        const int64_t tq = t0 + j;
+        const int64_t tc = tq < a.T ? tq : a.T - 1;
+        // ---- layer 1: B operand straight from the input rows ---------------------------------------------------------------
+        h16x8 bh[K1C > 10 ? K1C : 10], bl[K1C > 10 ? K1C : 10];
+#pragma unroll
+        for (int c = 0; c < K1C; ++c) {
+            const int k0 = 16 * c + 4 * hi, k1 = k0 + 8;
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 v0 = k0 < a.K1 ? ldg4(a.in + tc * a.in_ld + k0) : z, v1 = k1 < a.K1 ? ldg4(a.in + tc * a.in_ld + k1) : z;
+            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            split8u(v, bh[c], bl[c]);
+        }
+        float h[4][16];
+        ss_static_for<N1S>([&](auto ss_) {
+            constexpr int st = decltype(ss_)::value;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            ss_static_for<K1C>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                ss_pair<st * K1C + c>(ss, bh[c], bl[c], acc);
+            });
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b4 = par4(st * 32 + 8 * q + 4 * hi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[st][4 * q + e] = mc_act<ACT1>(fmaf(acc[4 * q + e], a.inv1, b4[e]));
+            }
+        });
+        // ---- layer 2 ---------------------------------------------------------------------------------------------------------------
+        if constexpr (L2) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) split8u(&h[c >> 1][8 * (c & 1)], bh[c], bl[c]);
+            ss_static_for<4>([&](auto ss_) {
+                constexpr int st = decltype(ss_)::value;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                ss_static_for<8>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    ss_pair<P1 + st * 8 + c>(ss, bh[c], bl[c], acc);
+                });
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 b4 = par4(128 + st * 32 + 8 * q + 4 * hi);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h[st][4 * q + e] = mc_act<ACT2>(fmaf(acc[4 * q + e], a.inv2, b4[e]));
+                }
+            });
+        }
+        // ---- layer 3 ---------------------------------------------------------------------------------------------------------------
+        if constexpr (K3C > 0) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) split8u(&h[c >> 1][8 * (c & 1)], bh[c], bl[c]);
+            if constexpr (K3C > 8) {
+#pragma unroll
+                for (int c = 8; c < K3C; ++c) {
+                    const float *e = a.extra + tc * a.extra_ld + 16 * (c - 8) + 4 * hi;
+                    const float4 v0 = ldg4(e), v1 = ldg4(e + 8);
+                    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    split8u(v, bh[c], bl[c]);
+                }
+            }
+            ss_static_for<N3S>([&](auto ss_) {
+                constexpr int st = decltype(ss_)::value;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                ss_static_for<K3C>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    ss_pair<P1 + P2 + st * K3C + c>(ss, bh[c], bl[c], acc);
+                });
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 b4 = par4(256 + st * 32 + 8 * q + 4 * hi);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h[st][4 * q + e] = fmaf(acc[4 * q + e], a.inv3, b4[e]);
+                }
+            });
+        }
+        // the stream is padded with zero pairs to a whole stage: walk them so that the ring and the fragment queue stay in step
+        if constexpr (PADDED > PAIRS) {
+            f32x16 dump;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dump[r] = 0.f;
+            ss_static_for<PADDED - PAIRS>([&](auto pp) { ss_pair<PAIRS + decltype(pp)::value>(ss, bh[0], bl[0], dump); });
+        }
+        // ---- rows out ------------------------------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int st = 0; st < NLAST; ++st)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<f32x4 *>(Ot + j * MC_OLD + st * 32 + 8 * q + 4 * hi) =
+                    f32x4{h[st][4 * q], h[st][4 * q + 1], h[st][4 * q + 2], h[st][4 * q + 3]};
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int n4 = (a.n_out + 3) >> 2;                                     // float4 per output row
+        for (int idx = lane; idx < 32 * n4; idx += 64) {
+            const int row = idx / n4, c4 = idx - row * n4;
+            const int64_t t = t0 + row;
+            if (t >= a.T) continue;
+            int64_t orow = t;
+            if (a.out_map) { orow = a.out_map[t]; if (orow < 0) continue; }
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(Ot + row * MC_OLD + 4 * c4);
+            float *dst = a.out + (size_t)orow * a.out_ld + 4 * c4;
+            if (4 * c4 + 4 <= a.n_out && !(a.out_ld & 3)) *reinterpret_cast<f32x4 *>(dst) = v;
+            else
+                for (int e = 0; e < 4 && 4 * c4 + e < a.n_out; ++e) dst[e] = v[e];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int K1C, int N1S, int ACT1, bool L2, int ACT2, int K3C, int N3S>
+static int launch_chain(const ChainArgs &a, hipStream_t st) {
+    static bool attr_set_dev[NMRF_MAX_DEV] = {};
+    static int n_cu_dev[NMRF_MAX_DEV] = {};
+    const int dev = nmrf_cur_device();
+    if (dev < 0) return NMRF_ELAUNCH;
+    const size_t lds = (size_t)SS_RING_BYTES + 4 * 32 * MC_OLD * 4 + 384 * 4;
+    auto kern = mlp_chain_kernel<K1C, N1S, ACT1, L2, ACT2, K3C, N3S>;
+    if (!attr_set_dev[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return NMRF_ELAUNCH;
+        attr_set_dev[dev] = true;
+    }
+    if (!n_cu_dev[dev]) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return NMRF_ELAUNCH;
+        n_cu_dev[dev] = prop.multiProcessorCount;
+    }
+    constexpr int PAIRS = K1C * N1S + (L2 ? 32 : 0) + K3C * N3S;
+    if (a.total_stages != (PAIRS + 7) / 8) return NMRF_EINVAL;
+    const int grid = a.n_tiles < n_cu_dev[dev] ? a.n_tiles : n_cu_dev[dev];
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+    return nmrf_launch_status();
+}
+
+// kind: 0 ffn (K1 160 -> 128 GELU -> 128) | 1 seed embed (K1 36 -> 128 GELU -> 128, [h | extra32] -> 128) |
+//       2 head (128 -> 128 ReLU -> 128 ReLU -> n_out <= 64) | 3 single Linear(128 -> n_out <= 64)
+extern "C" int nmrf_mlp_chain_f32(int kind, const float *in, int in_ld, int K1, const void *stream_w, int total_stages,
+                                  const float *b1, const float *b2, const float *b3, const float *extra, int extra_ld,
+                                  const float *inv_scales, int64_t T, float *out, int out_ld, int n_out, const int *out_map,
+                                  void *stream) {
+    if (!in || !stream_w || !out || !inv_scales) return NMRF_ENULL;
+    if (T < 1 || ceil_div64(T, MC_TOK) > 0x7fffffff || in_ld < K1 || (in_ld & 3) || (K1 & 3) || n_out < 1 || out_ld < n_out)
+        return NMRF_EINVAL;
+    ChainArgs a{in, in_ld, K1, stream_w, total_stages, b1, b2, b3, extra, extra_ld, out, out_ld, n_out, out_map, T,
+                (int)ceil_div64(T, MC_TOK), inv_scales[0], inv_scales[1], inv_scales[2]};
+    hipStream_t st = (hipStream_t)stream;
+    switch (kind) {
+        case 0:
+            if (K1 > 160 || n_out != 128) return NMRF_EINVAL;
+            return launch_chain<10, 4, 2, true, 0, 0, 0>(a, st);
+        case 1:
+            if (K1 > 48 || n_out != 128 || !extra || extra_ld < 32 || (extra_ld & 3)) return NMRF_EINVAL;
+            return launch_chain<3, 4, 2, true, 0, 10, 4>(a, st);
+        case 2:
+            if (K1 != 128 || n_out > 64) return NMRF_EINVAL;
+            return n_out > 32 ? launch_chain<8, 4, 1, true, 1, 8, 2>(a, st) : launch_chain<8, 4, 1, true, 1, 8, 1>(a, st);
+        case 3:
+            if (K1 != 128 || n_out > 64) return NMRF_EINVAL;
+            return n_out > 32 ? launch_chain<8, 2, 0, false, 0, 0, 0>(a, st) : launch_chain<8, 1, 0, false, 0, 0, 0>(a, st);
+        default: return NMRF_EINVAL;
+    }
+}

@@ -71,6 +71,7 @@ struct NmpBlockArgs {
     float *x_out;              // [T,128] x2 (x1 when MLP = false), or NULL
     float *q_out;              // [T,NQ] or NULL
     float *ln_out;             // [T,128] LNq(x2) or NULL
+    const int *ln_out_map;     // row of ln_out per token (negative: dropped) or NULL
     int64_t T;
     int n_tiles;
     float eps2, epsq;
@@ -234,14 +235,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     };
     // whole rows of the tile -> dst[t, col0 .. col0+128): lanes 0-31 one row, lanes 32-63 the next (512 B each)
-    auto flush_rows = [&](float *dst, int ld, int col0, int64_t t0) {
+    auto flush_rows = [&](float *dst, int ld, int col0, int64_t t0, const int *map = nullptr) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int row = 2 * i + hi;
             const float4 v = *reinterpret_cast<const float4 *>(Ot + row * NB_OLD + 4 * j);
-            if (t0 + row < a.T) stg4(dst + (size_t)(t0 + row) * ld + col0 + 4 * j, v);
+            if (t0 + row < a.T) {
+                int64_t orow = t0 + row;
+                if (map) orow = map[orow];
+                if (orow >= 0) stg4(dst + (size_t)orow * ld + col0 + 4 * j, v);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if (a.ln_out) {
 #pragma unroll
                     for (int st = 0; st < 4; ++st) stage_strip(ln[st], st * 32);
-                    flush_rows(a.ln_out, 128, 0, t0);
+                    flush_rows(a.ln_out, 128, 0, t0, a.ln_out_map);
                 }
 #pragma unroll
                 for (int c = 0; c < 8; ++c) split8u(&ln[c >> 1][8 * (c & 1)], bqh[c], bql[c]);
@@ -574,7 +579,7 @@ extern "C" int nmrf_nmp_block_f32(const float *x, const float *msg, const void *
                                   const float *ln2_g, const float *ln2_b, float eps2, const float *b1, const float *b2,
                                   const float *lnq_g, const float *lnq_b, float epsq, const float *extra, int extra_ld,
                                   int extra_div, const float *bq, int has_mlp, int KQ, int NQ, int64_t T, const float *inv_scales,
-                                  float *x_out, float *q_out, float *ln_out, void *stream) {
+                                  float *x_out, float *q_out, float *ln_out, const int *ln_out_map, void *stream) {
     if (!x || !stream_w || !inv_scales) return NMRF_ENULL;
     if (T < 1 || ceil_div64(T, NB_TOK) > 0x7fffffff) return NMRF_EINVAL;
     if (has_mlp && (!ln2_g || !ln2_b || !b1 || !b2)) return NMRF_ENULL;
@@ -588,7 +593,7 @@ extern "C" int nmrf_nmp_block_f32(const float *x, const float *msg, const void *
     const int want = (msg ? 4 : 0) + (has_mlp ? 32 : 0) + (q_out ? (NQ / 128) * (KQ / 16) / 2 : 0);
     if (total_stages != want || total_stages < 1) return NMRF_EINVAL;
     NmpBlockArgs a{x, msg, reinterpret_cast<const u32x4 *>(stream_w), total_stages, bp, ln2_g, ln2_b, b1, b2, lnq_g, lnq_b, extra,
-                   extra_ld, extra_div, bq, x_out, q_out, ln_out, T, (int)ceil_div64(T, NB_TOK), eps2, epsq, NQ, inv_scales[0], inv_scales[1], inv_scales[2], inv_scales[3], g_nb_stamps};
+                   extra_ld, extra_div, bq, x_out, q_out, ln_out, ln_out_map, T, (int)ceil_div64(T, NB_TOK), eps2, epsq, NQ, inv_scales[0], inv_scales[1], inv_scales[2], inv_scales[3], g_nb_stamps};
     hipStream_t st = (hipStream_t)stream;
     const int kqc = KQ / 16;
     if (has_mlp) {

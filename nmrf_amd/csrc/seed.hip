@@ -333,7 +333,7 @@ __device__ __forceinline__ void fourier_pad(int f, float *row, int ld) {
 }
 
 __global__ __launch_bounds__(256) void seed_features_kernel(const float *__restrict__ vol, const int64_t *__restrict__ seeds,
-        int64_t P, int G, int D, int N, float normalizer, float *__restrict__ cost, float *__restrict__ enc) {
+        int64_t P, int G, int D, int N, float normalizer, float *__restrict__ cost, float *__restrict__ enc, int enc_ld) {
     const int per = G * 9;
     const int slots = per + 16;                       // cost entries + 16 Fourier work items per token
     const int64_t total = P * N * slots;
@@ -348,39 +348,43 @@ __global__ __launch_bounds__(256) void seed_features_kernel(const float *__restr
             d = d < 0 ? 0 : (d > D - 1 ? D - 1 : d);
             cost[t * per + j] = vol[((size_t)p * G + g) * D + d];
         } else if (enc) {
-            fourier_write((float)seed, normalizer, j - per, enc + t * 31);
+            fourier_write((float)seed, normalizer, j - per, enc + t * enc_ld);
+            fourier_pad(j - per, enc + t * enc_ld, enc_ld);
         }
     }
 }
 
 extern "C" int nmrf_seed_features_f32(const float *vol, const int64_t *seeds, int64_t P, int G, int D, int N,
-                                      float normalizer, float *cost, float *enc, void *stream) {
+                                      float normalizer, float *cost, float *enc, int enc_ld, void *stream) {
     if (!vol || !seeds || !cost) return NMRF_ENULL;
-    if (P < 1 || G < 1 || D < 1 || N < 1) return NMRF_EINVAL;
+    if (P < 1 || G < 1 || D < 1 || N < 1 || (enc && enc_ld < 31)) return NMRF_EINVAL;
     int64_t total = P * N * (G * 9 + 16);
     int64_t blocks = ceil_div64(total, 256);
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(seed_features_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, vol, seeds, P, G,
-                       D, N, normalizer, cost, enc);
+                       D, N, normalizer, cost, enc, enc_ld);
     return nmrf_launch_status();
 }
 
 __global__ __launch_bounds__(256) void fourier_embed_kernel(const float *__restrict__ coord, int64_t T, float normalizer,
-                                                           float *__restrict__ enc, int ld) {
+                                                           float *__restrict__ enc, int ld, const int *__restrict__ out_map) {
     const int64_t total = T * 16;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         int64_t t = i >> 4;
-        fourier_write(coord[t], normalizer, (int)(i & 15), enc + t * ld);
-        fourier_pad((int)(i & 15), enc + t * ld, ld);
+        int64_t row = t;
+        if (out_map) { row = out_map[t]; if (row < 0) continue; }
+        fourier_write(coord[t], normalizer, (int)(i & 15), enc + row * ld);
+        fourier_pad((int)(i & 15), enc + row * ld, ld);
     }
 }
 
-extern "C" int nmrf_fourier_embed_f32(const float *coord, int64_t T, float normalizer, float *enc, int ld, void *stream) {
+extern "C" int nmrf_fourier_embed_f32(const float *coord, int64_t T, float normalizer, float *enc, int ld, const int *out_map,
+                                      void *stream) {
     if (!coord || !enc) return NMRF_ENULL;
     if (T < 1 || ld < 31) return NMRF_EINVAL;
     int64_t blocks = ceil_div64(T * 16, 256);
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(fourier_embed_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, coord, T,
-                       normalizer, enc, ld);
+                       normalizer, enc, ld, out_map);
     return nmrf_launch_status();
 }

@@ -112,25 +112,27 @@ def nms_topk(prob, k, eps, do_nms=True):
 
 
 @_on_device
-def seed_features(vol, seeds, normalizer):
+def seed_features(vol, seeds, normalizer, enc_ld=31):
     _chk(vol)
     _chk(seeds, dtype=torch.int64)
     p, g, d = vol.shape
     n = seeds.shape[1]
     cost = torch.empty(p * n, g * 9, device=vol.device, dtype=torch.float32)
-    enc = torch.empty(p * n, 31, device=vol.device, dtype=torch.float32)
-    _lib.check(_lib.load().nmrf_seed_features_f32(_p(vol), _p(seeds), p, g, d, n, float(normalizer), _p(cost), _p(enc),
+    enc = torch.empty(p * n, enc_ld, device=vol.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_seed_features_f32(_p(vol), _p(seeds), p, g, d, n, float(normalizer), _p(cost), _p(enc), enc_ld,
                                                   _stream()), "seed_features")
     return cost, enc
 
 
 @_on_device
-def fourier_embed(coord, normalizer, ld=31):
-    """-> [T, ld]: 31 Fourier columns, the rest (ld = 32: 16-byte rows for the fused block kernel) zero."""
-    _chk(coord)
+def fourier_embed(coord, normalizer, ld=31, out=None, out_map=None):
+    """-> [T, ld]: 31 Fourier columns, the rest (ld = 32: 16-byte rows for the fused block kernel) zero.
+    out / out_map: write token t to row out_map[t] of the given (pre-zeroed, padded-grid) tensor instead."""
+    _chk(coord, out)
+    _chk(out_map, dtype=torch.int32)
     t = coord.numel()
-    enc = torch.empty(t, ld, device=coord.device, dtype=torch.float32)
-    _lib.check(_lib.load().nmrf_fourier_embed_f32(_p(coord), t, float(normalizer), _p(enc), ld, _stream()),
+    enc = out if out is not None else torch.empty(t, ld, device=coord.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_fourier_embed_f32(_p(coord), t, float(normalizer), _p(enc), enc.shape[-1], _p(out_map), _stream()),
                "fourier_embed")
     return enc
 
@@ -348,8 +350,49 @@ def block_stream(wp=None, w1=None, w2=None, wq=None, kq=0):
     return stream, stream.shape[0] // 8, (ctypes.c_float * 4)(*inv)
 
 
+def chain_stream(weights, kps):
+    """Weight stream of one mlp_chain launch: the layers' pairs in order, rows zero-padded to a multiple of 32, zero pairs up to a
+    whole stage.  weights: list of [N,K] tensors; kps: padded K per layer.  -> (int32 [stages*8, 512], stages, 1/scales x3)"""
+    import ctypes
+    parts, inv = [], [1.0, 1.0, 1.0]
+    for i, (w, kp) in enumerate(zip(weights, kps)):
+        n = w.shape[0]
+        if n % 32:
+            w = torch.nn.functional.pad(w, (0, 0, 0, 32 - n % 32))
+        pk, inv[i] = pack_split_weight(w.contiguous(), kp)
+        parts.append(pk.view(-1, 512))
+    stream = torch.cat(parts)
+    if stream.shape[0] % 8:
+        stream = torch.cat((stream, stream.new_zeros(8 - stream.shape[0] % 8, 512)))
+    return stream.contiguous(), stream.shape[0] // 8, (ctypes.c_float * 3)(*inv)
+
+
 @_on_device
-def nmp_block(x, stream, stages, inv_scales, msg=None, bp=None, mlp=None, q=None, want_x=True):
+def mlp_chain(kind, x, k1, stream, stages, inv_scales, biases, n_out, extra=None, out=None, out_map=None):
+    """nmrf_mlp_chain_f32: kind 0 ffn | 1 seed embed | 2 three-layer ReLU head | 3 single Linear.  x [T, ld] (k1 live columns)."""
+    _chk(x, extra, out, *[b for b in biases if b is not None])
+    _chk(stream, out_map, dtype=torch.int32)
+    t, ld = x.shape
+    if out is None:
+        out = torch.empty(t, n_out, device=x.device, dtype=torch.float32)
+    b = list(biases) + [None] * (3 - len(biases))
+    name = "mlp_chain_kind%d" % kind
+    if kernel_hook is not None:
+        widths = {0: k1 * 128 + 128 * 128, 1: k1 * 128 + 128 * 128 + 160 * 128, 2: 2 * 128 * 128 + 128 * n_out, 3: 128 * n_out}[kind]
+        _hb(name + "_n%d" % n_out, row="A6/A9/A11/A13/A14 (N3)", bound="mfma", flops=2.0 * t * widths, bytes=4.0 * t * (k1 + n_out), split=True,
+            label="mlp_chain_kernel kind %d (%s, split-fp16 MFMA)" % (kind, ("ffn 160->128->128", "seed embed 36->128->128|32->128",
+                                                                            "head 128->128->128->%d" % n_out, "Linear 128->%d" % n_out)[kind]),
+            pmc=["mlp_chain_kernel"])
+    _lib.check(_lib.load().nmrf_mlp_chain_f32(kind, _p(x), ld, k1, _p(stream), stages, _p(b[0]), _p(b[1]), _p(b[2]), _p(extra),
+                                              0 if extra is None else extra.shape[-1], inv_scales, t, _p(out), out.shape[-1], n_out,
+                                              _p(out_map), _stream()), "mlp_chain")
+    if kernel_hook is not None:
+        _he(name + "_n%d" % n_out)
+    return out
+
+
+@_on_device
+def nmp_block(x, stream, stages, inv_scales, msg=None, bp=None, mlp=None, q=None, want_x=True, ln_out=None, ln_out_map=None):
     """One fused message-passing block (nmrf_nmp_block_f32).
     mlp = (ln2_gamma, ln2_beta, eps, b1, b2) or None;  q = dict(g, b, eps, extra=None, extra_div=1, bias=None, kq=0|128|160|192,
     nq=0 -> no q_out, ln_out=False) or None.  Returns (x_out | None, q_out | None, ln_out | None)."""
@@ -372,7 +415,10 @@ def nmp_block(x, stream, stages, inv_scales, msg=None, bp=None, mlp=None, q=None
             ld = extra.shape[-1]
     x_out = torch.empty_like(x) if want_x else None
     q_out = torch.empty(t, nq, device=x.device, dtype=torch.float32) if nq else None
-    ln_out = torch.empty_like(x) if want_ln else None
+    if want_ln and ln_out is None:
+        ln_out = torch.empty_like(x)
+    _chk(ln_out)
+    _chk(ln_out_map, dtype=torch.int32)
     if kernel_hook is not None:
         flops = 2.0 * t * ((128 * 128 if msg is not None else 0) + (2 * 128 * 512 if mlp is not None else 0) + kq * nq)
         nbytes = 4.0 * t * (128 * (1 + (msg is not None) + bool(want_x) + bool(want_ln)) + nq) + (4.0 * extra.numel() if extra is not None else 0)
@@ -385,7 +431,7 @@ def nmp_block(x, stream, stages, inv_scales, msg=None, bp=None, mlp=None, q=None
     _lib.check(_lib.load().nmrf_nmp_block_f32(_p(x), _p(msg), _p(stream), stages, _p(bp), _p(ln2_g), _p(ln2_b), float(eps2), _p(b1),
                                               _p(b2), _p(lq_g), _p(lq_b), float(epsq), _p(extra), ld, div, _p(bq),
                                               int(mlp is not None), kq, nq, t, inv_scales, _p(x_out), _p(q_out), _p(ln_out),
-                                              _stream()),
+                                              _p(ln_out_map), _stream()),
                "nmp_block")
     if kernel_hook is not None:
         _he(name)

@@ -40,6 +40,12 @@ class MLP(nn.Module):
         self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
 
     def forward(self, x):
+        if (_split() and x.is_cuda and self.num_layers == 3 and self.layers[0].in_features == 128
+                and self.layers[0].out_features == 128 and self.layers[1].out_features == 128 and self.layers[2].out_features <= 64):
+            if not hasattr(self, "_chain"):
+                self._chain = _ChainLauncher(2, self.layers, (128, 128, 128), self.layers[2].out_features)
+            shp = x.shape
+            return self._chain(x.reshape(-1, 128).contiguous(), 128).view(*shp[:-1], self.layers[2].out_features)
         for i, layer in enumerate(self.layers):
             last = i == self.num_layers - 1
             if (_fused() and x.is_cuda and layer.out_features % 32 == 0 and layer.out_features > 64
@@ -159,7 +165,7 @@ class _BlockLauncher:
                                              None if self.mlp is None else self.mlp[1].fc2.weight.contiguous(), wq, self.kq)
         return stream, stages, inv, bq, (0 if wq is None else wq.shape[0])
 
-    def __call__(self, x, msg=None, extra=None, extra_div=1, want_x=True):
+    def __call__(self, x, msg=None, extra=None, extra_div=1, want_x=True, ln_out=None, ln_out_map=None):
         stream, stages, inv, bq, nq = self.cache.get(self._params(), self._build)
         mlp = None
         if self.mlp is not None:
@@ -169,7 +175,40 @@ class _BlockLauncher:
         if self.nxt_norm is not None:
             q = dict(g=self.nxt_norm.weight, b=self.nxt_norm.bias, eps=self.nxt_norm.eps, extra=extra if self.kq > 128 else None,
                      extra_div=extra_div, bias=bq, kq=self.kq, nq=nq, ln_out=self.ln_out)
-        return K.nmp_block(x, stream, stages, inv, msg, None if self.proj is None else self.proj.bias, mlp, q, want_x=want_x)
+        return K.nmp_block(x, stream, stages, inv, msg, None if self.proj is None else self.proj.bias, mlp, q, want_x=want_x,
+                           ln_out=ln_out, ln_out_map=ln_out_map)
+
+
+class _ChainLauncher:
+    """One mlp_chain launch site (csrc/mlp_chain.hip): weights packed per parameter version."""
+
+    def __init__(self, kind, linears, kps, n_out):
+        self.kind, self.linears, self.kps, self.n_out = kind, tuple(linears), tuple(kps), n_out
+        self.cache = _FusedCache()
+
+    def __call__(self, x, k1, extra=None, out=None, out_map=None):
+        ps = tuple(l.weight for l in self.linears) + tuple(l.bias for l in self.linears if l.bias is not None)
+        stream, stages, inv = self.cache.get(ps, lambda: K.chain_stream([l.weight for l in self.linears], self.kps))
+        return K.mlp_chain(self.kind, x, k1, stream, stages, inv, [l.bias for l in self.linears], self.n_out, extra, out, out_map)
+
+
+def _pad_maps(dims, win, device, cache):
+    """int32 row maps between the dense token grid (b, h, w, n) and the grid zero-padded to a multiple of `win` (top = pad // 2,
+    NMP.py:745-762): (pdims, to_padded [T], to_dense [Tp] with -1 at pad tokens), or (dims, None, None) when nothing is padded."""
+    b, h, wd, n = dims
+    ph, pw = (-h) % win, (-wd) % win
+    if ph == 0 and pw == 0:
+        return dims, None, None
+    key = (dims, win, str(device))
+    if key not in cache:
+        hp, wp = h + ph, wd + pw
+        top, left = ph // 2, pw // 2
+        bi, yi, xi, ni = torch.meshgrid(torch.arange(b), torch.arange(h), torch.arange(wd), torch.arange(n), indexing="ij")
+        to_p = (((bi * hp + yi + top) * wp + xi + left) * n + ni).reshape(-1).to(torch.int32)
+        to_d = torch.full((b * hp * wp * n,), -1, dtype=torch.int32)
+        to_d[to_p.long()] = torch.arange(to_p.numel(), dtype=torch.int32)
+        cache[key] = ((b, hp, wp, n), to_p.to(device), to_d.to(device))
+    return cache[key]
 
 
 def _block_ok(*mods):
@@ -440,9 +479,17 @@ class Propagation(nn.Module):
         b, h, wd, cc = context.shape
         n = label_seed.shape[-1]
         dims = (b, h, wd, n)
+        split = (_split() and cc == 64 and self.embed_dim == 128 and self.cost_encoder[0].in_features <= 48
+                 and self.cost_encoder[0].in_features % 4 == 0 and all(_block_ok(l.nmp.proj, l.nmp.mlp) for l in self.layers))
+        ctx = context.reshape(b * h * wd, cc)
+        if split:
+            cost, enc = K.seed_features(cost_volume, label_seed, 3.14 / 64, 32)
+            if not hasattr(self, "_embed"):
+                self._embed = _ChainLauncher(1, (self.cost_encoder[0], self.cost_encoder[2], self.proj), (48, 128, 160), 128)
+            x = self._embed(cost, cost.shape[1], extra=enc)
+            return self._forward_blocks(x, ctx, dims).unsqueeze(0), label_seed.float()
         cost, enc = K.seed_features(cost_volume, label_seed, 3.14 / 64)
         x = self.proj(torch.cat((self.cost_encoder(cost), enc), -1))
-        ctx = context.reshape(b * h * wd, cc)
         if _split() and cc == 64 and self.embed_dim == 128 and all(_block_ok(l.nmp.proj, l.nmp.mlp) for l in self.layers):
             return self._forward_blocks(x.contiguous(), ctx, dims).unsqueeze(0), label_seed.float()
         y = None
@@ -491,11 +538,27 @@ class Inference(nn.Module):
     def _run(self, labels_flat, n, fmap1, fmap2, fmap1_gw, fmap2_gw):
         b, _, h, wd = fmap1.shape
         dims = (b, h, wd, n)
-        x = self.ffn(K.warp_corr_concat(labels_flat, fmap1, fmap2, fmap1_gw, fmap2_gw, n, self.cost_group))
         split = _split() and self.dim == 128 and all(
             _block_ok(l.nmp.proj, l.nmp.mlp, *((l.self_nmp.proj,) if hasattr(l, "self_nmp") else ())) for l in self.layers)
-        enc = K.fourier_embed(labels_flat, self.normalizer, 32 if split else 31)
         win = self.layers[0].window_size
+        wcc = K.warp_corr_concat(labels_flat, fmap1, fmap2, fmap1_gw, fmap2_gw, n, self.cost_group)
+        if split and wcc.shape[1] == 160 and self.ffn.fc1.out_features == 128 and self.ffn.fc2.out_features == 128:
+            # ffn and Fourier rows are written straight into the zero-padded token grid; the final norm is cropped on the way out
+            if not hasattr(self, "_maps"):
+                self._maps = {}
+                self._ffn = _ChainLauncher(0, (self.ffn.fc1, self.ffn.fc2), (160, 128), 128)
+            pdims, to_p, to_d = _pad_maps(dims, win, wcc.device, self._maps)
+            tp = pdims[0] * pdims[1] * pdims[2] * pdims[3]
+            if to_p is None:
+                x = self._ffn(wcc, 160)
+                enc = K.fourier_embed(labels_flat, self.normalizer, 32)
+            else:
+                x = self._ffn(wcc, 160, out=torch.zeros(tp, self.dim, device=wcc.device), out_map=to_p)
+                enc = K.fourier_embed(labels_flat, self.normalizer, 32, out=torch.zeros(tp, 32, device=wcc.device), out_map=to_p)
+            t_dense = dims[0] * dims[1] * dims[2] * dims[3]
+            return self._run_blocks(x, enc, pdims, to_d, t_dense)
+        x = self.ffn(wcc)
+        enc = K.fourier_embed(labels_flat, self.normalizer, 32 if split else 31)
         x, pdims, off = _pad_grid(x, dims, win)
         enc, _, _ = _pad_grid(enc, dims, win)
         x, enc = x.contiguous(), enc.contiguous()
@@ -512,7 +575,7 @@ class Inference(nn.Module):
             return _add_ln(x, y, self.norm)[1]
         return x if y is None else x + y
 
-    def _run_blocks(self, x, enc, pdims):
+    def _run_blocks(self, x, enc, pdims, to_dense=None, t_dense=None):
         """Per layer: [self-edge attention -> fused block (proj + residual -> window q|k|v)] (inference only), then
         window attention -> fused block (proj + residual + MLP -> the next layer's first q|k|v, or the final norm)."""
         n = pdims[3]
@@ -542,7 +605,14 @@ class Inference(nn.Module):
             else:
                 msg = m.attn(qkv, pdims, n > 1)                         # sibling mask for N > 1 (inference), none for refinement
             last = i + 1 == len(self._sites)
+            if last and self.norm is not None and to_dense is not None:       # final norm, cropped to the dense grid on the way out
+                ln = torch.empty(t_dense, self.dim, device=x.device)
+                self._launch[i + 1](x, msg, enc, 1, want_x=False, ln_out=ln, ln_out_map=to_dense)
+                return ln
             x, qkv, ln = self._launch[i + 1](x, msg, enc, 1, want_x=not last or self.norm is None)
+        if to_dense is not None:
+            keep = (to_dense >= 0).nonzero().squeeze(1)
+            return (ln if self.norm is not None else x).index_select(0, keep)
         return ln if self.norm is not None else x
 
     def forward(self, labels, fmap1, fmap2, fmap1_gw, fmap2_gw):

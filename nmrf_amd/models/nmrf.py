@@ -164,7 +164,13 @@ class NMRF(nn.Module):
         tgt = self.inference(labels_curr, fmap1, fmap2, fmap1_gw, fmap2_gw).view(-1, self.inference.dim)
         b, _, h8, w8 = fmap1.shape
         disp_delta = self.infer_head(tgt)                                   # [T,64]
-        score = K.linear_smalln(tgt, self.infer_score_head.weight, self.infer_score_head.bias)   # [T,64]; the 0.25 factor
+        from .nmp import _ChainLauncher, _split
+        if _split() and self.infer_score_head.in_features == 128 and self.infer_score_head.out_features <= 64:
+            if not hasattr(self, "_score"):
+                self._score = _ChainLauncher(3, (self.infer_score_head,), (128,), self.infer_score_head.out_features)
+            score = self._score(tgt, 128)
+        else:
+            score = K.linear_smalln(tgt, self.infer_score_head.weight, self.infer_score_head.bias)   # [T,64]; the 0.25 factor
         #                                                                     does not change the arg-max
         disp_curr = K.wta_median(disp_delta, score, labels_curr.reshape(-1).contiguous(), b, h8, w8, n)
 

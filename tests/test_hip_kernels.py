@@ -424,6 +424,58 @@ def test_nmp_block_fused(t_, proj, mlp, kq, nq, div, ln_out):
         report("block ln_out", lo.cpu(), rl, 1e-5, 1e-5)
 
 
+@pytest.mark.parametrize("kind,t_,n_out", [(0, 300, 128), (0, 29328, 128), (1, 1000, 128), (2, 517, 64), (2, 300, 16), (2, 4097, 1),
+                                           (3, 777, 64), (3, 40001, 64)])
+def test_mlp_chain_fused(kind, t_, n_out):
+    """csrc/mlp_chain.hip (ffn / seed embed / 3-layer ReLU heads / score head) against fp64, incl. the row map that writes the
+    zero-padded token grid in place."""
+    kk = K()
+    d = lambda v: None if v is None else v.to(DEV)
+    k1 = {0: 160, 1: 36, 2: 128, 3: 128}[kind]
+    x = rnd(t_, k1, seed=1, scale=1.5)
+    if kind == 0:
+        ws = [rnd(128, 160, seed=2, scale=0.1), rnd(128, 128, seed=3, scale=0.1)]
+        bs = [rnd(128, seed=4, scale=0.3), rnd(128, seed=5, scale=0.3)]
+        kps, extra = (160, 128), None
+        ref = F.gelu(x.double() @ ws[0].double().t() + bs[0].double()) @ ws[1].double().t() + bs[1].double()
+    elif kind == 1:
+        ws = [rnd(128, 36, seed=2, scale=0.2), rnd(128, 128, seed=3, scale=0.1), rnd(128, 159, seed=6, scale=0.1)]
+        bs = [rnd(128, seed=4, scale=0.3), rnd(128, seed=5, scale=0.3), None]
+        kps = (48, 128, 160)
+        extra = rnd(t_, 32, seed=7)
+        extra[:, 31] = 0
+        hdn = F.gelu(x.double() @ ws[0].double().t() + bs[0].double()) @ ws[1].double().t() + bs[1].double()
+        ref = torch.cat((hdn, extra[:, :31].double()), 1) @ ws[2].double().t()
+    elif kind == 2:
+        ws = [rnd(128, 128, seed=2, scale=0.1), rnd(128, 128, seed=3, scale=0.1), rnd(n_out, 128, seed=6, scale=0.1)]
+        bs = [rnd(128, seed=4, scale=0.3), rnd(128, seed=5, scale=0.3), rnd(n_out, seed=8, scale=0.3)]
+        kps, extra = (128, 128, 128), None
+        ref = F.relu(F.relu(x.double() @ ws[0].double().t() + bs[0].double()) @ ws[1].double().t() + bs[1].double()) @ ws[2].double().t() + bs[2].double()
+    else:
+        ws, bs, kps, extra = [rnd(n_out, 128, seed=2, scale=0.1)], [rnd(n_out, seed=4, scale=0.3)], (128,), None
+        ref = x.double() @ ws[0].double().t() + bs[0].double()
+    stream, stages, inv = kk.chain_stream([d(w) for w in ws], kps)
+    got = kk.mlp_chain(kind, d(x), k1, stream, stages, inv, [d(b) for b in bs], n_out, d(extra))
+    report("mlp_chain kind %d" % kind, got.cpu(), ref, 2e-5, 1e-5)
+    if kind == 0 and t_ < 1000:                       # row map: every other row of a twice as long zeroed buffer, the last 5 tokens dropped
+        omap = torch.arange(t_, dtype=torch.int32) * 2
+        omap[-5:] = -1
+        out = torch.zeros(2 * t_, 128, device=DEV)
+        kk.mlp_chain(kind, d(x), k1, stream, stages, inv, [d(b) for b in bs], n_out, None, out=out, out_map=d(omap))
+        out = out.cpu()
+        assert torch.equal(out[0:2 * (t_ - 5):2], got.cpu()[:t_ - 5]) and (out[1::2] == 0).all() and (out[2 * (t_ - 5):] == 0).all()
+
+
+def test_fourier_embed_row_map_and_padding_columns():
+    coord = rnd(500, seed=3).abs() * 40
+    omap = (torch.arange(500, dtype=torch.int32) + 7)
+    out = torch.zeros(520, 32, device=DEV)
+    K().fourier_embed(coord.to(DEV), 3.14 / 64, 32, out=out, out_map=omap.to(DEV))
+    dense = K().fourier_embed(coord.to(DEV), 3.14 / 64).cpu()
+    out = out.cpu()
+    assert torch.equal(out[7:507, :31], dense) and (out[:, 31] == 0).all() and (out[:7] == 0).all() and (out[507:] == 0).all()
+
+
 @pytest.mark.parametrize("b,c,h,w", [(2, 5, 7, 9), (1, 3, 188, 624), (2, 4, 47, 156), (2, 3, 94, 311), (1, 2, 1, 3), (1, 3, 127, 131)])
 def test_instance_norm_fused(b, c, h, w):
     x = rnd(b, c, h, w, seed=h, scale=3.0) + 1.5

@@ -390,3 +390,23 @@ def test_split_linears_flip_rate_matches_fp32_path(monkeypatch):
     record_disp_stats("KITTI hot path, split vs fp32-MFMA linears", disp_stats(split, fp32))
     assert s_split["median"] <= 1.5 * s_fp32["median"] + 1e-5, (s_split, s_fp32)
     assert s_split["frac_gt_0p5"] <= 3 * s_fp32["frac_gt_0p5"] + 64.0 / (h * w) + 1e-4, (s_split, s_fp32)
+
+
+@pytest.mark.parametrize("h,w", [(8, 13), (10, 12)])
+def test_padded_grid_row_maps_match_reference_padding(h, w):
+    """The in-place padded token grid (row maps, nmp.py:_pad_maps) against F.pad of the dense result and back (NMP.py:745-762,
+    786-788): both window stages on a grid that needs top/left and bottom/right padding."""
+    from nmrf_amd.models import nmp
+    b, n, win = 2, 4, 6
+    dims = (b, h, w, n)
+    pdims, to_p, to_d = nmp._pad_maps(dims, win, torch.device(DEV), {})
+    t_ = b * h * w * n
+    x = torch.arange(t_ * 3, dtype=torch.float32, device=DEV).view(t_, 3) + 1
+    xp_ref, pd, off = nmp._pad_grid(x, dims, win)
+    assert pd == pdims
+    xp = torch.zeros(pdims[0] * pdims[1] * pdims[2] * pdims[3], 3, device=DEV)
+    xp[to_p.long()] = x
+    assert torch.equal(xp, xp_ref.contiguous())
+    back = xp[(to_d >= 0).nonzero().squeeze(1)]
+    assert torch.equal(back, nmp._crop_grid(xp_ref.contiguous(), pdims, dims, off).contiguous()) and torch.equal(back, x)
+    assert torch.equal(to_d[to_p.long()].cpu(), torch.arange(t_, dtype=torch.int32))
