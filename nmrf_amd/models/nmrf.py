@@ -94,6 +94,7 @@ class NMRF(nn.Module):
         enc = self.backbone if self.compat else self.image_encoder
         feats = enc(torch.cat((img1, img2), 0))[::-1]
         b = img1.shape[0]
+        self._joint_feats = feats          # the un-split [2B,C,H,W] maps: hot_path re-uses them instead of re-concatenating the views
         return [f[:b].contiguous() for f in feats], [f[b:].contiguous() for f in feats]
 
     @torch.no_grad()
@@ -111,7 +112,10 @@ class NMRF(nn.Module):
         padder = InputPadder(image1.shape, mode="proposal", divis_by=self.divis_by)
         image1, image2 = padder.pad(image1, image2)
         fmap1_list, fmap2_list = self.extract_feature(image1, image2)
-        return self.hot_path(fmap1_list, fmap2_list, (h0, w0))
+        try:
+            return self.hot_path(fmap1_list, fmap2_list, (h0, w0))
+        finally:
+            self._joint_feats = None
 
     def _match_heads(self, left, right, cache):
         """concatconv / gw on both views as ONE stock 3x3 convolution: the two heads share their input, so their
@@ -123,7 +127,14 @@ class NMRF(nn.Module):
         b = left.shape[0]
         if not hasattr(cache, "wino"):
             cache.wino = {}
-        y = K.instance_norm(K.conv3x3_auto(torch.cat((left, right), 0), w3, cache.wino).contiguous(), relu=True)
+        both = None
+        for jf in getattr(self, "_joint_feats", None) or ():       # left / right are the two halves of one encoder output
+            if (jf.shape[0] == 2 * b and jf.shape[1:] == left.shape[1:] and jf.is_contiguous() and jf.data_ptr() == left.data_ptr()
+                    and jf[b:].data_ptr() == right.data_ptr()):
+                both = jf
+        if both is None:
+            both = torch.cat((left, right), 0)
+        y = K.instance_norm(K.conv3x3_auto(both, w3, cache.wino).contiguous(), relu=True)
         f = F.conv2d(y[:, 0:128], self.concatconv[3].weight)
         g = F.conv2d(y[:, 128:256], self.gw[3].weight)
         return f[:b].contiguous(), f[b:].contiguous(), g[:b].contiguous(), g[b:].contiguous()
