@@ -81,6 +81,25 @@ __device__ __forceinline__ void split_mma1(h16x8 ah, h16x8 al, h16x8 bh, h16x8 b
     acc = mfma16h(ah, bh, acc);
 }
 
+// Drop-in replacements of the two 16-step fp32 MFMA loops of the attention kernels (st = mfma32(kf[s], qf[s], st) and
+// acc = mfma32(vf[s], p[s], acc), s = 0..15): chunk c, slot jj of half hi takes the place of MFMA k-slot (step s = 8c + jj,
+// half hi), so every operand map of those kernels stays as it is; 2 x 3 MFMAs of 32 cycles instead of 16 of 64.
+__device__ __forceinline__ void split_dot16(const float *a, const float *b, f32x16 &acc) {
+    h16x8 ah[2], al[2], bh[2], bl[2];
+    split8u(a, ah[0], al[0]);
+    split8u(a + 8, ah[1], al[1]);
+    split8u(b, bh[0], bl[0]);
+    split8u(b + 8, bh[1], bl[1]);
+    split_mma1(ah[0], al[0], bh[0], bl[0], acc);
+    split_mma1(ah[1], al[1], bh[1], bl[1], acc);
+}
+__device__ __forceinline__ void split_dot16(const float *a, const f32x16 &b, f32x16 &acc) {
+    float bv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bv[r] = b[r];
+    split_dot16(a, bv, acc);
+}
+
 // k slot order of a B operand that is taken straight from a C/D result (and of every A operand contracted with it):
 // slot jj (0..7) of half hi of k chunk c  <->  k = 16*c + (jj&3) + 8*(jj>>2) + 4*hi.  With this order the 16 registers of
 // a 32-row D strip ARE two consecutive k chunks of the next contraction (regs 0-7 -> chunk 0, regs 8-15 -> chunk 1): no

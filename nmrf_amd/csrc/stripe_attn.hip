@@ -5,7 +5,8 @@
 // is one 128-byte line, shared through L1/L2 by the waves of the block, which walk the same stripe).
 // Flash-style streaming softmax, so the [T,T] matrix never exists (H9).
 //
-// Matrix-core formulation (v_mfma_f32_32x32x2_f32, exact fp32, 16 k-steps per 32-deep contraction):
+// Matrix-core formulation (round 1: v_mfma_f32_32x32x2_f32, 16 k-steps per 32-deep contraction; round 2: the same maps on
+// v_mfma_f32_32x32x16_f16 with split fp16 operand pairs, 2 chunks x 3 MFMAs of 32 cycles instead of 16 of 64 -- split_mfma.h):
 //   S^T[key][q]  = sum_c K[key][c] * Q[q][c]          A = K fragment, B = Q fragment
 //   O^T[d][q]   += sum_key V[key][d] * P[q][key]      A = V fragment, B = P (the S^T accumulator itself)
 // With the transposed forms the softmax statistics of query q live in lane q (both half-waves),
@@ -21,6 +22,7 @@
 // can fire (sibling mask on the diagonal tile, tail mask on the last tile); exp2 with log2(e) folded
 // into the q scale; the next K/V fragments are fetched while the current tile computes.
 #include "common.h"
+#include "split_mfma.h"
 #include <type_traits>
 #include <stdlib.h>
 
@@ -122,6 +124,11 @@ __global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__rest
                 qf[4 * c + 0] = v.x * sc2; qf[4 * c + 1] = v.y * sc2; qf[4 * c + 2] = v.z * sc2; qf[4 * c + 3] = v.w * sc2;
             }
         }
+        // both contractions run on the fp16 matrix pipe with split operands (split_mfma.h, single-accumulator form): chunk c,
+        // slot jj of half hi <-> MFMA k-slot (step s = 8c + jj, half hi) of the fp32 formulation above, so every map stays
+        h16x8 qh[2], ql[2];
+        split8u(qf, qh[0], ql[0]);
+        split8u(qf + 8, qh[1], ql[1]);
         const int n_kt = (g.Ts + SA_TILE - 1) / SA_TILE;
         const int per = (n_kt + KSPLIT - 1) / KSPLIT;
         const int kt_begin = ks * per, kt_end = (kt_begin + per < n_kt) ? kt_begin + per : n_kt;
@@ -197,8 +204,13 @@ __global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__rest
             f32x16 st;
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[r] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) st = mfma32(kf[s], qf[s], st);
+            {
+                h16x8 kh[2], kl[2];
+                split8u(kf, kh[0], kl[0]);
+                split8u(kf + 8, kh[1], kl[1]);
+                split_mma1(kh[0], kl[0], qh[0], ql[0], st);
+                split_mma1(kh[1], kl[1], qh[1], ql[1], st);
+            }
             if (STEADY) load_k_fast(kt + 2, kf);                // K fragment is dead: refill now
             else if (kt + 2 < kt_end) load_k(kt + 2, kf);
             if (!STEADY && kt == n_kt - 1) {                   // keys beyond the stripe (last tile only)
@@ -231,8 +243,18 @@ __global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__rest
             m_run = m_new;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc_o[r] *= alpha;
+            {
+                float pv[16];
 #pragma unroll
-            for (int s = 0; s < 16; ++s) acc_o = mfma32(vf[s], st[s], acc_o);
+                for (int r = 0; r < 16; ++r) pv[r] = st[r];
+                h16x8 ph[2], pl[2], vh[2], vl[2];
+                split8u(pv, ph[0], pl[0]);
+                split8u(pv + 8, ph[1], pl[1]);
+                split8u(vf, vh[0], vl[0]);
+                split8u(vf + 8, vh[1], vl[1]);
+                split_mma1(vh[0], vl[0], ph[0], pl[0], acc_o);
+                split_mma1(vh[1], vl[1], ph[1], pl[1], acc_o);
+            }
             if (STEADY) load_v_fast(kt + 2, vf);                // V fragment likewise
             else if (kt + 2 < kt_end) load_v(kt + 2, vf);
             if (CENSUS) { asm volatile("" :: "v"(acc_o[0])); if (kt - kt_begin < 6) SA_STAMP(2 + kt - kt_begin); }

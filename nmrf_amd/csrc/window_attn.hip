@@ -23,6 +23,7 @@
 // This is the generic kernel (runtime window size / labels per pixel) used by non-shipped configurations; the
 // shipped ones (6x6x4 inference windows, 4x4x1 refinement windows) run window_attn_fast_kernel below.
 #include "common.h"
+#include "split_mfma.h"
 
 struct WinGeom {
     int Hp, Wp, N, C, heads, win, shift, sibling;
@@ -191,8 +192,7 @@ __global__ __launch_bounds__(64 * NKT) void window_attn_kernel(const float *__re
         f32x16 st;
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) st = mfma32(kf[s], qf[s], st);
+        split_dot16(kf, qf, st);                            // S^T = K . Q^T on split-fp16 MFMA (split_mfma.h)
         if (kt + 1 < NKT) load_k(kt + 1, kf);               // K fragment is dead: refill it for the next tile now,
         //                                                     in flight during this tile's softmax and P.V
         float m_tile = -INFINITY;
@@ -235,8 +235,7 @@ __global__ __launch_bounds__(64 * NKT) void window_attn_kernel(const float *__re
 #pragma unroll
         for (int d = 0; d < 32; ++d) oe[d] *= alpha;
         // P.V on MFMA
-#pragma unroll
-        for (int s = 0; s < 16; ++s) acc_o = mfma32(vf[s], st[s], acc_o);
+        split_dot16(vf, st, acc_o);                         // O^T += V^T . P^T on split-fp16 MFMA
         if (kt + 1 < NKT) load_v(kt + 1, vf);               // same for V: in flight during the ev term and the next S^T
         // value-embedding term on the VALU: sum over key PIXELS of (sum_n p) * ev[rel(pq,pk)]
 #pragma unroll
@@ -532,8 +531,7 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
         f32x16 st;
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) st = mfma32(kf[s], qf[s], st);
+        split_dot16(kf, qf, st);                            // S^T = K . Q^T on split-fp16 MFMA (split_mfma.h)
         if (kt + 1 < NKT) load_k(kt + 1, kf);
         // relative-position terms: one b128 of KR^T per key quad, QR^T per key pixel
 #pragma unroll
@@ -594,8 +592,7 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
         for (int r = 0; r < 16; ++r) acc_o[r] *= alpha;
 #pragma unroll
         for (int r = 0; r < 8; ++r) oe[r] *= alpha;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) acc_o = mfma32(vf[s], st[s], acc_o);
+        split_dot16(vf, st, acc_o);                         // O^T += V^T . P^T on split-fp16 MFMA
         // value-embedding term: sum over key PIXELS of (sum_n p) * ev[rel(pq,pk)].  The two half-lanes of a query
         // swap the probabilities of their pixels, then each accumulates BOTH pixels for its own 16 channels.
 #pragma unroll

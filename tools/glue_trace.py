@@ -31,18 +31,16 @@ with torch.no_grad():
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
         model(sample)
         torch.cuda.synchronize()
-rows = collections.defaultdict(lambda: [0, 0.0])
-for ev in prof.events():
-    if not ev.name.startswith("aten::") or ev.device_time_total <= 0 or not ev.stack:
+avg = prof.key_averages(group_by_stack_n=12)
+rows = []
+for ev in avg:
+    t = getattr(ev, "self_device_time_total", 0) or 0
+    if t <= 0 or not ev.key.startswith("aten::"):
         continue
-    if ev.cpu_children and any(c.name.startswith("aten::") and c.device_time_total > 0 for c in ev.cpu_children):
-        continue                                        # count the innermost aten op only
-    frame = next((f for f in ev.stack if "nmrf_amd" in f and "kernels.py" not in f), ev.stack[0])
-    key = (ev.name, frame.strip()[-110:])
-    rows[key][0] += 1
-    rows[key][1] += ev.device_time_total
+    frame = next((f for f in (ev.stack or []) if "nmrf_amd" in f and "kernels.py" not in f), (ev.stack or ["?"])[0])
+    rows.append((t, ev.count, ev.key, frame.strip()[-120:]))
 tot = 0.0
-for (name, frame), (n, t) in sorted(rows.items(), key=lambda kv: -kv[1][1])[:45]:
-    print("%8.1f us  x%-3d %-28s %s" % (t, n, name, frame))
+for t, n, name, frame in sorted(rows, reverse=True)[:60]:
+    print("%8.1f us  x%-3d %-30s %s" % (t, n, name, frame))
     tot += t
 print("listed total %.1f us" % tot)
