@@ -242,6 +242,17 @@ int nmrf_mlp_chain_f32(int kind, const float *in, int in_ld, int K1, const void 
  * out: N * Kp * 4 bytes.  N % 32 == 0, Kp % 16 == 0, Kp >= K. */
 int nmrf_pack_split_weight_f32(const float *w, int N, int K, int Kp, float scale, void *out, void *stream);
 
+/* A1 + encoder input staging: replicate-pad both views right/bottom to (Hp, Wp) (InputPadder mode 'proposal',
+ * nmrf/utils/frame_utils.py:268-275), stack them along the batch (NMRF.py:173) and normalise 2*(x/255)-1 (backbone.py:86).
+ * img1, img2 [B,C,H,W] -> out [2B,C,Hp,Wp] (left views first). */
+int nmrf_prep_images_f32(const float *img1, const float *img2, int B, int C, int H, int W, int Hp, int Wp, float *out,
+                         void *stream);
+
+/* Encoder tail (N2): y [planes = 2B*C, H, W] = the last 1x1 convolution WITHOUT its bias -> x = y + bias[c] and the 2x2 average
+ * of x (backbone.py:96-98) in one pass.  H, W even. */
+int nmrf_bias_avgpool2_f32(const float *y, const float *bias, int64_t planes, int C, int H, int W, float *x, float *pooled,
+                           void *stream);
+
 /* Self-test: fills out[32*32] with the 32x32 product A*B computed by one wave of
  * v_mfma_f32_32x32x2_f32 (A [32,K], B [K,32] row-major, K even <= 64); pins the operand/accumulator
  * lane layout every attention kernel relies on. */

@@ -45,6 +45,8 @@ PROTOTYPES = {
     "nmrf_msda_backward_f64": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "nmrf_nmp_block_f32": [_P, _P, _P, _I, _P, _P, _P, _F, _P, _P, _P, _P, _F, _P, _I, _I, _P, _I, _I, _I, _L, _P, _P, _P, _P, _P, _P],
     "nmrf_pack_split_weight_f32": [_P, _I, _I, _I, _F, _P, _P],
+    "nmrf_prep_images_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "nmrf_bias_avgpool2_f32": [_P, _P, _L, _I, _I, _I, _P, _P, _P],
     "nmrf_selftest_mfma_f32": [_P, _P, _I, _P, _P],
     "nmrf_selftest_mfma_f16split": [_P, _P, _I, _I, _P, _P],
     "nmrf_selftest_lds_dma": [_P, _P, _I, _P],

@@ -144,3 +144,67 @@ extern "C" int nmrf_instance_norm_f32(const float *x, const float *residual, int
                        relu_out, ws, y);
     return nmrf_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Input staging of the CNN encoder in one pass: replicate-pad right/bottom to (Hp, Wp) (InputPadder mode 'proposal',
+// nmrf/utils/frame_utils.py:268-275), stack the two views along the batch (NMRF.py:173) and normalise
+// 2 * (x / 255) - 1 (nmrf/models/backbone.py:86), same fp32 operation order.  Replaces two replication pads, a cat and three
+// elementwise kernels.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prep_images_kernel(const float *__restrict__ img1, const float *__restrict__ img2, int B,
+                                                         int C, int H, int W, int Hp, int Wp, float *__restrict__ out) {
+    const int64_t total = (int64_t)2 * B * C * Hp * Wp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % Wp);
+        const int y = (int)((i / Wp) % Hp);
+        const int64_t pc = i / ((int64_t)Wp * Hp);                 // (view * B + b) * C + c
+        const int64_t v = pc / ((int64_t)B * C), bc = pc - v * (int64_t)B * C;
+        const float *src = (v == 0 ? img1 : img2) + bc * (int64_t)H * W;
+        const float px = src[(int64_t)(y < H ? y : H - 1) * W + (x < W ? x : W - 1)];
+        out[i] = 2.0f * (px / 255.0f) - 1.0f;
+    }
+}
+
+extern "C" int nmrf_prep_images_f32(const float *img1, const float *img2, int B, int C, int H, int W, int Hp, int Wp, float *out,
+                                    void *stream) {
+    if (!img1 || !img2 || !out) return NMRF_ENULL;
+    if (B < 1 || C < 1 || H < 1 || W < 1 || Hp < H || Wp < W) return NMRF_EINVAL;
+    int64_t blocks = ceil_div64((int64_t)2 * B * C * Hp * Wp, 256 * 4);
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(prep_images_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, img1, img2, B, C, H, W, Hp, Wp,
+                       out);
+    return nmrf_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Tail of the CNN encoder: y = conv1x1 output without its bias [BC planes of H x W]; x = y + bias[c] (the 1/4-resolution map)
+// and its 2x2 average (the 1/8 map, nmrf/models/backbone.py:96-98) in one pass over y.  H, W even; thread = one 2x2 cell.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bias_avgpool2_kernel(const float *__restrict__ y, const float *__restrict__ bias, int Cc,
+                                                           int H, int W, int64_t cells, float *__restrict__ x,
+                                                           float *__restrict__ pooled) {
+    const int W2 = W >> 1, H2 = H >> 1;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cells; i += (int64_t)gridDim.x * 256) {
+        const int cx = (int)(i % W2), cy = (int)((i / W2) % H2);
+        const int64_t plane = i / ((int64_t)W2 * H2);
+        const float bv = bias ? bias[plane % Cc] : 0.f;
+        const int64_t o = plane * (int64_t)H * W + (int64_t)(2 * cy) * W + 2 * cx;
+        const float2 t = *reinterpret_cast<const float2 *>(y + o), u = *reinterpret_cast<const float2 *>(y + o + W);
+        const float a = t.x + bv, b = t.y + bv, c = u.x + bv, d = u.y + bv;
+        *reinterpret_cast<float2 *>(x + o) = make_float2(a, b);
+        *reinterpret_cast<float2 *>(x + o + W) = make_float2(c, d);
+        pooled[i] = (((a + b) + c) + d) * 0.25f;          // ATen's avg_pool2d sums the window row by row, then divides
+    }
+}
+
+extern "C" int nmrf_bias_avgpool2_f32(const float *y, const float *bias, int64_t planes, int C, int H, int W, float *x, float *pooled,
+                                      void *stream) {
+    if (!y || !x || !pooled) return NMRF_ENULL;
+    if (planes < 1 || C < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) return NMRF_EINVAL;
+    const int64_t cells = planes * (int64_t)(H / 2) * (W / 2);
+    int64_t blocks = ceil_div64(cells, 256 * 2);
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(bias_avgpool2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, bias, C, H, W, cells, x,
+                       pooled);
+    return nmrf_launch_status();
+}

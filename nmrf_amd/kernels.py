@@ -530,6 +530,27 @@ def instance_norm(x, relu=False, residual=None, relu_out=False, eps=1e-5):
 
 
 @_on_device
+def prep_images(img1, img2, hp, wp):
+    """[B,3,H,W] x2 (0..255) -> [2B,3,hp,wp]: replicate-padded right/bottom, stacked, normalised to [-1,1] (one pass)."""
+    _chk(img1, img2)
+    b, c, h, w = img1.shape
+    out = torch.empty(2 * b, c, hp, wp, device=img1.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_prep_images_f32(_p(img1), _p(img2), b, c, h, w, hp, wp, _p(out), _stream()), "prep_images")
+    return out
+
+
+@_on_device
+def bias_avgpool2(y, bias):
+    """y [B,C,H,W] (bias-free conv output) -> (y + bias[c], its 2x2 average) in one pass."""
+    _chk(y, bias)
+    b, c, h, w = y.shape
+    x = torch.empty_like(y)
+    pooled = torch.empty(b, c, h // 2, w // 2, device=y.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_bias_avgpool2_f32(_p(y), _p(bias), b * c, c, h, w, _p(x), _p(pooled), _stream()), "bias_avgpool2")
+    return x, pooled
+
+
+@_on_device
 def msda_forward(value, shapes, lvl_start, loc, w):
     dt = value.dtype
     if dt not in (torch.float32, torch.float64):

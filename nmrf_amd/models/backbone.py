@@ -51,7 +51,9 @@ class ResidualBlock(nn.Module):
             c1 = K.conv3x3_auto(x, self.conv1.weight, self._wino1) if self.conv1.stride == (1, 1) else self.conv1(x)
             y = K.instance_norm(c1.contiguous(), relu=True)
             if self.downsample is not None:
-                x = K.instance_norm(self.downsample[0](x).contiguous())
+                # (the 1x1 conv's bias is a per-channel constant: InstanceNorm removes it, so the add is skipped)
+                d = self.downsample[0]
+                x = K.instance_norm(F.conv2d(x, d.weight, None, d.stride).contiguous())
             c2 = K.conv3x3_auto(y, self.conv2.weight, self._wino2)
             return K.instance_norm(c2.contiguous(), relu=True, residual=x.contiguous(), relu_out=True)
         y = self.relu(self.norm1(self.conv1(x)))
@@ -80,13 +82,21 @@ class Backbone(nn.Module):
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
-    def forward(self, x):
-        x = 2 * (x / 255.0) - 1.0
+    def forward(self, x, normalized=False):
+        """x [B,3,H,W] in 0..255 (or already in [-1,1] with normalized=True: NMRF.forward stages pad + stack + normalise in
+        one HIP pass)."""
+        if not normalized:
+            x = 2 * (x / 255.0) - 1.0
         if self.fused and _hip_ok(self, x):
             from .. import kernels as K
             x = K.instance_norm(self.conv1(x).contiguous(), relu=True)
-        else:
-            x = self.relu1(self.norm1(self.conv1(x)))
+            x = self.layer3(self.layer2(self.layer1(x)))
+            if x.shape[-1] % 2 == 0 and x.shape[-2] % 2 == 0:
+                y = F.conv2d(x, self.conv2.weight, None)
+                return list(K.bias_avgpool2(y.contiguous(), self.conv2.bias))     # bias add + 2x2 average in one pass
+            x = self.conv2(x)
+            return [x, F.avg_pool2d(x, 2, 2)]
+        x = self.relu1(self.norm1(self.conv1(x)))
         x = self.conv2(self.layer3(self.layer2(self.layer1(x))))
         return [x, F.avg_pool2d(x, 2, 2)]
 

@@ -109,9 +109,19 @@ class NMRF(nn.Module):
         image1 = sample["img1"].to(self.device)
         image2 = sample["img2"].to(self.device)
         h0, w0 = image1.shape[-2:]
-        padder = InputPadder(image1.shape, mode="proposal", divis_by=self.divis_by)
-        image1, image2 = padder.pad(image1, image2)
-        fmap1_list, fmap2_list = self.extract_feature(image1, image2)
+        enc = self.backbone if self.compat else self.image_encoder
+        from .backbone import Backbone
+        if isinstance(enc, Backbone) and image1.dtype == torch.float32 and image1.shape == image2.shape:
+            # pad (A1) + stack + normalise in one HIP pass, straight into the encoder
+            b = image1.shape[0]
+            hp, wp = h0 + (-h0) % self.divis_by, w0 + (-w0) % self.divis_by
+            feats = enc(K.prep_images(image1.contiguous(), image2.contiguous(), hp, wp), normalized=True)[::-1]
+            self._joint_feats = feats
+            fmap1_list, fmap2_list = [f[:b] for f in feats], [f[b:] for f in feats]
+        else:
+            padder = InputPadder(image1.shape, mode="proposal", divis_by=self.divis_by)
+            image1, image2 = padder.pad(image1, image2)
+            fmap1_list, fmap2_list = self.extract_feature(image1, image2)
         try:
             return self.hot_path(fmap1_list, fmap2_list, (h0, w0))
         finally:

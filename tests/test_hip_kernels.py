@@ -466,6 +466,21 @@ def test_mlp_chain_fused(kind, t_, n_out):
         assert torch.equal(out[0:2 * (t_ - 5):2], got.cpu()[:t_ - 5]) and (out[1::2] == 0).all() and (out[2 * (t_ - 5):] == 0).all()
 
 
+def test_prep_images_and_bias_avgpool():
+    """Encoder input staging (pad + stack + normalise) and tail (bias + 2x2 average) against the torch ops they replace."""
+    from nmrf_amd.frame_utils import InputPadder
+    img1, img2 = (rnd(2, 3, 37, 53, seed=1) + 1) * 127.5, (rnd(2, 3, 37, 53, seed=2) + 1) * 127.5
+    got = K().prep_images(img1.to(DEV), img2.to(DEV), 40, 56).cpu()
+    a, b = InputPadder(img1.shape, mode="proposal", divis_by=8).pad(img1, img2)
+    want = 2 * (torch.cat((a, b), 0) / 255.0) - 1.0
+    assert torch.equal(got, want)
+    y, bias = rnd(3, 5, 12, 18, seed=3), rnd(5, seed=4)
+    x, pooled = K().bias_avgpool2(y.to(DEV), bias.to(DEV))
+    ref = y + bias[None, :, None, None]
+    assert torch.equal(x.cpu(), ref)
+    report("avgpool", pooled.cpu(), F.avg_pool2d(ref, 2, 2), 1e-6)
+
+
 def test_fourier_embed_row_map_and_padding_columns():
     coord = rnd(500, seed=3).abs() * 40
     omap = (torch.arange(500, dtype=torch.int32) + 7)
