@@ -26,6 +26,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+FP16_MFMA_PEAK_TFLOPS = 2500.0       # same guide: dense fp16 / bf16 MFMA (v_mfma_f32_32x32x16_f16)
+SPLIT_MFMA_PEAK_TFLOPS = FP16_MFMA_PEAK_TFLOPS / 3     # split-operand kernels execute 3 fp16 MFMAs per algorithmic product
 HBM_PEAK_GBS = 8000.0                # same guide: HBM3E ~8 TB/s
 
 
@@ -255,8 +257,9 @@ def main():
     value = pairs_total / elapsed
     n = cfg.DPN.NUM_PROPOSALS
     # per-kernel records: ALGORITHMIC work per launch (SURVEY 8(d) formulas, recorded by the wrappers in nmrf_amd/kernels.py)
-    # / mean launch time measured above.  MFMA-bound kernels are priced against the fp32 MFMA peak, HBM-bound ones against
-    # 8 TB/s.  `traffic` / `mfma_busy` / `lds_bank_conflict_ratio` come from separate rocprofv3 --pmc passes (never collected
+    # / mean launch time measured above.  MFMA-bound kernels are priced against the peak of the pipe they run on -- fp32 MFMA
+    # (157.3 TFLOP/s) or, for the split-operand kernels, the fp16 MFMA peak / 3 (833 TFLOP/s of algorithmic products) --
+    # HBM-bound ones against 8 TB/s.  `traffic` / `mfma_busy` / `lds_bank_conflict_ratio` come from separate rocprofv3 --pmc passes (never collected
     # in this run): profiles/pmc_traffic.json, whose "_source" names the round and run they belong to; they are reported only
     # for the workload those passes were taken on (KITTI, batch 1).
     pmc = {}
@@ -280,7 +283,8 @@ def main():
         bound = meta.get("bound", "mfma")
         flops, nbytes = timer.mean_meta(k, "flops"), timer.mean_meta(k, "bytes")
         if bound == "mfma":
-            ach, peak, unit = flops / (ms * 1e-3) / 1e12, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s"
+            ach, unit = flops / (ms * 1e-3) / 1e12, "TFLOP/s"
+            peak = round(SPLIT_MFMA_PEAK_TFLOPS, 1) if meta.get("split") else FP32_MFMA_PEAK_TFLOPS
         else:
             ach, peak, unit = nbytes / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
         pr = pmc_rec(meta.get("pmc")) if pmc_ok else {}
@@ -288,6 +292,9 @@ def main():
                "unit": unit, "frac": round(ach / peak, 4), "traffic": pr.get("hbm_bytes"),
                "launch_ms": round(ms, 4), "launches_timed": cnt, "ms_per_forward": round(ms * cnt / n_timed_fwd, 4),
                "flop_per_launch": flops, "bytes_per_launch": nbytes}
+        if bound == "mfma":
+            rec["pipe"] = ("fp16 MFMA, split fp32 operands: peak = 2500 TFLOP/s / 3 products (csrc/split_mfma.h)" if meta.get("split")
+                           else "fp32 MFMA")
         if pr:
             rec["traffic_source"] = "profiles/pmc_traffic.json: " + str(pmc.get("_source", "?"))
             for key in ("mfma_busy", "lds_bank_conflict_ratio"):
@@ -311,9 +318,10 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": ("f32" if os.environ.get("NMRF_LINEAR", "split") == "fp32" else
-                      "f32 (storage, accumulation, attention, convolutions; the per-token linears multiply fp32 operands as "
-                      "fp16 hi/lo pairs on the fp16 MFMA, 3 products per term, ~2^-22 relative -- csrc/split_mfma.h; "
-                      "NMRF_LINEAR=fp32 runs them on the fp32 MFMA)"),
+                      "f32 (storage, accumulation, softmax / LayerNorm / GELU, convolutions; the contractions of the per-token "
+                      "linears and of the attention kernels multiply fp32 operands as fp16 hi/lo pairs on the fp16 MFMA, 3 products "
+                      "per term, ~2^-22 relative, fp32 accumulate -- csrc/split_mfma.h; NMRF_LINEAR=fp32 runs the linears on "
+                      "the fp32 MFMA)"),
             "data": "synthetic",
             "config": {"workload": "%s %dx%d stereo pairs, batch %d per GPU, %s backbone, D_max %d, %d/%d/%d prop/infer/refine "
                                    "layers, hash-formula weights" % (

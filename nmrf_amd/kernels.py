@@ -192,7 +192,7 @@ def stripe_attn(qkv, lepe_v, lepe_h, b, h, w, n):
     fn = _lib.load().nmrf_stripe_attn_f32
     _lib.check(fn(_p(qkv), _p(lepe_v), _p(lepe_h), b, h, w, n, c, 1, _p(out), _stream()), "stripe_attn(vertical)")
     # per (row, head): QK^T and PV, 2*T^2*32 FLOPs each, T = W*N, 2 heads of 32 channels
-    _hb("stripe_attn_horizontal", row="A7", bound="mfma", flops=b * h * 2 * 4.0 * 32 * (w * n) ** 2, bytes=4.0 * (qkv.numel() / 2 + t * c / 2),
+    _hb("stripe_attn_horizontal", row="A7", bound="mfma", split=True, flops=b * h * 2 * 4.0 * 32 * (w * n) ** 2, bytes=4.0 * (qkv.numel() / 2 + t * c / 2),
         label="stripe_attn_kernel<1> (horizontal stripes, A7)",
         pmc=["stripe_attn_kernel<1, 2, 1, false>", "stripe_attn_kernel<1, 2, 2, false>"])
     _lib.check(fn(_p(qkv), _p(lepe_v), _p(lepe_h), b, h, w, n, c, 2, _p(out), _stream()), "stripe_attn(horizontal)")
@@ -239,7 +239,7 @@ def window_attn(qkv, table, b, hp, wp, n, heads, win, shift, sibling_mask):
     out = torch.empty(t, c, device=qkv.device, dtype=torch.float32)
     tw = win * win * n                                 # reference form: 5 contractions of tw^2 x 32 MACs per (window, head)
     fast = {(6, 4): "window_attn_fast_kernel<5, 6, 4, 2, 3, false>", (4, 1): "window_attn_fast_kernel<1, 4, 1, 8, 2, false>"}
-    _hb("window_attn_w%d_n%d" % (win, n), row="A10" if n > 1 else "A13", bound="mfma",
+    _hb("window_attn_w%d_n%d" % (win, n), row="A10" if n > 1 else "A13", bound="mfma", split=True,
         flops=b * (hp // win) * (wp // win) * heads * 5 * 2.0 * tw * tw * 32, bytes=4.0 * (qkv.numel() + t * c),
         label="%s (%s windows, %s)" % (fast.get((win, n), "window_attn_kernel<%d>" % ((tw + 31) // 32)).split("<")[0] +
                                        "<win %d, N %d>" % (win, n), "inference" if n > 1 else "refinement",
