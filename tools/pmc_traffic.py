@@ -24,7 +24,7 @@ def main(src, dst_prefix):
     table = {}
     for p in "ABCD":
         for k, cs in load(os.path.join(src, "pass%s_counter_collection.csv" % p)).items():
-            if any(tag in k for tag in ("attn", "warp", "token_linear", "mlp", "seed", "cost_volume", "nms", "msda")):
+            if any(tag in k for tag in ("attn", "warp", "token_linear", "mlp", "nmp_block", "seed", "cost_volume", "nms", "msda")):
                 table.setdefault(k, {}).update({c: round(sum(v) / len(v)) for c, v in cs.items()})
     # model-level passes (bench.py, eager): only the Winograd conv is taken from them (mean over the layers of a forward)
     for pth in ("passM1", "passM2"):
