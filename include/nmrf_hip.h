@@ -27,7 +27,7 @@ extern "C" {
 
 const char *nmrf_strerror(int code);
 /* ABI version of this header; bumps on any signature change. */
-int nmrf_abi_version(void);   /* currently 12 */
+int nmrf_abi_version(void);   /* currently 13 */
 
 /* A2  group-wise correlation volume.
  * replaces build_correlation_volume + the permute of DPN.forward
@@ -219,6 +219,25 @@ int nmrf_nmp_block_f32(const float *x, const float *msg, const void *stream_w, i
                        const float *lnq_g, const float *lnq_b, float epsq, const float *extra, int extra_ld,
                        int extra_div, const float *bq, int has_mlp, int KQ, int NQ, int64_t T, const float *inv_scales,
                        float *x_out, float *q_out, float *ln_out, const int *ln_out_map, void *stream);
+
+/* Same operator as nmrf_nmp_block_f32 with 16 tokens per wave on v_mfma_f32_16x16x32_f16 (two waves per SIMD: one wave's loads,
+ * LayerNorm, GELU and stores run under the other's MFMAs; csrc/nmp_block16.hip).  Identical arguments; the weight stream is built
+ * from nmrf_pack_split_weight16_f32 pairs (16-row strips x 32-deep chunks) in the same consumption order: proj pairs (strip 0..7,
+ * chunk 0..3) | W1g[0] | W1g[1], W2g[0] | ... | W2g[15] with W1g[h] = pairs (strip 2h..2h+1, chunk 0..3), W2g[h] = pairs
+ * (strip 0..7, chunk h) | q pairs (strip, chunk) strip-major.  KQ in {0, 128, 160, 192}. */
+int nmrf_nmp_block16_f32(const float *x, const float *msg, const void *stream_w, int total_stages, const float *bp,
+                         const float *ln2_g, const float *ln2_b, float eps2, const float *b1, const float *b2,
+                         const float *lnq_g, const float *lnq_b, float epsq, const float *extra, int extra_ld,
+                         int extra_div, const float *bq, int has_mlp, int KQ, int NQ, int64_t T, const float *inv_scales,
+                         float *x_out, float *q_out, float *ln_out, const int *ln_out_map, void *stream);
+
+/* Weight packing for nmrf_nmp_block16_f32: w [N,K] -> N/16 x Kp/32 pairs of 2 KB in [strip][chunk] order; lane (i = l & 15,
+ * g = l >> 4) slot jj holds scale * w[16*strip + i][32*chunk + (jj&3) + 16*(jj>>2) + 4*g], zero beyond K; hi fragment then lo
+ * fragment.  N % 16 == 0, Kp % 32 == 0. */
+int nmrf_pack_split_weight16_f32(const float *w, int N, int K, int Kp, float scale, void *out, void *stream);
+
+/* Self-test of the 16x16x32 split form: out[16*16] = A[16,K] . B[K,16] on one wave (K % 32 == 0). */
+int nmrf_selftest_mfma16x16_f16split(const float *A, const float *Bm, int K, float *out, void *stream);
 
 /* Per-token MLP chains of the hot path, one launch each (csrc/mlp_chain.hip), split-operand fp16 MFMA:
  *   kind 0  Inference.ffn / Refinement.ffn: timm Mlp(160,128,128), GELU             (NMP.py:675, 735-741, 839-844)

@@ -1,0 +1,464 @@
+// nmp_block (see nmp_block.hip for the operator and the formulation) with 16 tokens per wave on v_mfma_f32_16x16x32_f16:
+// block = 8 waves x 16 tokens = the same 128 tokens and the same weight stream, but TWO waves per SIMD, so that one wave's
+// serial phases (row loads, LayerNorm, GELU, staging, row stores, barrier waits) run under the other wave's MFMAs.  The
+// 32-token kernel has one wave per SIMD at KITTI batch 1 (234 tiles for 256 CUs) and its census shows MFMAs (31 us) and everything
+// else (41 us) back to back with no overlap (profiles/r02e_block_experiments.txt).
+//
+// v_mfma_f32_16x16x32_f16 lane layout (g = lane >> 4, j = lane & 15; pinned by nmrf_selftest_mfma_f16split mode 4):
+//   A operand: lane holds A[i = j][k = 8g + 0..7]       B operand: lane holds B[k = 8g + 0..7][col = j]
+//   C/D      : reg r (0..3) of the lane is D[row = 4g + r][col = j]
+// Activations are the B operand with the token on j; a 16-row output strip s of a layer puts channel 16s + 4g + r into reg r,
+// and two consecutive strips ARE one 32-deep k chunk of the next layer with the slot order
+//   slot jj of k-group g  <->  k = 32c + (jj & 3) + 16 (jj >> 2) + 4g           (split_kslot16)
+// which the weight packing (nmrf_pack_split_weight16_f32) uses for every A operand.  A "pair" is still 2 KB (hi + lo fragment,
+// 64 lanes x 16 B) = one (16-row strip, 32-deep chunk); 8 pairs per 16 KB stage; same ring protocol as nmp_block.hip.
+#include "common.h"
+#include "split_mfma.h"
+#include <type_traits>
+#include <utility>
+
+typedef unsigned int b16_u32x4 __attribute__((ext_vector_type(4)));
+
+#define B16_TOK 128                // tokens per block (8 waves x 16)
+#define B16_THR 512
+#define B16_STAGE_U4 1024
+#define B16_RING 3
+#define B16_OLD 132
+#define B16_PF 4
+#define B16_PAR_OFF (B16_RING * B16_STAGE_U4 * 16 + 8 * 16 * B16_OLD * 4)
+#define B16P_BP 0
+#define B16P_G2 128
+#define B16P_B2N 256
+#define B16P_B1 384
+#define B16P_B2 896
+#define B16P_GQ 1024
+#define B16P_BQN 1152
+#define B16P_BQ 1280
+#define B16P_FLOATS (1280 + 512)
+
+__host__ __device__ __forceinline__ int split_kslot16(int jj, int g) { return (jj & 3) + 16 * (jj >> 2) + 4 * g; }
+
+__device__ __forceinline__ f32x4 mfma16x16h(h16x8 a, h16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ void split_mma16(h16x8 ah, h16x8 al, h16x8 bh, h16x8 bl, f32x4 &acc) {
+    acc = mfma16x16h(al, bh, acc);
+    acc = mfma16x16h(ah, bl, acc);
+    acc = mfma16x16h(ah, bh, acc);
+}
+
+template <class F, int... I>
+__device__ __forceinline__ void b16_static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void b16_static_for(F &&f) {
+    b16_static_for_impl(static_cast<F &&>(f), std::make_integer_sequence<int, N>{});
+}
+
+struct NmpBlock16Args {
+    const float *x, *msg;
+    const b16_u32x4 *stream;
+    int total_stages;
+    const float *bp, *ln2_g, *ln2_b, *b1, *b2, *lnq_g, *lnq_b, *extra;
+    int extra_ld, extra_div;
+    const float *bq;
+    float *x_out, *q_out, *ln_out;
+    const int *ln_out_map;
+    int64_t T;
+    int n_tiles;
+    float eps2, epsq;
+    int NQ;
+    float inv_p, inv_1, inv_2, inv_q;
+};
+
+// MLP: run fc1-GELU-fc2.  KQC: 32-deep k chunks of the q stage's operand [LNq(x2) | extra]: 0 none, 4 = LayerNorm only,
+// 5 = + 32 side columns (Fourier31 + 0), 6 = + 64 context columns.
+template <bool MLP, int KQC>
+__global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    b16_u32x4 *ring = reinterpret_cast<b16_u32x4 *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    float *Ot = reinterpret_cast<float *>(smem + B16_RING * B16_STAGE_U4 * 16) + wv * 16 * B16_OLD;     // wave-private [16][132]
+    float *Par = reinterpret_cast<float *>(smem + B16_PAR_OFF);
+    {
+        auto put = [&](int off, const float *src, int n) {
+            for (int i = tid; i < n; i += B16_THR) Par[off + i] = src ? src[i] : 0.f;
+        };
+        put(B16P_BP, a.bp, 128); put(B16P_G2, a.ln2_g, 128); put(B16P_B2N, a.ln2_b, 128); put(B16P_B1, a.b1, 512);
+        put(B16P_B2, a.b2, 128); put(B16P_GQ, a.lnq_g, 128); put(B16P_BQN, a.lnq_b, 128); put(B16P_BQ, a.bq, a.bq ? a.NQ : 512);
+    }
+    auto par4 = [&](int off) { return *reinterpret_cast<const f32x4 *>(Par + off); };
+
+    // ---- weight stream (protocol of nmp_block.hip; 512 threads move 2 x 16 B each per stage) -----------------------------------
+    b16_u32x4 R[2];
+    int src_stage = 0, wr_slot = 0, rd_slot = 0;
+    auto fetch = [&]() {
+        const b16_u32x4 *p = a.stream + (size_t)src_stage * B16_STAGE_U4 + tid;
+        R[0] = p[0]; R[1] = p[B16_THR];
+        src_stage = (src_stage + 1 == a.total_stages) ? 0 : src_stage + 1;
+    };
+    auto commit = [&]() {
+        b16_u32x4 *d = ring + wr_slot * B16_STAGE_U4 + tid;
+        d[0] = R[0]; d[B16_THR] = R[1];
+        wr_slot = (wr_slot == B16_RING - 1) ? 0 : wr_slot + 1;
+    };
+    const b16_u32x4 *cur = ring, *nxt = ring + B16_STAGE_U4;
+    h16x8 fqh[B16_PF], fql[B16_PF];
+    auto read_pair = [&](const b16_u32x4 *base, int p, h16x8 &h, h16x8 &l) {
+        h = *reinterpret_cast<const h16x8 *>(base + p * 128 + lane);
+        l = *reinterpret_cast<const h16x8 *>(base + p * 128 + 64 + lane);
+    };
+    bool have_barrier = true;
+    auto stage_top = [&]() {
+        if (!have_barrier) __syncthreads();
+        have_barrier = false;
+    };
+    auto stage_end = [&]() {
+        commit();
+        fetch();
+        rd_slot = (rd_slot == B16_RING - 1) ? 0 : rd_slot + 1;
+        cur = nxt;
+        nxt = ring + ((rd_slot == B16_RING - 1) ? 0 : rd_slot + 1) * B16_STAGE_U4;
+    };
+    auto consume = [&](auto pc, const h16x8 &bh, const h16x8 &bl, f32x4 &acc) {
+        constexpr int P = decltype(pc)::value;
+        const h16x8 ah = fqh[P % B16_PF], al = fql[P % B16_PF];
+        if constexpr (P + B16_PF < 8) read_pair(cur, P + B16_PF, fqh[P % B16_PF], fql[P % B16_PF]);
+        else read_pair(nxt, P + B16_PF - 8, fqh[P % B16_PF], fql[P % B16_PF]);
+        __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x10 | 0x400);       // pin the read-ahead (see nmp_block.hip)
+        split_mma16(ah, al, bh, bl, acc);
+    };
+    fetch(); commit();
+    fetch(); commit();
+    fetch();
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < B16_PF; ++p) read_pair(cur, p, fqh[p], fql[p]);
+
+    // the 4 C/D registers of a 16-channel strip <-> columns [col0, col0 + 16) of the wave's tile (lane-private addresses)
+    auto stage_strip = [&](const float *v, int col0) {
+        *reinterpret_cast<f32x4 *>(Ot + j * B16_OLD + col0 + 4 * g) = f32x4{v[0], v[1], v[2], v[3]};
+    };
+    auto unstage_strip = [&](float *v, int col0) {
+        const f32x4 t = *reinterpret_cast<const f32x4 *>(Ot + j * B16_OLD + col0 + 4 * g);
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+    };
+    // whole rows of the tile -> dst: lanes 0-31 one row, lanes 32-63 the next (512 B each)
+    auto flush_rows = [&](float *dst, int ld, int col0, int64_t t0, const int *map = nullptr) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 2 * i + (lane >> 5);
+            const float4 v = *reinterpret_cast<const float4 *>(Ot + row * B16_OLD + 4 * (lane & 31));
+            if (t0 + row < a.T) {
+                int64_t orow = t0 + row;
+                if (map) orow = map[orow];
+                if (orow >= 0) stg4(dst + (size_t)orow * ld + col0 + 4 * (lane & 31), v);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    // LayerNorm over the 128 channels of a token: a lane holds 32 of them (8 strips x 4), lanes j, j+16, j+32, j+48 the rest
+    auto group_sum = [&](float v) {
+        v += __shfl_xor(v, 16);
+        return half_sum(v);
+    };
+    auto layer_norm = [&](const float (&v)[32], int g_off, int b_off, float eps, float (&o)[32]) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) s += v[i];
+        const float mean = group_sum(s) * (1.0f / 128.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { const float d = v[i] - mean; q = fmaf(d, d, q); }
+        const float rstd = 1.0f / sqrtf(group_sum(q) * (1.0f / 128.0f) + eps);
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            const f32x4 gv = par4(g_off + 16 * st + 4 * g), bv = par4(b_off + 16 * st + 4 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[4 * st + e] = (v[4 * st + e] - mean) * rstd * gv[e] + bv[e];
+        }
+    };
+
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+        const int64_t t0 = (int64_t)tile * B16_TOK + wv * 16;
+        const int64_t tq = t0 + j;
+        const int64_t tc = tq < a.T ? tq : a.T - 1;
+        float x1[32];                                                          // channel 16*(i >> 2) + 4g + (i & 3)
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            const float4 v = ldg4(a.x + tc * 128 + 16 * st + 4 * g);
+            x1[4 * st] = v.x; x1[4 * st + 1] = v.y; x1[4 * st + 2] = v.z; x1[4 * st + 3] = v.w;
+        }
+        f32x4 acc[8];
+        // ---- stage P -----------------------------------------------------------------------------------------------------------
+        if (a.msg) {
+            h16x8 bmh[4], bml[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float4 v0 = ldg4(a.msg + tc * 128 + 32 * c + 4 * g), v1 = ldg4(a.msg + tc * 128 + 32 * c + 16 + 4 * g);
+                const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                split8u(v, bmh[c], bml[c]);
+            }
+            b16_static_for<8>([&](auto ss) {
+                constexpr int st = decltype(ss)::value;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[st][r] = 0.f;
+                if constexpr (st % 2 == 0) stage_top();
+                b16_static_for<4>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    consume(std::integral_constant<int, (st % 2) * 4 + c>{}, bmh[c], bml[c], acc[st]);
+                });
+                if constexpr (st % 2 == 1) stage_end();
+            });
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                const f32x4 b4 = par4(B16P_BP + 16 * st + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x1[4 * st + e] += fmaf(acc[st][e], a.inv_p, b4[e]);
+            }
+        }
+        // ---- stage M -----------------------------------------------------------------------------------------------------------
+        if constexpr (MLP) {
+            h16x8 bnh[4], bnl[4];
+            {
+                float ln[32];
+                layer_norm(x1, B16P_G2, B16P_B2N, a.eps2, ln);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) split8u(&ln[8 * c], bnh[c], bnl[c]);
+            }
+#pragma unroll
+            for (int st = 0; st < 8; ++st) stage_strip(&x1[4 * st], 16 * st);     // x1 waits in LDS while the hidden layer runs
+#pragma unroll
+            for (int st = 0; st < 8; ++st)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[st][r] = 0.f;
+            // hidden group hg = 32 hidden channels = two 16-row strips of fc1 = one k chunk of fc2
+            auto fc1 = [&](f32x4 &f0, f32x4 &f1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) f0[r] = f1[r] = 0.f;
+                stage_top();
+                b16_static_for<4>([&](auto cc) { consume(cc, bnh[decltype(cc)::value], bnl[decltype(cc)::value], f0); });
+                b16_static_for<4>([&](auto cc) {
+                    consume(std::integral_constant<int, 4 + decltype(cc)::value>{}, bnh[decltype(cc)::value], bnl[decltype(cc)::value], f1);
+                });
+                stage_end();
+            };
+            auto act_fc2 = [&](int hg, const f32x4 &f0, const f32x4 &f1) {
+                float hv[8];
+                const f32x4 ba = par4(B16P_B1 + 32 * hg + 4 * g), bb = par4(B16P_B1 + 32 * hg + 16 + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    hv[e] = gelu_fast(fmaf(f0[e], a.inv_1, ba[e]));
+                    hv[4 + e] = gelu_fast(fmaf(f1[e], a.inv_1, bb[e]));
+                }
+                h16x8 hh, hl;
+                split8u(hv, hh, hl);
+                stage_top();
+                b16_static_for<8>([&](auto cc) { consume(cc, hh, hl, acc[decltype(cc)::value]); });
+                stage_end();
+            };
+            f32x4 fa0, fa1, fb0, fb1;
+            fc1(fa0, fa1);
+#pragma unroll 1
+            for (int hg = 0; hg < 16; hg += 2) {
+                fc1(fb0, fb1);
+                act_fc2(hg, fa0, fa1);
+                if (hg + 2 < 16) fc1(fa0, fa1);
+                act_fc2(hg + 1, fb0, fb1);
+            }
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                unstage_strip(&x1[4 * st], 16 * st);
+                const f32x4 b4 = par4(B16P_B2 + 16 * st + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x1[4 * st + e] += fmaf(acc[st][e], a.inv_2, b4[e]);
+            }
+        }
+        if (a.x_out) {
+#pragma unroll
+            for (int st = 0; st < 8; ++st) stage_strip(&x1[4 * st], 16 * st);
+            flush_rows(a.x_out, 128, 0, t0);
+        }
+        // ---- stage Q -----------------------------------------------------------------------------------------------------------
+        if constexpr (KQC > 0) {
+            h16x8 bqh[KQC], bql[KQC];
+            {
+                float ln[32];
+                layer_norm(x1, B16P_GQ, B16P_BQN, a.epsq, ln);
+                if (a.ln_out) {
+#pragma unroll
+                    for (int st = 0; st < 8; ++st) stage_strip(&ln[4 * st], 16 * st);
+                    flush_rows(a.ln_out, 128, 0, t0, a.ln_out_map);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) split8u(&ln[8 * c], bqh[c], bql[c]);
+            }
+            if constexpr (KQC > 4) {
+                const float *e = a.extra + (tc / a.extra_div) * a.extra_ld;
+#pragma unroll
+                for (int c = 4; c < KQC; ++c) {
+                    const float4 v0 = ldg4(e + 32 * (c - 4) + 4 * g), v1 = ldg4(e + 32 * (c - 4) + 16 + 4 * g);
+                    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    split8u(v, bqh[c], bql[c]);
+                }
+            }
+            if (a.q_out) {
+                const int n_groups = a.NQ >> 7;
+#pragma unroll 1
+                for (int gq = 0; gq < n_groups; ++gq) {
+                    b16_static_for<8>([&](auto ss) {
+                        constexpr int sl = decltype(ss)::value;
+                        f32x4 qh;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) qh[r] = 0.f;
+                        b16_static_for<KQC>([&](auto cc) {
+                            constexpr int c = decltype(cc)::value;
+                            constexpr int pg = sl * KQC + c;
+                            if constexpr (pg % 8 == 0) stage_top();
+                            consume(std::integral_constant<int, pg % 8>{}, bqh[c], bql[c], qh);
+                            if constexpr (pg % 8 == 7) stage_end();
+                        });
+                        const f32x4 b4 = par4(B16P_BQ + gq * 128 + 16 * sl + 4 * g);
+                        float ov[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ov[e] = fmaf(qh[e], a.inv_q, b4[e]);
+                        stage_strip(ov, 16 * sl);
+                    });
+                    flush_rows(a.q_out, a.NQ, gq * 128, t0);
+                }
+            }
+        }
+    }
+}
+
+// w [N,K] fp32 -> N/16 x Kp/32 pairs in [strip][chunk] order: lane (i = l & 15, g = l >> 4) slot jj holds
+// scale * w[16*strip + i][32*chunk + split_kslot16(jj, g)], zero beyond K; hi fragment (1 KB) then lo fragment.
+__global__ __launch_bounds__(256) void pack_split_weight16_kernel(const float *__restrict__ w, int N, int K, int KC, float scale,
+                                                                 uint4 *__restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)(N / 16) * KC * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const int64_t pair = idx >> 6;
+    const int c = (int)(pair % KC), s = (int)(pair / KC);
+    const int n = s * 16 + (lane & 15), g = lane >> 4;
+    float v[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const int k = 32 * c + split_kslot16(jj, g);
+        v[jj] = k < K ? w[(int64_t)n * K + k] * scale : 0.f;
+    }
+    h16x8 vh, vl;
+    split8u(v, vh, vl);
+    out[pair * 128 + lane] = *reinterpret_cast<const uint4 *>(&vh);
+    out[pair * 128 + 64 + lane] = *reinterpret_cast<const uint4 *>(&vl);
+}
+
+extern "C" int nmrf_pack_split_weight16_f32(const float *w, int N, int K, int Kp, float scale, void *out, void *stream) {
+    if (!w || !out) return NMRF_ENULL;
+    if (N < 16 || (N & 15) || K < 1 || Kp < K || (Kp & 31) || !(scale > 0.f)) return NMRF_EINVAL;
+    const int KC = Kp / 32;
+    const int64_t total = (int64_t)(N / 16) * KC * 64;
+    hipLaunchKernelGGL(pack_split_weight16_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, w, N, K,
+                       KC, scale, reinterpret_cast<uint4 *>(out));
+    return nmrf_launch_status();
+}
+
+template <bool MLP, int KQC>
+static int launch_nmp_block16(const NmpBlock16Args &a, hipStream_t st) {
+    static bool attr_set_dev[NMRF_MAX_DEV] = {};
+    static int n_cu_dev[NMRF_MAX_DEV] = {};
+    const int dev = nmrf_cur_device();
+    if (dev < 0) return NMRF_ELAUNCH;
+    const size_t lds = (size_t)B16_PAR_OFF + B16P_FLOATS * sizeof(float);
+    if (!attr_set_dev[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(nmp_block16_kernel<MLP, KQC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return NMRF_ELAUNCH;
+        attr_set_dev[dev] = true;
+    }
+    if (!n_cu_dev[dev]) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return NMRF_ELAUNCH;
+        n_cu_dev[dev] = prop.multiProcessorCount;
+    }
+    const int grid = a.n_tiles < n_cu_dev[dev] ? a.n_tiles : n_cu_dev[dev];
+    hipLaunchKernelGGL((nmp_block16_kernel<MLP, KQC>), dim3(grid), dim3(B16_THR), lds, st, a);
+    return nmrf_launch_status();
+}
+
+extern "C" int nmrf_nmp_block16_f32(const float *x, const float *msg, const void *stream_w, int total_stages, const float *bp,
+                                    const float *ln2_g, const float *ln2_b, float eps2, const float *b1, const float *b2,
+                                    const float *lnq_g, const float *lnq_b, float epsq, const float *extra, int extra_ld,
+                                    int extra_div, const float *bq, int has_mlp, int KQ, int NQ, int64_t T, const float *inv_scales,
+                                    float *x_out, float *q_out, float *ln_out, const int *ln_out_map, void *stream) {
+    if (!x || !stream_w || !inv_scales) return NMRF_ENULL;
+    if (T < 1 || ceil_div64(T, B16_TOK) > 0x7fffffff) return NMRF_EINVAL;
+    if (has_mlp && (!ln2_g || !ln2_b || !b1 || !b2)) return NMRF_ENULL;
+    if (KQ != 0 && KQ != 128 && KQ != 160 && KQ != 192) return NMRF_EINVAL;
+    if (KQ && (!lnq_g || !lnq_b)) return NMRF_ENULL;
+    if (KQ > 128 && (!extra || extra_ld < KQ - 128 || (extra_ld & 3) || extra_div < 1)) return NMRF_EINVAL;
+    if (q_out && (KQ == 0 || NQ < 128 || (NQ & 127) || NQ > 512)) return NMRF_EINVAL;
+    if (ln_out && KQ == 0) return NMRF_EINVAL;
+    if (!q_out && !ln_out && !x_out) return NMRF_ENULL;
+    const int want = (msg ? 4 : 0) + (has_mlp ? 32 : 0) + (q_out ? (NQ / 128) * (KQ / 32) : 0);
+    if (total_stages != want || total_stages < 1) return NMRF_EINVAL;
+    NmpBlock16Args a{x, msg, reinterpret_cast<const b16_u32x4 *>(stream_w), total_stages, bp, ln2_g, ln2_b, b1, b2, lnq_g, lnq_b, extra,
+                     extra_ld, extra_div, bq, x_out, q_out, ln_out, ln_out_map, T, (int)ceil_div64(T, B16_TOK), eps2, epsq, NQ,
+                     inv_scales[0], inv_scales[1], inv_scales[2], inv_scales[3]};
+    hipStream_t st = (hipStream_t)stream;
+    const int kqc = KQ / 32;
+    if (has_mlp) {
+        switch (kqc) {
+            case 0: return launch_nmp_block16<true, 0>(a, st);
+            case 4: return launch_nmp_block16<true, 4>(a, st);
+            case 5: return launch_nmp_block16<true, 5>(a, st);
+            case 6: return launch_nmp_block16<true, 6>(a, st);
+        }
+    } else {
+        switch (kqc) {
+            case 0: return launch_nmp_block16<false, 0>(a, st);
+            case 4: return launch_nmp_block16<false, 4>(a, st);
+            case 5: return launch_nmp_block16<false, 5>(a, st);
+            case 6: return launch_nmp_block16<false, 6>(a, st);
+        }
+    }
+    return NMRF_EINVAL;
+}
+
+// self-test of the 16x16x32 form: out[16x16] = A[16,K] . B[K,16] (row-major fp32, K % 32 == 0) on one wave, split operands with
+// the k slots in split_kslot16 order on both sides
+__global__ __launch_bounds__(64) void selftest_mfma16x16_kernel(const float *__restrict__ A, const float *__restrict__ Bm, int K,
+                                                               float *__restrict__ out) {
+    const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int k = k0 + split_kslot16(jj, g);
+            av[jj] = A[j * K + k];
+            bv[jj] = Bm[k * 16 + j];
+        }
+        h16x8 ah, al, bh, bl;
+        split8u(av, ah, al);
+        split8u(bv, bh, bl);
+        split_mma16(ah, al, bh, bl, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(4 * g + r) * 16 + j] = acc[r];
+}
+
+extern "C" int nmrf_selftest_mfma16x16_f16split(const float *A, const float *Bm, int K, float *out, void *stream) {
+    if (!A || !Bm || !out) return NMRF_ENULL;
+    if (K < 32 || K > 1024 || (K & 31)) return NMRF_EINVAL;
+    hipLaunchKernelGGL(selftest_mfma16x16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, Bm, K, out);
+    return nmrf_launch_status();
+}

@@ -62,6 +62,14 @@ def mfma_selftest(a, bm):
 
 
 @_on_device
+def mfma16x16_selftest(a, bm):
+    _chk(a, bm)
+    out = torch.empty(16, 16, device=a.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_selftest_mfma16x16_f16split(_p(a), _p(bm), a.shape[1], _p(out), _stream()), "mfma 16x16 selftest")
+    return out
+
+
+@_on_device
 def mfma_f16split_selftest(a, bm, mode=0):
     _chk(a, bm)
     out = torch.empty(32, 32, device=a.device, dtype=torch.float32)
@@ -323,6 +331,48 @@ def pack_split_weight(weight, kp=None):
     return out, 1.0 / scale
 
 
+def _pack_scaled(weight, kp, fn_name, rows, kchunk):
+    import math
+    _chk(weight)
+    n, k = weight.shape
+    amax = float(weight.abs().max())
+    scale = 1.0 if not (amax > 0 and math.isfinite(amax)) else 2.0 ** min(40, max(-40, math.floor(math.log2(16383.0 / amax))))
+    out = torch.empty(n // rows, kp // kchunk, 512, device=weight.device, dtype=torch.int32)
+    _lib.check(getattr(_lib.load(), fn_name)(_p(weight), n, k, kp, scale, _p(out), _stream()), fn_name)
+    return out, 1.0 / scale
+
+
+@_on_device
+def pack_split_weight16(weight, kp):
+    """[N,K] -> (pairs [N/16, Kp/32, 512] for nmp_block16 (16-row strips x 32-deep chunks), 1/scale)."""
+    return _pack_scaled(weight, kp, "nmrf_pack_split_weight16_f32", 16, 32)
+
+
+def block_stream16(wp=None, w1=None, w2=None, wq=None, kq=0):
+    """Weight stream of one nmp_block16 launch (include/nmrf_hip.h): proj | W1 strip pairs interleaved with W2 k chunks | q."""
+    import ctypes
+    parts, inv = [], [1.0, 1.0, 1.0, 1.0]
+    if wp is not None:
+        pk, inv[0] = pack_split_weight16(wp, 128)
+        parts.append(pk.view(-1, 512))
+    if w1 is not None:
+        p1, inv[1] = pack_split_weight16(w1, 128)                          # [32 strips][4 chunks] = [16 groups][8 pairs]
+        p2, inv[2] = pack_split_weight16(w2, 512)                          # [8 strips][16 chunks]
+        p1 = p1.view(16, 8, 512)
+        p2 = p2.permute(1, 0, 2).contiguous()                             # [16 groups][8 strips]
+        seq = [p1[0]]
+        for h in range(15):
+            seq += [p1[h + 1], p2[h]]
+        seq.append(p2[15])
+        parts.append(torch.stack(seq).view(-1, 512))
+    if wq is not None:
+        pk, inv[3] = pack_split_weight16(wq, kq)
+        parts.append(pk.view(-1, 512))
+    stream = torch.cat(parts).contiguous()
+    assert stream.shape[0] % 8 == 0
+    return stream, stream.shape[0] // 8, (ctypes.c_float * 4)(*inv)
+
+
 def block_stream(wp=None, w1=None, w2=None, wq=None, kq=0):
     """Weight stream of one nmp_block launch, in the kernel's consumption order (include/nmrf_hip.h, nmrf_nmp_block_f32):
     proj pairs | W1 strips interleaved with W2 k-slices | q-stage pairs.
@@ -392,7 +442,8 @@ def mlp_chain(kind, x, k1, stream, stages, inv_scales, biases, n_out, extra=None
 
 
 @_on_device
-def nmp_block(x, stream, stages, inv_scales, msg=None, bp=None, mlp=None, q=None, want_x=True, ln_out=None, ln_out_map=None):
+def nmp_block(x, stream, stages, inv_scales, msg=None, bp=None, mlp=None, q=None, want_x=True, ln_out=None, ln_out_map=None,
+              tokens_per_wave=32):
     """One fused message-passing block (nmrf_nmp_block_f32).
     mlp = (ln2_gamma, ln2_beta, eps, b1, b2) or None;  q = dict(g, b, eps, extra=None, extra_div=1, bias=None, kq=0|128|160|192,
     nq=0 -> no q_out, ln_out=False) or None.  Returns (x_out | None, q_out | None, ln_out | None)."""
@@ -427,8 +478,10 @@ def nmp_block(x, stream, stages, inv_scales, msg=None, bp=None, mlp=None, q=None
             label="nmp_block_kernel<%s,%d> (%s%s%s fused, split-fp16 MFMA)" % (
                 "true" if mlp is not None else "false", kq // 16, "proj+residual " if msg is not None else "",
                 "LN+fc1+GELU+fc2 " if mlp is not None else "", ("LN+%d->%d" % (kq, nq)) if nq else ("final LN" if want_ln else "")),
-            pmc=["nmp_block_kernel<%s, %d>" % ("true" if mlp is not None else "false", kq // 16)])
-    _lib.check(_lib.load().nmrf_nmp_block_f32(_p(x), _p(msg), _p(stream), stages, _p(bp), _p(ln2_g), _p(ln2_b), float(eps2), _p(b1),
+            pmc=["nmp_block%s_kernel<%s, %d>" % ("" if tokens_per_wave == 32 else "16", "true" if mlp is not None else "false",
+                                                  kq // tokens_per_wave if tokens_per_wave == 16 else kq // 16)])
+    fn = _lib.load().nmrf_nmp_block_f32 if tokens_per_wave == 32 else _lib.load().nmrf_nmp_block16_f32
+    _lib.check(fn(_p(x), _p(msg), _p(stream), stages, _p(bp), _p(ln2_g), _p(ln2_b), float(eps2), _p(b1),
                                               _p(b2), _p(lq_g), _p(lq_b), float(epsq), _p(extra), ld, div, _p(bq),
                                               int(mlp is not None), kq, nq, t, inv_scales, _p(x_out), _p(q_out), _p(ln_out),
                                               _p(ln_out_map), _stream()),

@@ -136,6 +136,11 @@ class _Lin:
         return K.token_linear(x, pw, n, k, b, act=act, **kw)
 
 
+def _block_tokens():
+    """Tokens per wave of the fused block kernel: 16 (csrc/nmp_block16.hip, two waves per SIMD; default) or 32 (csrc/nmp_block.hip)."""
+    return 32 if os.environ.get("NMRF_BLOCK_TOKENS", "16") == "32" else 16
+
+
 class _BlockLauncher:
     """One nmp_block launch site of a stage: x1 = x + proj(msg); x2 = x1 + mlp(norm2(x1)); then the NEXT block's q|k|v on
     [norm(x2) | side] or the stage's final norm.  The weight stream and the fused bias are rebuilt when a parameter changes."""
@@ -143,6 +148,7 @@ class _BlockLauncher:
     def __init__(self, proj=None, mlp=None, nxt_norm=None, nxt_linears=(), kq=0, ln_out=False):
         self.proj, self.mlp, self.nxt_norm, self.nxt_linears, self.kq, self.ln_out = proj, mlp, nxt_norm, tuple(nxt_linears), kq, ln_out
         self.cache = _FusedCache()
+        self.tokens = _block_tokens()
 
     def _params(self):
         ps = []
@@ -160,9 +166,10 @@ class _BlockLauncher:
             k = max(l.in_features for l in self.nxt_linears)
             wq = torch.cat([_pad_cols(l.weight, k) for l in self.nxt_linears], 0).contiguous()
             bq = torch.cat([l.bias for l in self.nxt_linears]).contiguous()
-        stream, stages, inv = K.block_stream(None if self.proj is None else self.proj.weight.contiguous(),
-                                             None if self.mlp is None else self.mlp[1].fc1.weight.contiguous(),
-                                             None if self.mlp is None else self.mlp[1].fc2.weight.contiguous(), wq, self.kq)
+        build = K.block_stream if self.tokens == 32 else K.block_stream16
+        stream, stages, inv = build(None if self.proj is None else self.proj.weight.contiguous(),
+                                    None if self.mlp is None else self.mlp[1].fc1.weight.contiguous(),
+                                    None if self.mlp is None else self.mlp[1].fc2.weight.contiguous(), wq, self.kq)
         return stream, stages, inv, bq, (0 if wq is None else wq.shape[0])
 
     def __call__(self, x, msg=None, extra=None, extra_div=1, want_x=True, ln_out=None, ln_out_map=None):
@@ -176,7 +183,7 @@ class _BlockLauncher:
             q = dict(g=self.nxt_norm.weight, b=self.nxt_norm.bias, eps=self.nxt_norm.eps, extra=extra if self.kq > 128 else None,
                      extra_div=extra_div, bias=bq, kq=self.kq, nq=nq, ln_out=self.ln_out)
         return K.nmp_block(x, stream, stages, inv, msg, None if self.proj is None else self.proj.bias, mlp, q, want_x=want_x,
-                           ln_out=ln_out, ln_out_map=ln_out_map)
+                           ln_out=ln_out, ln_out_map=ln_out_map, tokens_per_wave=self.tokens)
 
 
 class _ChainLauncher:

@@ -43,7 +43,9 @@ class MSDeformAttn(nn.Module):
                 input_padding_mask=None):
         n, len_q, _ = query.shape
         _, len_in, _ = input_flatten.shape
-        assert int((input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum()) == len_in
+        if not (input_flatten.is_cuda and torch.cuda.is_current_stream_capturing()):
+            # (reads the device tensor back: the reference's check, ms_deform_attn.py:97; skipped while a hipGraph is being captured)
+            assert int((input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum()) == len_in
         value = self.value_proj(input_flatten)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], 0.0)

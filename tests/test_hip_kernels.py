@@ -68,6 +68,18 @@ def test_split_fp16_mfma_layout_and_precision(mode):
             k, mode, float(err.max()), float((fp32.double() - ref).abs().max()), float(ref.abs().max())))
 
 
+def test_split_fp16_mfma_16x16x32_layout():
+    """The 16-token kernels' MFMA form: A[16,K] . B[K,16] with the k slots in split_kslot16 order, against fp64."""
+    for k in (32, 128, 512):
+        a, b = rnd(16, k, seed=k), rnd(k, 16, seed=k + 1)
+        b += torch.arange(16)[None, :] * 0.01 + torch.arange(k)[:, None] * (0.1 / k)
+        got = K().mfma16x16_selftest(a.to(DEV), b.to(DEV)).cpu()
+        ref = a.double() @ b.double()
+        bound = 4e-7 * (a.double().abs() @ b.double().abs()) + 2.0 ** -25 * a.double().abs().sum(1, keepdim=True) + 1e-12
+        err = (got.double() - ref).abs()
+        assert (err <= bound).all(), (k, float((err / bound).max()), float(err.max()))
+
+
 def test_split_fp16_mfma_hi_only_is_fp16_grade_and_subnormal_probe():
     """mode 1 = plain fp16 product: ~2^-11 relative (what the lo' parts buy back), plus a probe of how the MFMA treats
     fp16-subnormal inputs (reported, not asserted: the split format does not depend on it)."""
@@ -391,8 +403,10 @@ def _block_ref(x, msg, wp, bp, mlp, q):
     (29952, True, True, 160, 384, 1, False),     # KITTI padded inference grid: 234 tiles
     (40001, True, True, 160, 384, 1, True),      # more tiles than CUs (persistent blocks re-read the stream), ragged tail
 ])
-def test_nmp_block_fused(t_, proj, mlp, kq, nq, div, ln_out):
-    """The fused block kernel (split-fp16 MFMA) against fp64, at the tolerances of the fp32-MFMA linears it replaces."""
+@pytest.mark.parametrize("tokens", [16, 32])
+def test_nmp_block_fused(t_, proj, mlp, kq, nq, div, ln_out, tokens):
+    """The fused block kernels (split-fp16 MFMA; 32 tokens per wave on 32x32x16 MFMAs, 16 per wave on 16x16x32) against fp64, at
+    the tolerances of the fp32-MFMA linears they replace."""
     kk = K()
     d = lambda v: None if v is None else v.to(DEV)
     x = rnd(t_, 128, seed=1, scale=2.0)
@@ -409,12 +423,13 @@ def test_nmp_block_fused(t_, proj, mlp, kq, nq, div, ln_out):
     bq = rnd(nq, seed=15) if nq else None
     if extra is not None and e == 32:
         extra[:, 31] = 0.0                                        # the pad column of the Fourier rows
-    stream, stages, inv = kk.block_stream(d(wp) if proj else None, d(w1) if mlp else None, d(w2) if mlp else None, d(wq), kq)
+    build = kk.block_stream if tokens == 32 else kk.block_stream16
+    stream, stages, inv = build(d(wp) if proj else None, d(w1) if mlp else None, d(w2) if mlp else None, d(wq), kq)
     q = None
     if kq:
         q = dict(g=d(gq), b=d(bqn), eps=1e-5, extra=d(extra), extra_div=div, bias=d(bq), kq=kq, nq=nq, ln_out=ln_out)
     xo, qo, lo = kk.nmp_block(d(x), stream, stages, inv, d(msg), d(bp) if proj else None,
-                              (d(g2), d(b2n), 1e-5, d(b1), d(b2)) if mlp else None, q, want_x=True)
+                              (d(g2), d(b2n), 1e-5, d(b1), d(b2)) if mlp else None, q, want_x=True, tokens_per_wave=tokens)
     rx, rq, rl = _block_ref(x, msg, wp, bp, (g2, b2n, w1, b1, w2, b2) if mlp else None,
                             dict(g=gq, b=bqn, w=wq, bias=bq, extra=extra, div=div) if kq else None)
     report("block x_out", xo.cpu(), rx, 2e-5, 1e-5)

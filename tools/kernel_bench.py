@@ -103,6 +103,12 @@ if "block" in which:
         print("   %-52s median %7.0f  min %7.0f  max %7.0f ticks" % (nm, np.median(d), d.min(), d.max()))
     tot = (st[:, :, 15] - st[:, :, 0]).reshape(-1)
     print("   total per wave: median %.0f ticks; first-start to last-end over blocks: %.0f ticks" % (np.median(tot), st[:, :, 15].max() - st[:, :, 0].min()))
+    s16, st16, i16 = K.block_stream16(wp, w1, w2, wq, 160)
+    timeit("nmp_block16 proj+mlp+qkv (16 tokens / wave)", lambda: K.nmp_block(x, s16, st16, i16, msg, bp, (g, be, 1e-5, b1, b2), qd, tokens_per_wave=16))
+    s16b, st16b, i16b = K.block_stream16(wp, None, None, wq, 160)
+    timeit("nmp_block16 proj+qkv (self block)", lambda: K.nmp_block(x, s16b, st16b, i16b, msg, bp, None, qd, tokens_per_wave=16))
+    s16c, st16c, i16c = K.block_stream16(wp, w1, w2, None, 0)
+    timeit("nmp_block16 proj+mlp", lambda: K.nmp_block(x, s16c, st16c, i16c, msg, bp, (g, be, 1e-5, b1, b2), None, tokens_per_wave=16))
     s2, st2, i2 = K.block_stream(wp, None, None, wq, 160)
     timeit("nmp_block proj+qkv (self block)", lambda: K.nmp_block(x, s2, st2, i2, msg, bp, None, qd))
     s3, st3, i3 = K.block_stream(None, None, None, wq, 160)
