@@ -74,7 +74,7 @@ struct NmpBlock16Args {
 
 // MLP: run fc1-GELU-fc2.  KQC: 32-deep k chunks of the q stage's operand [LNq(x2) | extra]: 0 none, 4 = LayerNorm only,
 // 5 = + 32 side columns (Fourier31 + 0), 6 = + 64 context columns.
-template <bool MLP, int KQC>
+template <bool MLP, int KQC, int DBG = 0>          // DBG: timing experiments of the debug build (wrong results)
 __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     b16_u32x4 *ring = reinterpret_cast<b16_u32x4 *>(smem);
@@ -113,12 +113,14 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
     };
     bool have_barrier = true;
     auto stage_top = [&]() {
-        if (!have_barrier) __syncthreads();
+        if (!have_barrier && !(DBG & 1)) __syncthreads();
         have_barrier = false;
     };
     auto stage_end = [&]() {
-        commit();
-        fetch();
+        if constexpr (!(DBG & 2)) {
+            commit();
+            fetch();
+        }
         rd_slot = (rd_slot == B16_RING - 1) ? 0 : rd_slot + 1;
         cur = nxt;
         nxt = ring + ((rd_slot == B16_RING - 1) ? 0 : rd_slot + 1) * B16_STAGE_U4;
@@ -126,10 +128,13 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
     auto consume = [&](auto pc, const h16x8 &bh, const h16x8 &bl, f32x4 &acc) {
         constexpr int P = decltype(pc)::value;
         const h16x8 ah = fqh[P % B16_PF], al = fql[P % B16_PF];
-        if constexpr (P + B16_PF < 8) read_pair(cur, P + B16_PF, fqh[P % B16_PF], fql[P % B16_PF]);
-        else read_pair(nxt, P + B16_PF - 8, fqh[P % B16_PF], fql[P % B16_PF]);
+        if constexpr (!(DBG & 4)) {
+            if constexpr (P + B16_PF < 8) read_pair(cur, P + B16_PF, fqh[P % B16_PF], fql[P % B16_PF]);
+            else read_pair(nxt, P + B16_PF - 8, fqh[P % B16_PF], fql[P % B16_PF]);
+        }
         __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x10 | 0x400);       // pin the read-ahead (see nmp_block.hip)
-        split_mma16(ah, al, bh, bl, acc);
+        if constexpr (!(DBG & 8)) split_mma16(ah, al, bh, bl, acc);
+        else acc[P & 3] += (float)ah[0] + (float)bl[1];
     };
     fetch(); commit();
     fetch(); commit();
@@ -371,15 +376,32 @@ extern "C" int nmrf_pack_split_weight16_f32(const float *w, int N, int K, int Kp
     return nmrf_launch_status();
 }
 
-template <bool MLP, int KQC>
+#ifdef NMRF_DEBUG_PROBES
+static int g_b16_variant = 0;
+extern "C" int nmrf_debug_nmp_block16_variant(int v) { g_b16_variant = v; return NMRF_OK; }
+#endif
+
+template <bool MLP, int KQC, int DBG = 0>
 static int launch_nmp_block16(const NmpBlock16Args &a, hipStream_t st) {
+#ifdef NMRF_DEBUG_PROBES
+    if constexpr (DBG == 0) {
+        switch (g_b16_variant) {
+            case 1: return launch_nmp_block16<MLP, KQC, 1>(a, st);
+            case 2: return launch_nmp_block16<MLP, KQC, 2>(a, st);
+            case 4: return launch_nmp_block16<MLP, KQC, 4>(a, st);
+            case 8: return launch_nmp_block16<MLP, KQC, 8>(a, st);
+            case 7: return launch_nmp_block16<MLP, KQC, 7>(a, st);
+            default: break;
+        }
+    }
+#endif
     static bool attr_set_dev[NMRF_MAX_DEV] = {};
     static int n_cu_dev[NMRF_MAX_DEV] = {};
     const int dev = nmrf_cur_device();
     if (dev < 0) return NMRF_ELAUNCH;
     const size_t lds = (size_t)B16_PAR_OFF + B16P_FLOATS * sizeof(float);
     if (!attr_set_dev[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(nmp_block16_kernel<MLP, KQC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(nmp_block16_kernel<MLP, KQC, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess)
             return NMRF_ELAUNCH;
         attr_set_dev[dev] = true;
@@ -390,7 +412,7 @@ static int launch_nmp_block16(const NmpBlock16Args &a, hipStream_t st) {
         n_cu_dev[dev] = prop.multiProcessorCount;
     }
     const int grid = a.n_tiles < n_cu_dev[dev] ? a.n_tiles : n_cu_dev[dev];
-    hipLaunchKernelGGL((nmp_block16_kernel<MLP, KQC>), dim3(grid), dim3(B16_THR), lds, st, a);
+    hipLaunchKernelGGL((nmp_block16_kernel<MLP, KQC, DBG>), dim3(grid), dim3(B16_THR), lds, st, a);
     return nmrf_launch_status();
 }
 
