@@ -27,7 +27,7 @@ extern "C" {
 
 const char *nmrf_strerror(int code);
 /* ABI version of this header; bumps on any signature change. */
-int nmrf_abi_version(void);   /* currently 13 */
+int nmrf_abi_version(void);   /* currently 14 */
 
 /* A2  group-wise correlation volume.
  * replaces build_correlation_volume + the permute of DPN.forward
@@ -260,6 +260,19 @@ int nmrf_mlp_chain_f32(int kind, const float *in, int in_ld, int K1, const void 
  * the low parts of every weight are then normal fp16 numbers.
  * out: N * Kp * 4 bytes.  N % 32 == 0, Kp % 16 == 0, Kp >= K. */
 int nmrf_pack_split_weight_f32(const float *w, int N, int K, int Kp, float scale, void *out, void *stream);
+
+/* N2: statistics pass of InstanceNorm2d alone: ws [planes][ceil(HW/8192)][2] = per-chunk (mean, M2) of x [planes, HW]. */
+int nmrf_instance_stats_f32(const float *x, int64_t planes, int64_t HW, float *ws, void *stream);
+
+/* N2: 1x1 convolution of a conv head with the InstanceNorm + ReLU in front of it folded into its operand load
+ * (nmrf/models/NMRF.py:56-65 `concatconv` / `gw`, DPN.py:45-49 `proj`: Conv3x3 - IN - ReLU - Conv1x1):
+ *   out[b,co,p] = sum_ci W[co,ci] * relu((x[b,c0+ci,p] - mean[b,c0+ci]) * rstd[b,c0+ci]) (+ bias[co])      (stats == NULL: plain x)
+ * x [B,Cx,HW] NCHW (the 3x3 conv output; several heads may share it through c0), stats = nmrf_instance_stats_f32 workspace of x,
+ * K in {64, 128} input channels, N % 64 == 0 output channels, out [B,N,HW].  stream_w = nmrf_pack_split_weight_f32(W[N,K], Kp = K)
+ * pairs (strip-major), total_stages = N/32 * K/16 / 8, inv_scale = 1 / its scale.  Split-operand fp16 MFMA. */
+int nmrf_conv1x1_in_relu_f32(const float *x, int B, int Cx, int64_t HW, int c0, int K, const float *stats, int chunks, float eps,
+                             const void *stream_w, int total_stages, float inv_scale, const float *bias, int N, float *out,
+                             void *stream);
 
 /* A1 + encoder input staging: replicate-pad both views right/bottom to (Hp, Wp) (InputPadder mode 'proposal',
  * nmrf/utils/frame_utils.py:268-275), stack them along the batch (NMRF.py:173) and normalise 2*(x/255)-1 (backbone.py:86).

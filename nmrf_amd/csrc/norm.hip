@@ -131,6 +131,16 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const float *__restrict__
     }
 }
 
+// statistics pass alone: ws [planes][ceil(HW / 8192)][2] = per-chunk (mean, M2), merged by the consumer (in_apply_kernel or the
+// fused 1x1 convolution of conv1x1.hip)
+extern "C" int nmrf_instance_stats_f32(const float *x, int64_t planes, int64_t HW, float *ws, void *stream) {
+    if (!x || !ws) return NMRF_ENULL;
+    if (planes < 1 || planes > 65535 || HW < 1) return NMRF_EINVAL;
+    const int chunks = (int)ceil_div64(HW, IN_CHUNK);
+    hipLaunchKernelGGL(in_stats_kernel, dim3(chunks, (unsigned)planes), dim3(256), 0, (hipStream_t)stream, x, HW, chunks, ws);
+    return nmrf_launch_status();
+}
+
 extern "C" int nmrf_instance_norm_f32(const float *x, const float *residual, int64_t planes, int64_t HW, float eps,
                                       int relu_mid, int relu_out, float *ws, float *y, void *stream) {
     if (!x || !ws || !y) return NMRF_ENULL;

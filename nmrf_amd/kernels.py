@@ -583,6 +583,40 @@ def instance_norm(x, relu=False, residual=None, relu_out=False, eps=1e-5):
 
 
 @_on_device
+def instance_stats(x):
+    """Statistics pass of InstanceNorm2d: x [B,C,H,W] -> per-chunk (mean, M2) workspace for conv1x1_in_relu."""
+    _chk(x)
+    b, c, h, w = x.shape
+    ws = torch.empty(b * c, (h * w + 8191) // 8192, 2, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_instance_stats_f32(_p(x), b * c, h * w, _p(ws), _stream()), "instance_stats")
+    return ws
+
+
+@_on_device
+def conv1x1_in_relu(x, c0, k, stats, packed, bias=None, eps=1e-5):
+    """out = Conv1x1(relu(InstanceNorm(x[:, c0:c0+k])))  (stats None: Conv1x1(x[:, c0:c0+k])).  packed = (stream, stages, 1/scale, N)."""
+    _chk(x, stats, bias)
+    stream, stages, inv, n = packed
+    _chk(stream, dtype=torch.int32)
+    b, cx, h, w = x.shape
+    out = torch.empty(b, n, h, w, device=x.device, dtype=torch.float32)
+    _hb("conv1x1_k%d_n%d" % (k, n), row="N2", bound="hbm", bytes=4.0 * b * h * w * (k + n), flops=2.0 * b * h * w * k * n, split=True,
+        label="conv1x1_kernel (InstanceNorm + ReLU + 1x1 conv %d->%d of the conv heads, N2)" % (k, n), pmc=["conv1x1_kernel<%d>" % (k // 16)])
+    _lib.check(_lib.load().nmrf_conv1x1_in_relu_f32(_p(x), b, cx, h * w, c0, k, _p(stats), 0 if stats is None else stats.shape[1],
+                                                    float(eps), _p(stream), stages, float(inv), _p(bias), n, _p(out), _stream()),
+               "conv1x1_in_relu")
+    _he("conv1x1_k%d_n%d" % (k, n))
+    return out
+
+
+def pack_conv1x1(weight):
+    """[N,K,1,1] conv weight -> (stream, stages, 1/scale, N) for conv1x1_in_relu."""
+    n, k = weight.shape[0], weight.shape[1]
+    pk, inv = pack_split_weight(weight.reshape(n, k).contiguous(), k)
+    return pk.view(-1, 512).contiguous(), pk.shape[0] * pk.shape[1] // 8, inv, n
+
+
+@_on_device
 def prep_images(img1, img2, hp, wp):
     """[B,3,H,W] x2 (0..255) -> [2B,3,hp,wp]: replicate-padded right/bottom, stacked, normalised to [-1,1] (one pass)."""
     _chk(img1, img2)

@@ -59,8 +59,16 @@ class DPN(nn.Module):
         if context is None:                                   # [B,Cctx,H,W] may be precomputed by the caller
             if torch.is_grad_enabled() and any(p.requires_grad for p in self.proj.parameters()):
                 raise NotImplementedError("nmrf_amd implements the inference path only: call under torch.no_grad()")
-            y = K.instance_norm(self.proj[0](fmap1_list[0]).contiguous(), relu=True)     # conv3x3 - IN - ReLU fused
-            context = self.proj[3](y)
+            raw = self.proj[0](fmap1_list[0]).contiguous()
+            w1 = self.proj[3].weight
+            import os
+            if os.environ.get("NMRF_CONV1X1", "1") != "0" and w1.shape[1] in (64, 128) and w1.shape[0] % 64 == 0:
+                from .nmp import _FusedCache                    # IN + ReLU folded into the 1x1 conv's operand load (csrc/conv1x1.hip)
+                if not hasattr(self, "_c1"):
+                    self._c1 = _FusedCache()
+                context = K.conv1x1_in_relu(raw, 0, w1.shape[1], K.instance_stats(raw), self._c1.get((w1,), lambda: K.pack_conv1x1(w1)))
+            else:
+                context = self.proj[3](K.instance_norm(raw, relu=True))     # conv3x3 - IN - ReLU fused
         context = context.permute(0, 2, 3, 1).contiguous()
         memory, seeds_f = self.propagation(cost_volume, seeds, context)
         outputs = self.prop_head(memory).view(-1, *seeds_f.shape)

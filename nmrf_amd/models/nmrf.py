@@ -144,9 +144,20 @@ class NMRF(nn.Module):
                 both = jf
         if both is None:
             both = torch.cat((left, right), 0)
-        y = K.instance_norm(K.conv3x3_auto(both, w3, cache.wino).contiguous(), relu=True)
-        f = F.conv2d(y[:, 0:128], self.concatconv[3].weight)
-        g = F.conv2d(y[:, 128:256], self.gw[3].weight)
+        raw = K.conv3x3_auto(both, w3, cache.wino).contiguous()
+        wf, wg = self.concatconv[3].weight, self.gw[3].weight
+        if (os.environ.get("NMRF_CONV1X1", "1") != "0" and wf.shape[1] == 128 and wg.shape[1] == 128 and wf.shape[0] % 64 == 0
+                and wg.shape[0] % 64 == 0):
+            # InstanceNorm + ReLU + the two 1x1 convs read the 3x3 output once: statistics pass, then one fused kernel per head
+            if not hasattr(cache, "c1"):
+                cache.c1 = (_FusedCache(), _FusedCache())
+            stats = K.instance_stats(raw)
+            f = K.conv1x1_in_relu(raw, 0, 128, stats, cache.c1[0].get((wf,), lambda: K.pack_conv1x1(wf)))
+            g = K.conv1x1_in_relu(raw, 128, 128, stats, cache.c1[1].get((wg,), lambda: K.pack_conv1x1(wg)))
+        else:
+            y = K.instance_norm(raw, relu=True)
+            f = F.conv2d(y[:, 0:128], wf)
+            g = F.conv2d(y[:, 128:256], wg)
         return f[:b].contiguous(), f[b:].contiguous(), g[:b].contiguous(), g[b:].contiguous()
 
     def hot_path(self, fmap1_list, fmap2_list, out_hw):

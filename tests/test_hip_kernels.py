@@ -481,6 +481,22 @@ def test_mlp_chain_fused(kind, t_, n_out):
         assert torch.equal(out[0:2 * (t_ - 5):2], got.cpu()[:t_ - 5]) and (out[1::2] == 0).all() and (out[2 * (t_ - 5):] == 0).all()
 
 
+@pytest.mark.parametrize("b,cx,c0,k,n,h,w,norm", [(2, 256, 128, 128, 256, 12, 39, True), (1, 256, 0, 128, 64, 47, 156, True),
+                                                  (2, 128, 0, 128, 64, 5, 7, True), (1, 64, 0, 64, 128, 9, 33, False),
+                                                  (2, 256, 0, 128, 64, 94, 312, True)])
+def test_conv1x1_in_relu_fused(b, cx, c0, k, n, h, w, norm):
+    """csrc/conv1x1.hip: Conv1x1(relu(InstanceNorm(x[:, c0:c0+k]))) against torch fp64 (tolerance of the split linears)."""
+    kk = K()
+    x = rnd(b, cx, h, w, seed=3, scale=2.0) + 0.3
+    wt, bias = rnd(n, k, 1, 1, seed=4, scale=0.1), rnd(n, seed=5, scale=0.2)
+    xs = x[:, c0:c0 + k].double()
+    a = F.relu(F.instance_norm(xs, eps=1e-5)) if norm else xs
+    ref = F.conv2d(a, wt.double(), bias.double())
+    stats = kk.instance_stats(x.to(DEV)) if norm else None
+    got = kk.conv1x1_in_relu(x.to(DEV), c0, k, stats, kk.pack_conv1x1(wt.to(DEV)), bias.to(DEV))
+    report("conv1x1", got.cpu(), ref, 2e-5, 1e-5)
+
+
 def test_prep_images_and_bias_avgpool():
     """Encoder input staging (pad + stack + normalise) and tail (bias + 2x2 average) against the torch ops they replace."""
     from nmrf_amd.frame_utils import InputPadder
