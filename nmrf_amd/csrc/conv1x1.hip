@@ -12,6 +12,7 @@
 
 #define C1_PIX 128
 #define C1_PF 4
+#define C1_OLD 132
 
 struct Conv1x1Args {
     const float *x;              // [B, Cx, HW]
@@ -36,6 +37,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1x1Args a) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, hi = lane >> 5;
     float *Aff = reinterpret_cast<float *>(smem + SS_RING_BYTES);           // [2][128]: scale, shift of the block's image
+    float *Ot = Aff + 256;                                                   // [64 co][C1_OLD] output staging
     SplitStream<C1_PF> ss;
     ss.init(a.stream, smem, a.total_stages, tid);
     const int n_strips = a.N >> 5;
@@ -73,25 +75,39 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1x1Args a) {
         }
         __syncthreads();
         // B operand: lane (pixel j, half hi), chunk c, slot jj <-> channel 16c + split_kslot(jj, hi)
-        const float *xb = a.x + ((size_t)b * a.Cx + a.c0) * a.HW + pc;
+        // Addresses as (uniform channel-row pointer) + (32-bit lane offset): the 64 loads of a lane then share ONE offset register
+        // (global_load saddr form) instead of 64 precomputed 64-bit addresses, which had pushed the kernel into scratch.
+        const float *xu = a.x + ((size_t)b * a.Cx + a.c0) * a.HW;             // uniform
+        const unsigned loff = (unsigned)(pc + (int64_t)(4 * hi) * a.HW);      // pixel + the lane half's 4 channels
+        const float *affl = Aff + 4 * hi;
         h16x8 bh[KC], bl[KC];
 #pragma unroll
         for (int c = 0; c < KC; ++c) {
             float v[8];
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) v[jj] = xb[(size_t)(16 * c + split_kslot(jj, hi)) * a.HW];
+            for (int jj = 0; jj < 8; ++jj) {
+                const float *row = xu + (size_t)(16 * c + (jj & 3) + 8 * (jj >> 2)) * a.HW;   // uniform
+                v[jj] = row[loff];
+            }
             if (a.stats) {
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) {
-                    const int ch = 16 * c + split_kslot(jj, hi);
-                    v[jj] = fmaxf(fmaf(v[jj], Aff[ch], Aff[128 + ch]), 0.f);
+                for (int g = 0; g < 2; ++g) {
+                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(affl + 16 * c + 8 * g);
+                    const f32x4 sh = *reinterpret_cast<const f32x4 *>(affl + 128 + 16 * c + 8 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[4 * g + e] = fmaxf(fmaf(v[4 * g + e], sc[e], sh[e]), 0.f);
                 }
             }
             split8u(v, bh[c], bl[c]);
         }
-        float *ob = a.out + (size_t)b * a.N * a.HW + p;
+        // Output: a C/D register is 32 pixels of one channel = a 128-byte piece; written as such (8 strips x 16 pieces per wave,
+        // 117 KB apart) the 1/4-resolution gw head ran at ~1 TB/s.  The four waves of the block stage each 32-channel strip in an
+        // LDS tile [32 co][128 px] and the block writes it out as 512-byte rows.
+        const int64_t pb = (int64_t)(tile - b * a.tiles_per_image) * C1_PIX;   // first pixel of the block
+        float *obase = a.out + (size_t)b * a.N * a.HW;
+        const bool vec_ok = (a.HW & 3) == 0;
 #pragma unroll 1
-        for (int s = 0; s < n_strips; s += 2) {                              // two strips = 2*KC pairs per iteration (KC even: whole stages)
+        for (int s = 0; s < n_strips; s += 2) {                              // two strips = 2*KC pairs per iteration (whole stages)
             ss_static_for<2>([&](auto hh) {
                 constexpr int half = decltype(hh)::value;
                 f32x16 acc;
@@ -102,14 +118,29 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1x1Args a) {
                     ss_pair<half * KC + c>(ss, bh[c], bl[c], acc);
                 });
                 const int co0 = 32 * (s + half);
-                if (p < a.HW && co0 < a.N) {
+                float *ot = Ot + half * 32 * C1_OLD;                          // one tile per strip of the pair: no barrier in between
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int co = co0 + mfma_row(r, hi);
-                        ob[(size_t)co * a.HW] = fmaf(acc[r], a.inv, a.bias ? a.bias[co] : 0.f);
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    const int row = mfma_row(r, hi);
+                    ot[row * C1_OLD + 32 * wv + j] = fmaf(acc[r], a.inv, a.bias ? a.bias[co0 + row] : 0.f);
                 }
             });
+            __syncthreads();
+            // 64 rows (2 strips x 32 channels) of 128 pixels: thread = (row = tid / 32 + 8 * pass, 4 pixels)
+#pragma unroll
+            for (int pass = 0; pass < 8; ++pass) {
+                const int row = (tid >> 5) + 8 * pass, px = (tid & 31) * 4;
+                const int co = 32 * s + row;
+                const int64_t pp = pb + px;
+                if (co < a.N && pp < a.HW) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(Ot + row * C1_OLD + px);
+                    float *dst = obase + (size_t)co * a.HW + pp;
+                    if (vec_ok && pp + 3 < a.HW) *reinterpret_cast<f32x4 *>(dst) = v;
+                    else
+                        for (int e = 0; e < 4 && pp + e < a.HW; ++e) dst[e] = v[e];
+                }
+            }
+            __syncthreads();                                                   // the tiles are rewritten by the next strip pair
         }
     }
 }
@@ -120,7 +151,7 @@ static int launch_conv1x1(const Conv1x1Args &a, hipStream_t st) {
     static int n_cu_dev[NMRF_MAX_DEV] = {};
     const int dev = nmrf_cur_device();
     if (dev < 0) return NMRF_ELAUNCH;
-    const size_t lds = (size_t)SS_RING_BYTES + 256 * sizeof(float);
+    const size_t lds = (size_t)SS_RING_BYTES + (256 + 64 * C1_OLD) * sizeof(float);
     if (!attr_set_dev[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_kernel<KC>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess)
