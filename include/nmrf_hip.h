@@ -27,7 +27,7 @@ extern "C" {
 
 const char *nmrf_strerror(int code);
 /* ABI version of this header; bumps on any signature change. */
-int nmrf_abi_version(void);   /* currently 14 */
+int nmrf_abi_version(void);   /* currently 15 */
 
 /* A2  group-wise correlation volume.
  * replaces build_correlation_volume + the permute of DPN.forward
@@ -273,6 +273,17 @@ int nmrf_instance_stats_f32(const float *x, int64_t planes, int64_t HW, float *w
 int nmrf_conv1x1_in_relu_f32(const float *x, int B, int Cx, int64_t HW, int c0, int K, const float *stats, int chunks, float eps,
                              const void *stream_w, int total_stages, float inv_scale, const float *bias, int N, float *out,
                              void *stream);
+
+/* N2: 3x3 / stride 1 / pad 1 / no-bias convolution as a direct implicit GEMM on the split-operand fp16 MFMA, optionally with the
+ * InstanceNorm + ReLU of its INPUT folded into the operand load (conv1 / conv2 of ResidualBlock, nmrf/models/backbone.py:38-46;
+ * first conv of concatconv / gw, nmrf/models/NMRF.py:56-65):
+ *   out[b,co,y,x] = sum_{ci,dy,dx} W[co,ci,dy,dx] * f(x[b,ci,y+dy-1,x+dx-1]),  f(v) = relu((v - mean[b,ci]) * rstd[b,ci]), or v when
+ *   stats == NULL (stats = nmrf_instance_stats_f32 workspace of x; zero padding applies after f).
+ * x [B,Ci,H,W], out [B,Co,H,W] NCHW fp32; Ci % 16 == 0 (<= 256 with stats); Co = groups * strips * 32, strips in {2,3,4}.
+ * stream_w: nmrf_pack_split_weight_f32 of the matrix Wm[Co][9*Ci], Wm[co][((ci/16 * 3 + dy) * 3 + dx) * 16 + ci%16] = W[co,ci,dy,dx],
+ * with its pairs reordered [group][chunk = 9*Ci/16][strip][512 x int32]; inv_scale = 1 / its scale. */
+int nmrf_conv3x3_split_f32(const float *x, int B, int Ci, int H, int W, const float *stats, int chunks, float eps,
+                           const void *stream_w, int strips, int groups, float inv_scale, int Co, float *out, void *stream);
 
 /* A1 + encoder input staging: replicate-pad both views right/bottom to (Hp, Wp) (InputPadder mode 'proposal',
  * nmrf/utils/frame_utils.py:268-275), stack them along the batch (NMRF.py:173) and normalise 2*(x/255)-1 (backbone.py:86).

@@ -9,6 +9,7 @@
 // 128-byte line on the way in, and a C/D register is one 128-byte line of an output channel on the way out.
 // Block = 4 waves x 32 pixels of one image.  Split-operand fp16 MFMA (split_mfma.h).
 #include "split_stream.h"
+#include "in_affine.h"
 
 #define C1_PIX 128
 #define C1_PF 4
@@ -52,24 +53,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1x1Args a) {
         __syncthreads();                                                       // previous tile is done with Aff
         if (tid < a.K) {
             float sc = 1.f, sh = 0.f;
-            if (a.stats) {
-                const float *w = a.stats + ((size_t)b * a.Cx + a.c0 + tid) * a.chunks * 2;
-                float mean = 0.f;
-                for (int c = 0; c < a.chunks; ++c) {
-                    const int64_t nb = (int64_t)c * 8192;
-                    mean += w[2 * c] * (float)((nb + 8192 < a.HW ? nb + 8192 : a.HW) - nb);
-                }
-                mean /= (float)a.HW;
-                float m2 = 0.f;
-                for (int c = 0; c < a.chunks; ++c) {
-                    const int64_t nb = (int64_t)c * 8192;
-                    const float nc = (float)((nb + 8192 < a.HW ? nb + 8192 : a.HW) - nb);
-                    const float d = w[2 * c] - mean;
-                    m2 += w[2 * c + 1] + d * d * nc;
-                }
-                sc = 1.0f / sqrtf(m2 / (float)a.HW + a.eps);
-                sh = -mean * sc;
-            }
+            if (a.stats) in_affine_of(a.stats + ((size_t)b * a.Cx + a.c0 + tid) * a.chunks * 2, a.chunks, a.HW, a.eps, sc, sh);
             Aff[tid] = sc;
             Aff[128 + tid] = sh;
         }

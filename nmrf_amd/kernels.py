@@ -518,17 +518,79 @@ def conv3x3_wino(x, packed_u, co):
     return y
 
 
-def conv3x3_auto(x, weight, cache):
-    """3x3 / stride 1 / pad 1 / no-bias convolution: the fused Winograd MFMA kernel where it has enough blocks to fill
-    the chip (>= 512: measured 1.1-1.66x MIOpen there, 0.8x at 144 blocks), MIOpen otherwise.  NMRF_WINO=0 forces MIOpen.
+def _conv3_plan(co, tiles):
+    """(strips, groups) of conv3x3_split for `co` output channels: 32-channel strips per block x channel groups (blockIdx.y).
+    Two strips per block (three resident blocks per CU, most blocks) unless the launch is large enough to fill the chip with
+    four (the halo is then staged once for 128 channels instead of twice)."""
+    k = co // 32
+    forced = os.environ.get("NMRF_CONV3_STRIPS")
+    if forced and k % int(forced) == 0:
+        return int(forced), k // int(forced)
+    if k % 4 == 0 and tiles * (k // 4) >= 2048:
+        return 4, k // 4
+    if k % 2 == 0:
+        return 2, k // 2
+    if k % 3 == 0:
+        return 3, k // 3
+    return None
+
+
+@_on_device
+def pack_conv3x3(weight, strips, groups):
+    """[Co,Ci,3,3] conv weight -> (stream [groups, 9*Ci/16, strips, 512] int32, 1/scale) for conv3x3_split: the matrix
+    Wm[co][((ci/16 * 3 + dy) * 3 + dx) * 16 + ci%16] as split-fp16 MFMA fragment pairs, chunk-major within a channel group."""
+    co, ci = weight.shape[0], weight.shape[1]
+    wm = weight.reshape(co, ci // 16, 16, 3, 3).permute(0, 1, 3, 4, 2).reshape(co, 9 * ci).contiguous()
+    pk, inv = pack_split_weight(wm, 9 * ci)                                   # [co/32, 9*ci/16, 512]
+    return pk.view(groups, strips, 9 * ci // 16, 512).permute(0, 2, 1, 3).contiguous(), inv
+
+
+@_on_device
+def conv3x3_split(x, packed, co, stats=None, eps=1e-5):
+    """3x3 / stride 1 / pad 1 / no-bias convolution (NCHW fp32) as a direct implicit GEMM on the split-operand fp16 MFMA;
+    stats (instance_stats(x)): conv(relu(InstanceNorm(x))) with the normalisation folded into the operand load.
+    packed = (stream, strips, groups, 1/scale) of pack_conv3x3."""
+    stream, strips, groups, inv = packed
+    _chk(x, stats)
+    _chk(stream, dtype=torch.int32)
+    b, ci, h, w = x.shape
+    y = torch.empty(b, co, h, w, device=x.device, dtype=torch.float32)
+    name = "conv3x3_split_s%d" % strips
+    _hb(name, row="N2", bound="mfma", flops=2.0 * 9 * b * ci * co * h * w, bytes=4.0 * (x.numel() + y.numel()), split=True,
+        label="conv3x3_split_kernel<%d> (3x3 stride-1 convs of the backbone / conv heads, N2; mean over layers; direct-form "
+        "FLOPs)" % strips, pmc=["conv3x3_split_kernel<%d>" % strips])
+    _lib.check(_lib.load().nmrf_conv3x3_split_f32(_p(x), b, ci, h, w, _p(stats), 0 if stats is None else stats.shape[1], float(eps),
+                                                  _p(stream), strips, groups, float(inv), co, _p(y), _stream()), "conv3x3_split")
+    _he(name)
+    return y
+
+
+def conv3x3_auto(x, weight, cache, stats=None):
+    """3x3 / stride 1 / pad 1 / no-bias convolution [of relu(InstanceNorm(x)) when `stats` = instance_stats(x) is given].
+    Default: the direct split-fp16 MFMA kernel (conv3x3.hip).  NMRF_CONV3=wino: the round-1 Winograd fp32-MFMA kernel where it has
+    enough blocks to fill the chip, MIOpen otherwise; NMRF_CONV3=miopen: always MIOpen.  Unsupported channel counts -> MIOpen.
     `cache`: a dict owned by the caller, holds the packed filter per weight version."""
     co, ci = weight.shape[0], weight.shape[1]
     b, _, h, w = x.shape
+    mode = os.environ.get("NMRF_CONV3", "split")
+    if os.environ.get("NMRF_WINO", "1") == "0":
+        mode = "miopen"
+    key = (weight.data_ptr(), weight._version, mode)
+    hip = x.is_cuda and x.dtype == torch.float32 and ci % 16 == 0 and co % 32 == 0
+    if hip and mode == "split" and (stats is None or ci <= 256):
+        plan = _conv3_plan(co, b * ((h + 7) // 8) * ((w + 31) // 32))
+        if plan is not None:
+            if cache.get("key") != key + plan:
+                with torch.no_grad():
+                    cache["packed"] = pack_conv3x3(weight, *plan)
+                cache["key"] = key + plan
+            stream, inv = cache["packed"]
+            return conv3x3_split(x.contiguous(), (stream, plan[0], plan[1], inv), co, stats)
+    if stats is not None:                                  # the other paths take the normalised activation
+        x = instance_norm(x.contiguous(), relu=True)
     blocks = ((w + 1) // 2 + 31) // 32 * (((h + 1) // 2 + 1) // 2) * b * (co // 32)
-    if (not x.is_cuda or ci % 16 or co % 32 or blocks < 512 or os.environ.get("NMRF_WINO", "1") == "0"
-            or x.dtype != torch.float32):
+    if not hip or mode == "miopen" or blocks < 512:
         return torch.nn.functional.conv2d(x, weight, None, 1, 1)
-    key = (weight.data_ptr(), weight._version)
     if cache.get("key") != key:
         with torch.no_grad():
             cache["packed"] = wino_pack_filter(weight)

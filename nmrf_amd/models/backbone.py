@@ -1,5 +1,6 @@
 """CNN feature encoder.  Stock PyTorch-ROCm (MIOpen) by north_star, except what SURVEY 8(f) N2 pulled in: InstanceNorm
-(+ReLU / residual) on the fused HIP kernels and the large 3x3 stride-1 convolutions on the Winograd MFMA kernel.
+(+ReLU / residual) on the fused HIP kernels and the 3x3 stride-1 convolutions on the direct split-fp16 MFMA kernel
+(csrc/conv3x3.hip; norm1 + ReLU of a residual block folded into conv2's operand load).
 
 Parameter names follow the reference's `Backbone` (nmrf/models/backbone.py:16-98) so released
 checkpoints load with strict=True: conv1, layer{1,2,3}.{0,1}.{conv1,conv2,downsample.0}, conv2.
@@ -49,12 +50,13 @@ class ResidualBlock(nn.Module):
             # InstanceNorm + ReLU (+ residual add + ReLU) in two HIP passes instead of 4-6 torch kernels
             from .. import kernels as K
             c1 = K.conv3x3_auto(x, self.conv1.weight, self._wino1) if self.conv1.stride == (1, 1) else self.conv1(x)
-            y = K.instance_norm(c1.contiguous(), relu=True)
+            c1 = c1.contiguous()
             if self.downsample is not None:
                 # (the 1x1 conv's bias is a per-channel constant: InstanceNorm removes it, so the add is skipped)
                 d = self.downsample[0]
                 x = K.instance_norm(F.conv2d(x, d.weight, None, d.stride).contiguous())
-            c2 = K.conv3x3_auto(y, self.conv2.weight, self._wino2)
+            # norm1 + ReLU live only inside conv2's operand load: statistics pass, then the conv reads the raw conv1 output
+            c2 = K.conv3x3_auto(c1, self.conv2.weight, self._wino2, stats=K.instance_stats(c1))
             return K.instance_norm(c2.contiguous(), relu=True, residual=x.contiguous(), relu_out=True)
         y = self.relu(self.norm1(self.conv1(x)))
         y = self.relu(self.norm2(self.conv2(y)))

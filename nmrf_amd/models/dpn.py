@@ -59,7 +59,9 @@ class DPN(nn.Module):
         if context is None:                                   # [B,Cctx,H,W] may be precomputed by the caller
             if torch.is_grad_enabled() and any(p.requires_grad for p in self.proj.parameters()):
                 raise NotImplementedError("nmrf_amd implements the inference path only: call under torch.no_grad()")
-            raw = self.proj[0](fmap1_list[0]).contiguous()
+            if not hasattr(self, "_c3"):
+                self._c3 = {}
+            raw = K.conv3x3_auto(fmap1_list[0], self.proj[0].weight, self._c3).contiguous()
             w1 = self.proj[3].weight
             import os
             if os.environ.get("NMRF_CONV1X1", "1") != "0" and w1.shape[1] in (64, 128) and w1.shape[0] % 64 == 0:

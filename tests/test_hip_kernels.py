@@ -545,6 +545,41 @@ def test_conv3x3_winograd(b, ci, co, h, w):
     report("conv3x3_wino", got, ref, 2e-5 * (ci ** 0.5), 1e-5)
 
 
+@pytest.mark.parametrize("b,ci,co,h,w,strips,norm", [
+    (1, 16, 64, 4, 64, 2, False), (2, 32, 64, 7, 9, 2, True), (1, 64, 64, 47, 156, 2, True), (2, 96, 96, 23, 70, 3, True),
+    (1, 128, 128, 12, 33, 2, False), (1, 128, 128, 12, 33, 4, True), (2, 128, 256, 24, 78, 2, False), (1, 128, 256, 9, 40, 4, True),
+    (1, 16, 64, 1, 1, 2, False), (2, 64, 64, 192, 624, 2, True)])
+def test_conv3x3_split(b, ci, co, h, w, strips, norm):
+    """csrc/conv3x3.hip: direct split-fp16 MFMA conv [of relu(InstanceNorm(x))] against torch fp64; tolerance of the split
+    linears scaled by sqrt(taps) (2^-22-relative products, fp32 accumulation over 9*Ci terms).  The last case is layer1 of the
+    KITTI backbone (B=2 views, 1/2 resolution)."""
+    kk = K()
+    x = rnd(b, ci, h, w, seed=21, scale=2.0) + (0.4 if norm else 0.0)
+    wt = rnd(co, ci, 3, 3, seed=22, scale=0.2)
+    a = F.relu(F.instance_norm(x.double(), eps=1e-5)) if norm else x.double()
+    ref = F.conv2d(a, wt.double(), None, 1, 1)
+    xd = x.to(DEV)
+    stats = kk.instance_stats(xd) if norm else None
+    groups = co // (32 * strips)
+    stream, inv = kk.pack_conv3x3(wt.to(DEV), strips, groups)
+    got = kk.conv3x3_split(xd, (stream, strips, groups, inv), co, stats).cpu()
+    report("conv3x3_split", got, ref, 2e-5 * 3, 1e-5)
+
+
+def test_conv3x3_auto_paths_agree(monkeypatch):
+    """The dispatcher: split kernel (default) vs the Winograd / MIOpen paths on the same input, with and without folded stats."""
+    kk = K()
+    x = (rnd(2, 64, 40, 200, seed=5, scale=1.5) + 0.2).to(DEV)
+    wt = rnd(96, 64, 3, 3, seed=6, scale=0.1).to(DEV)
+    outs = {}
+    for mode in ("split", "wino", "miopen"):
+        monkeypatch.setenv("NMRF_CONV3", mode)
+        outs[mode] = (kk.conv3x3_auto(x, wt, {}).cpu(), kk.conv3x3_auto(x, wt, {}, stats=kk.instance_stats(x)).cpu())
+    for mode in ("wino", "miopen"):
+        for i in range(2):
+            report("conv3x3_auto %s[%d]" % (mode, i), outs["split"][i], outs[mode][i].double(), 2e-4, 1e-5)
+
+
 @pytest.mark.parametrize("b,h,w,k,nlab", [(1, 16, 24, 4, 3), (2, 37, 53, 4, 40), (1, 64, 64, 2, 1000), (1, 8, 8, 8, 2)])
 def test_superpixel_downsample_unpinned(b, h, w, k, nlab):
     """A16: HIP kernel vs its CPU restatement, bit-exact (the restatement itself is unpinned: no reference source)."""

@@ -320,23 +320,31 @@ if "linear_timing" in which:
 
 if "conv" in which:
     import torch.nn.functional as F
-    for (bb, ci, co, hh, ww) in ((2, 64, 64, 188, 624), (2, 96, 96, 94, 312), (2, 128, 128, 94, 312), (2, 128, 256, 94, 312),
-                                 (2, 256, 256, 47, 156), (1, 256, 128, 47, 156)):
+    for (bb, ci, co, hh, ww) in ((2, 64, 64, 192, 624), (2, 96, 96, 96, 312), (2, 96, 128, 96, 312), (2, 128, 128, 96, 312),
+                                 (2, 128, 256, 96, 312), (2, 128, 256, 48, 156), (1, 128, 128, 48, 156)):
         xx = mk("cx%d" % ci, bb * args.batch, ci, hh, ww)
         wt = mk("cw%d%d" % (ci, co), co, ci, 3, 3) * 0.05
         pu = K.wino_pack_filter(wt)
+        st = K.instance_stats(xx)
         fl = 2.0 * bb * args.batch * ci * co * 9 * hh * ww
-        e = []
-        for nm, fn in (("MIOpen", lambda: F.conv2d(xx, wt, None, 1, 1)), ("wino  ", lambda: K.conv3x3_wino(xx, pu, co))):
+        cands = [("MIOpen", lambda: F.conv2d(xx, wt, None, 1, 1)), ("wino", lambda: K.conv3x3_wino(xx, pu, co))]
+        for strips in (2, 3, 4):
+            if (co // 32) % strips == 0:
+                pk = K.pack_conv3x3(wt, strips, co // 32 // strips)
+                packed = (pk[0], strips, co // 32 // strips, pk[1])
+                cands.append(("split%d" % strips, lambda packed=packed: K.conv3x3_split(xx, packed, co)))
+                cands.append(("split%d+IN" % strips, lambda packed=packed: K.conv3x3_split(xx, packed, co, st)))
+        line = "conv3x3 %3d->%3d @%dx%dx%d :" % (ci, co, bb * args.batch, hh, ww)
+        for nm, fn in cands:
             fn(); fn(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(args.iters):
                 fn()
             e1.record(); torch.cuda.synchronize()
-            e.append(e0.elapsed_time(e1) * 1e3 / args.iters)
-        print("conv3x3 %3d->%3d @%dx%dx%d : MIOpen %7.1f us (%5.1f TF/s eff)   wino %7.1f us (%5.1f TF/s eff)  x%.2f"
-              % (ci, co, bb * args.batch, hh, ww, e[0], fl / e[0] / 1e6, e[1], fl / e[1] / 1e6, e[0] / e[1]), flush=True)
+            us = e0.elapsed_time(e1) * 1e3 / args.iters
+            line += "  %s %.1f us (%.0f TF/s)" % (nm, us, fl / us / 1e6)
+        print(line, flush=True)
 
 if "conv_timing" in which:
     import numpy as np
