@@ -520,13 +520,14 @@ def conv3x3_wino(x, packed_u, co):
 
 def _conv3_plan(co, tiles):
     """(strips, groups) of conv3x3_split for `co` output channels: 32-channel strips per block x channel groups (blockIdx.y).
-    Two strips per block (three resident blocks per CU, most blocks) unless the launch is large enough to fill the chip with
-    four (the halo is then staged once for 128 channels instead of twice)."""
+    Two strips per block (three resident blocks per CU, most blocks) unless the launch still fills the chip with four (the
+    halo is then staged once for 128 channels instead of twice; measured at KITTI B=1: 128->256 at 1/4 res, 480 blocks of four
+    strips 93 us vs 960 of two 103 us; 128->128 at 1/4 res, 240 vs 480 blocks: 56 vs 53 us; 128->256 at 1/8 res: 47 vs 34 us)."""
     k = co // 32
     forced = os.environ.get("NMRF_CONV3_STRIPS")
     if forced and k % int(forced) == 0:
         return int(forced), k // int(forced)
-    if k % 4 == 0 and tiles * (k // 4) >= 2048:
+    if k % 4 == 0 and tiles * (k // 4) >= 400:
         return 4, k // 4
     if k % 2 == 0:
         return 2, k // 2
