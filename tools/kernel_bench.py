@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--which", default="window,stripe,refine,warp")
+ap.add_argument("--xscale", type=float, default=1.0, help="conv section: scale of the input (fp16 subnormal probe)")
 args = ap.parse_args()
 dev = "cuda"
 b, h, w, n = args.batch, 47, 156, 4
@@ -322,7 +323,7 @@ if "conv" in which:
     import torch.nn.functional as F
     for (bb, ci, co, hh, ww) in ((2, 64, 64, 192, 624), (2, 96, 96, 96, 312), (2, 96, 128, 96, 312), (2, 128, 128, 96, 312),
                                  (2, 128, 256, 96, 312), (2, 128, 256, 48, 156), (1, 128, 128, 48, 156)):
-        xx = mk("cx%d" % ci, bb * args.batch, ci, hh, ww)
+        xx = mk("cx%d" % ci, bb * args.batch, ci, hh, ww) * args.xscale
         wt = mk("cw%d%d" % (ci, co), co, ci, 3, 3) * 0.05
         pu = K.wino_pack_filter(wt)
         st = K.instance_stats(xx)
