@@ -285,6 +285,19 @@ int nmrf_conv1x1_in_relu_f32(const float *x, int B, int Cx, int64_t HW, int c0, 
 int nmrf_conv3x3_split_f32(const float *x, int B, int Ci, int H, int W, const float *stats, int chunks, float eps,
                            const void *stream_w, int strips, int groups, float inv_scale, int Co, float *out, void *stream);
 
+/* N2: the same kernel for other tap counts / strides of the backbone (nmrf/models/backbone.py:70,74):
+ *   kt = 3, stride = 2, pad = 1: the 3x3 / stride-2 convolution of layer2.0 (strips in {2,3});
+ *   kt = 4, stride = 1, pad = 2: a 4x4 convolution with padding 2 before / 1 after -- the 7x7 / stride-2 / pad-3 stem over the 2x2
+ *                                space-to-depth image of nmrf_prep_images_s2d_f32 (Ci = 16, strips = 2).
+ * x [B,Ci,H,W]; out [B,Co,Ho,Wo] with Ho = (H - 1) / stride + 1 (total padding kt - 1).  stream_w: as nmrf_conv3x3_split_f32 with
+ * Wm[co][((ci/16 * kt + dy) * kt + dx) * 16 + ci%16] = W[co,ci,dy,dx] and 9 replaced by kt * kt. */
+int nmrf_conv_split_f32(const float *x, int B, int Ci, int H, int W, const float *stats, int chunks, float eps, const void *stream_w,
+                        int kt, int stride, int pad, int strips, int groups, float inv_scale, int Co, float *out, void *stream);
+
+/* Encoder input staging as nmrf_prep_images_f32, written as the 2x2 space-to-depth image: out [2B, 16, Hp/2, Wp/2], channel
+ * c*4 + p*2 + q = normalised padded pixel (2Y+p, 2X+q) of colour c (3 colours), channels 12..15 zero.  Hp, Wp even. */
+int nmrf_prep_images_s2d_f32(const float *img1, const float *img2, int B, int H, int W, int Hp, int Wp, float *out, void *stream);
+
 /* A1 + encoder input staging: replicate-pad both views right/bottom to (Hp, Wp) (InputPadder mode 'proposal',
  * nmrf/utils/frame_utils.py:268-275), stack them along the batch (NMRF.py:173) and normalise 2*(x/255)-1 (backbone.py:86).
  * img1, img2 [B,C,H,W] -> out [2B,C,Hp,Wp] (left views first). */

@@ -22,26 +22,42 @@
 #include "split_stream.h"
 #include "in_affine.h"
 
-#define C3_TR 8
-#define C3_TC 32
-#define C3_HR (C3_TR + 2)
-#define C3_HC (C3_TC + 2)
-#define C3_NPIX (C3_HR * C3_HC)          // 340 halo pixels
+#define C3_TC 32                          // tile columns = the MFMA's 32 columns
 #define C3_PSTRIDE 80                     // bytes per pixel record
-#define C3_NITEM (2 * C3_NPIX)            // (pixel, 8-channel half) items per slab
-#define C3_IPT 3                          // items per thread: ceil(680 / 256)
 #define C3_AFF 256                        // channels of the affine table
 #define C3_OUTSIDE 0xffffffffu
 // s_waitcnt immediate of gfx9: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14; here vmcnt = n, the others unconstrained
 #define C3_VMCNT(n) (((n) & 15) | (((n) >> 4) << 14) | 0x0f70)
 
+// Generalisations of the 3x3 / stride-1 kernel (template parameters KT = taps per side, STRIDE):
+//   * STRIDE 2 (layer2.0.conv1 of the backbone, nmrf/models/backbone.py:74): a wave owns ONE output row (G = 1 pixel group), the
+//     tile is 4 rows x 32 columns, the halo (2*4+1) x (2*32+1); halo columns are stored de-interleaved (even columns, then odd) so
+//     that the 32 lanes of a tap still read 32 consecutive 80-byte records.
+//   * KT 4 (the 7x7 / stride-2 stem, backbone.py:70, as a 4x4 / stride-1 convolution over the 2x2 space-to-depth image: 12
+//     channels padded to one 16-channel slab, pad 2 before / 1 after): same kernel, four taps per stage.
+template <int KT, int STRIDE>
+struct C3Geom {
+    static constexpr int G = STRIDE == 1 ? 2 : 1;              // 32-pixel groups (output rows) per wave
+    static constexpr int TR = 4 * G;                           // tile rows
+    static constexpr int HR = (TR - 1) * STRIDE + KT;          // halo rows
+    static constexpr int HC = (C3_TC - 1) * STRIDE + KT;       // halo columns
+    static constexpr int NPIX = HR * HC;
+    static constexpr int IPT = (2 * NPIX + 255) / 256;         // (pixel, 8-channel half) items per thread
+    static constexpr int EVEN = (HC + 1) / 2;                  // STRIDE 2: records of the even halo columns of a row
+    // record of halo pixel (py, px)
+    __host__ __device__ static constexpr int rec(int py, int px) {
+        return STRIDE == 1 ? py * HC + px : py * HC + (px & 1) * EVEN + (px >> 1);
+    }
+};
+
 struct Conv3Args {
     const float *x;              // [B, Ci, H, W]
-    int Ci, H, W;
+    int Ci, H, W;                // input size
+    int Ho, Wo, pad;             // output size; padding before (rows and columns)
     const float *stats;          // in_stats workspace of x ([B*Ci][chunks][2]) or NULL
     int chunks;
     float eps;
-    const ss_u32x4 *wstream;     // [groups][Ci/16 * 3 stages][3 * STRIPS pairs][128] 16-byte words
+    const ss_u32x4 *wstream;     // [groups][Ci/16 * KT stages][KT * STRIPS pairs][128] 16-byte words
     int64_t group_stride;        // 16-byte words between channel groups
     float *out;                  // [B, Co, H, W]
     int Co;
@@ -54,10 +70,12 @@ struct Conv3Args {
 // vmcnt waits that the LDS-DMA needs are written out by hand at the call sites.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int STRIPS>
-__global__ __launch_bounds__(256, STRIPS == 2 ? 3 : 2) void conv3x3_split_kernel(Conv3Args a) {
+template <int STRIPS, int KT, int STRIDE>
+__global__ __launch_bounds__(256, STRIDE == 2 ? 1 : (STRIPS == 2 ? 3 : 2)) void conv3x3_split_kernel(Conv3Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int STAGE_U4 = STRIPS * 3 * 128;              // 16-byte words per weight stage
+    using GM = C3Geom<KT, STRIDE>;
+    constexpr int G = GM::G, C3_TR = GM::TR, C3_HC = GM::HC, C3_NPIX = GM::NPIX, C3_IPT = GM::IPT, C3_NITEM = 2 * GM::NPIX;
+    constexpr int STAGE_U4 = STRIPS * KT * 128;             // 16-byte words per weight stage
     ss_u32x4 *ring = reinterpret_cast<ss_u32x4 *>(smem);                       // 2 slots
     unsigned char *tile = smem + 2 * STAGE_U4 * 16;
     float *Aff = reinterpret_cast<float *>(tile + C3_NPIX * C3_PSTRIDE);        // [2][C3_AFF]: scale, shift
@@ -72,21 +90,21 @@ __global__ __launch_bounds__(256, STRIPS == 2 ? 3 : 2) void conv3x3_split_kernel
     const int rem = t - b * a.tiles_per_image;
     const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
     const int y0 = ty * C3_TR, x0 = tx * C3_TC;
-    const int64_t HW = (int64_t)a.H * a.W;
+    const int64_t HW = (int64_t)a.H * a.W, HWo = (int64_t)a.Ho * a.Wo;
     const int grp = blockIdx.y;
     const ss_u32x4 *wst = a.wstream + (size_t)grp * a.group_stride;
-    const int n_slabs = a.Ci >> 4, total = n_slabs * 3;
+    const int n_slabs = a.Ci >> 4, total = n_slabs * KT;
 
     // ---- weight stages: global -> LDS ring by LDS-DMA (global_load_lds_dwordx4: lane l's 16 bytes land at wave-uniform base +
-    // 16 l; pinned by nmrf_selftest_lds_dma), no staging registers.  A stage is 6 * STRIPS one-KB wave-instructions, dealt to
+    // 16 l; pinned by nmrf_selftest_lds_dma), no staging registers.  A stage is 2 * KT * STRIPS one-KB wave-instructions, dealt to
     // the 4 waves; issued at the top of stage g-1 into the slot stage g-2 vacated, waited for (vmcnt) before barrier g.
     auto dma_w = [&](int g, int slot) {
         const ss_u32x4 *src = wst + (size_t)g * STAGE_U4 + lane;
         ss_u32x4 *dst = ring + slot * STAGE_U4;
 #pragma unroll
-        for (int k = 0; k < (6 * STRIPS + 3) / 4; ++k) {
+        for (int k = 0; k < (2 * KT * STRIPS + 3) / 4; ++k) {
             const int n = wv + 4 * k;                                            // wave-uniform
-            if (n < 6 * STRIPS)
+            if (n < 2 * KT * STRIPS)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 64 * n),
                                                  (__attribute__((address_space(3))) void *)(dst + 64 * n), 16, 0, 0);
         }
@@ -110,9 +128,10 @@ __global__ __launch_bounds__(256, STRIPS == 2 ? 3 : 2) void conv3x3_split_kernel
     for (int k = 0; k < C3_IPT; ++k) {
         const int i = tid + 256 * k;
         const int h = i >= C3_NPIX ? 1 : 0;
-        const int p = i - h * C3_NPIX;
-        const int py = p / C3_HC, px = p - py * C3_HC;
-        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        const int p = i - h * C3_NPIX;                                          // record index
+        const int py = p / C3_HC, q = p - py * C3_HC;
+        const int px = STRIDE == 1 ? q : (q < GM::EVEN ? 2 * q : 2 * (q - GM::EVEN) + 1);
+        const int gy = y0 * STRIDE - a.pad + py, gx = x0 * STRIDE - a.pad + px;
         const bool item = i < C3_NITEM;
         const bool inside = item && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         loff[k] = inside ? (unsigned)((int64_t)(4 * h) * HW + (int64_t)gy * a.W + gx) : C3_OUTSIDE;
@@ -158,17 +177,17 @@ __global__ __launch_bounds__(256, STRIPS == 2 ? 3 : 2) void conv3x3_split_kernel
         }
     };
 
-    f32x16 acc[STRIPS][2];
+    f32x16 acc[STRIPS][G];
 #pragma unroll
     for (int s = 0; s < STRIPS; ++s)
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
+        for (int g = 0; g < G; ++g)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[s][g][r] = 0.f;
 
     prefetch_tile(0);
 
-    const unsigned char *tb0 = tile + ((2 * wv) * C3_HC + j) * C3_PSTRIDE + hi * 32;
+    const unsigned char *tb0 = tile + ((G * wv * STRIDE) * C3_HC + j) * C3_PSTRIDE + hi * 32;    // halo row of the wave's first output row, tap 0
     int dy = 0, slab = 0;
 #pragma unroll 1
     for (int g = 0; g < total; ++g) {
@@ -182,7 +201,7 @@ __global__ __launch_bounds__(256, STRIPS == 2 ? 3 : 2) void conv3x3_split_kernel
             lds_barrier();
             write_tile(slab);
             lds_barrier();
-            dma_w(g + 1, (g + 1) & 1);           // (total = 3 * slabs: a dy == 0 stage is never the last one)
+            dma_w(g + 1, (g + 1) & 1);           // (total = KT * slabs: a dy == 0 stage is never the last one)
             prefetch_tile(slab + 1 < n_slabs ? slab + 1 : slab);            // (always 24 loads: the vmcnt bookkeeping counts them)
         } else if (dy == 1) {
             __builtin_amdgcn_s_waitcnt(C3_VMCNT(C3_IPT * 8));
@@ -193,95 +212,137 @@ __global__ __launch_bounds__(256, STRIPS == 2 ? 3 : 2) void conv3x3_split_kernel
             lds_barrier();
             if (g + 1 < total) dma_w(g + 1, (g + 1) & 1);
         }
-        // ---- stage g: taps (dy, 0..2) of this slab against STRIPS strips --------------------------------------------------------
+        // ---- stage g: taps (dy, 0..KT-1) of this slab against STRIPS strips ---------------------------------------------------------
         const ss_u32x4 *wb = ring + (g & 1) * STAGE_U4 + lane;
         const unsigned char *tb = tb0 + dy * (C3_HC * C3_PSTRIDE);
-        h16x8 ah[2], al[2], bh[2][2], bl[2][2];
-        auto read_a = [&](int q, int buf) {
-            ah[buf] = *reinterpret_cast<const h16x8 *>(wb + q * 128);
-            al[buf] = *reinterpret_cast<const h16x8 *>(wb + q * 128 + 64);
-        };
-        auto read_b = [&](int dx, int buf) {
+        // record offset of tap dx relative to tap 0 (STRIDE 2: odd taps live in the odd-column half of the row)
+        auto tap_rec = [](int dx) { return STRIDE == 1 ? dx : (dx & 1) * GM::EVEN + (dx >> 1); };
+        if constexpr (G == 2) {
+            h16x8 ah[2], al[2], bh[2][2], bl[2][2];
+            auto read_a = [&](int q, int buf) {
+                ah[buf] = *reinterpret_cast<const h16x8 *>(wb + q * 128);
+                al[buf] = *reinterpret_cast<const h16x8 *>(wb + q * 128 + 64);
+            };
+            auto read_b = [&](int dx, int buf) {
 #pragma unroll
-            for (int gg = 0; gg < 2; ++gg) {
-                const unsigned char *p = tb + (gg * C3_HC + dx) * C3_PSTRIDE;
-                bh[buf][gg] = *reinterpret_cast<const h16x8 *>(p);
-                bl[buf][gg] = *reinterpret_cast<const h16x8 *>(p + 16);
-            }
-        };
-        read_b(0, 0);
-        read_a(0, 0);
-        ss_static_for<3 * STRIPS>([&](auto qq) {
-            constexpr int q = decltype(qq)::value;
-            constexpr int dx = q / STRIPS, s = q % STRIPS;
-            if constexpr (q + 1 < 3 * STRIPS) read_a(q + 1, (q + 1) & 1);
-            if constexpr (s == STRIPS - 1 && dx < 2) read_b(dx + 1, (dx + 1) & 1);
-            // LDS reads may not sink below this point, MFMAs may not rise above it (see nmp_block.hip)
-            __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x10 | 0x400);
-            const h16x8 fh = ah[q & 1], fl = al[q & 1];
-            // small terms first; the two pixel groups alternate so that consecutive MFMAs never share an accumulator
-            acc[s][0] = mfma16h(fl, bh[dx & 1][0], acc[s][0]);
-            acc[s][1] = mfma16h(fl, bh[dx & 1][1], acc[s][1]);
-            acc[s][0] = mfma16h(fh, bl[dx & 1][0], acc[s][0]);
-            acc[s][1] = mfma16h(fh, bl[dx & 1][1], acc[s][1]);
-            acc[s][0] = mfma16h(fh, bh[dx & 1][0], acc[s][0]);
-            acc[s][1] = mfma16h(fh, bh[dx & 1][1], acc[s][1]);
-        });
-        if (++dy == 3) { dy = 0; ++slab; }
+                for (int gg = 0; gg < 2; ++gg) {
+                    const unsigned char *p = tb + (gg * STRIDE * C3_HC + tap_rec(dx)) * C3_PSTRIDE;
+                    bh[buf][gg] = *reinterpret_cast<const h16x8 *>(p);
+                    bl[buf][gg] = *reinterpret_cast<const h16x8 *>(p + 16);
+                }
+            };
+            read_b(0, 0);
+            read_a(0, 0);
+            ss_static_for<KT * STRIPS>([&](auto qq) {
+                constexpr int q = decltype(qq)::value;
+                constexpr int dx = q / STRIPS, s = q % STRIPS;
+                if constexpr (q + 1 < KT * STRIPS) read_a(q + 1, (q + 1) & 1);
+                if constexpr (s == STRIPS - 1 && dx < KT - 1) read_b(dx + 1, (dx + 1) & 1);
+                // LDS reads may not sink below this point, MFMAs may not rise above it (see nmp_block.hip)
+                __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x10 | 0x400);
+                const h16x8 fh = ah[q & 1], fl = al[q & 1];
+                // small terms first; the two pixel groups alternate so that consecutive MFMAs never share an accumulator
+                acc[s][0] = mfma16h(fl, bh[dx & 1][0], acc[s][0]);
+                acc[s][1] = mfma16h(fl, bh[dx & 1][1], acc[s][1]);
+                acc[s][0] = mfma16h(fh, bl[dx & 1][0], acc[s][0]);
+                acc[s][1] = mfma16h(fh, bl[dx & 1][1], acc[s][1]);
+                acc[s][0] = mfma16h(fh, bh[dx & 1][0], acc[s][0]);
+                acc[s][1] = mfma16h(fh, bh[dx & 1][1], acc[s][1]);
+            });
+        } else {
+            // one pixel group per wave: a tap's fragments of ALL strips are read together and the MFMAs go term-major over the
+            // strips, so that consecutive MFMAs never share an accumulator
+            h16x8 ah[2][STRIPS], al[2][STRIPS], bh[2], bl[2];
+            auto read_tap = [&](int dx, int buf) {
+                const unsigned char *p = tb + tap_rec(dx) * C3_PSTRIDE;
+                bh[buf] = *reinterpret_cast<const h16x8 *>(p);
+                bl[buf] = *reinterpret_cast<const h16x8 *>(p + 16);
+#pragma unroll
+                for (int s = 0; s < STRIPS; ++s) {
+                    ah[buf][s] = *reinterpret_cast<const h16x8 *>(wb + (dx * STRIPS + s) * 128);
+                    al[buf][s] = *reinterpret_cast<const h16x8 *>(wb + (dx * STRIPS + s) * 128 + 64);
+                }
+            };
+            read_tap(0, 0);
+            ss_static_for<KT>([&](auto dd) {
+                constexpr int dx = decltype(dd)::value;
+                if constexpr (dx + 1 < KT) read_tap(dx + 1, (dx + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x10 | 0x400);
+#pragma unroll
+                for (int s = 0; s < STRIPS; ++s) acc[s][0] = mfma16h(al[dx & 1][s], bh[dx & 1], acc[s][0]);
+#pragma unroll
+                for (int s = 0; s < STRIPS; ++s) acc[s][0] = mfma16h(ah[dx & 1][s], bl[dx & 1], acc[s][0]);
+#pragma unroll
+                for (int s = 0; s < STRIPS; ++s) acc[s][0] = mfma16h(ah[dx & 1][s], bh[dx & 1], acc[s][0]);
+            });
+        }
+        if (++dy == KT) { dy = 0; ++slab; }
     }
 
     // ---- epilogue: a C/D register is 32 consecutive pixels of one output channel ---------------------------------------------------
     const int co_base = grp * STRIPS * 32;
-    float *ou = a.out + ((size_t)b * a.Co + co_base) * HW;                      // uniform
+    float *ou = a.out + ((size_t)b * a.Co + co_base) * HWo;                     // uniform
     const int x = x0 + j;
 #pragma unroll
-    for (int gg = 0; gg < 2; ++gg) {
-        const int y = y0 + 2 * wv + gg;
-        if (y >= a.H || x >= a.W) continue;
-        const unsigned oo = (unsigned)((int64_t)(4 * hi) * HW + (int64_t)y * a.W + x);
+    for (int gg = 0; gg < G; ++gg) {
+        const int y = y0 + G * wv + gg;
+        if (y >= a.Ho || x >= a.Wo) continue;
+        const unsigned oo = (unsigned)((int64_t)(4 * hi) * HWo + (int64_t)y * a.Wo + x);
 #pragma unroll
         for (int s = 0; s < STRIPS; ++s)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                (ou + (size_t)(32 * s + (r & 3) + 8 * (r >> 2)) * HW)[oo] = acc[s][gg][r] * a.inv;
+                (ou + (size_t)(32 * s + (r & 3) + 8 * (r >> 2)) * HWo)[oo] = acc[s][gg][r] * a.inv;
     }
 }
 
-template <int STRIPS>
+template <int STRIPS, int KT, int STRIDE>
 static int launch_conv3(const Conv3Args &a, int groups, hipStream_t st) {
     static bool attr_set_dev[NMRF_MAX_DEV] = {};
     const int dev = nmrf_cur_device();
     if (dev < 0) return NMRF_ELAUNCH;
-    const size_t lds = (size_t)2 * STRIPS * 3 * 2048 + C3_NPIX * C3_PSTRIDE + 2 * C3_AFF * sizeof(float);
+    const size_t lds = (size_t)2 * STRIPS * KT * 2048 + C3Geom<KT, STRIDE>::NPIX * C3_PSTRIDE + 2 * C3_AFF * sizeof(float);
     if (!attr_set_dev[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_split_kernel<STRIPS>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_split_kernel<STRIPS, KT, STRIDE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return NMRF_ELAUNCH;
         attr_set_dev[dev] = true;
     }
-    hipLaunchKernelGGL((conv3x3_split_kernel<STRIPS>), dim3(8 * a.per_xcd, groups), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv3x3_split_kernel<STRIPS, KT, STRIDE>), dim3(8 * a.per_xcd, groups), dim3(256), lds, st, a);
     return nmrf_launch_status();
+}
+
+extern "C" int nmrf_conv_split_f32(const float *x, int B, int Ci, int H, int W, const float *stats, int chunks, float eps,
+                                   const void *stream_w, int kt, int stride, int pad, int strips, int groups, float inv_scale,
+                                   int Co, float *out, void *stream) {
+    if (!x || !stream_w || !out) return NMRF_ENULL;
+    if (B < 1 || H < 1 || W < 1 || Ci < 16 || (Ci & 15) || strips < 2 || strips > 4 || groups < 1 || Co != strips * groups * 32 ||
+        (stats && (chunks < 1 || Ci > C3_AFF)) || pad < 0 || pad >= kt)
+        return NMRF_EINVAL;
+    const int Ho = (H + kt - 1 - kt) / stride + 1, Wo = (W + kt - 1 - kt) / stride + 1;     // total padding kt - 1 (pad before, rest after)
+    const int64_t HW = (int64_t)H * W;
+    if (HW * 8 + HW > 0xffffffffLL) return NMRF_EINVAL;                         // 32-bit lane offsets
+    const int tr = stride == 1 ? 8 : 4;
+    const int tx = (Wo + C3_TC - 1) / C3_TC, ty = (Ho + tr - 1) / tr;
+    const int64_t n = (int64_t)tx * ty * B;
+    if (n > 0x7ffffff) return NMRF_EINVAL;
+    Conv3Args a{x, Ci, H, W, Ho, Wo, pad, stats, chunks, eps, reinterpret_cast<const ss_u32x4 *>(stream_w),
+                (int64_t)(Ci / 16) * kt * strips * kt * 128, out, Co, inv_scale, tx, tx * ty, (int)n, (int)((n + 7) / 8)};
+    hipStream_t st = (hipStream_t)stream;
+    const int key = kt * 100 + stride * 10 + strips;
+    switch (key) {
+        case 312: return launch_conv3<2, 3, 1>(a, groups, st);
+        case 313: return launch_conv3<3, 3, 1>(a, groups, st);
+        case 314: return launch_conv3<4, 3, 1>(a, groups, st);
+        case 322: return launch_conv3<2, 3, 2>(a, groups, st);
+        case 323: return launch_conv3<3, 3, 2>(a, groups, st);
+        case 412: return launch_conv3<2, 4, 1>(a, groups, st);
+        default: return NMRF_EINVAL;
+    }
 }
 
 extern "C" int nmrf_conv3x3_split_f32(const float *x, int B, int Ci, int H, int W, const float *stats, int chunks, float eps,
                                       const void *stream_w, int strips, int groups, float inv_scale, int Co, float *out,
                                       void *stream) {
-    if (!x || !stream_w || !out) return NMRF_ENULL;
-    if (B < 1 || H < 1 || W < 1 || Ci < 16 || (Ci & 15) || strips < 2 || strips > 4 || groups < 1 || Co != strips * groups * 32 ||
-        (stats && (chunks < 1 || Ci > C3_AFF)))
-        return NMRF_EINVAL;
-    const int64_t HW = (int64_t)H * W;
-    if (HW * 8 + HW > 0xffffffffLL) return NMRF_EINVAL;                         // 32-bit lane offsets
-    const int tx = (W + C3_TC - 1) / C3_TC, ty = (H + C3_TR - 1) / C3_TR;
-    const int64_t n = (int64_t)tx * ty * B;
-    if (n > 0x7ffffff) return NMRF_EINVAL;
-    Conv3Args a{x, Ci, H, W, stats, chunks, eps, reinterpret_cast<const ss_u32x4 *>(stream_w),
-                (int64_t)(Ci / 16) * 3 * strips * 3 * 128, out, Co, inv_scale, tx, tx * ty, (int)n, (int)((n + 7) / 8)};
-    hipStream_t st = (hipStream_t)stream;
-    switch (strips) {
-        case 2: return launch_conv3<2>(a, groups, st);
-        case 3: return launch_conv3<3>(a, groups, st);
-        case 4: return launch_conv3<4>(a, groups, st);
-        default: return NMRF_EINVAL;
-    }
+    return nmrf_conv_split_f32(x, B, Ci, H, W, stats, chunks, eps, stream_w, 3, 1, 1, strips, groups, inv_scale, Co, out, stream);
 }

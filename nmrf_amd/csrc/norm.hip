@@ -186,6 +186,39 @@ extern "C" int nmrf_prep_images_f32(const float *img1, const float *img2, int B,
     return nmrf_launch_status();
 }
 
+// Same staging, written as the 2x2 space-to-depth image the stem convolution consumes (conv3x3.hip, KT = 4): out [2B, 16, Hp/2, Wp/2],
+// channel c*4 + p*2 + q = padded / normalised pixel (2Y + p, 2X + q) of colour c (C == 3), channels 12..15 zero.
+__global__ __launch_bounds__(256) void prep_images_s2d_kernel(const float *__restrict__ img1, const float *__restrict__ img2, int B,
+                                                             int H, int W, int H2, int W2, float *__restrict__ out) {
+    const int64_t total = (int64_t)2 * B * 16 * H2 * W2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int X = (int)(i % W2);
+        const int Y = (int)((i / W2) % H2);
+        const int64_t pc = i / ((int64_t)W2 * H2);                 // (view * B + b) * 16 + ch
+        const int ch = (int)(pc & 15);
+        const int64_t vb = pc >> 4, v = vb / B, bb = vb - v * B;
+        float r = 0.f;
+        if (ch < 12) {
+            const int c = ch >> 2, y = 2 * Y + ((ch >> 1) & 1), x = 2 * X + (ch & 1);
+            const float *src = (v == 0 ? img1 : img2) + (bb * 3 + c) * (int64_t)H * W;
+            const float px = src[(int64_t)(y < H ? y : H - 1) * W + (x < W ? x : W - 1)];
+            r = 2.0f * (px / 255.0f) - 1.0f;
+        }
+        out[i] = r;
+    }
+}
+
+extern "C" int nmrf_prep_images_s2d_f32(const float *img1, const float *img2, int B, int H, int W, int Hp, int Wp, float *out,
+                                        void *stream) {
+    if (!img1 || !img2 || !out) return NMRF_ENULL;
+    if (B < 1 || H < 1 || W < 1 || Hp < H || Wp < W || (Hp & 1) || (Wp & 1)) return NMRF_EINVAL;
+    int64_t blocks = ceil_div64((int64_t)2 * B * 16 * (Hp / 2) * (Wp / 2), 256 * 4);
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(prep_images_s2d_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, img1, img2, B, H, W, Hp / 2,
+                       Wp / 2, out);
+    return nmrf_launch_status();
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Tail of the CNN encoder: y = conv1x1 output without its bias [BC planes of H x W]; x = y + bias[c] (the 1/4-resolution map)
 // and its 2x2 average (the 1/8 map, nmrf/models/backbone.py:96-98) in one pass over y.  H, W even; thread = one 2x2 cell.

@@ -538,32 +538,99 @@ def _conv3_plan(co, tiles):
 
 @_on_device
 def pack_conv3x3(weight, strips, groups):
-    """[Co,Ci,3,3] conv weight -> (stream [groups, 9*Ci/16, strips, 512] int32, 1/scale) for conv3x3_split: the matrix
-    Wm[co][((ci/16 * 3 + dy) * 3 + dx) * 16 + ci%16] as split-fp16 MFMA fragment pairs, chunk-major within a channel group."""
-    co, ci = weight.shape[0], weight.shape[1]
-    wm = weight.reshape(co, ci // 16, 16, 3, 3).permute(0, 1, 3, 4, 2).reshape(co, 9 * ci).contiguous()
-    pk, inv = pack_split_weight(wm, 9 * ci)                                   # [co/32, 9*ci/16, 512]
-    return pk.view(groups, strips, 9 * ci // 16, 512).permute(0, 2, 1, 3).contiguous(), inv
+    """[Co,Ci,KT,KT] conv weight (KT = 3 or 4) -> (stream [groups, KT*KT*Ci/16, strips, 512] int32, 1/scale) for conv3x3_split /
+    conv_split: the matrix Wm[co][((ci/16 * KT + dy) * KT + dx) * 16 + ci%16] as split-fp16 MFMA fragment pairs, chunk-major
+    within a channel group."""
+    co, ci, kt = weight.shape[0], weight.shape[1], weight.shape[2]
+    wm = weight.reshape(co, ci // 16, 16, kt, kt).permute(0, 1, 3, 4, 2).reshape(co, kt * kt * ci).contiguous()
+    pk, inv = pack_split_weight(wm, kt * kt * ci)                             # [co/32, kt*kt*ci/16, 512]
+    return pk.view(groups, strips, kt * kt * ci // 16, 512).permute(0, 2, 1, 3).contiguous(), inv
 
 
 @_on_device
-def conv3x3_split(x, packed, co, stats=None, eps=1e-5):
-    """3x3 / stride 1 / pad 1 / no-bias convolution (NCHW fp32) as a direct implicit GEMM on the split-operand fp16 MFMA;
-    stats (instance_stats(x)): conv(relu(InstanceNorm(x))) with the normalisation folded into the operand load.
-    packed = (stream, strips, groups, 1/scale) of pack_conv3x3."""
+def conv_split(x, packed, co, kt=3, stride=1, pad=1, stats=None, eps=1e-5):
+    """KTxKT convolution (NCHW fp32, no bias, padding `pad` before and KT-1-pad after) as a direct implicit GEMM on the
+    split-operand fp16 MFMA (csrc/conv3x3.hip); stats (instance_stats(x)): conv(relu(InstanceNorm(x))) with the normalisation
+    folded into the operand load.  packed = (stream, strips, groups, 1/scale) of pack_conv3x3."""
     stream, strips, groups, inv = packed
     _chk(x, stats)
     _chk(stream, dtype=torch.int32)
     b, ci, h, w = x.shape
-    y = torch.empty(b, co, h, w, device=x.device, dtype=torch.float32)
-    name = "conv3x3_split_s%d" % strips
-    _hb(name, row="N2", bound="mfma", flops=2.0 * 9 * b * ci * co * h * w, bytes=4.0 * (x.numel() + y.numel()), split=True,
-        label="conv3x3_split_kernel<%d> (3x3 stride-1 convs of the backbone / conv heads, N2; mean over layers; direct-form "
-        "FLOPs)" % strips, pmc=["conv3x3_split_kernel<%d>" % strips])
-    _lib.check(_lib.load().nmrf_conv3x3_split_f32(_p(x), b, ci, h, w, _p(stats), 0 if stats is None else stats.shape[1], float(eps),
-                                                  _p(stream), strips, groups, float(inv), co, _p(y), _stream()), "conv3x3_split")
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    y = torch.empty(b, co, ho, wo, device=x.device, dtype=torch.float32)
+    name = "conv_split_k%d_s%d_%d" % (kt, stride, strips)
+    if kt == 3 and stride == 1:
+        label = ("conv3x3_split_kernel<%d,3,1> (3x3 stride-1 convs of the backbone / conv heads, N2; mean over layers; "
+                 "direct-form FLOPs)" % strips)
+    else:
+        label = "conv3x3_split_kernel<%d,%d,%d> (%s, N2)" % (strips, kt, stride, "7x7/2 stem as 4x4 over space-to-depth" if kt == 4
+                                                             else "3x3 stride-2 conv of layer2")
+    _hb(name, row="N2", bound="mfma", flops=2.0 * kt * kt * b * ci * co * ho * wo, bytes=4.0 * (x.numel() + y.numel()), split=True,
+        label=label, pmc=["conv3x3_split_kernel<%d, %d, %d>" % (strips, kt, stride)])
+    _lib.check(_lib.load().nmrf_conv_split_f32(_p(x), b, ci, h, w, _p(stats), 0 if stats is None else stats.shape[1], float(eps),
+                                               _p(stream), kt, stride, pad, strips, groups, float(inv), co, _p(y), _stream()),
+               "conv_split")
     _he(name)
     return y
+
+
+def conv3x3_split(x, packed, co, stats=None, eps=1e-5):
+    """3x3 / stride 1 / pad 1 / no-bias convolution: conv_split with its defaults."""
+    return conv_split(x, packed, co, 3, 1, 1, stats, eps)
+
+
+def _cached_pack(cache, key, make):
+    if cache.get("key") != key:
+        with torch.no_grad():
+            cache["packed"] = make()
+        cache["key"] = key
+    return cache["packed"]
+
+
+def conv3x3_s2_auto(x, weight, cache):
+    """3x3 / stride 2 / pad 1 / no-bias convolution (layer2.0.conv1): split-fp16 MFMA kernel, or MIOpen (NMRF_CONV3 != split,
+    unsupported channel counts)."""
+    co, ci = weight.shape[0], weight.shape[1]
+    k = co // 32
+    strips = 3 if k % 3 == 0 else (2 if k % 2 == 0 else 0)
+    if (not x.is_cuda or x.dtype != torch.float32 or ci % 16 or co % 32 or not strips
+            or os.environ.get("NMRF_CONV3", "split") != "split" or os.environ.get("NMRF_WINO", "1") == "0"):
+        return torch.nn.functional.conv2d(x, weight, None, 2, 1)
+    groups = k // strips
+    stream, inv = _cached_pack(cache, (weight.data_ptr(), weight._version, "s2"), lambda: pack_conv3x3(weight, strips, groups))
+    return conv_split(x.contiguous(), (stream, strips, groups, inv), co, 3, 2, 1)
+
+
+def stem_s2d_weight(weight):
+    """[Co,3,7,7] stride-2 / pad-3 stem filter -> [Co,16,4,4] filter of the equivalent stride-1 convolution (pad 2 before, 1 after)
+    over the 2x2 space-to-depth image (channel c*4 + p*2 + q = pixel (2Y+p, 2X+q) of colour c):
+    W'[co, c*4+p*2+q, ty, tx] = W[co, c, 2*ty+p-1, 2*tx+q-1] (zero where that index leaves 0..6)."""
+    co = weight.shape[0]
+    wp = torch.zeros(co, 3, 8, 8, device=weight.device, dtype=weight.dtype)
+    wp[:, :, 1:, 1:] = weight                                                # index k+1 = 2*t + p
+    w2 = wp.view(co, 3, 4, 2, 4, 2).permute(0, 1, 3, 5, 2, 4).reshape(co, 12, 4, 4)       # [co, (c,p,q), ty, tx]
+    out = torch.zeros(co, 16, 4, 4, device=weight.device, dtype=weight.dtype)
+    out[:, :12] = w2
+    return out
+
+
+@_on_device
+def prep_images_s2d(img1, img2, hp, wp):
+    """prep_images written as the space-to-depth image of the stem: [2B,16,hp/2,wp/2]."""
+    _chk(img1, img2)
+    b, c, h, w = img1.shape
+    assert c == 3 and hp % 2 == 0 and wp % 2 == 0
+    out = torch.empty(2 * b, 16, hp // 2, wp // 2, device=img1.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_prep_images_s2d_f32(_p(img1), _p(img2), b, h, w, hp, wp, _p(out), _stream()), "prep_images_s2d")
+    return out
+
+
+def stem_conv_s2d(x_s2d, weight, cache):
+    """The 7x7 / stride-2 / pad-3 stem convolution on the space-to-depth image (prep_images_s2d): [2B,16,H/2,W/2] -> [2B,Co,H/2,W/2]."""
+    co = weight.shape[0]
+    stream, inv = _cached_pack(cache, (weight.data_ptr(), weight._version, "stem"),
+                               lambda: pack_conv3x3(stem_s2d_weight(weight), 2, co // 64))
+    return conv_split(x_s2d, (stream, 2, co // 64, inv), co, 4, 1, 2)
 
 
 def conv3x3_auto(x, weight, cache, stats=None):

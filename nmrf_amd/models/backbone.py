@@ -49,7 +49,12 @@ class ResidualBlock(nn.Module):
         if self.fused and _hip_ok(self, x):
             # InstanceNorm + ReLU (+ residual add + ReLU) in two HIP passes instead of 4-6 torch kernels
             from .. import kernels as K
-            c1 = K.conv3x3_auto(x, self.conv1.weight, self._wino1) if self.conv1.stride == (1, 1) else self.conv1(x)
+            if self.conv1.stride == (1, 1):
+                c1 = K.conv3x3_auto(x, self.conv1.weight, self._wino1)
+            elif self.conv1.stride == (2, 2):
+                c1 = K.conv3x3_s2_auto(x, self.conv1.weight, self._wino1)
+            else:
+                c1 = self.conv1(x)
             c1 = c1.contiguous()
             if self.downsample is not None:
                 # (the 1x1 conv's bias is a per-channel constant: InstanceNorm removes it, so the add is skipped)
@@ -86,12 +91,17 @@ class Backbone(nn.Module):
 
     def forward(self, x, normalized=False):
         """x [B,3,H,W] in 0..255 (or already in [-1,1] with normalized=True: NMRF.forward stages pad + stack + normalise in
-        one HIP pass)."""
+        one HIP pass; normalized="s2d": that pass wrote the 2x2 space-to-depth image [B,16,H/2,W/2] the stem kernel consumes)."""
         if not normalized:
             x = 2 * (x / 255.0) - 1.0
         if self.fused and _hip_ok(self, x):
             from .. import kernels as K
-            x = K.instance_norm(self.conv1(x).contiguous(), relu=True)
+            if normalized == "s2d":
+                if not hasattr(self, "_stem"):
+                    self._stem = {}
+                x = K.instance_norm(K.stem_conv_s2d(x, self.conv1.weight, self._stem), relu=True)
+            else:
+                x = K.instance_norm(self.conv1(x).contiguous(), relu=True)
             x = self.layer3(self.layer2(self.layer1(x)))
             if x.shape[-1] % 2 == 0 and x.shape[-2] % 2 == 0:
                 y = F.conv2d(x, self.conv2.weight, None)

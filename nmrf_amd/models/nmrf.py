@@ -115,7 +115,14 @@ class NMRF(nn.Module):
             # pad (A1) + stack + normalise in one HIP pass, straight into the encoder
             b = image1.shape[0]
             hp, wp = h0 + (-h0) % self.divis_by, w0 + (-w0) % self.divis_by
-            feats = enc(K.prep_images(image1.contiguous(), image2.contiguous(), hp, wp), normalized=True)[::-1]
+            stem = enc.conv1
+            if (enc.fused and os.environ.get("NMRF_CONV3", "split") == "split" and os.environ.get("NMRF_WINO", "1") != "0"
+                    and image1.shape[1] == 3 and hp % 2 == 0 and wp % 2 == 0 and stem.weight.shape[0] % 64 == 0
+                    and tuple(stem.weight.shape[1:]) == (3, 7, 7) and stem.stride == (2, 2) and stem.padding == (3, 3)):
+                # the stem (7x7 / stride 2) runs as a 4x4 convolution over the 2x2 space-to-depth image: staged in that layout
+                feats = enc(K.prep_images_s2d(image1.contiguous(), image2.contiguous(), hp, wp), normalized="s2d")[::-1]
+            else:
+                feats = enc(K.prep_images(image1.contiguous(), image2.contiguous(), hp, wp), normalized=True)[::-1]
             self._joint_feats = feats
             fmap1_list, fmap2_list = [f[:b] for f in feats], [f[b:] for f in feats]
         else:

@@ -566,6 +566,40 @@ def test_conv3x3_split(b, ci, co, h, w, strips, norm):
     report("conv3x3_split", got, ref, 2e-5 * 3, 1e-5)
 
 
+@pytest.mark.parametrize("b,ci,co,h,w,norm", [(1, 16, 64, 8, 64, False), (2, 64, 96, 37, 70, True), (1, 32, 64, 9, 33, False),
+                                               (2, 64, 96, 188, 624, False), (1, 64, 96, 1, 2, False)])
+def test_conv3x3_stride2_split(b, ci, co, h, w, norm):
+    """csrc/conv3x3.hip, STRIDE = 2 (one output row per wave, de-interleaved halo columns) against torch fp64; the 188x624 case is
+    layer2.0.conv1 of the KITTI backbone."""
+    kk = K()
+    x = rnd(b, ci, h, w, seed=31, scale=2.0) + (0.4 if norm else 0.0)
+    wt = rnd(co, ci, 3, 3, seed=32, scale=0.2)
+    a = F.relu(F.instance_norm(x.double(), eps=1e-5)) if norm else x.double()
+    ref = F.conv2d(a, wt.double(), None, 2, 1)
+    xd = x.to(DEV)
+    strips = 3 if co % 96 == 0 else 2
+    stream, inv = kk.pack_conv3x3(wt.to(DEV), strips, co // (32 * strips))
+    got = kk.conv_split(xd, (stream, strips, co // (32 * strips), inv), co, 3, 2, 1, kk.instance_stats(xd) if norm else None).cpu()
+    report("conv3x3_s2", got, ref, 6e-5, 1e-5)
+    if not norm:
+        report("conv3x3_s2_auto", kk.conv3x3_s2_auto(xd, wt.to(DEV), {}).cpu(), ref, 6e-5, 1e-5)
+
+
+@pytest.mark.parametrize("b,h,w,hp,wp", [(1, 16, 64, 16, 64), (2, 37, 53, 40, 56), (1, 375, 1242, 376, 1248)])
+def test_stem_space_to_depth(b, h, w, hp, wp):
+    """The 7x7 / stride-2 / pad-3 stem as a 4x4 convolution over the space-to-depth image: staging kernel bit-exact against
+    prep_images + pixel_unshuffle, the convolution against torch fp64 on the padded, normalised images."""
+    kk = K()
+    img1, img2 = (rnd(b, 3, h, w, seed=41) + 1) * 127.5, (rnd(b, 3, h, w, seed=42) + 1) * 127.5
+    wt = rnd(64, 3, 7, 7, seed=43, scale=0.1)
+    flat = kk.prep_images(img1.to(DEV), img2.to(DEV), hp, wp)
+    s2d = kk.prep_images_s2d(img1.to(DEV), img2.to(DEV), hp, wp)
+    assert torch.equal(s2d[:, :12].cpu(), F.pixel_unshuffle(flat, 2).cpu()) and (s2d[:, 12:] == 0).all()
+    got = kk.stem_conv_s2d(s2d, wt.to(DEV), {}).cpu()
+    ref = F.conv2d(flat.cpu().double(), wt.double(), None, 2, 3)
+    report("stem", got, ref, 3e-5, 1e-5)
+
+
 def test_conv3x3_auto_paths_agree(monkeypatch):
     """The dispatcher: split kernel (default) vs the Winograd / MIOpen paths on the same input, with and without folded stats."""
     kk = K()
