@@ -111,15 +111,6 @@ __global__ __launch_bounds__(256, STRIDE == 2 ? 1 : (STRIPS == 2 ? 3 : 2)) void 
     };
     dma_w(0, 0);
 
-    // ---- per-channel affine of this image (InstanceNorm folded into the load) ----------------------------------------------
-    if (a.stats)
-        for (int c = tid; c < a.Ci; c += 256) {
-            float sc, sh;
-            in_affine_of(a.stats + ((size_t)b * a.Ci + c) * a.chunks * 2, a.chunks, HW, a.eps, sc, sh);
-            Aff[c] = sc;
-            Aff[C3_AFF + c] = sh;
-        }
-
     // ---- halo items of this thread: (pixel p of the 10 x 34 halo, channel half h) ------------------------------------------
     const float *xu = a.x + (size_t)b * a.Ci * HW;                             // uniform
     unsigned loff[C3_IPT];          // lane offset into a channel row (pixel + the half's 4 channels); C3_OUTSIDE when outside
@@ -186,6 +177,16 @@ __global__ __launch_bounds__(256, STRIDE == 2 ? 1 : (STRIPS == 2 ? 3 : 2)) void 
             for (int r = 0; r < 16; ++r) acc[s][g][r] = 0.f;
 
     prefetch_tile(0);
+
+    // ---- per-channel affine of this image (InstanceNorm folded into the load); after the first halo loads are in flight: one
+    // memory round trip for both ----------------------------------------------
+    if (a.stats)
+        for (int c = tid; c < a.Ci; c += 256) {
+            float sc, sh;
+            in_affine_of(a.stats + ((size_t)b * a.Ci + c) * a.chunks * 2, a.chunks, HW, a.eps, sc, sh);
+            Aff[c] = sc;
+            Aff[C3_AFF + c] = sh;
+        }
 
     const unsigned char *tb0 = tile + ((G * wv * STRIDE) * C3_HC + j) * C3_PSTRIDE + hi * 32;    // halo row of the wave's first output row, tap 0
     int dy = 0, slab = 0;

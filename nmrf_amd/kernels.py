@@ -475,11 +475,14 @@ def nmp_block(x, stream, stages, inv_scales, msg=None, bp=None, mlp=None, q=None
         nbytes = 4.0 * t * (128 * (1 + (msg is not None) + bool(want_x) + bool(want_ln)) + nq) + (4.0 * extra.numel() if extra is not None else 0)
         name = "nmp_block_p%d_m%d_q%dx%d" % (msg is not None, mlp is not None, kq, nq)
         _hb(name, row="A7/A10/A13 (N3)", bound="mfma", flops=flops, bytes=nbytes, split=True,
-            label="nmp_block_kernel<%s,%d> (%s%s%s fused, split-fp16 MFMA)" % (
-                "true" if mlp is not None else "false", kq // 16, "proj+residual " if msg is not None else "",
-                "LN+fc1+GELU+fc2 " if mlp is not None else "", ("LN+%d->%d" % (kq, nq)) if nq else ("final LN" if want_ln else "")),
-            pmc=["nmp_block%s_kernel<%s, %d>" % ("" if tokens_per_wave == 32 else "16", "true" if mlp is not None else "false",
-                                                  kq // tokens_per_wave if tokens_per_wave == 16 else kq // 16)])
+            label="%s<%s,%d> (%s%s%s fused, split-fp16 MFMA, %d tokens per wave)" % (
+                "nmp_block_kernel" if tokens_per_wave == 32 else "nmp_block16_kernel",
+                "true" if mlp is not None else "false", kq // 16 if tokens_per_wave == 32 else (kq + 31) // 32,
+                "proj+residual " if msg is not None else "",
+                "LN+fc1+GELU+fc2 " if mlp is not None else "", ("LN+%d->%d" % (kq, nq)) if nq else ("final LN" if want_ln else ""),
+                tokens_per_wave),
+            pmc=["nmp_block_kernel<%s, %d, 1, 4, false, 0>" % ("true" if mlp is not None else "false", kq // 16) if tokens_per_wave == 32
+                 else "nmp_block16_kernel<%s, %d, 0>" % ("true" if mlp is not None else "false", (kq + 31) // 32)])
     fn = _lib.load().nmrf_nmp_block_f32 if tokens_per_wave == 32 else _lib.load().nmrf_nmp_block16_f32
     _lib.check(fn(_p(x), _p(msg), _p(stream), stages, _p(bp), _p(ln2_g), _p(ln2_b), float(eps2), _p(b1),
                                               _p(b2), _p(lq_g), _p(lq_b), float(epsq), _p(extra), ld, div, _p(bq),

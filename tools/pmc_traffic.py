@@ -26,10 +26,10 @@ def main(src, dst_prefix):
         for k, cs in load(os.path.join(src, "pass%s_counter_collection.csv" % p)).items():
             if any(tag in k for tag in ("attn", "warp", "token_linear", "mlp", "nmp_block", "seed", "cost_volume", "nms", "msda")):
                 table.setdefault(k, {}).update({c: round(sum(v) / len(v)) for c, v in cs.items()})
-    # model-level passes (bench.py, eager): only the Winograd conv is taken from them (mean over the layers of a forward)
-    for pth in ("passM1", "passM2"):
+    # model-level passes (bench.py, eager): the conv kernels are taken from them (mean over the layers of a forward)
+    for pth in ("passM1", "passM2", "passM3"):
         for k, cs in load(os.path.join(src, pth + "_counter_collection.csv")).items():
-            if k.startswith("conv3x3_wino"):
+            if k.startswith(("conv3x3_wino", "conv3x3_split", "conv1x1")):
                 table.setdefault(k, {}).update({c: round(sum(v) / len(v)) for c, v in cs.items()})
     traffic = {"_source": os.path.basename(dst_prefix) + " (rocprofv3 --pmc passes of tools/gpu_pmc.sh, mean per dispatch)"}
     for k, c in table.items():
