@@ -222,9 +222,10 @@ int nmrf_nmp_block_f32(const float *x, const float *msg, const void *stream_w, i
 
 /* Same operator as nmrf_nmp_block_f32 with 16 tokens per wave on v_mfma_f32_16x16x32_f16 (two waves per SIMD: one wave's loads,
  * LayerNorm, GELU and stores run under the other's MFMAs; csrc/nmp_block16.hip).  Identical arguments; the weight stream is built
- * from nmrf_pack_split_weight16_f32 pairs (16-row strips x 32-deep chunks) in the same consumption order: proj pairs (strip 0..7,
- * chunk 0..3) | W1g[0] | W1g[1], W2g[0] | ... | W2g[15] with W1g[h] = pairs (strip 2h..2h+1, chunk 0..3), W2g[h] = pairs
- * (strip 0..7, chunk h) | q pairs (strip, chunk) strip-major.  KQ in {0, 128, 160, 192}. */
+ * from nmrf_pack_split_weight16_f32 pairs (16-row strips x 32-deep chunks) in the same consumption order: proj | W1g[0] | W1g[1],
+ * W2g[0] | ... | W2g[15] | q, where proj, every W1g[h] (strips 2h, 2h+1) and q list their strips two at a time, interleaved chunk
+ * by chunk -- (s, c0) (s+1, c0) (s, c1) (s+1, c1) ... -- and W2g[h] = pairs (strip 0..7, chunk h): the kernel feeds two adjacent
+ * pairs, which share their activation operand, to two accumulators with alternating MFMAs.  KQ in {0, 128, 160, 192}. */
 int nmrf_nmp_block16_f32(const float *x, const float *msg, const void *stream_w, int total_stages, const float *bp,
                          const float *ln2_g, const float *ln2_b, float eps2, const float *b1, const float *b2,
                          const float *lnq_g, const float *lnq_b, float epsq, const float *extra, int extra_ld,

@@ -11,7 +11,9 @@
 // and two consecutive strips ARE one 32-deep k chunk of the next layer with the slot order
 //   slot jj of k-group g  <->  k = 32c + (jj & 3) + 16 (jj >> 2) + 4g           (split_kslot16)
 // which the weight packing (nmrf_pack_split_weight16_f32) uses for every A operand.  A "pair" is still 2 KB (hi + lo fragment,
-// 64 lanes x 16 B) = one (16-row strip, 32-deep chunk); 8 pairs per 16 KB stage; same ring protocol as nmp_block.hip.
+// 64 lanes x 16 B) = one (16-row strip, 32-deep chunk); 8 pairs per 16 KB stage; same ring protocol as nmp_block.hip.  Stream
+// order: within proj / fc1 / q two adjacent strips are interleaved chunk by chunk (s0c0 s1c0 s0c1 s1c1 ...), so that the two
+// pairs of a `consume2` share their B operand and alternate between two accumulators.
 #include "common.h"
 #include "split_mfma.h"
 #include <type_traits>
@@ -136,6 +138,35 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
         if constexpr (!(DBG & 8)) split_mma16(ah, al, bh, bl, acc);
         else acc[P & 3] += (float)ah[0] + (float)bl[1];
     };
+    // Two consecutive pairs (P0 even, P0 + 1) against ONE B operand into two accumulators, the six MFMAs alternating between
+    // them: a dependent MFMA then issues 2 slots after its predecessor instead of back to back (three MFMAs chained on one
+    // accumulator stall on each other).  The stream interleaves the two strips that share a chunk for this (block_stream16).
+    auto consume2 = [&](auto pc, const h16x8 &bh, const h16x8 &bl, f32x4 &acc0, f32x4 &acc1) {
+        constexpr int P0 = decltype(pc)::value, P1 = P0 + 1;
+        static_assert(P0 % 2 == 0 && B16_PF % 2 == 0, "pairs of one consume2 share a stage and use different read-ahead slots");
+        const h16x8 ah0 = fqh[P0 % B16_PF], al0 = fql[P0 % B16_PF], ah1 = fqh[P1 % B16_PF], al1 = fql[P1 % B16_PF];
+        if constexpr (!(DBG & 4)) {
+            if constexpr (P0 + B16_PF < 8) {
+                read_pair(cur, P0 + B16_PF, fqh[P0 % B16_PF], fql[P0 % B16_PF]);
+                read_pair(cur, P1 + B16_PF, fqh[P1 % B16_PF], fql[P1 % B16_PF]);
+            } else {
+                read_pair(nxt, P0 + B16_PF - 8, fqh[P0 % B16_PF], fql[P0 % B16_PF]);
+                read_pair(nxt, P1 + B16_PF - 8, fqh[P1 % B16_PF], fql[P1 % B16_PF]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x10 | 0x400);       // pin the read-ahead (see nmp_block.hip)
+        if constexpr (!(DBG & 8)) {
+            acc0 = mfma16x16h(al0, bh, acc0);
+            acc1 = mfma16x16h(al1, bh, acc1);
+            acc0 = mfma16x16h(ah0, bl, acc0);
+            acc1 = mfma16x16h(ah1, bl, acc1);
+            acc0 = mfma16x16h(ah0, bh, acc0);
+            acc1 = mfma16x16h(ah1, bh, acc1);
+        } else {
+            acc0[P0 & 3] += (float)ah0[0] + (float)bl[1];
+            acc1[P0 & 3] += (float)ah1[0] + (float)bl[1];
+        }
+    };
     fetch(); commit();
     fetch(); commit();
     fetch();
@@ -211,16 +242,16 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
                 const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
                 split8u(v, bmh[c], bml[c]);
             }
-            b16_static_for<8>([&](auto ss) {
-                constexpr int st = decltype(ss)::value;
+            b16_static_for<4>([&](auto kk) {                                  // strips 2k, 2k+1 = one stage
+                constexpr int k = decltype(kk)::value;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[st][r] = 0.f;
-                if constexpr (st % 2 == 0) stage_top();
+                for (int r = 0; r < 4; ++r) acc[2 * k][r] = acc[2 * k + 1][r] = 0.f;
+                stage_top();
                 b16_static_for<4>([&](auto cc) {
                     constexpr int c = decltype(cc)::value;
-                    consume(std::integral_constant<int, (st % 2) * 4 + c>{}, bmh[c], bml[c], acc[st]);
+                    consume2(std::integral_constant<int, 2 * c>{}, bmh[c], bml[c], acc[2 * k], acc[2 * k + 1]);
                 });
-                if constexpr (st % 2 == 1) stage_end();
+                stage_end();
             });
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
@@ -249,9 +280,9 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) f0[r] = f1[r] = 0.f;
                 stage_top();
-                b16_static_for<4>([&](auto cc) { consume(cc, bnh[decltype(cc)::value], bnl[decltype(cc)::value], f0); });
                 b16_static_for<4>([&](auto cc) {
-                    consume(std::integral_constant<int, 4 + decltype(cc)::value>{}, bnh[decltype(cc)::value], bnl[decltype(cc)::value], f1);
+                    constexpr int c = decltype(cc)::value;
+                    consume2(std::integral_constant<int, 2 * c>{}, bnh[c], bnl[c], f0, f1);
                 });
                 stage_end();
             };
@@ -266,7 +297,10 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
                 h16x8 hh, hl;
                 split8u(hv, hh, hl);
                 stage_top();
-                b16_static_for<8>([&](auto cc) { consume(cc, hh, hl, acc[decltype(cc)::value]); });
+                b16_static_for<4>([&](auto cc) {
+                    constexpr int p = 2 * decltype(cc)::value;
+                    consume2(std::integral_constant<int, p>{}, hh, hl, acc[p], acc[p + 1]);
+                });
                 stage_end();
             };
             f32x4 fa0, fa1, fb0, fb1;
@@ -318,23 +352,26 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
                 const int n_groups = a.NQ >> 7;
 #pragma unroll 1
                 for (int gq = 0; gq < n_groups; ++gq) {
-                    b16_static_for<8>([&](auto ss) {
-                        constexpr int sl = decltype(ss)::value;
-                        f32x4 qh;
+                    b16_static_for<4>([&](auto ss) {                          // strips 2sp, 2sp+1 of the group, chunk-interleaved
+                        constexpr int sp = decltype(ss)::value;
+                        f32x4 qh0, qh1;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) qh[r] = 0.f;
+                        for (int r = 0; r < 4; ++r) qh0[r] = qh1[r] = 0.f;
                         b16_static_for<KQC>([&](auto cc) {
                             constexpr int c = decltype(cc)::value;
-                            constexpr int pg = sl * KQC + c;
+                            constexpr int pg = sp * 2 * KQC + 2 * c;
                             if constexpr (pg % 8 == 0) stage_top();
-                            consume(std::integral_constant<int, pg % 8>{}, bqh[c], bql[c], qh);
-                            if constexpr (pg % 8 == 7) stage_end();
+                            consume2(std::integral_constant<int, pg % 8>{}, bqh[c], bql[c], qh0, qh1);
+                            if constexpr (pg % 8 == 6) stage_end();
                         });
-                        const f32x4 b4 = par4(B16P_BQ + gq * 128 + 16 * sl + 4 * g);
+                        const f32x4 ba = par4(B16P_BQ + gq * 128 + 32 * sp + 4 * g), bb = par4(B16P_BQ + gq * 128 + 32 * sp + 16 + 4 * g);
                         float ov[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) ov[e] = fmaf(qh[e], a.inv_q, b4[e]);
-                        stage_strip(ov, 16 * sl);
+                        for (int e = 0; e < 4; ++e) ov[e] = fmaf(qh0[e], a.inv_q, ba[e]);
+                        stage_strip(ov, 32 * sp);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ov[e] = fmaf(qh1[e], a.inv_q, bb[e]);
+                        stage_strip(ov, 32 * sp + 16);
                     });
                     flush_rows(a.q_out, a.NQ, gq * 128, t0);
                 }

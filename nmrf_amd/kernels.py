@@ -349,16 +349,20 @@ def pack_split_weight16(weight, kp):
 
 
 def block_stream16(wp=None, w1=None, w2=None, wq=None, kq=0):
-    """Weight stream of one nmp_block16 launch (include/nmrf_hip.h): proj | W1 strip pairs interleaved with W2 k chunks | q."""
+    """Weight stream of one nmp_block16 launch (include/nmrf_hip.h): proj | W1 strip pairs interleaved with W2 k chunks | q;
+    within proj / W1 / q two adjacent 16-row strips are interleaved chunk by chunk (the kernel feeds them to two accumulators)."""
     import ctypes
     parts, inv = [], [1.0, 1.0, 1.0, 1.0]
+    def ilv(pk):                                                          # [strips][chunks] -> strip pairs interleaved chunk by chunk
+        n, c = pk.shape[0], pk.shape[1]
+        return pk.view(n // 2, 2, c, 512).permute(0, 2, 1, 3).contiguous()
     if wp is not None:
         pk, inv[0] = pack_split_weight16(wp, 128)
-        parts.append(pk.view(-1, 512))
+        parts.append(ilv(pk).view(-1, 512))
     if w1 is not None:
         p1, inv[1] = pack_split_weight16(w1, 128)                          # [32 strips][4 chunks] = [16 groups][8 pairs]
         p2, inv[2] = pack_split_weight16(w2, 512)                          # [8 strips][16 chunks]
-        p1 = p1.view(16, 8, 512)
+        p1 = ilv(p1).view(16, 8, 512)
         p2 = p2.permute(1, 0, 2).contiguous()                             # [16 groups][8 strips]
         seq = [p1[0]]
         for h in range(15):
@@ -367,7 +371,7 @@ def block_stream16(wp=None, w1=None, w2=None, wq=None, kq=0):
         parts.append(torch.stack(seq).view(-1, 512))
     if wq is not None:
         pk, inv[3] = pack_split_weight16(wq, kq)
-        parts.append(pk.view(-1, 512))
+        parts.append(ilv(pk).view(-1, 512))
     stream = torch.cat(parts).contiguous()
     assert stream.shape[0] % 8 == 0
     return stream, stream.shape[0] // 8, (ctypes.c_float * 4)(*inv)
