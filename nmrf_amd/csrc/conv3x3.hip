@@ -63,15 +63,23 @@ struct Conv3Args {
     int Co;
     float inv;
     int tiles_x, tiles_per_image, n_tiles, per_xcd;
+    unsigned long long *stamps;  // debug build: s_memtime stamps of the first 128 tiles (DBG & 64)
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads (and a workgroup fence, once LDS-DMA is outstanding) also drains
 // the vector-memory counter: every barrier would wait for the halo prefetch that is meant to stay in flight across a slab.  The
 // vmcnt waits that the LDS-DMA needs are written out by hand at the call sites.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <bool SKIP = false>
+__device__ __forceinline__ void lds_barrier() {
+    if constexpr (SKIP) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
-template <int STRIPS, int KT, int STRIDE>
-__global__ __launch_bounds__(256, STRIDE == 2 ? 1 : (STRIPS == 2 ? 3 : 2)) void conv3x3_split_kernel(Conv3Args a) {
+// DBG: timing experiments of the tools-only debug build (wrong results): 1 no weight DMA after the first stage, 2 no halo
+// restaging after the first slab, 4 no barriers, 8 no MFMAs, 16 no output stores, 32 no LDS fragment reads after a stage's first,
+// 64 s_memtime stamps per wave of the first 128 tiles
+template <int STRIPS, int KT, int STRIDE, int DBG = 0>
+__global__ __launch_bounds__(256, STRIDE == 2 ? 1 : (STRIPS == 2 && KT == 3 ? 3 : 2)) void conv3x3_split_kernel(Conv3Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using GM = C3Geom<KT, STRIDE>;
     constexpr int G = GM::G, C3_TR = GM::TR, C3_HC = GM::HC, C3_NPIX = GM::NPIX, C3_IPT = GM::IPT, C3_NITEM = 2 * GM::NPIX;
@@ -86,6 +94,10 @@ __global__ __launch_bounds__(256, STRIDE == 2 ? 1 : (STRIPS == 2 ? 3 : 2)) void 
     // consecutive block ids are dealt round-robin to the 8 XCDs: give each XCD a contiguous run of tiles (shared halos in its L2)
     const int t = (blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);
     if (t >= a.n_tiles) return;
+    unsigned long long acc_wait = 0, acc_comp = 0, t_prev = 0;
+#define C3_STAMP(k) do { if constexpr ((DBG & 64) != 0) { if (lane == 0 && t < 128 && blockIdx.y == 0) a.stamps[(t * 4 + wv) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#define C3_NOW() (((DBG & 64) != 0) ? __builtin_amdgcn_s_memtime() : 0ull)
+    C3_STAMP(0);
     const int b = t / a.tiles_per_image;
     const int rem = t - b * a.tiles_per_image;
     const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
@@ -99,6 +111,7 @@ __global__ __launch_bounds__(256, STRIDE == 2 ? 1 : (STRIPS == 2 ? 3 : 2)) void 
     // 16 l; pinned by nmrf_selftest_lds_dma), no staging registers.  A stage is 2 * KT * STRIPS one-KB wave-instructions, dealt to
     // the 4 waves; issued at the top of stage g-1 into the slot stage g-2 vacated, waited for (vmcnt) before barrier g.
     auto dma_w = [&](int g, int slot) {
+        if ((DBG & 1) && g > 1) return;
         const ss_u32x4 *src = wst + (size_t)g * STAGE_U4 + lane;
         ss_u32x4 *dst = ring + slot * STAGE_U4;
 #pragma unroll
@@ -128,46 +141,52 @@ __global__ __launch_bounds__(256, STRIDE == 2 ? 1 : (STRIPS == 2 ? 3 : 2)) void 
         loff[k] = inside ? (unsigned)((int64_t)(4 * h) * HW + (int64_t)gy * a.W + gx) : C3_OUTSIDE;
         ldo[k] = item ? p * C3_PSTRIDE + h * 32 : -1;
     }
-    float Rt[C3_IPT][8];
-    auto prefetch_tile = [&](int slab) {
+    // One item = the 8 channels of (halo pixel, channel half): 8 scalar loads (a channel row is HW floats away from the next), then
+    // normalise / zero the padding / split, then two 16-byte LDS stores.  The three steps are spread over a slab's stages: the
+    // loads of slab s+1 are issued BETWEEN the MFMAs of slab s's first stage, converted between the MFMAs of its last stage, and
+    // stored at the slab change -- only the stores and two barriers are left outside the matrix stream (census of the first
+    // version, which did all of it at the slab change: halo restaging 25 % of a wave's time, 1.9k cycles per slab for the load
+    // issue alone, 1.3k for the conversion; profiles/r02o_conv_census.txt).  The compiler's scheduler sinks such side work below
+    // the MFMAs of its block, so the order is written out and fenced (sched_barrier(0)) MFMA by MFMA.
+    float Rt[C3_IPT][8];               // raw fp32 channels of an item (slot jj <-> channel (jj & 3) + 8 (jj >> 2) + 4 h)
+    unsigned Pk[C3_IPT][8];            // the same item converted: packed fp16 pairs, words 0..3 = hi, 4..7 = lo
+    // part i (0..3) of an item = its slots 2i, 2i+1 = one packed word of hi and one of lo
+    auto load_part = [&](int k, int i, int slab) {
         const float *xs = xu + (size_t)(16 * slab) * HW;                        // uniform
+        const unsigned o = loff[k] == C3_OUTSIDE ? 0u : loff[k];                // (any valid address; the value is discarded)
 #pragma unroll
-        for (int k = 0; k < C3_IPT; ++k) {
-            const unsigned o = loff[k] == C3_OUTSIDE ? 0u : loff[k];            // (any valid address; the value is discarded)
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) Rt[k][jj] = (xs + (size_t)((jj & 3) + 8 * (jj >> 2)) * HW)[o];
-        }
+        for (int jj = 2 * i; jj < 2 * i + 2; ++jj) Rt[k][jj] = (xs + (size_t)((jj & 3) + 8 * (jj >> 2)) * HW)[o];
     };
-    auto write_tile = [&](int slab) {
-#pragma unroll
-        for (int k = 0; k < C3_IPT; ++k) {
-            if (ldo[k] < 0) continue;
-            float v[8];
+    auto convert_part = [&](int k, int i, int slab) {
+        f32x2 v = {Rt[k][2 * i], Rt[k][2 * i + 1]};
+        if (a.stats) {
             const int hh = (tid + 256 * k) >= C3_NPIX ? 1 : 0;
-            if (a.stats) {
-                const float *af = Aff + 16 * slab + 4 * hh;
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(af + 8 * g);
-                    const f32x4 sh = *reinterpret_cast<const f32x4 *>(af + C3_AFF + 8 * g);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[4 * g + e] = fmaxf(fmaf(Rt[k][4 * g + e], sc[e], sh[e]), 0.f);
-                }
-            } else {
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) v[jj] = Rt[k][jj];
-            }
-            if (loff[k] == C3_OUTSIDE) {                                                    // zero padding applies AFTER the normalisation
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) v[jj] = 0.f;
-            }
-            h16x8 vh, vl;
-            split8u(v, vh, vl);
-            *reinterpret_cast<h16x8 *>(tile + ldo[k]) = vh;
-            *reinterpret_cast<h16x8 *>(tile + ldo[k] + 16) = vl;
+            const float *af = Aff + 16 * slab + 4 * hh + ((2 * i) & 3) + 8 * ((2 * i) >> 2);
+            const f32x2 sc = *reinterpret_cast<const f32x2 *>(af), sh = *reinterpret_cast<const f32x2 *>(af + C3_AFF);
+            v[0] = fmaxf(fmaf(v[0], sc[0], sh[0]), 0.f);
+            v[1] = fmaxf(fmaf(v[1], sc[1], sh[1]), 0.f);
         }
+        if (loff[k] == C3_OUTSIDE) v = f32x2{0.f, 0.f};                          // zero padding applies AFTER the normalisation
+        h16x2 h2, l2;
+        split2u(v, h2, l2);
+        Pk[k][i] = *reinterpret_cast<const unsigned *>(&h2);
+        Pk[k][4 + i] = *reinterpret_cast<const unsigned *>(&l2);
+    };
+    auto store_item = [&](int k) {
+        if (ldo[k] < 0) return;
+        *reinterpret_cast<ss_u32x4 *>(tile + ldo[k]) = ss_u32x4{Pk[k][0], Pk[k][1], Pk[k][2], Pk[k][3]};
+        *reinterpret_cast<ss_u32x4 *>(tile + ldo[k] + 16) = ss_u32x4{Pk[k][4], Pk[k][5], Pk[k][6], Pk[k][7]};
     };
 
+    auto mma = [](const h16x8 &x, const h16x8 &y, const f32x16 &c) -> f32x16 {
+        if constexpr (DBG & 8) {                 // keep the operands alive, no matrix work
+            f32x16 r = c;
+            r[0] += (float)x[0] + (float)y[1];
+            return r;
+        } else {
+            return mfma16h(x, y, c);
+        }
+    };
     f32x16 acc[STRIPS][G];
 #pragma unroll
     for (int s = 0; s < STRIPS; ++s)
@@ -176,10 +195,13 @@ __global__ __launch_bounds__(256, STRIDE == 2 ? 1 : (STRIPS == 2 ? 3 : 2)) void 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[s][g][r] = 0.f;
 
-    prefetch_tile(0);
+#pragma unroll
+    for (int k = 0; k < C3_IPT; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_part(k, i, 0);
 
     // ---- per-channel affine of this image (InstanceNorm folded into the load); after the first halo loads are in flight: one
-    // memory round trip for both ----------------------------------------------
+    // memory round trip for both
     if (a.stats)
         for (int c = tid; c < a.Ci; c += 256) {
             float sc, sh;
@@ -187,32 +209,61 @@ __global__ __launch_bounds__(256, STRIDE == 2 ? 1 : (STRIPS == 2 ? 3 : 2)) void 
             Aff[c] = sc;
             Aff[C3_AFF + c] = sh;
         }
+    __builtin_amdgcn_s_waitcnt(C3_VMCNT(0));
+    C3_STAMP(1);
+    lds_barrier<(DBG & 4) != 0>();               // stage 0 of the weights and the affine table are visible
+    C3_STAMP(2);
+#pragma unroll
+    for (int k = 0; k < C3_IPT; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) convert_part(k, i, 0);
 
     const unsigned char *tb0 = tile + ((G * wv * STRIDE) * C3_HC + j) * C3_PSTRIDE + hi * 32;    // halo row of the wave's first output row, tap 0
-    int dy = 0, slab = 0;
-#pragma unroll 1
-    for (int g = 0; g < total; ++g) {
+    constexpr int NSTEP = G == 2 ? KT * STRIPS : KT;                            // MFMA groups of a stage
+    // the side work of MFMA group q of stage dy: item k rides with group k * NSTEP / IPT, its part i behind the group's MFMA i
+    auto side = [&](auto dd, auto qq, auto ii, int nslab) {
+        constexpr int dy = decltype(dd)::value, q = decltype(qq)::value, i = decltype(ii)::value;
+        if constexpr ((DBG & 2) == 0 && i < 4) {
+            ss_static_for<C3_IPT>([&](auto kk) {
+                constexpr int k = decltype(kk)::value;
+                if constexpr (k * NSTEP / C3_IPT == q) {
+                    if constexpr (dy == 0) load_part(k, i, nslab);
+                    if constexpr (dy == KT - 1) convert_part(k, i, nslab);
+                }
+            });
+        }
+        if constexpr (dy == 0 || dy == KT - 1) __builtin_amdgcn_sched_barrier(0);     // keep it here: between MFMA i and MFMA i+1
+    };
+    auto stage = [&](auto dd, int slab) {
+        constexpr int dy = decltype(dd)::value;
+        const int g = slab * KT + dy;
+        const int nslab = slab + 1 < n_slabs ? slab + 1 : slab;                 // (the last slab reloads itself: same vmcnt bookkeeping)
         // Top of stage g: this wave's share of stage g has landed (vmcnt), then the barrier: every wave is done with stage g-1 and
         // stage g is visible; then the DMA of stage g+1 into the slot stage g-1 vacated.  vmcnt is in order: the DMA that the
-        // dy == 1 stage waits for was issued BEFORE the 24 halo loads of the next slab, which stay in flight; the others after.
-        // (s_waitcnt as the builtin and inside each branch: the compiler's own wait-count bookkeeping then knows that nothing is
-        //  pending where the halo registers are reused, and adds no vmcnt(0) of its own behind the fresh DMA issue)
-        if (dy == 0) {
+        // dy == 1 stage waits for was issued BEFORE the 8 * IPT halo loads riding with stage dy == 0, which stay in flight until the
+        // slab's last stage converts them; the others after.  (s_waitcnt as the builtin: the compiler's own wait-count bookkeeping
+        // then knows what is pending and adds no vmcnt(0) of its own behind the fresh DMA issue.)
+        t_prev = C3_NOW();
+        if constexpr (dy == 0) {
             __builtin_amdgcn_s_waitcnt(C3_VMCNT(0));
-            lds_barrier();
-            write_tile(slab);
-            lds_barrier();
+            lds_barrier<(DBG & 4) != 0>();
+            if (!(DBG & 2) || slab == 0) {
+#pragma unroll
+                for (int k = 0; k < C3_IPT; ++k) store_item(k);
+            }
+            lds_barrier<(DBG & 4) != 0>();
             dma_w(g + 1, (g + 1) & 1);           // (total = KT * slabs: a dy == 0 stage is never the last one)
-            prefetch_tile(slab + 1 < n_slabs ? slab + 1 : slab);            // (always 24 loads: the vmcnt bookkeeping counts them)
-        } else if (dy == 1) {
-            __builtin_amdgcn_s_waitcnt(C3_VMCNT(C3_IPT * 8));
-            lds_barrier();
-            dma_w(g + 1, (g + 1) & 1);
+        } else if constexpr (dy == 1) {
+            __builtin_amdgcn_s_waitcnt(C3_VMCNT((DBG & 2) ? 0 : C3_IPT * 8));
+            lds_barrier<(DBG & 4) != 0>();
+            if (g + 1 < total) dma_w(g + 1, (g + 1) & 1);
         } else {
             __builtin_amdgcn_s_waitcnt(C3_VMCNT(0));
-            lds_barrier();
+            lds_barrier<(DBG & 4) != 0>();
             if (g + 1 < total) dma_w(g + 1, (g + 1) & 1);
         }
+        { const unsigned long long n = C3_NOW(); acc_wait += n - t_prev; t_prev = n; }
+        if (g == 0) C3_STAMP(3);
         // ---- stage g: taps (dy, 0..KT-1) of this slab against STRIPS strips ---------------------------------------------------------
         const ss_u32x4 *wb = ring + (g & 1) * STAGE_U4 + lane;
         const unsigned char *tb = tb0 + dy * (C3_HC * C3_PSTRIDE);
@@ -234,21 +285,28 @@ __global__ __launch_bounds__(256, STRIDE == 2 ? 1 : (STRIPS == 2 ? 3 : 2)) void 
             };
             read_b(0, 0);
             read_a(0, 0);
+            if constexpr (DBG & 32) { read_b(1, 1); read_a(1, 1); }
             ss_static_for<KT * STRIPS>([&](auto qq) {
                 constexpr int q = decltype(qq)::value;
                 constexpr int dx = q / STRIPS, s = q % STRIPS;
-                if constexpr (q + 1 < KT * STRIPS) read_a(q + 1, (q + 1) & 1);
-                if constexpr (s == STRIPS - 1 && dx < KT - 1) read_b(dx + 1, (dx + 1) & 1);
-                // LDS reads may not sink below this point, MFMAs may not rise above it (see nmp_block.hip)
+                if constexpr (!(DBG & 32)) {
+                    if constexpr (q + 1 < KT * STRIPS) read_a(q + 1, (q + 1) & 1);
+                    if constexpr (s == STRIPS - 1 && dx < KT - 1) read_b(dx + 1, (dx + 1) & 1);
+                }
+                // LDS reads may not sink below this point, MFMAs may not rise above it (ALU / vector memory may cross)
                 __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x10 | 0x400);
                 const h16x8 fh = ah[q & 1], fl = al[q & 1];
                 // small terms first; the two pixel groups alternate so that consecutive MFMAs never share an accumulator
-                acc[s][0] = mfma16h(fl, bh[dx & 1][0], acc[s][0]);
-                acc[s][1] = mfma16h(fl, bh[dx & 1][1], acc[s][1]);
-                acc[s][0] = mfma16h(fh, bl[dx & 1][0], acc[s][0]);
-                acc[s][1] = mfma16h(fh, bl[dx & 1][1], acc[s][1]);
-                acc[s][0] = mfma16h(fh, bh[dx & 1][0], acc[s][0]);
-                acc[s][1] = mfma16h(fh, bh[dx & 1][1], acc[s][1]);
+                acc[s][0] = mma(fl, bh[dx & 1][0], acc[s][0]);
+                side(dd, qq, std::integral_constant<int, 0>{}, nslab);
+                acc[s][1] = mma(fl, bh[dx & 1][1], acc[s][1]);
+                side(dd, qq, std::integral_constant<int, 1>{}, nslab);
+                acc[s][0] = mma(fh, bl[dx & 1][0], acc[s][0]);
+                side(dd, qq, std::integral_constant<int, 2>{}, nslab);
+                acc[s][1] = mma(fh, bl[dx & 1][1], acc[s][1]);
+                side(dd, qq, std::integral_constant<int, 3>{}, nslab);
+                acc[s][0] = mma(fh, bh[dx & 1][0], acc[s][0]);
+                acc[s][1] = mma(fh, bh[dx & 1][1], acc[s][1]);
             });
         } else {
             // one pixel group per wave: a tap's fragments of ALL strips are read together and the MFMAs go term-major over the
@@ -265,20 +323,29 @@ __global__ __launch_bounds__(256, STRIDE == 2 ? 1 : (STRIPS == 2 ? 3 : 2)) void 
                 }
             };
             read_tap(0, 0);
-            ss_static_for<KT>([&](auto dd) {
-                constexpr int dx = decltype(dd)::value;
+            ss_static_for<KT>([&](auto qq) {
+                constexpr int dx = decltype(qq)::value;
                 if constexpr (dx + 1 < KT) read_tap(dx + 1, (dx + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x10 | 0x400);
-#pragma unroll
-                for (int s = 0; s < STRIPS; ++s) acc[s][0] = mfma16h(al[dx & 1][s], bh[dx & 1], acc[s][0]);
-#pragma unroll
-                for (int s = 0; s < STRIPS; ++s) acc[s][0] = mfma16h(ah[dx & 1][s], bl[dx & 1], acc[s][0]);
-#pragma unroll
-                for (int s = 0; s < STRIPS; ++s) acc[s][0] = mfma16h(ah[dx & 1][s], bh[dx & 1], acc[s][0]);
+                ss_static_for<3 * STRIPS>([&](auto mm) {                        // term-major over the strips
+                    constexpr int m = decltype(mm)::value, term = m / STRIPS, s = m % STRIPS;
+                    if constexpr (term == 0) acc[s][0] = mma(al[dx & 1][s], bh[dx & 1], acc[s][0]);
+                    if constexpr (term == 1) acc[s][0] = mma(ah[dx & 1][s], bl[dx & 1], acc[s][0]);
+                    if constexpr (term == 2) acc[s][0] = mma(ah[dx & 1][s], bh[dx & 1], acc[s][0]);
+                    if constexpr (m < 4) side(dd, qq, mm, nslab);
+                });
             });
         }
-        if (++dy == KT) { dy = 0; ++slab; }
-    }
+        if constexpr ((DBG & 64) != 0) {
+            asm volatile("s_nop 0" :: "v"(acc[0][0][0]));     // (the stamp waits for the stage's last MFMA)
+            acc_comp += C3_NOW() - t_prev;
+            if (g == 0) C3_STAMP(4);
+            if (g == KT - 1) C3_STAMP(5);
+        }
+    };
+#pragma unroll 1
+    for (int slab = 0; slab < n_slabs; ++slab) ss_static_for<KT>([&](auto dd) { stage(dd, slab); });
+    C3_STAMP(6);
 
     // ---- epilogue: a C/D register is 32 consecutive pixels of one output channel ---------------------------------------------------
     const int co_base = grp * STRIPS * 32;
@@ -293,23 +360,64 @@ __global__ __launch_bounds__(256, STRIDE == 2 ? 1 : (STRIPS == 2 ? 3 : 2)) void 
         for (int s = 0; s < STRIPS; ++s)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                (ou + (size_t)(32 * s + (r & 3) + 8 * (r >> 2)) * HWo)[oo] = acc[s][gg][r] * a.inv;
+                if (!(DBG & 16) || acc[s][gg][r] == 123.456f)
+                    (ou + (size_t)(32 * s + (r & 3) + 8 * (r >> 2)) * HWo)[oo] = acc[s][gg][r] * a.inv;
+    }
+    C3_STAMP(7);
+    if constexpr ((DBG & 64) != 0) {
+        if (lane == 0 && t < 128 && blockIdx.y == 0) {
+            a.stamps[(t * 4 + wv) * 16 + 8] = acc_wait;
+            a.stamps[(t * 4 + wv) * 16 + 9] = acc_comp;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            a.stamps[(t * 4 + wv) * 16 + 11] = __builtin_amdgcn_s_memtime();
+        }
     }
 }
 
-template <int STRIPS, int KT, int STRIDE>
+#ifdef NMRF_DEBUG_PROBES
+static int g_conv3_variant = 0;
+static unsigned long long *g_conv3_stamps = nullptr;
+extern "C" int nmrf_debug_conv3_variant(int v) { g_conv3_variant = v; return NMRF_OK; }
+// stamps: device buffer of 128 tiles x 4 waves x 16 words, or NULL to switch the timing build off
+extern "C" int nmrf_debug_conv3_timing(void *stamps) { g_conv3_stamps = (unsigned long long *)stamps; return NMRF_OK; }
+#endif
+
+template <int STRIPS, int KT, int STRIDE, int DBG = 0>
 static int launch_conv3(const Conv3Args &a, int groups, hipStream_t st) {
+#ifdef NMRF_DEBUG_PROBES
+    if constexpr (DBG == 0 && KT == 3 && STRIDE == 1 && STRIPS != 3) {
+        if (g_conv3_stamps) {
+            Conv3Args b = a;
+            b.stamps = g_conv3_stamps;
+            return launch_conv3<STRIPS, KT, STRIDE, 64>(b, groups, st);
+        }
+        switch (g_conv3_variant) {
+            case 1: return launch_conv3<STRIPS, KT, STRIDE, 1>(a, groups, st);
+            case 2: return launch_conv3<STRIPS, KT, STRIDE, 2>(a, groups, st);
+            case 3: return launch_conv3<STRIPS, KT, STRIDE, 3>(a, groups, st);
+            case 4: return launch_conv3<STRIPS, KT, STRIDE, 4>(a, groups, st);
+            case 7: return launch_conv3<STRIPS, KT, STRIDE, 7>(a, groups, st);
+            case 8: return launch_conv3<STRIPS, KT, STRIDE, 8>(a, groups, st);
+            case 16: return launch_conv3<STRIPS, KT, STRIDE, 16>(a, groups, st);
+            case 23: return launch_conv3<STRIPS, KT, STRIDE, 23>(a, groups, st);
+            case 32: return launch_conv3<STRIPS, KT, STRIDE, 32>(a, groups, st);
+            case 55: return launch_conv3<STRIPS, KT, STRIDE, 55>(a, groups, st);
+            case 63: return launch_conv3<STRIPS, KT, STRIDE, 63>(a, groups, st);
+            default: break;
+        }
+    }
+#endif
     static bool attr_set_dev[NMRF_MAX_DEV] = {};
     const int dev = nmrf_cur_device();
     if (dev < 0) return NMRF_ELAUNCH;
     const size_t lds = (size_t)2 * STRIPS * KT * 2048 + C3Geom<KT, STRIDE>::NPIX * C3_PSTRIDE + 2 * C3_AFF * sizeof(float);
     if (!attr_set_dev[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_split_kernel<STRIPS, KT, STRIDE>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_split_kernel<STRIPS, KT, STRIDE, DBG>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return NMRF_ELAUNCH;
         attr_set_dev[dev] = true;
     }
-    hipLaunchKernelGGL((conv3x3_split_kernel<STRIPS, KT, STRIDE>), dim3(8 * a.per_xcd, groups), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv3x3_split_kernel<STRIPS, KT, STRIDE, DBG>), dim3(8 * a.per_xcd, groups), dim3(256), lds, st, a);
     return nmrf_launch_status();
 }
 
@@ -328,7 +436,7 @@ extern "C" int nmrf_conv_split_f32(const float *x, int B, int Ci, int H, int W, 
     const int64_t n = (int64_t)tx * ty * B;
     if (n > 0x7ffffff) return NMRF_EINVAL;
     Conv3Args a{x, Ci, H, W, Ho, Wo, pad, stats, chunks, eps, reinterpret_cast<const ss_u32x4 *>(stream_w),
-                (int64_t)(Ci / 16) * kt * strips * kt * 128, out, Co, inv_scale, tx, tx * ty, (int)n, (int)((n + 7) / 8)};
+                (int64_t)(Ci / 16) * kt * strips * kt * 128, out, Co, inv_scale, tx, tx * ty, (int)n, (int)((n + 7) / 8), nullptr};
     hipStream_t st = (hipStream_t)stream;
     const int key = kt * 100 + stride * 10 + strips;
     switch (key) {
@@ -347,3 +455,17 @@ extern "C" int nmrf_conv3x3_split_f32(const float *x, int B, int Ci, int H, int 
                                       void *stream) {
     return nmrf_conv_split_f32(x, B, Ci, H, W, stats, chunks, eps, stream_w, 3, 1, 1, strips, groups, inv_scale, Co, out, stream);
 }
+
+#ifdef NMRF_DEBUG_PROBES
+// resident blocks per CU of the three stride-1 3x3 variants, as the runtime sees them
+extern "C" int nmrf_debug_conv3_occupancy(int *out3) {
+    const size_t tile = C3Geom<3, 1>::NPIX * C3_PSTRIDE + 2 * C3_AFF * sizeof(float);
+    hipFuncSetAttribute((const void *)conv3x3_split_kernel<2, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void *)conv3x3_split_kernel<3, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void *)conv3x3_split_kernel<4, 3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(out3 + 0, conv3x3_split_kernel<2, 3, 1>, 256, 2 * 2 * 3 * 2048 + tile);
+    hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(out3 + 1, conv3x3_split_kernel<3, 3, 1>, 256, 2 * 3 * 3 * 2048 + tile);
+    hipError_t e3 = hipOccupancyMaxActiveBlocksPerMultiprocessor(out3 + 2, conv3x3_split_kernel<4, 3, 1>, 256, 2 * 4 * 3 * 2048 + tile);
+    return (e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess) ? 0 : -2;
+}
+#endif

@@ -35,7 +35,7 @@ def timeit(name, fn):
         fn()
     e1.record()
     torch.cuda.synchronize()
-    print("%-28s %9.2f us / call" % (name, e0.elapsed_time(e1) * 1e3 / args.iters), flush=True)
+    print("%-64s %9.2f us / call" % (name, e0.elapsed_time(e1) * 1e3 / args.iters), flush=True)
 
 
 import ctypes
@@ -346,6 +346,63 @@ if "conv" in which:
             us = e0.elapsed_time(e1) * 1e3 / args.iters
             line += "  %s %.1f us (%.0f TF/s)" % (nm, us, fl / us / 1e6)
         print(line, flush=True)
+
+if "conv_census" in which:
+    # timing experiments of the direct split conv (debug build): which resource the main loop waits for
+    _l.nmrf_debug_conv3_variant.restype = ctypes.c_int
+    for (bb, ci, co, hh, ww, strips) in ((2, 64, 64, 188, 624, 2), (2, 256, 256, 94, 312, 4), (2, 128, 128, 94, 312, 2)):
+        xx = mk("cx%d" % ci, bb, ci, hh, ww)
+        wt = mk("cw%d%d" % (ci, co), co, ci, 3, 3) * 0.05
+        pk = K.pack_conv3x3(wt, strips, co // 32 // strips)
+        packed = (pk[0], strips, co // 32 // strips, pk[1])
+        for var, tag in ((0, "product (first call)"), (0, "product"), (1, "no weight DMA"), (2, "no halo restaging"), (4, "no barriers"), (8, "no MFMA"),
+                         (16, "no output stores"), (3, "no DMA, no restaging"), (7, "no DMA / restaging / barriers"),
+                         (23, "no DMA / restaging / barriers / stores"), (32, "no LDS fragment reads"),
+                         (55, "MFMAs only (no DMA / restaging / barriers / stores / fragment reads)"), (63, "nothing (launch + prologue)")):
+            _l.nmrf_debug_conv3_variant(var)
+            timeit("conv3x3 %d->%d @%dx%dx%d strips %d: %s" % (ci, co, bb, hh, ww, strips, tag), lambda: K.conv3x3_split(xx, packed, co))
+        _l.nmrf_debug_conv3_variant(0)
+
+if "conv_stamps" in which:
+    import numpy as np
+    occ = (ctypes.c_int * 3)(-1, -1, -1)
+    _l.nmrf_debug_conv3_occupancy.restype = ctypes.c_int
+    _l.nmrf_debug_conv3_occupancy(occ)
+    print("conv3x3_split runtime occupancy (blocks/CU): strips 2: %d  3: %d  4: %d" % tuple(occ), flush=True)
+    _l.nmrf_debug_conv3_timing.restype = ctypes.c_int
+    for (bb, ci, co, hh, ww, strips) in ((2, 64, 64, 188, 624, 2), (2, 256, 256, 94, 312, 4)):
+        xx = mk("cx%d" % ci, bb, ci, hh, ww)
+        wt = mk("cw%d%d" % (ci, co), co, ci, 3, 3) * 0.05
+        pk = K.pack_conv3x3(wt, strips, co // 32 // strips)
+        packed = (pk[0], strips, co // 32 // strips, pk[1])
+        K.conv3x3_split(xx, packed, co); torch.cuda.synchronize()
+        stamps = torch.zeros(128 * 4 * 16, dtype=torch.int64, device=dev)
+        _l.nmrf_debug_conv3_timing(ctypes.c_void_p(stamps.data_ptr()))
+        K.conv3x3_split(xx, packed, co)
+        torch.cuda.synchronize()
+        _l.nmrf_debug_conv3_timing(None)
+        st = stamps.cpu().numpy().reshape(128, 4, 16).astype(np.int64)
+        st = st[st[:, 0, 0] > 0]
+        t0 = st[:, :, 0].min()
+        print("conv3x3 %d->%d strips %d: %d stamped tiles of XCD 0; s_memtime ticks of 10 ns" % (ci, co, strips, st.shape[0]))
+        order = np.argsort(st[:, 0, 0])
+        gen = (st[:, 0, 0] - t0) > 0.25 * (st[:, :, 11].max() - t0)          # tiles that started late = second generation
+        for nm, sel in (("first-generation tiles", ~gen), ("later tiles", gen)):
+            if not sel.any():
+                continue
+            s2 = st[sel]
+            def med(a):
+                return float(np.median(a))
+            print("  %s (%d): start +%.0f | first loads landed +%.0f | barrier +%.0f | halo written +%.0f | stage 0 done +%.0f | slab 0 "
+                  "done +%.0f | loop done +%.0f | stores issued +%.0f | stores drained +%.0f" % (
+                      nm, s2.shape[0], med(s2[:, :, 0] - t0), med(s2[:, :, 1] - s2[:, :, 0]), med(s2[:, :, 2] - s2[:, :, 1]),
+                      med(s2[:, :, 3] - s2[:, :, 2]), med(s2[:, :, 4] - s2[:, :, 3]), med(s2[:, :, 5] - s2[:, :, 4]),
+                      med(s2[:, :, 6] - s2[:, :, 5]), med(s2[:, :, 7] - s2[:, :, 6]), med(s2[:, :, 11] - s2[:, :, 7])))
+            print("     per wave, summed over stages: waits (vmcnt + barrier) %.0f | compute (LDS reads + MFMAs) %.0f | halo restaging %.0f | "
+                  "whole wave %.0f" % (med(s2[:, :, 8]), med(s2[:, :, 9]), med(s2[:, :, 10]), med(s2[:, :, 11] - s2[:, :, 0])))
+            print("     of the dy == 0 waits: vmcnt %.0f ; of the restaging: until the halo is written %.0f, until the second barrier %.0f, "
+                  "DMA + prefetch issue %.0f" % (med(s2[:, :, 12]), med(s2[:, :, 13]), med(s2[:, :, 14]), med(s2[:, :, 10] - s2[:, :, 14])))
+        print("  kernel span on XCD 0: %.0f ticks" % (st[:, :, 11].max() - t0))
 
 if "conv_timing" in which:
     import numpy as np
