@@ -291,8 +291,13 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
                 const f32x4 ba = par4(B16P_B1 + 32 * hg + 4 * g), bb = par4(B16P_B1 + 32 * hg + 16 + 4 * g);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    hv[e] = gelu_fast(fmaf(f0[e], a.inv_1, ba[e]));
-                    hv[4 + e] = gelu_fast(fmaf(f1[e], a.inv_1, bb[e]));
+                    if constexpr (DBG & 16) {                                  // (timing experiment: no GELU)
+                        hv[e] = fmaf(f0[e], a.inv_1, ba[e]);
+                        hv[4 + e] = fmaf(f1[e], a.inv_1, bb[e]);
+                    } else {
+                        hv[e] = gelu_fast(fmaf(f0[e], a.inv_1, ba[e]));
+                        hv[4 + e] = gelu_fast(fmaf(f1[e], a.inv_1, bb[e]));
+                    }
                 }
                 h16x8 hh, hl;
                 split8u(hv, hh, hl);
@@ -428,6 +433,8 @@ static int launch_nmp_block16(const NmpBlock16Args &a, hipStream_t st) {
             case 4: return launch_nmp_block16<MLP, KQC, 4>(a, st);
             case 8: return launch_nmp_block16<MLP, KQC, 8>(a, st);
             case 7: return launch_nmp_block16<MLP, KQC, 7>(a, st);
+            case 16: return launch_nmp_block16<MLP, KQC, 16>(a, st);
+            case 24: return launch_nmp_block16<MLP, KQC, 24>(a, st);
             default: break;
         }
     }

@@ -6,6 +6,7 @@ Parameter names follow the reference's `Backbone` (nmrf/models/backbone.py:16-98
 checkpoints load with strict=True: conv1, layer{1,2,3}.{0,1}.{conv1,conv2,downsample.0}, conv2.
 """
 import logging
+import os
 
 import torch
 import torch.nn as nn
@@ -104,7 +105,16 @@ class Backbone(nn.Module):
                 x = K.instance_norm(self.conv1(x).contiguous(), relu=True)
             x = self.layer3(self.layer2(self.layer1(x)))
             if x.shape[-1] % 2 == 0 and x.shape[-2] % 2 == 0:
-                y = F.conv2d(x, self.conv2.weight, None)
+                w2 = self.conv2.weight
+                if w2.shape[1] in (64, 128) and w2.shape[0] % 64 == 0 and os.environ.get("NMRF_CONV1X1", "1") != "0":
+                    if not hasattr(self, "_c2"):
+                        self._c2 = {}
+                    key = (w2.data_ptr(), w2._version)
+                    if self._c2.get("key") != key:
+                        self._c2 = {"key": key, "packed": K.pack_conv1x1(w2)}
+                    y = K.conv1x1_in_relu(x.contiguous(), 0, w2.shape[1], None, self._c2["packed"])      # plain 1x1 conv (no norm)
+                else:
+                    y = F.conv2d(x, w2, None)
                 return list(K.bias_avgpool2(y.contiguous(), self.conv2.bias))     # bias add + 2x2 average in one pass
             x = self.conv2(x)
             return [x, F.avg_pool2d(x, 2, 2)]

@@ -107,7 +107,7 @@ if "block" in which:
     s16, st16, i16 = K.block_stream16(wp, w1, w2, wq, 160)
     timeit("nmp_block16 proj+mlp+qkv (16 tokens / wave)", lambda: K.nmp_block(x, s16, st16, i16, msg, bp, (g, be, 1e-5, b1, b2), qd, tokens_per_wave=16))
     _l.nmrf_debug_nmp_block16_variant.restype = ctypes.c_int
-    for var, tag in ((1, "no barrier"), (2, "no commit/fetch"), (4, "no LDS fragment reads"), (8, "no MFMA"), (7, "no barrier/commit/fetch/reads")):
+    for var, tag in ((1, "no barrier"), (2, "no commit/fetch"), (4, "no LDS fragment reads"), (8, "no MFMA"), (7, "no barrier/commit/fetch/reads"), (16, "no GELU"), (24, "no GELU, no MFMA")):
         _l.nmrf_debug_nmp_block16_variant(var)
         timeit("nmp_block16 DBG " + tag, lambda: K.nmp_block(x, s16, st16, i16, msg, bp, (g, be, 1e-5, b1, b2), qd, tokens_per_wave=16))
     _l.nmrf_debug_nmp_block16_variant(0)
