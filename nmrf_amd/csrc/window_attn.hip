@@ -302,12 +302,12 @@ __global__ __launch_bounds__(64 * NKT) void window_attn_kernel(const float *__re
 #define WA_TROW 32                         // floats per staged table row; 16-byte chunks are XOR-swizzled by (row & 7)
 #define WA_LOG2E 1.4426950408889634f
 
-template <int NKT, int WIN, int NL, int WPB>
+template <int NKT, int WIN, int NL, int WPB, int PK = 1>
 struct WinFastLds {
     static constexpr int W2 = WIN * WIN;
     static constexpr int R = (2 * WIN - 1) * (2 * WIN - 1);
     static constexpr int Tw = W2 * NL;
-    static constexpr int TS = (Tw + 3) / 4 * 4;           // token stride of the QR^T / KR^T rows
+    static constexpr int TS = (Tw * PK + 3) / 4 * 4;      // token stride of the QR^T / KR^T rows (PK windows side by side)
     static constexpr int TP = NKT * 32;
     static constexpr bool QLDS = NKT > 1;
     static constexpr int SLOT = 2 * W2 * TS + 32 + (QLDS ? NKT * 16 * 64 : 0) + TP;   // floats per window slot
@@ -320,12 +320,17 @@ struct WinFastLds {
 #define WA_CENSUS(k, v) do { if (TIMED && tid == 0) \
         stamps[(size_t)64 * NKT * WPB * 16 + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 3 + (k)] = (v); } while (0)
 
-template <int NKT, int WIN, int NL, int WPB, int OCC, bool TIMED = false>
+// PK = 2 (refinement windows: 16 tokens): TWO windows share a wave's 32-token tile -- tokens 0..15 of window 2k, 16..31 of window
+// 2k+1; the off-diagonal quarters of S^T are masked.  Every per-lane phase (relative-position dots, softmax, value-embedding
+// term) then works on 32 real tokens instead of 16, and one MFMA pair serves two windows.
+template <int NKT, int WIN, int NL, int WPB, int OCC, bool TIMED = false, int PK = 1>
 __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(const float *__restrict__ qkv,
         const float *__restrict__ table, WinGeom g, float scale, float *__restrict__ out,
         unsigned long long *__restrict__ stamps = nullptr) {
-    using L = WinFastLds<NKT, WIN, NL, WPB>;
+    using L = WinFastLds<NKT, WIN, NL, WPB, PK>;
     constexpr int TP = L::TP, W2 = L::W2, R = L::R, Tw = L::Tw, TS = L::TS;
+    constexpr int TwE = Tw * PK;                    // tokens of a wave's tile
+    static_assert(PK == 1 || (PK == 2 && NKT == 1 && NL == 1 && 2 * Tw <= 32), "two windows per tile: one key tile, one label");
     constexpr int NTHR = 64 * NKT * WPB;
     constexpr int SPAN = 2 * WIN - 1;
     constexpr int TAB_IT = (R * 8 + NTHR - 1) / NTHR;
@@ -349,10 +354,11 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
     unsigned *rowoff = reinterpret_cast<unsigned *>(qsc + (QLDS ? NKT * 16 * 64 : 0));   // [TP]
 
     const int nwx = g.Wp / WIN, nwin = nwx * (g.Hp / WIN);
-    const int win_raw = blockIdx.x * WPB + slot;
-    const bool win_ok = win_raw < nwin;             // wave-uniform; idle slots keep running (barriers) on window 0
-    const int widx = win_ok ? win_raw : 0;
-    const int wj = widx % nwx, wi = widx / nwx;
+    const int win_raw = (blockIdx.x * WPB + slot) * PK;      // first window of the wave; idle ones keep running (barriers) on window 0
+    auto window_of = [&](int i) -> int {            // window of tile token i
+        const int w = win_raw + (PK == 2 && i >= Tw ? 1 : 0);
+        return w < nwin ? w : 0;
+    };
     const int head = blockIdx.y, bimg = blockIdx.z;
     const unsigned ld = 3u * g.C;
     const int tab_ld = 3 * g.C;
@@ -360,7 +366,10 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
     const float sc2 = scale * WA_LOG2E;
 
     auto token_row = [&](int i) -> unsigned {
-        int ii = i < Tw ? i : Tw - 1;               // padded tokens alias the last real one (always masked)
+        int ii = i < TwE ? i : TwE - 1;             // padded tokens alias the last real one (always masked)
+        const int widx = window_of(ii);
+        const int wj = widx % nwx, wi = widx / nwx;
+        if (PK == 2 && ii >= Tw) ii -= Tw;
         int pt = ii / NL, n = ii - pt * NL;
         int a = pt / WIN, b = pt - a * WIN;
         int Y = wi * WIN + a + g.shift, X = wj * WIN + b + g.shift;
@@ -374,8 +383,12 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
     WA_CENSUS(1, wall_clock64());
     // ---- earliest load: phase-0 operand (q or k of token 32*qt+qi) --------------------------------------
     const int tok = 32 * qt + qi;
-    const bool tok_ok = tok < Tw;
-    const int tokc = tok_ok ? tok : Tw - 1;
+    const bool tok_ok = tok < TwE;
+    const int tokc = tok_ok ? tok : TwE - 1;
+    const int tokl = PK == 2 && tokc >= Tw ? tokc - Tw : tokc;           // token inside its own window
+    const bool win_ok = win_raw + (PK == 2 && tokc >= Tw ? 1 : 0) < nwin;  // (wave-uniform for PK == 1)
+    const int my_w = window_of(tokc);
+    const int wj = my_w % nwx, wi = my_w / nwx;     // window of this lane's token
     const unsigned trow = token_row(tokc);
     float vec[32];
     {
@@ -438,7 +451,7 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
         const float sc = hi ? 1.0f : sc2;
 #pragma unroll
         for (int c = 0; c < 32; ++c) vec[c] *= sc;
-        const int pt = tok / NL;
+        const int pt = tokl / NL;
         const int at = pt / WIN, bt = pt - at * WIN;
         const float *tab = hi ? tab_b : tab_a;
         float *dst = (hi ? krt : qrt) + tok;
@@ -492,15 +505,17 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
     WA_STAMP(5);
 
     // ---- phase 1 ---------------------------------------------------------------------------------------
-    const int q_pix = tokc / NL;
+    const int q_pix = tokl / NL;
     const int qa = q_pix / WIN, qb = q_pix - qa * WIN;
+    auto local_key = [&](int key) -> int { return PK == 2 && key >= Tw ? key - Tw : key; };    // key inside its own window
     auto region = [&](int a, int b) -> int {       // Swin shift regions on the rolled grid (NMP.py:211-239)
         int Yr = wi * WIN + a, Xr = wj * WIN + b;
         int fy = Yr < g.Hp - WIN ? 0 : (Yr < g.Hp - g.shift ? 1 : 2);
         int fx = Xr < g.Wp - WIN ? 0 : (Xr < g.Wp - g.shift ? 1 : 2);
         return fy * 3 + fx;
     };
-    const bool need_shift = g.shift && (wi == g.Hp / WIN - 1 || wj == nwx - 1);     // wave-uniform
+    const bool on_border = g.shift && (wi == g.Hp / WIN - 1 || wj == nwx - 1);
+    const bool need_shift = PK == 1 ? on_border : (__builtin_amdgcn_ballot_w64(on_border) != 0);     // wave-uniform
     const int q_reg = need_shift ? region(qa, qb) : 0;
     const bool sib = g.sibling && NL > 1;
 
@@ -541,17 +556,22 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
             const float krv[4] = {kr4.x, kr4.y, kr4.z, kr4.w};
 #pragma unroll
             for (int pp = 0; pp < PPQ; ++pp) {
-                int pk = keyq / NL + pp;
+                int pk = local_key(keyq) / NL + pp;
                 pk = pk < W2 ? pk : W2 - 1;
                 const float qv = qrt_q[pk * TS];
 #pragma unroll
                 for (int e = 0; e < NL; ++e) st[4 * rq + pp * NL + e] += qv + krv[pp * NL + e];
             }
         }
-        if (kt == NKT - 1 && Tw < TP) {                                      // keys beyond the window (last tile only)
+        if (kt == NKT - 1 && TwE < TP) {                                     // keys beyond the window (last tile only)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if (k0 + mfma_row(r, hi) >= Tw) st[r] = -INFINITY;
+                if (k0 + mfma_row(r, hi) >= TwE) st[r] = -INFINITY;
+        }
+        if constexpr (PK == 2) {                                              // keys of the other window of the tile
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if ((mfma_row(r, hi) >= Tw) != (tokc >= Tw)) st[r] = -INFINITY;
         }
         if (sib && kt == qt) {                                                // sibling labels of the query's own pixel
 #pragma unroll
@@ -565,7 +585,7 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
             for (int rq = 0; rq < 4; ++rq)
 #pragma unroll
                 for (int pp = 0; pp < PPQ; ++pp) {
-                    int pk = (k0 + 8 * rq + 4 * hi) / NL + pp;
+                    int pk = local_key(k0 + 8 * rq + 4 * hi) / NL + pp;
                     pk = pk < W2 ? pk : W2 - 1;
                     const bool other = region(pk / WIN, pk % WIN) != q_reg;
 #pragma unroll
@@ -597,7 +617,7 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
         // swap the probabilities of their pixels, then each accumulates BOTH pixels for its own 16 channels.
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
-            if (kt == NKT - 1 && 32 * (NKT - 1) + 8 * rq >= Tw) continue;     // quad pair entirely beyond the window
+            if (kt == NKT - 1 && 32 * (NKT - 1) + 8 * rq >= TwE) continue;    // quad pair entirely beyond the window
 #pragma unroll
             for (int pp = 0; pp < PPQ; ++pp) {
                 float p0 = st[4 * rq + pp * NL];
@@ -607,7 +627,7 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
                 half_swap(p0, p1);                 // p0 = probability mass of the hi=0 lane's pixel, p1 = of the hi=1 lane's
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
-                    int pk = (k0 + 8 * rq + 4 * h2) / NL + pp;
+                    int pk = local_key(k0 + 8 * rq + 4 * h2) / NL + pp;
                     pk = pk < W2 ? pk : W2 - 1;
                     const int ka = pk / WIN, kb = pk - ka * WIN;
                     const int rr = ev_r0 - (ka * SPAN + kb);
@@ -641,21 +661,21 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
     WA_CENSUS(2, wall_clock64());
 }
 
-template <int NKT, int WIN, int NL, int WPB, int OCC>
+template <int NKT, int WIN, int NL, int WPB, int OCC, int PK = 1>
 static int launch_window_fast(const float *qkv, const float *table, const WinGeom &g, int B, float *out, hipStream_t st) {
-    using L = WinFastLds<NKT, WIN, NL, WPB>;
+    using L = WinFastLds<NKT, WIN, NL, WPB, PK>;
     static_assert(L::BYTES <= 160 * 1024, "LDS budget of one CU");
     static bool attr_done = false;      // set once per instantiation, outside any stream capture
     if (L::BYTES > 64 * 1024 && !attr_done) {
         attr_done = true;
-        if (hipFuncSetAttribute((const void *)window_attn_fast_kernel<NKT, WIN, NL, WPB, OCC>,
+        if (hipFuncSetAttribute((const void *)window_attn_fast_kernel<NKT, WIN, NL, WPB, OCC, false, PK>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES) != hipSuccess)
             return NMRF_ELAUNCH;
     }
     const int nwin = (g.Hp / WIN) * (g.Wp / WIN);
-    dim3 grid((nwin + WPB - 1) / WPB, g.heads, B);
-    hipLaunchKernelGGL((window_attn_fast_kernel<NKT, WIN, NL, WPB, OCC>), grid, dim3(64 * NKT * WPB), L::BYTES, st, qkv, table,
-                       g, 1.0f / sqrtf(32.0f), out, (unsigned long long *)nullptr);
+    dim3 grid((nwin + WPB * PK - 1) / (WPB * PK), g.heads, B);
+    hipLaunchKernelGGL((window_attn_fast_kernel<NKT, WIN, NL, WPB, OCC, false, PK>), grid, dim3(64 * NKT * WPB), L::BYTES, st, qkv,
+                       table, g, 1.0f / sqrtf(32.0f), out, (unsigned long long *)nullptr);
     return nmrf_launch_status();
 }
 
@@ -715,7 +735,7 @@ extern "C" int nmrf_window_attn_f32(const float *qkv, const float *table, int B,
     hipStream_t st = (hipStream_t)stream;
     if ((int64_t)B * Hp * Wp * N * 3 * C < ((int64_t)1 << 32)) {                            // 32-bit element offsets
         if (win == 6 && N == 4) return launch_window_fast<5, 6, 4, 2, 3>(qkv, table, g, B, out, st);   // inference windows
-        if (win == 4 && N == 1) return launch_window_fast<1, 4, 1, 8, 2>(qkv, table, g, B, out, st);   // refinement windows
+        if (win == 4 && N == 1) return launch_window_fast<1, 4, 1, 8, 2, 2>(qkv, table, g, B, out, st);   // refinement windows, two per tile
     }
     switch (nkt) {                                                                         // any other configuration
         case 1: return launch_window<1>(qkv, table, g, B, out, st);
