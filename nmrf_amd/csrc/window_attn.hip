@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64 * NKT) void window_attn_kernel(const float *__re
 //     pixel probabilities), so no cross-half reduction is left at the end;
 //   * the scaled Q fragment lives in LDS when NKT > 1 (16 VGPRs less across the tile loop).
 // =================================================================================================
-#define WA_TROW 32                         // floats per staged table row; 16-byte chunks are XOR-swizzled by (row & 7)
+#define WA_TROW 32                         // floats per staged table row
 #define WA_LOG2E 1.4426950408889634f
 
 template <int NKT, int WIN, int NL, int WPB, int PK = 1>
@@ -307,11 +307,20 @@ struct WinFastLds {
     static constexpr int W2 = WIN * WIN;
     static constexpr int R = (2 * WIN - 1) * (2 * WIN - 1);
     static constexpr int Tw = W2 * NL;
-    static constexpr int TS = (Tw * PK + 3) / 4 * 4;      // token stride of the QR^T / KR^T rows (PK windows side by side)
+    // token stride of the QR^T / KR^T rows (PK windows side by side); NL == 1: every lane of a b128 phase reads a different KR^T row,
+    // so the stride is padded to 4 (mod 16) floats -- 16 different 16-byte bank slots (a stride of 32 floats hit two of them)
+    static constexpr int TS = (Tw * PK + 3) / 4 * 4 + (NL == 1 ? 4 : 0);
+    // staged embedding tables: chunk-major [8 chunks][POSN row slots][4 floats]; row (ra, rb) of the (2 WIN - 1)^2 table sits in
+    // slot tab_pos(ra, rb).  WIN == 4: slot mod 16 = (ra % 4) * 4 + rb % 4 -- the 16 pixels of a window (4 consecutive ra x 4
+    // consecutive rb for any key pixel) read 16 different bank slots; otherwise slot = row: a b128 phase holds 4 consecutive
+    // pixels (NL == 4), whose rows differ by 1..3 or wrap by SPAN - WIN + {1, 2}: distinct mod 16 as well.  (The first layout,
+    // row-major with the chunks XOR-swizzled by row & 7, measured a conflict ratio of 0.40 / 0.47: rows 8 apart collided.)
+    static constexpr int GB = (2 * WIN - 1 + 3) / 4;
+    static constexpr int POSN = WIN == 4 ? GB * GB * 16 : R;
     static constexpr int TP = NKT * 32;
     static constexpr bool QLDS = NKT > 1;
     static constexpr int SLOT = 2 * W2 * TS + 32 + (QLDS ? NKT * 16 * 64 : 0) + TP;   // floats per window slot
-    static constexpr size_t BYTES = (size_t)(2 * R * WA_TROW + WPB * SLOT) * 4;
+    static constexpr size_t BYTES = (size_t)(2 * POSN * WA_TROW + WPB * SLOT) * 4;
 };
 
 // TIMED: debug instantiation writing s_memtime stamps per wave and a per-block census (nmrf_debug_window_timing).
@@ -339,14 +348,21 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
     static_assert(NL == 1 || NL == 2 || NL == 4, "fast path: labels per pixel must divide 4");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *tab_a = smem;                            // ek [R][32]   (later: ev), swizzled
-    float *tab_b = tab_a + R * WA_TROW;             // eq*s*log2e [R][32], swizzled
+    float *tab_a = smem;                            // ek (later: ev), chunk-major [8][POSN][4]
+    float *tab_b = tab_a + L::POSN * WA_TROW;       // eq*s*log2e, same layout
+    constexpr int POSN = L::POSN;
+    auto tab_pos = [](int ra, int rb) -> int {      // row slot of table row (ra, rb), see WinFastLds
+        return WIN == 4 ? ((ra >> 2) * L::GB + (rb >> 2)) * 16 + (ra & 3) * 4 + (rb & 3) : ra * SPAN + rb;
+    };
+    auto tab_off = [&](int r, int c) -> int {       // float offset of chunk c of table row r (row-major index)
+        return (c * POSN + (WIN == 4 ? tab_pos(r / SPAN, r % SPAN) : r)) * 4;
+    };
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int slot = wv / NKT, qt = wv - slot * NKT;   // window slot of the block, query tile inside the window
     const int qi = lane & 31, hi = lane >> 5;
-    float *slot_mem = tab_b + R * WA_TROW + slot * L::SLOT;
+    float *slot_mem = tab_b + POSN * WA_TROW + slot * L::SLOT;
     float *qrt = slot_mem;                          // [W2][TS]   QR^T : [key pixel][query token]
     float *krt = qrt + W2 * TS;                     // [W2][TS]+32 KR^T : [query pixel][key token]; the last tile's quad
     //                                                 reads may run past Tw (those keys are masked)
@@ -415,10 +431,9 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
         for (int it = 0; it < TAB_IT; ++it) {
             const int i = tid + it * NTHR;
             if (i < R * 8) {
-                const int r = i >> 3;
-                const int sw = (((i & 7) ^ (r & 7)) << 2);
-                stg4(tab_a + r * WA_TROW + sw, te[it]);
-                stg4(tab_b + r * WA_TROW + sw, make_float4(tq[it].x * sc2, tq[it].y * sc2, tq[it].z * sc2, tq[it].w * sc2));
+                const int sw = tab_off(i >> 3, i & 7);
+                stg4(tab_a + sw, te[it]);
+                stg4(tab_b + sw, make_float4(tq[it].x * sc2, tq[it].y * sc2, tq[it].z * sc2, tq[it].w * sc2));
             }
         }
     }
@@ -462,13 +477,11 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
 #pragma unroll 2
             for (int bj = 0; bj < WIN; ++bj) {
                 const int db = hi ? (bj - bt) : (bt - bj);
-                const int rr = rrow + db;
-                const float *e = tab + rr * WA_TROW;
-                const int sx = rr & 7;
+                const float *e = tab + (WIN == 4 ? tab_pos(da + WIN - 1, db + WIN - 1) : rrow + db) * 4;
                 f32x2 s0 = {0.f, 0.f}, s1 = {0.f, 0.f};           // two packed accumulators: 16 v_pk_fma_f32 per dot
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    const float4 t = *reinterpret_cast<const float4 *>(e + ((c ^ sx) << 2));
+                    const float4 t = *reinterpret_cast<const float4 *>(e + c * (POSN * 4));
                     s0 = pk_fma(f32x2{vec[4 * c + 0], vec[4 * c + 1]}, f32x2{t.x, t.y}, s0);
                     s1 = pk_fma(f32x2{vec[4 * c + 2], vec[4 * c + 3]}, f32x2{t.z, t.w}, s1);
                 }
@@ -499,7 +512,7 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
 #pragma unroll
     for (int it = 0; it < TAB_IT; ++it) {
         const int i = tid + it * NTHR;
-        if (i < R * 8) stg4(tab_a + (i >> 3) * WA_TROW + ((((i & 7) ^ ((i >> 3) & 7))) << 2), tv[it]);
+        if (i < R * 8) stg4(tab_a + tab_off(i >> 3, i & 7), tv[it]);
     }
     __syncthreads();
     WA_STAMP(5);
@@ -528,7 +541,8 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
     float m_run = -INFINITY, l_run = 0.f;
     const float *qrt_q = qrt + tokc;
     const float *krt_q = krt + q_pix * TS;
-    const int ev_r0 = (qa + WIN - 1) * SPAN + (qb + WIN - 1);                          // rel(pq, pixel 0)
+    // rel(pq, pixel 0), plus this half's chunk offset (its chunks are 2 gq + hi) in row-slot units
+    const int ev_r0 = (qa + WIN - 1) * SPAN + (qb + WIN - 1) + hi * POSN;
 
 #pragma unroll 1
     for (int kt = 0; kt < NKT; ++kt) {
@@ -630,19 +644,19 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
                     int pk = local_key(k0 + 8 * rq + 4 * h2) / NL + pp;
                     pk = pk < W2 ? pk : W2 - 1;
                     const int ka = pk / WIN, kb = pk - ka * WIN;
-                    const int rr = ev_r0 - (ka * SPAN + kb);
-                    const float *e = tab_a + rr * WA_TROW;
-                    const int sx = rr & 7;
+                    const float *e = tab_a + (WIN == 4 ? tab_pos(qa - ka + WIN - 1, qb - kb + WIN - 1) + hi * POSN : ev_r0 - (ka * SPAN + kb)) * 4;
                     const float psv = h2 ? p1 : p0;
                     const f32x2 ps = {psv, psv};
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {               // channels 8*gq + 4*hi .. +3  = O^T registers 4*gq .. 4*gq+3
-                        const float4 t = *reinterpret_cast<const float4 *>(e + (((2 * gq + hi) ^ sx) << 2));
+                        const float4 t = *reinterpret_cast<const float4 *>(e + 2 * gq * (POSN * 4));
                         oe[2 * gq + 0] = pk_fma(ps, f32x2{t.x, t.y}, oe[2 * gq + 0]);
                         oe[2 * gq + 1] = pk_fma(ps, f32x2{t.z, t.w}, oe[2 * gq + 1]);
                     }
                 }
             }
+            // (the table reads carry immediate offsets now: without a fence the scheduler hoists all 32 of a tile and spills)
+            if (NKT > 1) __builtin_amdgcn_sched_barrier(0);
         }
         WA_STAMP(6 + kt);
     }
