@@ -738,6 +738,11 @@ extern "C" int nmrf_debug_window_timing(const float *qkv, const float *table, in
 }
 #endif  // NMRF_DEBUG_PROBES
 
+#ifdef NMRF_DEBUG_PROBES
+static int g_window_pack1 = 0;      // tools: run the refinement windows one per tile (A/B of the packing)
+extern "C" int nmrf_debug_window_pack1(int v) { g_window_pack1 = v; return NMRF_OK; }
+#endif
+
 extern "C" int nmrf_window_attn_f32(const float *qkv, const float *table, int B, int Hp, int Wp, int N, int C, int heads,
                                     int win, int shift, int sibling_mask, float *out, void *stream) {
     if (!qkv || !table || !out) return NMRF_ENULL;
@@ -749,6 +754,9 @@ extern "C" int nmrf_window_attn_f32(const float *qkv, const float *table, int B,
     hipStream_t st = (hipStream_t)stream;
     if ((int64_t)B * Hp * Wp * N * 3 * C < ((int64_t)1 << 32)) {                            // 32-bit element offsets
         if (win == 6 && N == 4) return launch_window_fast<5, 6, 4, 2, 3>(qkv, table, g, B, out, st);   // inference windows
+#ifdef NMRF_DEBUG_PROBES
+        if (win == 4 && N == 1 && g_window_pack1) return launch_window_fast<1, 4, 1, 8, 2, 1>(qkv, table, g, B, out, st);
+#endif
         if (win == 4 && N == 1) return launch_window_fast<1, 4, 1, 8, 2, 2>(qkv, table, g, B, out, st);   // refinement windows, two per tile
     }
     switch (nkt) {                                                                         // any other configuration

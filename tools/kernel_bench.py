@@ -149,6 +149,10 @@ if "refine" in which:
     qkv, table = mk("q3", b * hp * wp, 384), mk("t3", 49, 384)
     for shift in (0, 2):
         timeit("window_attn 4x4x1 shift=%d" % shift, lambda: K.window_attn(qkv, table, b, hp, wp, 1, 4, 4, shift, False))
+    _l.nmrf_debug_window_pack1.restype = ctypes.c_int
+    _l.nmrf_debug_window_pack1(1)
+    timeit("window_attn 4x4x1 shift=0, ONE window per tile", lambda: K.window_attn(qkv, table, b, hp, wp, 1, 4, 4, 0, False))
+    _l.nmrf_debug_window_pack1(0)
 if "warp" in which:
     f1, f2 = mk("f1", b, 64, h, w), mk("f2", b, 64, h, w)
     g1, g2 = mk("g1", b, 256, h, w), mk("g2", b, 256, h, w)
