@@ -61,39 +61,34 @@ extern "C" int nmrf_add_ln_concat_f32(const float *x, const float *y, float *x_o
 
 // ------------------------------------------------------------------------------------------------
 // A10(i): self-edge attention among the N sibling labels of one pixel.
-// One thread = one (token, head): 32-wide q in registers, N keys/values streamed as float4.
+// Eight lanes = one (token, head): lane c holds channels 4c..4c+3 of the 32-wide head slice, so every load instruction of a
+// wave reads 8 full 128-byte lines (8 (token, head) slices) -- the first version (one thread per (token, head), 72 float4 loads
+// each touching 64 different lines for 16 bytes) was bound by cache-line look-ups at 2.5 TB/s.  q.k = 4 FMAs per lane + a
+// three-step butterfly over the 8 lanes; the softmax is replicated; out = sum_j p_j v_j on the lane's own 4 channels.
 // ------------------------------------------------------------------------------------------------
 #define SA_MAXN 8
 __global__ __launch_bounds__(256) void self_attn_kernel(const float *__restrict__ qkv, int64_t T, int N, int C, int heads,
                                                        float scale, float *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= T * heads) return;
-    const int64_t t = i / heads;
-    const int h = (int)(i - t * heads);
+    const int c = (int)(i & 7);
+    const int64_t grp = i >> 3;
+    const bool ok = grp < T * heads;
+    const int64_t gc = ok ? grp : T * heads - 1;                   // (idle lanes of the last wave shadow the last group: shuffles stay defined)
+    const int64_t t = gc / heads;
+    const int h = (int)(gc - t * heads);
     const int64_t t0 = (t / N) * N;
     const size_t ld = (size_t)3 * C;
-    float q[32];
-    {
-        const float *qp = qkv + t * ld + h * 32;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            float4 v = ldg4(qp + c * 4);
-            q[c * 4 + 0] = v.x; q[c * 4 + 1] = v.y; q[c * 4 + 2] = v.z; q[c * 4 + 3] = v.w;
-        }
-    }
+    const float4 q = ldg4(qkv + t * ld + h * 32 + c * 4);
     float logit[SA_MAXN];
     float m = -INFINITY;
 #pragma unroll
     for (int j = 0; j < SA_MAXN; ++j) {
         if (j < N) {
-            const float *kp = qkv + (t0 + j) * ld + C + h * 32;
-            float s = 0.f;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                float4 v = ldg4(kp + c * 4);
-                s = fmaf(q[c * 4 + 0], v.x, s); s = fmaf(q[c * 4 + 1], v.y, s);
-                s = fmaf(q[c * 4 + 2], v.z, s); s = fmaf(q[c * 4 + 3], v.w, s);
-            }
+            const float4 k = ldg4(qkv + (t0 + j) * ld + C + h * 32 + c * 4);
+            float s = fmaf(q.w, k.w, fmaf(q.z, k.z, fmaf(q.y, k.y, q.x * k.x)));
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            s += __shfl_xor(s, 4);
             logit[j] = s * scale;
             m = fmaxf(m, logit[j]);
         } else {
@@ -104,31 +99,22 @@ __global__ __launch_bounds__(256) void self_attn_kernel(const float *__restrict_
 #pragma unroll
     for (int j = 0; j < SA_MAXN; ++j) { logit[j] = (j < N) ? expf(logit[j] - m) : 0.f; z += logit[j]; }
     const float rz = 1.0f / z;
-    float o[32];
-#pragma unroll
-    for (int c = 0; c < 32; ++c) o[c] = 0.f;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < SA_MAXN; ++j) {
         if (j < N) {
             const float pj = logit[j] * rz;
-            const float *vp = qkv + (t0 + j) * ld + 2 * C + h * 32;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                float4 v = ldg4(vp + c * 4);
-                o[c * 4 + 0] = fmaf(pj, v.x, o[c * 4 + 0]); o[c * 4 + 1] = fmaf(pj, v.y, o[c * 4 + 1]);
-                o[c * 4 + 2] = fmaf(pj, v.z, o[c * 4 + 2]); o[c * 4 + 3] = fmaf(pj, v.w, o[c * 4 + 3]);
-            }
+            const float4 v = ldg4(qkv + (t0 + j) * ld + 2 * C + h * 32 + c * 4);
+            o.x = fmaf(pj, v.x, o.x); o.y = fmaf(pj, v.y, o.y); o.z = fmaf(pj, v.z, o.z); o.w = fmaf(pj, v.w, o.w);
         }
     }
-    float *op = out + t * C + h * 32;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) stg4(op + c * 4, make_float4(o[c * 4], o[c * 4 + 1], o[c * 4 + 2], o[c * 4 + 3]));
+    if (ok) stg4(out + t * C + h * 32 + c * 4, o);
 }
 
 extern "C" int nmrf_self_attn_f32(const float *qkv, int64_t T, int N, int C, int heads, float *out, void *stream) {
     if (!qkv || !out) return NMRF_ENULL;
     if (T < 1 || N < 1 || N > SA_MAXN || T % N || heads < 1 || heads * 32 != C) return NMRF_EINVAL;
-    dim3 grid((unsigned)ceil_div64(T * heads, 256));
+    dim3 grid((unsigned)ceil_div64(T * heads * 8, 256));
     hipLaunchKernelGGL(self_attn_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, T, N, C, heads,
                        1.0f / sqrtf(32.0f), out);
     return nmrf_launch_status();
