@@ -406,7 +406,11 @@ if "conv_stamps" in which:
                   "whole wave %.0f" % (med(s2[:, :, 8]), med(s2[:, :, 9]), med(s2[:, :, 10]), med(s2[:, :, 11] - s2[:, :, 0])))
             print("     of the dy == 0 waits: vmcnt %.0f ; of the restaging: until the halo is written %.0f, until the second barrier %.0f, "
                   "DMA + prefetch issue %.0f" % (med(s2[:, :, 12]), med(s2[:, :, 13]), med(s2[:, :, 14]), med(s2[:, :, 10] - s2[:, :, 14])))
-        print("  kernel span on XCD 0: %.0f ticks" % (st[:, :, 11].max() - t0))
+        starts = np.sort(st[:, 0, 0] - st[:, 0, 0].min())
+        ends = np.sort(st[:, :, 11].max(axis=1) - st[:, 0, 0].min())
+        print("  block start times on XCD 0 (cycles after the first), sorted, every 8th:", " ".join("%d" % v for v in starts[::8]))
+        print("  block end times, sorted, every 8th:", " ".join("%d" % v for v in ends[::8]))
+        print("  kernel span on XCD 0: %.0f cycles" % (st[:, :, 11].max() - st[:, 0, 0].min()))
 
 if "conv_timing" in which:
     import numpy as np
