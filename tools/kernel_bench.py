@@ -389,15 +389,14 @@ if "conv_stamps" in which:
         st = st[st[:, 0, 0] > 0]
         t0 = st[:, :, 0].min()
         print("conv3x3 %d->%d strips %d: %d stamped tiles of XCD 0; s_memtime ticks of 10 ns" % (ci, co, strips, st.shape[0]))
-        order = np.argsort(st[:, 0, 0])
-        gen = (st[:, 0, 0] - t0) > 0.25 * (st[:, :, 11].max() - t0)          # tiles that started late = second generation
-        for nm, sel in (("first-generation tiles", ~gen), ("later tiles", gen)):
+        gen = np.zeros(st.shape[0], dtype=bool)
+        for nm, sel in (("stamped tiles", ~gen),):
             if not sel.any():
                 continue
             s2 = st[sel]
             def med(a):
                 return float(np.median(a))
-            print("  %s (%d): start +%.0f | first loads landed +%.0f | barrier +%.0f | halo written +%.0f | stage 0 done +%.0f | slab 0 "
+            print("  %s (%d): (start %.0f) | first loads landed +%.0f | barrier +%.0f | halo written +%.0f | stage 0 done +%.0f | slab 0 "
                   "done +%.0f | loop done +%.0f | stores issued +%.0f | stores drained +%.0f" % (
                       nm, s2.shape[0], med(s2[:, :, 0] - t0), med(s2[:, :, 1] - s2[:, :, 0]), med(s2[:, :, 2] - s2[:, :, 1]),
                       med(s2[:, :, 3] - s2[:, :, 2]), med(s2[:, :, 4] - s2[:, :, 3]), med(s2[:, :, 5] - s2[:, :, 4]),
@@ -406,11 +405,7 @@ if "conv_stamps" in which:
                   "whole wave %.0f" % (med(s2[:, :, 8]), med(s2[:, :, 9]), med(s2[:, :, 10]), med(s2[:, :, 11] - s2[:, :, 0])))
             print("     of the dy == 0 waits: vmcnt %.0f ; of the restaging: until the halo is written %.0f, until the second barrier %.0f, "
                   "DMA + prefetch issue %.0f" % (med(s2[:, :, 12]), med(s2[:, :, 13]), med(s2[:, :, 14]), med(s2[:, :, 10] - s2[:, :, 14])))
-        starts = np.sort(st[:, 0, 0] - st[:, 0, 0].min())
-        ends = np.sort(st[:, :, 11].max(axis=1) - st[:, 0, 0].min())
-        print("  block start times on XCD 0 (cycles after the first), sorted, every 8th:", " ".join("%d" % v for v in starts[::8]))
-        print("  block end times, sorted, every 8th:", " ".join("%d" % v for v in ends[::8]))
-        print("  kernel span on XCD 0: %.0f cycles" % (st[:, :, 11].max() - st[:, 0, 0].min()))
+        # (s_memtime counters of different CUs are not synchronised: only differences inside one wave are meaningful)
 
 if "conv_timing" in which:
     import numpy as np
