@@ -298,6 +298,9 @@ def main():
         for nm in names or []:
             if nm in pmc:
                 return pmc[nm]
+            for key, val in pmc.items():              # (a name ending in "," or "<" is a prefix: trailing template arguments vary)
+                if nm[-1:] in ",<" and key.startswith(nm) and isinstance(val, dict):
+                    return val
         return {}
 
     roof, others = None, []

@@ -33,11 +33,13 @@
 //   * STRIDE 2 (layer2.0.conv1 of the backbone, nmrf/models/backbone.py:74): a wave owns ONE output row (G = 1 pixel group), the
 //     tile is 4 rows x 32 columns, the halo (2*4+1) x (2*32+1); halo columns are stored de-interleaved (even columns, then odd) so
 //     that the 32 lanes of a tap still read 32 consecutive 80-byte records.
+//   * ROWS 1 at stride 1: the same one-row-per-wave form (4 x 32 tile) for maps too small to fill the chip with 8 x 32 tiles (the
+//     1/8-resolution DPN context conv at batch 1: 60 blocks of 24 stages -> 120 blocks of half the work).
 //   * KT 4 (the 7x7 / stride-2 stem, backbone.py:70, as a 4x4 / stride-1 convolution over the 2x2 space-to-depth image: 12
 //     channels padded to one 16-channel slab, pad 2 before / 1 after): same kernel, four taps per stage.
-template <int KT, int STRIDE>
+template <int KT, int STRIDE, int ROWS = (STRIDE == 1 ? 2 : 1)>
 struct C3Geom {
-    static constexpr int G = STRIDE == 1 ? 2 : 1;              // 32-pixel groups (output rows) per wave
+    static constexpr int G = ROWS;                             // 32-pixel groups (output rows) per wave
     static constexpr int TR = 4 * G;                           // tile rows
     static constexpr int HR = (TR - 1) * STRIDE + KT;          // halo rows
     static constexpr int HC = (C3_TC - 1) * STRIDE + KT;       // halo columns
@@ -78,10 +80,10 @@ __device__ __forceinline__ void lds_barrier() {
 // DBG: timing experiments of the tools-only debug build (wrong results): 1 no weight DMA after the first stage, 2 no halo
 // restaging after the first slab, 4 no barriers, 8 no MFMAs, 16 no output stores, 32 no LDS fragment reads after a stage's first,
 // 64 s_memtime stamps per wave of the first 128 tiles
-template <int STRIPS, int KT, int STRIDE, int DBG = 0>
+template <int STRIPS, int KT, int STRIDE, int DBG = 0, int ROWS = (STRIDE == 1 ? 2 : 1)>
 __global__ __launch_bounds__(256, STRIDE == 2 ? 1 : (STRIPS == 2 && KT == 3 ? 3 : 2)) void conv3x3_split_kernel(Conv3Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    using GM = C3Geom<KT, STRIDE>;
+    using GM = C3Geom<KT, STRIDE, ROWS>;
     constexpr int G = GM::G, C3_TR = GM::TR, C3_HC = GM::HC, C3_NPIX = GM::NPIX, C3_IPT = GM::IPT, C3_NITEM = 2 * GM::NPIX;
     constexpr int STAGE_U4 = STRIPS * KT * 128;             // 16-byte words per weight stage
     ss_u32x4 *ring = reinterpret_cast<ss_u32x4 *>(smem);                       // 2 slots
@@ -382,10 +384,10 @@ extern "C" int nmrf_debug_conv3_variant(int v) { g_conv3_variant = v; return NMR
 extern "C" int nmrf_debug_conv3_timing(void *stamps) { g_conv3_stamps = (unsigned long long *)stamps; return NMRF_OK; }
 #endif
 
-template <int STRIPS, int KT, int STRIDE, int DBG = 0>
+template <int STRIPS, int KT, int STRIDE, int DBG = 0, int ROWS = (STRIDE == 1 ? 2 : 1)>
 static int launch_conv3(const Conv3Args &a, int groups, hipStream_t st) {
 #ifdef NMRF_DEBUG_PROBES
-    if constexpr (DBG == 0 && KT == 3 && STRIDE == 1 && STRIPS != 3) {
+    if constexpr (DBG == 0 && KT == 3 && STRIDE == 1 && STRIPS != 3 && ROWS == 2) {
         if (g_conv3_stamps) {
             Conv3Args b = a;
             b.stamps = g_conv3_stamps;
@@ -410,14 +412,14 @@ static int launch_conv3(const Conv3Args &a, int groups, hipStream_t st) {
     static bool attr_set_dev[NMRF_MAX_DEV] = {};
     const int dev = nmrf_cur_device();
     if (dev < 0) return NMRF_ELAUNCH;
-    const size_t lds = (size_t)2 * STRIPS * KT * 2048 + C3Geom<KT, STRIDE>::NPIX * C3_PSTRIDE + 2 * C3_AFF * sizeof(float);
+    const size_t lds = (size_t)2 * STRIPS * KT * 2048 + C3Geom<KT, STRIDE, ROWS>::NPIX * C3_PSTRIDE + 2 * C3_AFF * sizeof(float);
     if (!attr_set_dev[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_split_kernel<STRIPS, KT, STRIDE, DBG>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_split_kernel<STRIPS, KT, STRIDE, DBG, ROWS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return NMRF_ELAUNCH;
         attr_set_dev[dev] = true;
     }
-    hipLaunchKernelGGL((conv3x3_split_kernel<STRIPS, KT, STRIDE, DBG>), dim3(8 * a.per_xcd, groups), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv3x3_split_kernel<STRIPS, KT, STRIDE, DBG, ROWS>), dim3(8 * a.per_xcd, groups), dim3(256), lds, st, a);
     return nmrf_launch_status();
 }
 
@@ -431,8 +433,11 @@ extern "C" int nmrf_conv_split_f32(const float *x, int B, int Ci, int H, int W, 
     const int Ho = (H + kt - 1 - kt) / stride + 1, Wo = (W + kt - 1 - kt) / stride + 1;     // total padding kt - 1 (pad before, rest after)
     const int64_t HW = (int64_t)H * W;
     if (HW * 8 + HW > 0xffffffffLL) return NMRF_EINVAL;                         // 32-bit lane offsets
-    const int tr = stride == 1 ? 8 : 4;
-    const int tx = (Wo + C3_TC - 1) / C3_TC, ty = (Ho + tr - 1) / tr;
+    // small maps: one output row per wave (4-row tiles) when the 8-row tiling leaves most of the chip idle
+    const int tx = (Wo + C3_TC - 1) / C3_TC;
+    const bool small = stride == 1 && kt == 3 && strips == 2 && (int64_t)tx * ((Ho + 7) / 8) * B * groups <= 256;
+    const int tr = stride == 1 && !small ? 8 : 4;
+    const int ty = (Ho + tr - 1) / tr;
     const int64_t n = (int64_t)tx * ty * B;
     if (n > 0x7ffffff) return NMRF_EINVAL;
     Conv3Args a{x, Ci, H, W, Ho, Wo, pad, stats, chunks, eps, reinterpret_cast<const ss_u32x4 *>(stream_w),
@@ -440,7 +445,7 @@ extern "C" int nmrf_conv_split_f32(const float *x, int B, int Ci, int H, int W, 
     hipStream_t st = (hipStream_t)stream;
     const int key = kt * 100 + stride * 10 + strips;
     switch (key) {
-        case 312: return launch_conv3<2, 3, 1>(a, groups, st);
+        case 312: return small ? launch_conv3<2, 3, 1, 0, 1>(a, groups, st) : launch_conv3<2, 3, 1>(a, groups, st);
         case 313: return launch_conv3<3, 3, 1>(a, groups, st);
         case 314: return launch_conv3<4, 3, 1>(a, groups, st);
         case 322: return launch_conv3<2, 3, 2>(a, groups, st);

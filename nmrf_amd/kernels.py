@@ -573,7 +573,7 @@ def conv_split(x, packed, co, kt=3, stride=1, pad=1, stats=None, eps=1e-5):
         label = "conv3x3_split_kernel<%d,%d,%d> (%s, N2)" % (strips, kt, stride, "7x7/2 stem as 4x4 over space-to-depth" if kt == 4
                                                              else "3x3 stride-2 conv of layer2")
     _hb(name, row="N2", bound="mfma", flops=2.0 * kt * kt * b * ci * co * ho * wo, bytes=4.0 * (x.numel() + y.numel()), split=True,
-        label=label, pmc=["conv3x3_split_kernel<%d, %d, %d>" % (strips, kt, stride)])
+        label=label, pmc=["conv3x3_split_kernel<%d, %d, %d," % (strips, kt, stride)])
     _lib.check(_lib.load().nmrf_conv_split_f32(_p(x), b, ci, h, w, _p(stats), 0 if stats is None else stats.shape[1], float(eps),
                                                _p(stream), kt, stride, pad, strips, groups, float(inv), co, _p(y), _stream()),
                "conv_split")
