@@ -49,28 +49,34 @@ class DPN(nn.Module):
         prob = K.dpn_filter_softmax(cost_volume, m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias)
         return prob, K.nms_topk(prob, self.num_proposals, self.eps)
 
-    def forward(self, cost_volume, fmap1_list, context=None):
-        """cost_volume: [B,G,D,H,W] (reference layout) or token-major [B*H*W,G,D].
+    def context(self, fmap):
+        """proj (Conv3x3 - IN - ReLU - Conv1x1, DPN.py:45-49) of the 1/8-resolution left feature map -> [B,Cctx,H,W]."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.proj.parameters()):
+            raise NotImplementedError("nmrf_amd implements the inference path only: call under torch.no_grad()")
+        if not hasattr(self, "_c3"):
+            self._c3 = {}
+        raw = K.conv3x3_auto(fmap, self.proj[0].weight, self._c3).contiguous()
+        w1 = self.proj[3].weight
+        import os
+        if os.environ.get("NMRF_CONV1X1", "1") != "0" and w1.shape[1] in (64, 128) and w1.shape[0] % 64 == 0:
+            from .nmp import _FusedCache                    # IN + ReLU folded into the 1x1 conv's operand load (csrc/conv1x1.hip)
+            if not hasattr(self, "_c1"):
+                self._c1 = _FusedCache()
+            return K.conv1x1_in_relu(raw, 0, w1.shape[1], K.instance_stats(raw), self._c1.get((w1,), lambda: K.pack_conv1x1(w1)))
+        return self.proj[3](K.instance_norm(raw, relu=True))     # conv3x3 - IN - ReLU fused
+
+    def forward(self, cost_volume, fmap1_list, context=None, context_ready=None):
+        """cost_volume: [B,G,D,H,W] (reference layout) or token-major [B*H*W,G,D].  context: [B,Cctx,H,W] precomputed by the
+        caller (possibly on another stream: context_ready = the event recorded behind it, waited for where it is first used).
         Returns (cost_volume [P,G,D], prob [P,D], label_seeds [P,N] float, labels [1,P,N])."""
         if cost_volume.dim() == 5:
             b, g, d, h, w = cost_volume.shape
             cost_volume = cost_volume.permute(0, 3, 4, 1, 2).reshape(b * h * w, g, d).contiguous()
         prob, seeds = self.seeds(cost_volume)
-        if context is None:                                   # [B,Cctx,H,W] may be precomputed by the caller
-            if torch.is_grad_enabled() and any(p.requires_grad for p in self.proj.parameters()):
-                raise NotImplementedError("nmrf_amd implements the inference path only: call under torch.no_grad()")
-            if not hasattr(self, "_c3"):
-                self._c3 = {}
-            raw = K.conv3x3_auto(fmap1_list[0], self.proj[0].weight, self._c3).contiguous()
-            w1 = self.proj[3].weight
-            import os
-            if os.environ.get("NMRF_CONV1X1", "1") != "0" and w1.shape[1] in (64, 128) and w1.shape[0] % 64 == 0:
-                from .nmp import _FusedCache                    # IN + ReLU folded into the 1x1 conv's operand load (csrc/conv1x1.hip)
-                if not hasattr(self, "_c1"):
-                    self._c1 = _FusedCache()
-                context = K.conv1x1_in_relu(raw, 0, w1.shape[1], K.instance_stats(raw), self._c1.get((w1,), lambda: K.pack_conv1x1(w1)))
-            else:
-                context = self.proj[3](K.instance_norm(raw, relu=True))     # conv3x3 - IN - ReLU fused
+        if context is None:
+            context = self.context(fmap1_list[0])
+        elif context_ready is not None:
+            torch.cuda.current_stream().wait_event(context_ready)
         context = context.permute(0, 2, 3, 1).contiguous()
         memory, seeds_f = self.propagation(cost_volume, seeds, context)
         outputs = self.prop_head(memory).view(-1, *seeds_f.shape)

@@ -185,7 +185,14 @@ class NMRF(nn.Module):
                 self._side_stream = torch.cuda.Stream(device=fmap1_list[0].device)
             side = self._side_stream
             side.wait_stream(main)
+        context, ctx_ready = None, None
         with torch.cuda.stream(side):
+            if overlap and os.environ.get("NMRF_CTX_SIDE", "1") != "0":
+                # the DPN context convs first: the seed stage (cost volume, conv1d + softmax, NMS: latency-bound) runs beside them
+                context = self.dpn.context(fmap1_list[0])
+                ctx_ready = torch.cuda.Event()
+                ctx_ready.record(side)
+                context.record_stream(main)
             heads8 = self._match_heads(fmap1_list[0], fmap2_list[0], self._head_cache8)
             heads4 = self._match_heads(fmap1_list[1], fmap2_list[1], self._head_cache4)
             if overlap:
@@ -193,7 +200,7 @@ class NMRF(nn.Module):
                     t.record_stream(main)
 
         cost_volume = K.cost_volume(fmap1_list[0], fmap2_list[0], self.max_disp // 8, self.dpn.cost_group)
-        _, prob, label_seeds, labels = self.dpn(cost_volume, fmap1_list)
+        _, prob, label_seeds, labels = self.dpn(cost_volume, fmap1_list, context=context, context_ready=ctx_ready)
         labels_curr = labels[-1]                                            # [P, N]
         if overlap:
             main.wait_stream(side)
