@@ -5,16 +5,22 @@
 
 // ------------------------------------------------------------------------------------------------
 // A2: group-wise correlation volume.  One block = one (b, g, y, 64-wide x tile).
-// The 64 channels of the group are streamed through LDS in chunks of CK: f1 tile [CK][64],
+// The channels of the group go through LDS in passes of CK (= all 64 of them at the shipped sizes: with 16 per pass the block
+// paid four exposed load latencies and eight barriers -- 50 us for 564 blocks): f1 tile [CK][64],
 // f2 tile [CK][64+D-1] (left halo, zero for x<0).  Wave w of the block owns disparities
 // {w, w+4, w+8, ...}; lane = x, so the f2 reads of one wave are consecutive LDS addresses.
 // ------------------------------------------------------------------------------------------------
-#define CV_CK 16
+#define CV_CK 64                           // channels staged per pass: a whole group at the shipped 256 / 4 (one load phase, one barrier pair)
 #define CV_TX 64
 #define CV_MAXD 64
 
+// DT: the number of disparities at compile time (0 = run-time D): the inner loop is then 1 LDS read with an immediate offset + 1
+// FMA per (channel, disparity) instead of ~5 instructions of predicates and address arithmetic (the kernel was bound by them).
+template <int DT>
 __global__ __launch_bounds__(256) void cost_volume_kernel(const float *__restrict__ f1, const float *__restrict__ f2,
-                                                          int C, int H, int W, int D, int G, float *__restrict__ vol) {
+                                                          int C, int H, int W, int D_rt, int G, float *__restrict__ vol) {
+    const int D = DT ? DT : D_rt;
+    constexpr int NJ = DT ? (DT + 3) / 4 : CV_MAXD / 4;
     __shared__ float s1[CV_CK][CV_TX];
     __shared__ float s2[CV_CK][CV_TX + CV_MAXD];
     const int x0 = blockIdx.x * CV_TX;
@@ -27,9 +33,9 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(const float *__restric
     const float *p1 = f1 + ((size_t)b * C + (size_t)g * cpg) * plane + (size_t)y * W;
     const float *p2 = f2 + ((size_t)b * C + (size_t)g * cpg) * plane + (size_t)y * W;
 
-    float acc[CV_MAXD / 4];
+    float acc[NJ];
 #pragma unroll
-    for (int j = 0; j < CV_MAXD / 4; ++j) acc[j] = 0.f;
+    for (int j = 0; j < NJ; ++j) acc[j] = 0.f;
 
     for (int c0 = 0; c0 < cpg; c0 += CV_CK) {
         __syncthreads();
@@ -45,25 +51,36 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(const float *__restric
             s2[c][xx] = (c0 + c < cpg && x >= 0 && x < W) ? p2[(size_t)(c0 + c) * plane + x] : 0.f;
         }
         __syncthreads();
+        const float *r2 = &s2[0][0] + lane + halo - wv;                     // disparity d = wv + 4 j sits 4 j floats below
 #pragma unroll 4
         for (int c = 0; c < CV_CK; ++c) {
             float a = s1[c][lane];
 #pragma unroll
-            for (int j = 0; j < CV_MAXD / 4; ++j) {
-                int d = wv + 4 * j;
-                if (d < D) acc[j] = fmaf(a, s2[c][lane + halo - d], acc[j]);
+            for (int j = 0; j < NJ; ++j) {
+                if (DT % 4 == 0 && DT) acc[j] = fmaf(a, r2[c * (CV_TX + CV_MAXD) - 4 * j], acc[j]);
+                else if (wv + 4 * j < D) acc[j] = fmaf(a, r2[c * (CV_TX + CV_MAXD) - 4 * j], acc[j]);
             }
         }
     }
-    const int x = x0 + lane;
-    if (x < W) {
+    // Output through LDS: a pixel's D values of this group are one contiguous run of vol; written straight from the registers
+    // (lane = x, one disparity per store) every store instruction hits 64 different lines for 4 bytes each.  The tile is
+    // transposed in LDS ([x][D + 1]: odd stride, conflict-free; it reuses s2) and written as runs of consecutive floats.
+    __syncthreads();                                                        // all waves are done reading s2
+    float *so = &s2[0][0];                                                  // 64 x (D + 1) <= CV_CK x (CV_TX + CV_MAXD) floats
+    const int sld = D + 1;
+    {
         const float inv = 1.0f / (float)cpg;
-        float *o = vol + ((((size_t)b * H + y) * W + x) * G + g) * D;
 #pragma unroll
-        for (int j = 0; j < CV_MAXD / 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             int d = wv + 4 * j;
-            if (d < D) o[d] = acc[j] * inv;
+            if (d < D) so[lane * sld + d] = acc[j] * inv;
         }
+    }
+    __syncthreads();
+    const int nx = W - x0 < CV_TX ? W - x0 : CV_TX;                         // pixels of this tile inside the row
+    for (int i = threadIdx.x; i < nx * D; i += 256) {
+        const int px = i / D, d = i - px * D;
+        vol[((((size_t)b * H + y) * W + x0 + px) * G + g) * D + d] = so[px * sld + d];
     }
 }
 
@@ -72,7 +89,13 @@ extern "C" int nmrf_cost_volume_f32(const float *f1, const float *f2, int B, int
     if (!f1 || !f2 || !vol) return NMRF_ENULL;
     if (B < 1 || C < 1 || H < 1 || W < 1 || G < 1 || C % G || D < 1 || D > CV_MAXD) return NMRF_EINVAL;
     dim3 grid((W + CV_TX - 1) / CV_TX, H, B * G);
-    hipLaunchKernelGGL(cost_volume_kernel, grid, dim3(256), 0, (hipStream_t)stream, f1, f2, C, H, W, D, G, vol);
+    hipStream_t st = (hipStream_t)stream;
+    switch (D) {                        // D_max / 8 of the shipped configs: 320, 256, 192
+        case 40: hipLaunchKernelGGL(cost_volume_kernel<40>, grid, dim3(256), 0, st, f1, f2, C, H, W, D, G, vol); break;
+        case 32: hipLaunchKernelGGL(cost_volume_kernel<32>, grid, dim3(256), 0, st, f1, f2, C, H, W, D, G, vol); break;
+        case 24: hipLaunchKernelGGL(cost_volume_kernel<24>, grid, dim3(256), 0, st, f1, f2, C, H, W, D, G, vol); break;
+        default: hipLaunchKernelGGL(cost_volume_kernel<0>, grid, dim3(256), 0, st, f1, f2, C, H, W, D, G, vol); break;
+    }
     return nmrf_launch_status();
 }
 

@@ -92,7 +92,7 @@ def cost_volume(f1, f2, num_disp, groups):
     b, c, h, w = f1.shape
     vol = torch.empty(b * h * w, groups, num_disp, device=f1.device, dtype=torch.float32)
     _hb("cost_volume", row="A2", bound="hbm", bytes=4.0 * (2 * f1.numel() + vol.numel()), flops=2.0 * b * h * w * num_disp * c,
-        label="cost_volume_kernel (group-wise correlation volume, A2)", pmc=["cost_volume_kernel"])
+        label="cost_volume_kernel (group-wise correlation volume, A2)", pmc=["cost_volume_kernel<"])
     _lib.check(_lib.load().nmrf_cost_volume_f32(_p(f1), _p(f2), b, c, h, w, num_disp, groups, _p(vol), _stream()),
                "cost_volume")
     _he("cost_volume")
