@@ -193,11 +193,11 @@ extern "C" int nmrf_dpn_filter_softmax_f32(const float *vol, const float *w0, co
 // ------------------------------------------------------------------------------------------------
 #define TK_MAXD 64
 struct TkQ {
-    float *v;       // [TK_MAXD][64]
+    float *v;       // [TK_MAXD][rows per block]
     int *i;
-    int lane;
-    __device__ __forceinline__ float &V(int j) { return v[j * 64 + lane]; }
-    __device__ __forceinline__ int &I(int j) { return i[j * 64 + lane]; }
+    int lane, ld;
+    __device__ __forceinline__ float &V(int j) { return v[j * ld + lane]; }
+    __device__ __forceinline__ int &I(int j) { return i[j * ld + lane]; }
 };
 __device__ __forceinline__ bool tk_gt(float xv, float yv) { return (isnan(xv) && !isnan(yv)) || (xv > yv); }
 
@@ -291,21 +291,25 @@ __device__ void tk_nth_element(TkQ q, int n, int nth) {
     tk_insertion_sort(q, first, last);
 }
 
+// RPB rows (pixels) per one-wave block.  A row's introselect is serial and data-dependent, so the 64 rows of a wave diverge and
+// the wave pays for the union of their paths (49 us for the 7 332 pixels of a KITTI pair = 115 waves on a chip with 8 192 wave
+// slots).  With fewer rows per wave -- down to one, on lane 0 -- the paths diverge less and the idle slots are used instead.
+template <int RPB>
 __global__ __launch_bounds__(64) void nms_topk_kernel(const float *__restrict__ prob, int64_t P, int D, int K, float eps,
                                                      int do_nms, int64_t *__restrict__ seeds) {
-    __shared__ float sv[TK_MAXD * 64];
-    __shared__ int si[TK_MAXD * 64];
+    __shared__ float sv[TK_MAXD * RPB];
+    __shared__ int si[TK_MAXD * RPB];
     const int lane = threadIdx.x;
-    const int64_t p0 = (int64_t)blockIdx.x * 64;
-    const int rows = (int)((P - p0) < 64 ? (P - p0) : 64);
+    const int64_t p0 = (int64_t)blockIdx.x * RPB;
+    const int rows = (int)((P - p0) < RPB ? (P - p0) : RPB);
     // coalesced staging: element (row r, bin j) of the tile is at linear index r*D + j
     for (int i = lane; i < rows * D; i += 64) {
         int r = i / D, j = i - r * D;
-        sv[j * 64 + r] = prob[(size_t)p0 * D + i];
+        sv[j * RPB + r] = prob[(size_t)p0 * D + i];
     }
     __syncthreads();
     if (lane >= rows) return;
-    TkQ q{sv, si, lane};
+    TkQ q{sv, si, lane, RPB};
     if (do_nms) {
         float prev = -INFINITY, cur = q.V(0);
         for (int j = 0; j < D; ++j) {
@@ -323,12 +327,21 @@ __global__ __launch_bounds__(64) void nms_topk_kernel(const float *__restrict__ 
     for (int j = 0; j < K; ++j) seeds[(size_t)(p0 + lane) * K + j] = (int64_t)q.I(j);
 }
 
+template <int RPB>
+static void launch_nms_topk(const float *prob, int64_t P, int D, int K, float eps, int do_nms, int64_t *seeds, hipStream_t st) {
+    hipLaunchKernelGGL(nms_topk_kernel<RPB>, dim3((unsigned)ceil_div64(P, RPB)), dim3(64), 0, st, prob, P, D, K, eps, do_nms, seeds);
+}
+
 extern "C" int nmrf_nms_topk_f32(const float *prob, int64_t P, int D, int K, float eps, int do_nms, int64_t *seeds,
                                  void *stream) {
     if (!prob || !seeds) return NMRF_ENULL;
     if (P < 1 || D < 1 || D > TK_MAXD || K < 1 || K > 8 || K > D || K * 64 <= D) return NMRF_EINVAL;
-    dim3 grid((unsigned)ceil_div64(P, 64));
-    hipLaunchKernelGGL(nms_topk_kernel, grid, dim3(64), 0, (hipStream_t)stream, prob, P, D, K, eps, do_nms, seeds);
+    hipStream_t st = (hipStream_t)stream;
+    // as few rows per wave as keeps the launch within one generation of ~8k resident waves
+    if (P <= 8192) launch_nms_topk<1>(prob, P, D, K, eps, do_nms, seeds, st);
+    else if (P <= 4 * 8192) launch_nms_topk<4>(prob, P, D, K, eps, do_nms, seeds, st);
+    else if (P <= 16 * 8192) launch_nms_topk<16>(prob, P, D, K, eps, do_nms, seeds, st);
+    else launch_nms_topk<64>(prob, P, D, K, eps, do_nms, seeds, st);
     return nmrf_launch_status();
 }
 
