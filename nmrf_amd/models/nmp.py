@@ -560,8 +560,16 @@ class Inference(nn.Module):
                 x = self._ffn(wcc, 160)
                 enc = K.fourier_embed(labels_flat, self.normalizer, 32)
             else:
-                x = self._ffn(wcc, 160, out=torch.zeros(tp, self.dim, device=wcc.device), out_map=to_p)
-                enc = K.fourier_embed(labels_flat, self.normalizer, 32, out=torch.zeros(tp, 32, device=wcc.device), out_map=to_p)
+                # the padded grids are persistent: their padding rows are zeroed once and never written (the row maps only address
+                # real tokens), the interior is overwritten by every forward -- no fill kernels on the hot path
+                gkey = (tp, wcc.device)
+                if not hasattr(self, "_grids"):
+                    self._grids = {}
+                if gkey not in self._grids:
+                    self._grids[gkey] = (torch.zeros(tp, self.dim, device=wcc.device), torch.zeros(tp, 32, device=wcc.device))
+                xbuf, ebuf = self._grids[gkey]
+                x = self._ffn(wcc, 160, out=xbuf, out_map=to_p)
+                enc = K.fourier_embed(labels_flat, self.normalizer, 32, out=ebuf, out_map=to_p)
             t_dense = dims[0] * dims[1] * dims[2] * dims[3]
             return self._run_blocks(x, enc, pdims, to_d, t_dense)
         x = self.ffn(wcc)

@@ -165,3 +165,32 @@ def test_shard_range_partitions_exactly():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [e - b for b, e in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_stem_space_to_depth_weight_is_the_same_convolution():
+    """nmrf_amd.kernels.stem_s2d_weight: the 7x7 / stride-2 / pad-3 stem equals a 4x4 / stride-1 convolution (pad 2 before, 1
+    after) over the 2x2 space-to-depth image with the transformed filter -- checked in fp64 on the CPU (the HIP path runs
+    exactly this reformulation, tests/test_hip_kernels.py::test_stem_space_to_depth)."""
+    import torch.nn.functional as F
+    from nmrf_amd.kernels import stem_s2d_weight
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 3, 24, 40, generator=g, dtype=torch.float64)
+    w = torch.randn(8, 3, 7, 7, generator=g, dtype=torch.float64)
+    ref = F.conv2d(x, w, None, 2, 3)
+    s2d = torch.zeros(2, 16, 12, 20, dtype=torch.float64)
+    s2d[:, :12] = F.pixel_unshuffle(x, 2)
+    got = F.conv2d(F.pad(s2d, (2, 1, 2, 1)), stem_s2d_weight(w))
+    assert got.shape == ref.shape and float((got - ref).abs().max()) < 1e-12
+    assert float(stem_s2d_weight(w)[:, 12:].abs().max()) == 0.0
+
+
+def test_conv_plan_covers_the_backbone_channel_counts():
+    """(strips, groups) of the direct conv: strips * groups * 32 == Co for every channel count of the CNN encoder and the heads;
+    four strips only when the launch still fills the chip; unsupported counts fall back (None)."""
+    from nmrf_amd.kernels import _conv3_plan
+    for co in (64, 96, 128, 192, 256, 384):
+        for tiles in (30, 240, 960, 5000):
+            strips, groups = _conv3_plan(co, tiles)
+            assert strips in (2, 3, 4) and strips * groups * 32 == co
+    assert _conv3_plan(256, 240) == (4, 2) and _conv3_plan(256, 60) == (2, 4) and _conv3_plan(128, 240) == (2, 2)
+    assert _conv3_plan(32, 100) is None and _conv3_plan(160, 100) is None
