@@ -236,7 +236,7 @@ def test_window_attention(b, hp, wp, n, win, shift, sib):
     report("window_attn", got, ref.reshape(tkn, 128), 2e-5, 1e-5)
 
 
-@pytest.mark.parametrize("b,h,w,n", [(2, 6, 70, 4), (1, 9, 33, 1), (1, 47, 156, 4)])
+@pytest.mark.parametrize("b,h,w,n", [(2, 6, 70, 4), (1, 9, 33, 1), (1, 47, 156, 4), (2, 94, 312, 1), (2, 5, 64, 2), (1, 3, 36, 4)])
 def test_warp_corr_concat(b, h, w, n):
     f1, f2 = rnd(b, 64, h, w, seed=1), rnd(b, 64, h, w, seed=2)
     g1, g2 = rnd(b, 256, h, w, seed=3), rnd(b, 256, h, w, seed=4)
