@@ -149,6 +149,18 @@ def test_nms_topk_random_ties_match_aten_cpu():
     assert torch.equal(K().nms_topk(p.to(DEV), 4, 1e-3).cpu(), O.nms_topk(p, 4, 1e-3))
 
 
+@pytest.mark.parametrize("rows", [8192, 8193, 20000, 40000, 140000])
+def test_nms_topk_every_rows_per_wave_variant(rows):
+    """The launcher picks 1 / 4 / 16 / 64 rows per wave by problem size (csrc/seed.hip): every variant against ATen's CPU top-k on
+    tie-rich rows, and with the suppression against the oracle."""
+    gen = torch.Generator().manual_seed(rows)
+    x = torch.randint(0, 5, (rows, 40), generator=gen).float()
+    x[::4] = torch.rand(x[::4].shape, generator=gen)
+    assert torch.equal(K().nms_topk(x.to(DEV), 4, 0.0, do_nms=False).cpu(), torch.topk(x, 4, dim=-1).indices)
+    p = torch.softmax(x[:6000] * 2.0, -1).repeat((rows + 5999) // 6000, 1)[:rows].contiguous()
+    assert torch.equal(K().nms_topk(p.to(DEV), 4, 1e-3).cpu(), O.nms_topk(p, 4, 1e-3))
+
+
 def test_nms_topk_on_reference_prob_gives_reference_seeds():
     for name in ("e2e_a", "e2e_b", "e2e_c"):
         g = golden(name)
