@@ -755,9 +755,13 @@ extern "C" int nmrf_window_attn_f32(const float *qkv, const float *table, int B,
     if ((int64_t)B * Hp * Wp * N * 3 * C < ((int64_t)1 << 32)) {                            // 32-bit element offsets
         if (win == 6 && N == 4) return launch_window_fast<5, 6, 4, 2, 3>(qkv, table, g, B, out, st);   // inference windows
 #ifdef NMRF_DEBUG_PROBES
-        if (win == 4 && N == 1 && g_window_pack1) return launch_window_fast<1, 4, 1, 8, 2, 1>(qkv, table, g, B, out, st);
+        if (win == 4 && N == 1 && g_window_pack1 == 1) return launch_window_fast<1, 4, 1, 8, 2, 1>(qkv, table, g, B, out, st);
+        if (win == 4 && N == 1 && g_window_pack1 == 2) return launch_window_fast<1, 4, 1, 8, 2, 2>(qkv, table, g, B, out, st);
+        if (win == 4 && N == 1 && g_window_pack1 == 3) return launch_window_fast<1, 4, 1, 2, 3, 2>(qkv, table, g, B, out, st);
+        if (win == 4 && N == 1 && g_window_pack1 == 4) return launch_window_fast<1, 4, 1, 8, 1, 2>(qkv, table, g, B, out, st);
 #endif
-        if (win == 4 && N == 1) return launch_window_fast<1, 4, 1, 8, 2, 2>(qkv, table, g, B, out, st);   // refinement windows, two per tile
+        // refinement windows, two per tile, four tiles per block (three blocks per CU: 24.0 us; eight tiles per block: 26.6 us)
+        if (win == 4 && N == 1) return launch_window_fast<1, 4, 1, 4, 3, 2>(qkv, table, g, B, out, st);
     }
     switch (nkt) {                                                                         // any other configuration
         case 1: return launch_window<1>(qkv, table, g, B, out, st);

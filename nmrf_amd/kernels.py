@@ -246,13 +246,14 @@ def window_attn(qkv, table, b, hp, wp, n, heads, win, shift, sibling_mask):
     assert t == b * hp * wp * n
     out = torch.empty(t, c, device=qkv.device, dtype=torch.float32)
     tw = win * win * n                                 # reference form: 5 contractions of tw^2 x 32 MACs per (window, head)
-    fast = {(6, 4): "window_attn_fast_kernel<5, 6, 4, 2, 3, false>", (4, 1): "window_attn_fast_kernel<1, 4, 1, 8, 2, false>"}
+    fast = {(6, 4): "window_attn_fast_kernel<5, 6, 4, 2, 3,", (4, 1): "window_attn_fast_kernel<1, 4, 1, 4, 3,"}
     _hb("window_attn_w%d_n%d" % (win, n), row="A10" if n > 1 else "A13", bound="mfma", split=True,
         flops=b * (hp // win) * (wp // win) * heads * 5 * 2.0 * tw * tw * 32, bytes=4.0 * (qkv.numel() + t * c),
         label="%s (%s windows, %s)" % (fast.get((win, n), "window_attn_kernel<%d>" % ((tw + 31) // 32)).split("<")[0] +
                                        "<win %d, N %d>" % (win, n), "inference" if n > 1 else "refinement",
                                        "A10" if n > 1 else "A13"),
-        pmc=[fast.get((win, n), "window_attn_kernel<%d>" % ((tw + 31) // 32))])
+        pmc=[fast.get((win, n), "window_attn_kernel<%d>" % ((tw + 31) // 32))] + (["window_attn_fast_kernel<1, 4, 1, 8, 2, false, 2>"]
+                                                                                    if (win, n) == (4, 1) else []))
     _lib.check(_lib.load().nmrf_window_attn_f32(_p(qkv), _p(table), b, hp, wp, n, c, heads, win, shift,
                                                 int(bool(sibling_mask)), _p(out), _stream()), "window_attn")
     _he("window_attn_w%d_n%d" % (win, n))

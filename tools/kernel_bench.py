@@ -150,8 +150,10 @@ if "refine" in which:
     for shift in (0, 2):
         timeit("window_attn 4x4x1 shift=%d" % shift, lambda: K.window_attn(qkv, table, b, hp, wp, 1, 4, 4, shift, False))
     _l.nmrf_debug_window_pack1.restype = ctypes.c_int
-    _l.nmrf_debug_window_pack1(1)
-    timeit("window_attn 4x4x1 shift=0, ONE window per tile", lambda: K.window_attn(qkv, table, b, hp, wp, 1, 4, 4, 0, False))
+    for var, tag in ((1, "ONE window per tile"), (2, "8 tiles per block, launch bound 2"), (3, "2 tiles per block"),
+                     (4, "8 tiles per block, launch bound 1")):
+        _l.nmrf_debug_window_pack1(var)
+        timeit("window_attn 4x4x1 shift=0, " + tag, lambda: K.window_attn(qkv, table, b, hp, wp, 1, 4, 4, 0, False))
     _l.nmrf_debug_window_pack1(0)
 if "warp" in which:
     f1, f2 = mk("f1", b, 64, h, w), mk("f2", b, 64, h, w)
