@@ -316,7 +316,9 @@ struct WinFastLds {
     // pixels (NL == 4), whose rows differ by 1..3 or wrap by SPAN - WIN + {1, 2}: distinct mod 16 as well.  (The first layout,
     // row-major with the chunks XOR-swizzled by row & 7, measured a conflict ratio of 0.40 / 0.47: rows 8 apart collided.)
     static constexpr int GB = (2 * WIN - 1 + 3) / 4;
-    static constexpr int POSN = WIN == 4 ? GB * GB * 16 : R;
+    // (+ 1: consecutive chunks of one row then sit 16 bytes apart modulo the 256-byte bank row, so the eight lanes that stage a
+    //  row write eight different slots; the reads at a fixed chunk keep their bijection)
+    static constexpr int POSN = WIN == 4 ? GB * GB * 16 + 1 : R;
     static constexpr int TP = NKT * 32;
     static constexpr bool QLDS = NKT > 1;
     static constexpr int SLOT = 2 * W2 * TS + 32 + (QLDS ? NKT * 16 * 64 : 0) + TP;   // floats per window slot
