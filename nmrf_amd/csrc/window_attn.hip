@@ -681,12 +681,14 @@ template <int NKT, int WIN, int NL, int WPB, int OCC, int PK = 1>
 static int launch_window_fast(const float *qkv, const float *table, const WinGeom &g, int B, float *out, hipStream_t st) {
     using L = WinFastLds<NKT, WIN, NL, WPB, PK>;
     static_assert(L::BYTES <= 160 * 1024, "LDS budget of one CU");
-    static bool attr_done = false;      // set once per instantiation, outside any stream capture
-    if (L::BYTES > 64 * 1024 && !attr_done) {
-        attr_done = true;
+    static bool attr_set_dev[NMRF_MAX_DEV] = {};      // set once per instantiation and device, outside any stream capture
+    const int dev = nmrf_cur_device();
+    if (dev < 0) return NMRF_ELAUNCH;
+    if (L::BYTES > 64 * 1024 && !attr_set_dev[dev]) {
         if (hipFuncSetAttribute((const void *)window_attn_fast_kernel<NKT, WIN, NL, WPB, OCC, false, PK>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES) != hipSuccess)
             return NMRF_ELAUNCH;
+        attr_set_dev[dev] = true;
     }
     const int nwin = (g.Hp / WIN) * (g.Wp / WIN);
     dim3 grid((nwin + WPB * PK - 1) / (WPB * PK), g.heads, B);
@@ -700,12 +702,14 @@ static int launch_window(const float *qkv, const float *table, const WinGeom &g,
     const int TP = NKT * 32, W2 = g.win * g.win;
     size_t smem = (size_t)(2 * g.R * 32 + 2 * W2 * TP) * sizeof(float) + (size_t)TP * sizeof(int);
     if (smem > 160 * 1024) return NMRF_EINVAL;
-    static bool attr_done = false;      // set once per instantiation, outside any stream capture
-    if (smem > 64 * 1024 && !attr_done) {
-        attr_done = true;
+    static size_t attr_smem_dev[NMRF_MAX_DEV] = {};   // largest request so far per device (the size depends on the geometry)
+    const int dev = nmrf_cur_device();
+    if (dev < 0) return NMRF_ELAUNCH;
+    if (smem > 64 * 1024 && smem > attr_smem_dev[dev]) {
         if (hipFuncSetAttribute((const void *)window_attn_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem) != hipSuccess)
             return NMRF_ELAUNCH;
+        attr_smem_dev[dev] = smem;
     }
     dim3 grid((g.Hp / g.win) * (g.Wp / g.win), g.heads, B);
     hipLaunchKernelGGL((window_attn_kernel<NKT>), grid, dim3(64 * NKT), smem, st, qkv, table, g,

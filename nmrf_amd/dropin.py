@@ -51,6 +51,15 @@ def _extension_module():
     return m
 
 
+def _have(name):
+    if name in sys.modules:
+        return True
+    try:
+        return importlib.util.find_spec(name) is not None
+    except (ImportError, ValueError):
+        return False
+
+
 class _AliasLoader(importlib.abc.Loader):
     def __init__(self, target):
         self.target = target
@@ -58,10 +67,17 @@ class _AliasLoader(importlib.abc.Loader):
     def create_module(self, spec):
         if self.target is None:
             return _extension_module()
-        return importlib.import_module(self.target)         # the very same module object under a second name
+        mod = importlib.import_module(self.target)          # the very same module object under a second name
+        self._identity = (mod.__spec__, getattr(mod, "__loader__", None), getattr(mod, "__package__", None))
+        return mod
 
     def exec_module(self, module):
-        pass
+        # importlib's module_from_spec() has just stamped the ALIAS spec / loader / package on the real nmrf_amd module
+        # (_init_module_attrs with override for __spec__): put its own identity back, so that its relative imports keep
+        # resolving inside nmrf_amd (no ImportWarning about __package__ != __spec__.parent) and importlib.reload works
+        ident = getattr(self, "_identity", None)
+        if ident is not None:
+            module.__spec__, module.__loader__, module.__package__ = ident
 
 
 class _PatchLoader(importlib.abc.Loader):
@@ -90,7 +106,7 @@ class DropinFinder(importlib.abc.MetaPathFinder):
             return importlib.machinery.ModuleSpec(fullname, _AliasLoader(ALIASES[fullname]), is_package=is_pkg)
         if fullname == EXTENSION:
             return importlib.machinery.ModuleSpec(fullname, _AliasLoader(None))
-        if fullname == "nmrf.config" and importlib.util.find_spec("yacs") is None:
+        if fullname == "nmrf.config" and not _have("yacs"):
             return importlib.machinery.ModuleSpec(fullname, _AliasLoader("nmrf_amd.config"), is_package=True)
         if fullname == PATCHED and not self._busy:
             self._busy = True

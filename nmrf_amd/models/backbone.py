@@ -138,8 +138,8 @@ def create_backbone(cfg):
         return Backbone(cfg.BACKBONE.OUT_CHANNELS, cfg.BACKBONE.NORM_FN)
     if kind == "swin":
         from .swin_neck import SwinAdaptor
-        if cfg.BACKBONE.DROP_PATH != 0:
-            raise NotImplementedError("inference build: BACKBONE.DROP_PATH must be 0 (stochastic depth is training-only)")
+        # both shipped Swin-T configs set DROP_PATH 0.4 (configs/sceneflow_swint.yaml): stochastic depth is the identity under
+        # model.eval(), the only mode this build runs (NMRF.forward raises in training mode), so the rate is accepted and unused
         backbone = SwinAdaptor(cfg.BACKBONE.OUT_CHANNELS, cfg.BACKBONE.DROP_PATH)
         if cfg.BACKBONE.WEIGHT_URL:                   # pretrained Swin-T trunk (nmrf/models/backbone.py:188-196)
             weight = checkpoint_filter_fn(torch.load(cfg.BACKBONE.WEIGHT_URL, map_location="cpu"))

@@ -562,7 +562,10 @@ class Inference(nn.Module):
             else:
                 # the padded grids are persistent: their padding rows are zeroed once and never written (the row maps only address
                 # real tokens), the interior is overwritten by every forward -- no fill kernels on the hot path
-                gkey = (tp, wcc.device)
+                # keyed like the row maps (geometry, not size): two inputs with the same padded size but different padding
+                # (KITTI 1242x375 vs 1224x370 -> both 48x156 cells) must not share a buffer, or the rows that were real tokens of
+                # the first become non-zero "padding" of the second
+                gkey = (dims, win, str(wcc.device))
                 if not hasattr(self, "_grids"):
                     self._grids = {}
                 if gkey not in self._grids:

@@ -289,7 +289,7 @@ def nms_topk(prob, k, eps):
 # --------------------------------------------------------------------------- #
 def fourier_embed(coord, normalizer, n_freq=15):
     c = coord.unsqueeze(-1) * normalizer
-    f = c * (2.0 ** torch.arange(n_freq, dtype=torch.float32))
+    f = c * (2.0 ** torch.arange(n_freq, dtype=coord.dtype))
     return torch.cat((f.sin(), f.cos(), c), -1)
 
 
@@ -311,7 +311,7 @@ def seed_embed(cv, seeds, w):
     cost = sample_cost(cv, seeds)
     feat = F.linear(F.gelu(_lin(cost, w, pre + ".cost_encoder.0")), w[pre + ".cost_encoder.2.weight"],
                     w[pre + ".cost_encoder.2.bias"])
-    enc = fourier_embed(seeds.float(), 3.14 / 64)
+    enc = fourier_embed(seeds.to(cv.dtype), 3.14 / 64)
     return F.linear(torch.cat((feat, enc), -1), w[pre + ".proj.weight"])
 
 
@@ -405,8 +405,8 @@ def warp_row(fmap, disp):
     Weights follow ATen's vectorised CPU kernel: w=ix-floor(ix), e=1-w, ..."""
     b, c, h, wd = fmap.shape
     n = disp.shape[-1]
-    xs = torch.arange(wd, dtype=torch.float32).view(1, 1, wd, 1)
-    ys = torch.arange(h, dtype=torch.float32).view(1, h, 1, 1).expand(1, h, wd, 1)
+    xs = torch.arange(wd, dtype=fmap.dtype).view(1, 1, wd, 1)
+    ys = torch.arange(h, dtype=fmap.dtype).view(1, h, 1, 1).expand(1, h, wd, 1)
     gx = 2 * (xs + (-disp)) / (wd - 1) - 1
     gy = (2 * (ys + torch.zeros_like(disp)) / (h - 1) - 1)
     ix = (gx + 1) * ((wd - 1) / 2)
@@ -661,7 +661,7 @@ def hot_path(w, cfg, feats8, feats4, pad_hw, out_hw, stages=None):
     seeds = nms_topk(prob, n, cfg.eps)
     ctx = conv_head(l8, w, "dpn.proj").permute(0, 2, 3, 1)
     mem = propagation(cv, seeds, ctx, w, cfg, dims8, stages)
-    labels = F.relu(_relu_mlp(mem, w, "dpn.prop_head").view(-1, n) + seeds.float())
+    labels = F.relu(_relu_mlp(mem, w, "dpn.prop_head").view(-1, n) + seeds.to(mem.dtype))
 
     f1, f2 = conv_head(l8, w, "concatconv"), conv_head(r8, w, "concatconv")
     g1, g2 = conv_head(l8, w, "gw"), conv_head(r8, w, "gw")
@@ -677,7 +677,7 @@ def hot_path(w, cfg, feats8, feats4, pad_hw, out_hw, stages=None):
     out = {
         "proposal": labels.view(b, -1, n),
         "prob": prob,
-        "initial_proposal": seeds.float().view(b, -1, n),
+        "initial_proposal": seeds.to(mem.dtype).view(b, -1, n),
         "disp": disp,
         "disp_pred": pred,
     }

@@ -111,3 +111,52 @@ def test_without_the_hook_the_checkout_wins():
         r = subprocess.run([sys.executable, os.path.join(tmp, "inference.py")], capture_output=True, text=True,
                            env=dict(os.environ, PYTHONPATH=ROOT), cwd="/", timeout=300)
         assert r.returncode != 0 and "must be shadowed" in r.stderr
+
+
+REAL_CHECKOUT = "/root/reference"
+REAL_DRIVER = """
+import os, sys, warnings
+sys.path.insert(0, {root!r})
+from tools import refshim
+refshim.install(third_party_only=True)        # timm / yacs / cv2 / torchvision stand-ins: the user's environment, not the checkout
+import nmrf_amd.dropin as D
+D.install()
+sys.path.insert(0, {ref!r})                   # what `python inference.py` does with the script directory
+warnings.simplefilter("error", ImportWarning)
+for script, lo, hi in (("inference.py", 7, 12), ("main.py", 14, 19)):
+    src = "\\n".join(open(os.path.join({ref!r}, script)).read().splitlines()[lo - 1:hi])
+    assert "build_model" in src, src
+    ns = {{}}
+    exec(compile(src, script, "exec"), ns)
+    print(script, ns["build_model"].__module__)
+import nmrf.config, nmrf.utils.frame_utils as fu
+print("config", nmrf.config.__file__)
+print("frame_utils", fu.__file__, hasattr(fu, "InputPadder"), fu.downsample_disp.__module__)
+cfg = ns["get_cfg"]() if "get_cfg" in ns else nmrf.config.get_cfg()
+cfg.freeze()
+model, criterion = ns["build_model"](cfg)
+print("model", type(model).__module__, criterion, sum(p.numel() for p in model.parameters()))
+import nmrf_amd.models.nmp as nmp, importlib
+print("identity", nmp.__spec__.name, nmp.__package__)
+importlib.reload(nmp)
+"""
+
+
+def test_real_checkout_import_lines_resolve_through_the_hook():
+    """Build container only (the reference never travels: skipped where /root/reference is absent).  The actual import lines of
+    the reference's inference.py:7-12 and main.py:14-19 are executed against the REAL checkout with the hook installed:
+    nmrf.models / ops come from nmrf_amd, nmrf.config / nmrf.data / nmrf.utils from the checkout, build_model(cfg) takes the
+    checkout's own yacs config and returns this build's NMRF (6 113 210 parameters); the aliased modules keep their
+    own __spec__ (no ImportWarning, importlib.reload works)."""
+    import pytest
+    if not os.path.isfile(os.path.join(REAL_CHECKOUT, "inference.py")):
+        pytest.skip("no reference checkout on this machine")
+    r = subprocess.run([sys.executable, "-c", REAL_DRIVER.format(root=ROOT, ref=REAL_CHECKOUT)], capture_output=True, text=True,
+                       cwd="/", timeout=300, env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = dict(line.split(" ", 1) for line in r.stdout.strip().splitlines())
+    assert out["inference.py"] == "nmrf_amd.models" and out["main.py"] == "nmrf_amd.models"
+    assert out["config"] == os.path.join(REAL_CHECKOUT, "nmrf", "config", "__init__.py")
+    assert out["frame_utils"] == "%s True nmrf_amd.frame_utils" % os.path.join(REAL_CHECKOUT, "nmrf", "utils", "frame_utils.py")
+    assert out["model"] == "nmrf_amd.models.nmrf None 6113210"
+    assert out["identity"] == "nmrf_amd.models.nmp nmrf_amd.models"

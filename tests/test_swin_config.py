@@ -70,3 +70,19 @@ def test_swin_model_on_gpu():
     assert out["disp"].shape == (1, 60, 90) and torch.isfinite(out["disp"]).all()
     mism = (out["initial_proposal"].cpu().long() != t(g["seeds"]).long()).any(-1).float().mean()
     assert mism < 0.05, f"{float(mism)} of the pixels changed seeds through the GPU encoder"
+
+
+def test_shipped_swint_yaml_keys_build_verbatim():
+    """configs/sceneflow_swint.yaml and kitti_mix_train_swint.yaml of the reference set BACKBONE.DROP_PATH 0.4; stochastic depth is
+    the identity in eval mode, so build_model must accept the keys exactly as shipped (it used to raise)."""
+    from nmrf_amd.config import get_cfg
+    from nmrf_amd.models import build_model
+    cfg = get_cfg()
+    cfg.merge_from_list(["DATASETS.DIVIS_BY", 32, "BACKBONE.MODEL_TYPE", "swin", "BACKBONE.OUT_CHANNELS", 128,
+                         "BACKBONE.DROP_PATH", 0.4, "BACKBONE.COMPAT", False])
+    cfg.freeze()
+    model, criterion = build_model(cfg)
+    assert criterion is None and hasattr(model, "image_encoder") and model.divis_by == 32
+    model.eval()
+    with pytest.raises(NotImplementedError):
+        model.train()({"img1": torch.zeros(1, 3, 32, 32), "img2": torch.zeros(1, 3, 32, 32)})

@@ -136,7 +136,10 @@ class _CfgNode(dict):
             node[parts[-1]] = val
 
 
-def install():
+def install(third_party_only=False):
+    """third_party_only=True: only the stand-ins for timm / yacs / omegaconf / cv2 / imageio / termcolor (what a user's
+    environment would provide) -- no MSDA stand-in and no sys.path entry: tests/test_dropin_cpu.py uses this to run the real
+    checkout's import lines through nmrf_amd.dropin."""
     if "nmrf" in sys.modules and getattr(sys.modules["nmrf"], "__file__", "").startswith(REF):
         return
     timm = _mod("timm")
@@ -162,6 +165,19 @@ def install():
     tc = _mod("termcolor")
     tc.colored = lambda s, *a, **k: s
 
+    if "torchvision" not in sys.modules:
+        try:
+            import torchvision  # noqa: F401
+        except ImportError:                                  # nmrf/utils/misc.py:23-24, nmrf/data/transforms.py:14: names only
+            tv = _mod("torchvision")
+            tv.__version__ = "0.20.0"
+            tvt = _mod("torchvision.transforms")
+            tvt.ColorJitter = tvt.Compose = type("_Unused", (), {"__init__": lambda self, *a, **k: None})
+            tvt.functional = _mod("torchvision.transforms.functional")
+            tv.transforms = tvt
+
+    if third_party_only:
+        return
     msda = _mod("MultiScaleDeformableAttention")
 
     def _fwd(value, shapes, lvl_start, loc, w, im2col_step):
