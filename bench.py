@@ -1,8 +1,12 @@
 #!/usr/bin/env python
 """Throughput bench of the NMRF-Stereo inference hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W                     # N > 1: starts its own N workers (one per GPU), like
+                                                                      # the reference's launcher (main.py:87-144, mp.start_processes)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W   # same workers
+
+Without a GPU (build container) `--gpus N` still runs: N gloo ranks on CPU with a stand-in forward -- launcher / batch split /
+gather plumbing only, the JSON line says `"valid": false`.
 
 A "step" = one NMRF.forward (backbone + hot path) over one batch of synthetic stereo pairs already
 resident in HBM (BASELINE.json configs[1]: KITTI 1242x375, batch 1 per GPU, CNN backbone, 5/5/5
@@ -31,7 +35,7 @@ SPLIT_MFMA_PEAK_TFLOPS = FP16_MFMA_PEAK_TFLOPS / 3     # split-operand kernels e
 HBM_PEAK_GBS = 8000.0                # same guide: HBM3E ~8 TB/s
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -48,7 +52,8 @@ def parse():
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL result gather at N>1")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find mode)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the result gather even at N=1 (smoke)")
-    return ap.parse_args()
+    ap.add_argument("--sync-gather", action="store_true", help="gather on the compute stream inside every step (round-2 behaviour)")
+    return ap.parse_args(argv)
 
 
 class KernelTimer:
@@ -121,14 +126,92 @@ def cpu_baseline(height, width, infer_layers, max_disp=320):
                       % (width, height, nthr, dt, dt1, cores)}
 
 
-def main():
-    args = parse()
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _worker(local_rank, world, port, argv):
+    """One rank of a self-launched job (the counterpart of main.py:147-180 `_distributed_worker`)."""
+    os.environ.update(RANK=str(local_rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    run(parse(argv))
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N`: no torchrun around us -> start the N workers ourselves (spawn, one per GPU); rank 0 prints
+        if torch.cuda.is_available() and torch.cuda.device_count() < args.gpus:
+            raise SystemExit("--gpus %d but only %d visible" % (args.gpus, torch.cuda.device_count()))
+        import torch.multiprocessing as mp
+        mp.start_processes(_worker, args=(args.gpus, _free_port(), argv), nprocs=args.gpus, join=True, start_method="spawn")
+        return
+    run(args)
+
+
+def run_plumbing(args, rank, world):
+    """No GPU on this host: the launcher, the batch split and the result gather on `world` gloo ranks with a stand-in forward
+    (the product has no CPU path and none is faked: the JSON line carries "valid": false)."""
+    import torch.distributed as dist
+    from nmrf_amd.parallel import OverlappedGather, shard_range
+    from nmrf_amd.utils.hashinit import synthetic_pair
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    b = args.batch
+    lo, hi = shard_range(world * b, rank, world)
+    h, w = min(args.height, 48), min(args.width, 96)
+    pairs = [synthetic_pair(h, w, seed=1000 + i)[:2] for i in range(lo, hi)]
+    img1, img2 = torch.stack([p[0] for p in pairs]), torch.stack([p[1] for p in pairs])
+    gath = OverlappedGather()
+    step = lambda: gath.submit((img1.mean(1) - img2.mean(1)).abs())
+    for _ in range(max(args.warmup, 1)):
+        out = step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    want = torch.stack([(lambda p: (p[0].mean(0) - p[1].mean(0)).abs())(synthetic_pair(h, w, seed=1000 + i)[:2]) for i in range(world * b)])
+    ok = bool(torch.equal(out, want))                       # every rank holds all disparities, in rank order
+    if rank == 0:
+        print(json.dumps({"metric": "stereo pairs/sec at %dx%d" % (args.width, args.height), "value": None,
+                          "unit": "stereo pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic", "valid": False,
+                          "config": {"workload": "PLUMBING ONLY: no GPU on this host, stand-in forward on %d gloo ranks (launcher, batch "
+                                                 "split, result gather); not a measurement" % world,
+                                     "global_batch": world * b, "parallelism": "batch-shard x%d" % world, "launch": "cpu stand-in",
+                                     "result_gather": world > 1, "gather_correct": ok}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("gathered result differs from the single-process result")
+
+
+def run(args):
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        if world == 1:
+            raise SystemExit("bench.py needs an MI355X: the NMRF hot path has no CPU path (only `--gpus N`, N > 1, runs its "
+                             "launcher / gather plumbing on gloo without one)")
+        return run_plumbing(args, rank, world)
     import torch.distributed as dist
     if args.miopen_find:
         torch.backends.cudnn.benchmark = True
@@ -144,7 +227,7 @@ def main():
     from nmrf_amd import kernels as K
     from nmrf_amd.config import get_cfg
     from nmrf_amd.models import build_model
-    from nmrf_amd.parallel import gather_disparity
+    from nmrf_amd.parallel import OverlappedGather, gather_disparity
     from nmrf_amd.utils.hashinit import apply_hash_weights, synthetic_pair
 
     cfg = get_cfg()
@@ -165,13 +248,15 @@ def main():
     def forward():
         return model(sample)["disp"]
 
+    overlapped = OverlappedGather()                           # the gather rides a side stream behind the next step's compute
+
     def gather(disp):
         if use_dist and not args.no_gather:
             if world == 1:                                    # --force-dist smoke: the collective on a 1-rank group
                 g = torch.empty_like(disp)
                 dist.all_gather_into_tensor(g, disp.contiguous())
                 return g
-            return gather_disparity(disp)
+            return gather_disparity(disp) if args.sync_gather else overlapped.submit(disp)
         return disp
 
     def step():
@@ -208,6 +293,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             run()
+        overlapped.finish()                                   # every gather of the timed steps has landed inside the timed region
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -216,6 +302,19 @@ def main():
             tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
+        # the collective alone ("report the gather time separately"): 10 back-to-back all-gathers of one step's output
+        gather_ms = None
+        if use_dist and world > 1 and not args.no_gather:
+            d0 = static_out if graph is not None else forward()
+            gather_disparity(d0)
+            torch.cuda.synchronize()
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g0.record()
+            for _ in range(10):
+                gather_disparity(d0)
+            g1.record()
+            torch.cuda.synchronize()
+            gather_ms = g0.elapsed_time(g1) / 10
 
         # dominant hand-written kernel, timed live with HIP events on its launching stream (eager launches,
         # same inputs, right after the timed region so clocks/caches are in the same state)
@@ -228,6 +327,7 @@ def main():
         n_timed_fwd = max(3, min(args.steps, 10))
         for _ in range(n_timed_fwd):
             step()
+        overlapped.finish()
         torch.cuda.synchronize()
         timer.enabled = False
         if prev_overlap is None:
@@ -257,25 +357,34 @@ def main():
         # end-to-end figure with fresh inputs per step: the double-buffered driver (nmrf_amd/driver.py) fed from HOST
         # memory -- H2D of the next batch and D2H of the previous one overlap the compute, eager launches (no hipGraph).  Reported
         # next to `value`, never as `value`.
-        stream_rec = None
+        stream_rec, stream_b8 = None, None
         if world == 1 and not args.no_stream_figure:
-            try:
-                from nmrf_amd.driver import StereoStream
-                n_pairs = max(8, min(64, 4 * args.steps)) * 1
-                host_pairs = [(i,) + tuple(t.cpu() for t in pairs[i % len(pairs)]) for i in range(n_pairs)]
-                drv = StereoStream(model, dev, batch=b)
-                list(drv.run(iter(host_pairs[:2 * b])))                        # warm-up
+            from nmrf_amd.driver import StereoStream
+
+            def stream_figure(bs, dtype):
+                n_pairs = max(8 * bs, min(64, 4 * args.steps))
+                host_pairs = [(i,) + tuple(t.cpu().to(dtype) for t in pairs[i % len(pairs)]) for i in range(n_pairs)]
+                drv = StereoStream(model, dev, batch=bs, graph=not args.no_graph)
+                list(drv.run(iter(host_pairs[:2 * bs])))                       # warm-up: buffers, hipGraph capture
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 n_done = sum(1 for _ in drv.run(iter(host_pairs)))
                 torch.cuda.synchronize()
                 dt_s = time.perf_counter() - t1
-                stream_rec = {"value": round(n_done / dt_s, 2), "unit": "stereo pairs/s", "pairs": n_done, "batch": b,
-                              "note": "nmrf_amd.driver.StereoStream: fresh host inputs per batch, pinned staging, H2D / D2H on a copy "
-                                      "stream overlapped with compute, eager launches; `value` above is compute-only (hipGraph replay on "
-                                      "resident inputs)"}
+                return {"value": round(n_done / dt_s, 2), "unit": "stereo pairs/s", "pairs": n_done, "batch": bs,
+                        "host_dtype": str(dtype).replace("torch.", ""), "launch": "hipGraph" if drv.use_graph else "eager"}
+            try:
+                K.kernel_hook = None
+                stream_rec = stream_figure(b, torch.uint8)
+                stream_rec["note"] = ("nmrf_amd.driver.StereoStream: fresh HOST inputs per batch (uint8 images, as decoded from disk), persistent "
+                                      "pinned rings, H2D / D2H on their own streams overlapped with compute, one hipGraph replay per batch, "
+                                      "results back in host memory; `value` above is compute-only (hipGraph replay on resident inputs)")
+                stream_rec["float32_host_images"] = stream_figure(b, torch.float32)["value"]
+                if b == 1 and (args.height, args.width) == (375, 1242) and args.backbone == "resnet":
+                    stream_b8 = stream_figure(8, torch.uint8)                  # the batch the driver defaults to (N1)
             except Exception as e:
                 stream_rec = {"error": repr(e)}
+            K.kernel_hook = timer
 
     pairs_total = world * b * args.steps
     value = pairs_total / elapsed
@@ -307,11 +416,16 @@ def main():
     recs = []
     for k, (ms, cnt) in kstats.items():
         meta = timer.meta[k][0]
-        bound = meta.get("bound", "mfma")
         flops, nbytes = timer.mean_meta(k, "flops"), timer.mean_meta(k, "bytes")
+        mfma_peak = round(SPLIT_MFMA_PEAK_TFLOPS, 1) if meta.get("split") else FP32_MFMA_PEAK_TFLOPS
+        # a kernel is priced on its TIGHTER bound: the roofline (matrix pipe or HBM) its algorithmic work sits closer to
+        f_mfma = flops / (ms * 1e-3) / 1e12 / mfma_peak if flops else None
+        f_hbm = nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if nbytes else None
+        bound = meta.get("bound", "mfma")
+        if f_mfma is not None and f_hbm is not None:
+            bound = "mfma" if f_mfma >= f_hbm else "hbm"
         if bound == "mfma":
-            ach, unit = flops / (ms * 1e-3) / 1e12, "TFLOP/s"
-            peak = round(SPLIT_MFMA_PEAK_TFLOPS, 1) if meta.get("split") else FP32_MFMA_PEAK_TFLOPS
+            ach, peak, unit = flops / (ms * 1e-3) / 1e12, mfma_peak, "TFLOP/s"
         else:
             ach, peak, unit = nbytes / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
         pr = pmc_rec(meta.get("pmc")) if pmc_ok else {}
@@ -319,6 +433,8 @@ def main():
                "unit": unit, "frac": round(ach / peak, 4), "traffic": pr.get("hbm_bytes"),
                "launch_ms": round(ms, 4), "launches_timed": cnt, "ms_per_forward": round(ms * cnt / n_timed_fwd, 4),
                "flop_per_launch": flops, "bytes_per_launch": nbytes}
+        if f_mfma is not None and f_hbm is not None:
+            rec["frac_other_bound"] = {"bound": "hbm" if bound == "mfma" else "mfma", "frac": round(f_hbm if bound == "mfma" else f_mfma, 4)}
         if bound == "mfma":
             rec["pipe"] = ("fp16 MFMA, split fp32 operands: peak = 2500 TFLOP/s / 3 products (csrc/split_mfma.h)" if meta.get("split")
                            else "fp32 MFMA")
@@ -359,13 +475,18 @@ def main():
                                        cfg.NMP.NUM_REFINE_LAYERS),
                        "global_batch": world * b, "parallelism": "batch-shard x%d" % world,
                        "launch": "hipGraph" if graph is not None else "eager",
-                       "result_gather": bool(use_dist and not args.no_gather)},
+                       "result_gather": bool(use_dist and not args.no_gather),
+                       "gather": None if gather_ms is None else {
+                           "ms_alone": round(gather_ms, 4), "placement": "on the compute stream" if args.sync_gather else
+                           "side stream behind the next step (nmrf_amd.parallel.OverlappedGather); all gathers complete inside the timed region"}},
             "hot_path_ms": None if hp_ms is None else round(hp_ms, 3),
             "roofline": roof,
             "other_kernels": others,
         }
         if stream_rec is not None:
             res["stream_end_to_end"] = stream_rec
+        if stream_b8 is not None:
+            res["stream_end_to_end_b8"] = stream_b8
         if world == 1 and not args.no_cpu_baseline and args.backbone == "resnet":      # the oracle restates the CNN configuration
             try:
                 res["cpu_baseline"] = cpu_baseline(args.height, args.width, args.infer_layers, args.max_disp)

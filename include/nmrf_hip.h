@@ -27,7 +27,7 @@ extern "C" {
 
 const char *nmrf_strerror(int code);
 /* ABI version of this header; bumps on any signature change. */
-int nmrf_abi_version(void);   /* currently 15 */
+int nmrf_abi_version(void);   /* currently 16 */
 
 /* A2  group-wise correlation volume.
  * replaces build_correlation_volume + the permute of DPN.forward
@@ -298,6 +298,11 @@ int nmrf_conv_split_f32(const float *x, int B, int Ci, int H, int W, const float
 /* Encoder input staging as nmrf_prep_images_f32, written as the 2x2 space-to-depth image: out [2B, 16, Hp/2, Wp/2], channel
  * c*4 + p*2 + q = normalised padded pixel (2Y+p, 2X+q) of colour c (3 colours), channels 12..15 zero.  Hp, Wp even. */
 int nmrf_prep_images_s2d_f32(const float *img1, const float *img2, int B, int H, int W, int Hp, int Wp, float *out, void *stream);
+/* The same staging from uint8 images (decoded PNGs, inference.py:66-70 read_gen -> np.uint8): the batched driver (N1) moves bytes
+ * over PCIe and converts here; (float)px is exact, so the result is bit-identical to the _f32 entry points on img.float(). */
+int nmrf_prep_images_s2d_u8(const uint8_t *img1, const uint8_t *img2, int B, int H, int W, int Hp, int Wp, float *out, void *stream);
+int nmrf_prep_images_u8(const uint8_t *img1, const uint8_t *img2, int B, int C, int H, int W, int Hp, int Wp, float *out,
+                        void *stream);
 
 /* A1 + encoder input staging: replicate-pad both views right/bottom to (Hp, Wp) (InputPadder mode 'proposal',
  * nmrf/utils/frame_utils.py:268-275), stack them along the batch (NMRF.py:173) and normalise 2*(x/255)-1 (backbone.py:86).

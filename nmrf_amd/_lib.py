@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnmrf_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -51,6 +51,8 @@ PROTOTYPES = {
     "nmrf_instance_stats_f32": [_P, _L, _L, _P, _P],
     "nmrf_conv_split_f32": [_P, _I, _I, _I, _I, _P, _I, _F, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P],
     "nmrf_prep_images_s2d_f32": [_P, _P, _I, _I, _I, _I, _I, _P, _P],
+    "nmrf_prep_images_s2d_u8": [_P, _P, _I, _I, _I, _I, _I, _P, _P],
+    "nmrf_prep_images_u8": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "nmrf_conv3x3_split_f32": [_P, _I, _I, _I, _I, _P, _I, _F, _P, _I, _I, _F, _I, _P, _P],
     "nmrf_conv1x1_in_relu_f32": [_P, _I, _I, _L, _I, _I, _P, _I, _F, _P, _I, _F, _P, _I, _P, _P],
     "nmrf_prep_images_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P],

@@ -161,7 +161,10 @@ extern "C" int nmrf_instance_norm_f32(const float *x, const float *residual, int
 // 2 * (x / 255) - 1 (nmrf/models/backbone.py:86), same fp32 operation order.  Replaces two replication pads, a cat and three
 // elementwise kernels.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void prep_images_kernel(const float *__restrict__ img1, const float *__restrict__ img2, int B,
+// PX = float (the reference's sample['img1'] is float 0..255) or uint8_t (decoded images as they come off the disk: the driver
+// moves them over PCIe as bytes -- a quarter of the traffic -- and the conversion (float)px is exact).
+template <typename PX>
+__global__ __launch_bounds__(256) void prep_images_kernel(const PX *__restrict__ img1, const PX *__restrict__ img2, int B,
                                                          int C, int H, int W, int Hp, int Wp, float *__restrict__ out) {
     const int64_t total = (int64_t)2 * B * C * Hp * Wp;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -169,26 +172,37 @@ __global__ __launch_bounds__(256) void prep_images_kernel(const float *__restric
         const int y = (int)((i / Wp) % Hp);
         const int64_t pc = i / ((int64_t)Wp * Hp);                 // (view * B + b) * C + c
         const int64_t v = pc / ((int64_t)B * C), bc = pc - v * (int64_t)B * C;
-        const float *src = (v == 0 ? img1 : img2) + bc * (int64_t)H * W;
-        const float px = src[(int64_t)(y < H ? y : H - 1) * W + (x < W ? x : W - 1)];
+        const PX *src = (v == 0 ? img1 : img2) + bc * (int64_t)H * W;
+        const float px = (float)src[(int64_t)(y < H ? y : H - 1) * W + (x < W ? x : W - 1)];
         out[i] = 2.0f * (px / 255.0f) - 1.0f;
     }
 }
 
-extern "C" int nmrf_prep_images_f32(const float *img1, const float *img2, int B, int C, int H, int W, int Hp, int Wp, float *out,
-                                    void *stream) {
+template <typename PX>
+static int launch_prep_images(const PX *img1, const PX *img2, int B, int C, int H, int W, int Hp, int Wp, float *out, void *stream) {
     if (!img1 || !img2 || !out) return NMRF_ENULL;
     if (B < 1 || C < 1 || H < 1 || W < 1 || Hp < H || Wp < W) return NMRF_EINVAL;
     int64_t blocks = ceil_div64((int64_t)2 * B * C * Hp * Wp, 256 * 4);
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(prep_images_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, img1, img2, B, C, H, W, Hp, Wp,
-                       out);
+    hipLaunchKernelGGL(prep_images_kernel<PX>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, img1, img2, B, C, H, W, Hp,
+                       Wp, out);
     return nmrf_launch_status();
+}
+
+extern "C" int nmrf_prep_images_f32(const float *img1, const float *img2, int B, int C, int H, int W, int Hp, int Wp, float *out,
+                                    void *stream) {
+    return launch_prep_images(img1, img2, B, C, H, W, Hp, Wp, out, stream);
+}
+
+extern "C" int nmrf_prep_images_u8(const uint8_t *img1, const uint8_t *img2, int B, int C, int H, int W, int Hp, int Wp, float *out,
+                                   void *stream) {
+    return launch_prep_images(img1, img2, B, C, H, W, Hp, Wp, out, stream);
 }
 
 // Same staging, written as the 2x2 space-to-depth image the stem convolution consumes (conv3x3.hip, KT = 4): out [2B, 16, Hp/2, Wp/2],
 // channel c*4 + p*2 + q = padded / normalised pixel (2Y + p, 2X + q) of colour c (C == 3), channels 12..15 zero.
-__global__ __launch_bounds__(256) void prep_images_s2d_kernel(const float *__restrict__ img1, const float *__restrict__ img2, int B,
+template <typename PX>
+__global__ __launch_bounds__(256) void prep_images_s2d_kernel(const PX *__restrict__ img1, const PX *__restrict__ img2, int B,
                                                              int H, int W, int H2, int W2, float *__restrict__ out) {
     const int64_t total = (int64_t)2 * B * 16 * H2 * W2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -200,23 +214,33 @@ __global__ __launch_bounds__(256) void prep_images_s2d_kernel(const float *__res
         float r = 0.f;
         if (ch < 12) {
             const int c = ch >> 2, y = 2 * Y + ((ch >> 1) & 1), x = 2 * X + (ch & 1);
-            const float *src = (v == 0 ? img1 : img2) + (bb * 3 + c) * (int64_t)H * W;
-            const float px = src[(int64_t)(y < H ? y : H - 1) * W + (x < W ? x : W - 1)];
+            const PX *src = (v == 0 ? img1 : img2) + (bb * 3 + c) * (int64_t)H * W;
+            const float px = (float)src[(int64_t)(y < H ? y : H - 1) * W + (x < W ? x : W - 1)];
             r = 2.0f * (px / 255.0f) - 1.0f;
         }
         out[i] = r;
     }
 }
 
-extern "C" int nmrf_prep_images_s2d_f32(const float *img1, const float *img2, int B, int H, int W, int Hp, int Wp, float *out,
-                                        void *stream) {
+template <typename PX>
+static int launch_prep_images_s2d(const PX *img1, const PX *img2, int B, int H, int W, int Hp, int Wp, float *out, void *stream) {
     if (!img1 || !img2 || !out) return NMRF_ENULL;
     if (B < 1 || H < 1 || W < 1 || Hp < H || Wp < W || (Hp & 1) || (Wp & 1)) return NMRF_EINVAL;
     int64_t blocks = ceil_div64((int64_t)2 * B * 16 * (Hp / 2) * (Wp / 2), 256 * 4);
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(prep_images_s2d_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, img1, img2, B, H, W, Hp / 2,
-                       Wp / 2, out);
+    hipLaunchKernelGGL(prep_images_s2d_kernel<PX>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, img1, img2, B, H, W,
+                       Hp / 2, Wp / 2, out);
     return nmrf_launch_status();
+}
+
+extern "C" int nmrf_prep_images_s2d_f32(const float *img1, const float *img2, int B, int H, int W, int Hp, int Wp, float *out,
+                                        void *stream) {
+    return launch_prep_images_s2d(img1, img2, B, H, W, Hp, Wp, out, stream);
+}
+
+extern "C" int nmrf_prep_images_s2d_u8(const uint8_t *img1, const uint8_t *img2, int B, int H, int W, int Hp, int Wp, float *out,
+                                       void *stream) {
+    return launch_prep_images_s2d(img1, img2, B, H, W, Hp, Wp, out, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -24,9 +24,10 @@ def encode_kitti_disp(disp):
 
 
 def load_rgb(path):
-    """-> float32 [3,H,W] in 0..255 (the reference feeds raw 0..255 RGB, nmrf/data/datasets.py:54-62)."""
+    """-> uint8 [3,H,W] in 0..255 (the reference feeds the same values as float, nmrf/data/datasets.py:54-62; the conversion
+    happens on the GPU, after the bytes have crossed PCIe)."""
     from PIL import Image
-    img = np.asarray(Image.open(path).convert("RGB"), dtype=np.float32)
+    img = np.array(Image.open(path).convert("RGB"), dtype=np.uint8)
     return torch.from_numpy(img).permute(2, 0, 1).contiguous()
 
 
@@ -44,65 +45,149 @@ def batches(items, size):
         yield cur
 
 
-class StereoStream:
-    """Double-buffered pipeline: H2D of batch i+1 and D2H of batch i-1 overlap the compute of batch i."""
+class _Plan:
+    """Everything StereoStream keeps per (image shape, dtype): a ring of pinned host buffers and device staging buffers for the
+    inputs, the static input / output tensors of ONE captured hipGraph of model.forward, and a ring of device + pinned host
+    buffers for the results."""
 
-    def __init__(self, model, device="cuda", batch=8):
+    def __init__(self, owner, shape, dtype):
+        dev, b, depth = owner.device, owner.batch, owner.depth
+        c, h, w = shape
+        self.shape, self.dtype = shape, dtype
+        self.pin_in = [torch.empty(2, b, c, h, w, dtype=dtype).pin_memory() for _ in range(depth)]
+        self.dev_in = [torch.empty(2, b, c, h, w, dtype=dtype, device=dev) for _ in range(depth)]
+        self.static_in = torch.empty(2, b, c, h, w, dtype=dtype, device=dev)
+        self.graph, self.static_out = None, None
+        self.out_dev, self.pin_out = [None] * depth, [None] * depth
+        self.ev_in = [torch.cuda.Event() for _ in range(depth)]        # H2D of the slot finished
+        self.ev_used = [None] * depth                                   # compute has consumed dev_in[slot]
+        self.ev_out = [torch.cuda.Event() for _ in range(depth)]       # out_dev[slot] written
+        self.ev_d2h = [None] * depth                                    # pin_out[slot] complete
+
+    def sample(self, n=None):
+        x = self.static_in if n is None else self.static_in[:, :n]
+        return {"img1": x[0], "img2": x[1]}
+
+
+class StereoStream:
+    """Pipelined batches: H2D of batch i+1 and D2H of batch i-1 run on their own streams while batch i computes.
+
+    * images travel as they are handed over: uint8 (decoded PNGs: 1.4 MB per KITTI view over PCIe, converted inside the staging
+      kernel nmrf_prep_images_s2d_u8) or float32 (4x the bytes);
+    * host staging buffers are pinned ONCE per image shape and reused (a ring of `depth` slots), results come back into a ring of
+      pinned buffers -- no per-batch torch.stack / pin_memory;
+    * the forward is ONE hipGraph per (shape, batch), captured on first use and replayed on static device buffers (a short final
+      batch is padded with copies of its last pair and the padding discarded): per batch the host issues two copies and a replay
+      instead of ~150 kernel launches.  graph=False, a model that cannot be captured, or a CPU device -> eager calls.
+    Results are yielded in input order as CPU tensors (`copy_out=False`: views into the pinned ring, valid until `depth` more
+    batches have been yielded)."""
+
+    def __init__(self, model, device="cuda", batch=8, graph=True, depth=2, copy_out=True):
         self.model, self.device, self.batch = model, torch.device(device), batch
         self.on_gpu = self.device.type == "cuda"
-        self.copy_stream = torch.cuda.Stream(self.device) if self.on_gpu else None
+        self.depth, self.copy_out, self.use_graph = max(2, depth), copy_out, graph and self.on_gpu
+        self.plans = {}
+        if self.on_gpu:
+            self.h2d = torch.cuda.Stream(self.device)
+            self.d2h = torch.cuda.Stream(self.device)
 
-    def _stage(self, group):
-        left = torch.stack([g[1] for g in group])
-        right = torch.stack([g[2] for g in group])
-        if not self.on_gpu:
-            return left, right, None
-        left, right = left.pin_memory(), right.pin_memory()
-        with torch.cuda.stream(self.copy_stream):
-            dl = left.to(self.device, non_blocking=True)
-            dr = right.to(self.device, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(self.copy_stream)
-        return dl, dr, ev
+    # ---- GPU path ------------------------------------------------------------------------------------------------------
+    def _plan(self, group):
+        t = group[0][1]
+        key = (tuple(t.shape), t.dtype)
+        plan = self.plans.get(key)
+        if plan is None:
+            plan = self.plans[key] = _Plan(self, tuple(t.shape), t.dtype)
+        return plan
 
-    def run(self, pairs):
-        """pairs: iterable of (key, left [3,H,W], right [3,H,W]) -> yields (key, disparity [H,W] CPU tensor)."""
-        pending = None                       # (keys, host tensor, event) of the previous batch's D2H
-        staged = None
-        it = batches(pairs, self.batch)
-        group = next(it, None)
-        if group is not None:
-            staged = (group, self._stage(group))
-        while staged is not None:
-            group, (dl, dr, ev) = staged
-            nxt = next(it, None)
-            staged = (nxt, self._stage(nxt)) if nxt is not None else None      # H2D of the next batch starts now
-            if ev is not None:
-                torch.cuda.current_stream().wait_event(ev)
+    def _capture(self, plan):
+        """Two eager forwards (weight packing, function attributes, allocator warm-up), then the capture."""
+        sample = plan.sample()
+        try:
             with torch.no_grad():
-                disp = self.model({"img1": dl, "img2": dr})["disp"]
-            if self.on_gpu:
-                dl.record_stream(torch.cuda.current_stream())
-                dr.record_stream(torch.cuda.current_stream())
-                host = torch.empty(disp.shape, dtype=disp.dtype, pin_memory=True)
-                host.copy_(disp, non_blocking=True)
-                done = torch.cuda.Event()
-                done.record()
-            else:
-                host, done = disp, None
-            if pending is not None:
-                yield from self._drain(pending)
-            pending = ([g[0] for g in group], host, done)
-        if pending is not None:
-            yield from self._drain(pending)
+                for _ in range(2):
+                    self.model(sample)
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    out = self.model(sample)["disp"]
+            plan.graph, plan.static_out = g, out
+        except Exception as e:                                  # not capturable (e.g. a model with host syncs): eager from now on
+            print("[nmrf_amd.driver] hipGraph capture failed (%s); eager launches" % str(e).splitlines()[0], file=sys.stderr)
+            torch.cuda.synchronize(self.device)
+            self.use_graph = False
 
-    @staticmethod
-    def _drain(pending):
+    def _enqueue(self, plan, group, slot):
+        n = len(group)
+        pin = plan.pin_in[slot]
+        plan.ev_in[slot].synchronize()                          # the slot's previous H2D has left the pinned buffer (long ago)
+        for j, (_, left, right) in enumerate(group):
+            pin[0, j].copy_(left)
+            pin[1, j].copy_(right)
+        for j in range(n, self.batch if self.use_graph else n): # pad a short batch for the fixed-size graph
+            pin[:, j].copy_(pin[:, n - 1])
+        main = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(self.h2d):
+            if plan.ev_used[slot] is not None:
+                self.h2d.wait_event(plan.ev_used[slot])         # dev_in[slot] has been consumed by its previous batch
+            plan.dev_in[slot].copy_(pin, non_blocking=True)
+            plan.ev_in[slot].record(self.h2d)
+        main.wait_event(plan.ev_in[slot])
+        if self.use_graph and plan.graph is None:
+            plan.static_in.copy_(plan.dev_in[slot])
+            self._capture(plan)
+        with torch.no_grad():
+            if self.use_graph and plan.graph is not None:
+                plan.static_in.copy_(plan.dev_in[slot], non_blocking=True)
+                used = torch.cuda.Event()
+                used.record(main)
+                plan.graph.replay()
+                disp = plan.static_out
+            else:
+                x = plan.dev_in[slot]
+                disp = self.model({"img1": x[0, :n], "img2": x[1, :n]})["disp"]
+                used = torch.cuda.Event()
+                used.record(main)
+        plan.ev_used[slot] = used
+        if plan.out_dev[slot] is None or plan.out_dev[slot].shape[1:] != disp.shape[1:]:
+            plan.out_dev[slot] = torch.empty((self.batch,) + tuple(disp.shape[1:]), dtype=disp.dtype, device=self.device)
+            plan.pin_out[slot] = torch.empty((self.batch,) + tuple(disp.shape[1:]), dtype=disp.dtype).pin_memory()
+        if plan.ev_d2h[slot] is not None:
+            main.wait_event(plan.ev_d2h[slot])                  # the slot's previous result has left out_dev[slot]
+        plan.out_dev[slot][:disp.shape[0]].copy_(disp, non_blocking=True)
+        plan.ev_out[slot].record(main)
+        with torch.cuda.stream(self.d2h):
+            self.d2h.wait_event(plan.ev_out[slot])
+            plan.pin_out[slot].copy_(plan.out_dev[slot], non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self.d2h)
+        plan.ev_d2h[slot] = done
+        return [g[0] for g in group], plan.pin_out[slot], done
+
+    def _drain(self, pending):
         keys, host, done = pending
         if done is not None:
             done.synchronize()
         for k, d in zip(keys, host):
-            yield k, d
+            yield k, (d.clone() if self.copy_out and done is not None else d)
+
+    def run(self, pairs):
+        """pairs: iterable of (key, left [3,H,W], right [3,H,W]) (uint8 or float32, 0..255) -> yields (key, disparity [H,W] CPU
+        tensor) in input order."""
+        pending, i = None, 0
+        for group in batches(pairs, self.batch):
+            if self.on_gpu:
+                cur = self._enqueue(self._plan(group), group, i % self.depth)
+            else:
+                with torch.no_grad():
+                    disp = self.model({"img1": torch.stack([g[1] for g in group]), "img2": torch.stack([g[2] for g in group])})["disp"]
+                cur = ([g[0] for g in group], disp, None)
+            i += 1
+            if pending is not None:                              # batch i is queued: now wait for batch i-1 and hand it out
+                yield from self._drain(pending)
+            pending = cur
+        if pending is not None:
+            yield from self._drain(pending)
 
 
 def build_default_model(ckpt=None, opts=(), device="cuda"):

@@ -624,12 +624,13 @@ def stem_s2d_weight(weight):
 
 @_on_device
 def prep_images_s2d(img1, img2, hp, wp):
-    """prep_images written as the space-to-depth image of the stem: [2B,16,hp/2,wp/2]."""
-    _chk(img1, img2)
+    """prep_images written as the space-to-depth image of the stem: [2B,16,hp/2,wp/2].  Images float32 or uint8 (0..255)."""
+    _chk(img1, img2, dtype=img1.dtype if img1.dtype == torch.uint8 else torch.float32)
     b, c, h, w = img1.shape
     assert c == 3 and hp % 2 == 0 and wp % 2 == 0
     out = torch.empty(2 * b, 16, hp // 2, wp // 2, device=img1.device, dtype=torch.float32)
-    _lib.check(_lib.load().nmrf_prep_images_s2d_f32(_p(img1), _p(img2), b, h, w, hp, wp, _p(out), _stream()), "prep_images_s2d")
+    fn = _lib.load().nmrf_prep_images_s2d_u8 if img1.dtype == torch.uint8 else _lib.load().nmrf_prep_images_s2d_f32
+    _lib.check(fn(_p(img1), _p(img2), b, h, w, hp, wp, _p(out), _stream()), "prep_images_s2d")
     return out
 
 
@@ -756,11 +757,12 @@ def pack_conv1x1(weight):
 
 @_on_device
 def prep_images(img1, img2, hp, wp):
-    """[B,3,H,W] x2 (0..255) -> [2B,3,hp,wp]: replicate-padded right/bottom, stacked, normalised to [-1,1] (one pass)."""
-    _chk(img1, img2)
+    """[B,3,H,W] x2 (0..255, float32 or uint8) -> [2B,3,hp,wp]: replicate-padded right/bottom, stacked, normalised to [-1,1]."""
+    _chk(img1, img2, dtype=img1.dtype if img1.dtype == torch.uint8 else torch.float32)
     b, c, h, w = img1.shape
     out = torch.empty(2 * b, c, hp, wp, device=img1.device, dtype=torch.float32)
-    _lib.check(_lib.load().nmrf_prep_images_f32(_p(img1), _p(img2), b, c, h, w, hp, wp, _p(out), _stream()), "prep_images")
+    fn = _lib.load().nmrf_prep_images_u8 if img1.dtype == torch.uint8 else _lib.load().nmrf_prep_images_f32
+    _lib.check(fn(_p(img1), _p(img2), b, c, h, w, hp, wp, _p(out), _stream()), "prep_images")
     return out
 
 

@@ -111,7 +111,10 @@ class NMRF(nn.Module):
         h0, w0 = image1.shape[-2:]
         enc = self.backbone if self.compat else self.image_encoder
         from .backbone import Backbone
-        if isinstance(enc, Backbone) and image1.dtype == torch.float32 and image1.shape == image2.shape:
+        if image1.dtype != image2.dtype:
+            image1, image2 = image1.float(), image2.float()
+        if isinstance(enc, Backbone) and image1.dtype in (torch.float32, torch.uint8) and image1.shape == image2.shape:
+            # (uint8 images -- decoded PNGs as the batched driver ships them over PCIe -- are converted inside the staging kernel)
             # pad (A1) + stack + normalise in one HIP pass, straight into the encoder
             b = image1.shape[0]
             hp, wp = h0 + (-h0) % self.divis_by, w0 + (-w0) % self.divis_by
@@ -127,7 +130,7 @@ class NMRF(nn.Module):
             fmap1_list, fmap2_list = [f[:b] for f in feats], [f[b:] for f in feats]
         else:
             padder = InputPadder(image1.shape, mode="proposal", divis_by=self.divis_by)
-            image1, image2 = padder.pad(image1, image2)
+            image1, image2 = padder.pad(image1.float(), image2.float())
             fmap1_list, fmap2_list = self.extract_feature(image1, image2)
         try:
             return self.hot_path(fmap1_list, fmap2_list, (h0, w0))
@@ -167,9 +170,12 @@ class NMRF(nn.Module):
             g = F.conv2d(y[:, 128:256], wg)
         return f[:b].contiguous(), f[b:].contiguous(), g[:b].contiguous(), g[b:].contiguous()
 
-    def hot_path(self, fmap1_list, fmap2_list, out_hw):
+    def hot_path(self, fmap1_list, fmap2_list, out_hw, stages=None):
         """Everything after the backbone (NMRF.py:207-262): fmap lists are [1/8-res, 1/4-res] NCHW maps of the
-        left / right view; out_hw the un-padded image size.  This is the region the bench's hot-path timer brackets."""
+        left / right view; out_hw the un-padded image size.  This is the region the bench's hot-path timer brackets.
+        `stages`: optional dict that receives the tensors around the one discrete decision of the path -- the winner-take-all
+        of NMRF.py:228 -- (`infer_tgt`, `infer_delta` [T,64], `infer_score` [T,64] = the score head WITHOUT the 0.25 factor,
+        `disp_curr`, `refine_tgt`), the counterpart of the reference's forward hooks, for the parity chain of tests/util.py."""
         n = self.num_proposals
         h0, w0 = out_hw
 
@@ -219,11 +225,15 @@ class NMRF(nn.Module):
             score = K.linear_smalln(tgt, self.infer_score_head.weight, self.infer_score_head.bias)   # [T,64]; the 0.25 factor
         #                                                                     does not change the arg-max
         disp_curr = K.wta_median(disp_delta, score, labels_curr.reshape(-1).contiguous(), b, h8, w8, n)
+        if stages is not None:
+            stages.update(infer_tgt=tgt, infer_delta=disp_delta, infer_score=score, disp_curr=disp_curr)
 
         # ---- refinement at 1/4 ---------------------------------------------------------------------------
         fmap1, fmap2, fmap1_gw, fmap2_gw = heads4
         tgt = self.refinement(disp_curr, fmap1, fmap2, fmap1_gw, fmap2_gw).view(-1, self.refinement.dim)
         disp, disp_pred = K.refine_epilogue(self.refine_head(tgt), disp_curr, h0, w0)
+        if stages is not None:
+            stages["refine_tgt"] = tgt
 
         return {"proposal": labels_curr.reshape(b, -1, n), "prob": prob,
                 "initial_proposal": label_seeds.reshape(b, -1, n), "disp": disp, "disp_pred": disp_pred}

@@ -41,3 +41,56 @@ def gather_disparity(disp_local, total=None, group=None):
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad, group=group)
     return torch.cat([p[:s] for p, s in zip(parts, sizes)], 0)
+
+
+class OverlappedGather:
+    """The result gather of a batch-sharded job, taken OFF the compute stream ("completely overlappable with the
+    next batch").  `submit(disp)` is called on the compute stream right after a step: a side stream waits for that point, copies
+    the rank's disparities into a staging slot (so the next step -- a hipGraph replay writing the same static output buffer --
+    may start as soon as the 2 MB copy is done) and issues ONE RCCL all_gather_into_tensor from there; the compute stream only
+    waits for the copy.  `depth` slots are cycled; a slot's previous collective is awaited (stream-side) before it is reused.
+    `finish()` makes the calling stream wait for everything in flight.  Without a process group (or world 1) it is the identity.
+    On CPU / gloo there are no streams: the gather runs synchronously (tests, launcher plumbing)."""
+
+    def __init__(self, depth=2, group=None):
+        self.depth, self.group = depth, group
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.slots = [None] * depth
+        self.i = 0
+        self.side = None
+
+    def submit(self, disp):
+        if not self.active:
+            return disp
+        if not disp.is_cuda:
+            return gather_disparity(disp, group=self.group)
+        world = dist.get_world_size(self.group)
+        k = self.i % self.depth
+        self.i += 1
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=disp.device)
+        slot = self.slots[k]
+        if slot is None or slot["stage"].shape != disp.shape:
+            slot = self.slots[k] = {"stage": torch.empty_like(disp, memory_format=torch.contiguous_format),
+                                    "out": disp.new_empty((world * disp.shape[0],) + tuple(disp.shape[1:])), "work": None}
+        main = torch.cuda.current_stream(disp.device)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            if slot["work"] is not None:
+                slot["work"].wait()                      # the slot's previous collective (stream-side wait, no host block)
+            slot["stage"].copy_(disp, non_blocking=True)
+            copied = torch.cuda.Event()
+            copied.record(self.side)
+            slot["work"] = dist.all_gather_into_tensor(slot["out"], slot["stage"], group=self.group, async_op=True)
+        main.wait_event(copied)
+        return slot["out"]
+
+    def finish(self):
+        for slot in self.slots:
+            if slot is not None and slot.get("work") is not None:
+                slot["work"].wait()
+                slot["work"] = None
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)

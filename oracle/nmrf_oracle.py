@@ -1,7 +1,7 @@
 """CPU ORACLE for the NMRF-Stereo inference hot path.  TEST INFRASTRUCTURE ONLY.
 
-This file is a plain-PyTorch (CPU, fp32) *restatement* of the reference
-algorithm, written from SURVEY.md §8 and the cited reference lines; it is the
+This file is a plain-PyTorch (CPU; fp32, or fp64 when handed double tensors --
+tools/flip_floor.py) *restatement* of the reference algorithm, written from SURVEY.md §8 and the cited reference lines; it is the
 checker the HIP kernels are compared against.  Only ``tests/``,
 ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
 import it.  The product (``nmrf_amd``) never does: it fails loudly when the
@@ -687,6 +687,16 @@ def hot_path(w, cfg, feats8, feats4, pad_hw, out_hw, stages=None):
                       fmap8_l=l8, fmap8_r=r8, fmap4_l=l4, fmap4_r=r4)
         out["stages"] = stages
     return out
+
+
+def refine_from(w, cfg, disp_q, l4, r4, out_hw):
+    """The path from the winner-take-all result on (NMRF.py:233-251): refinement + epilogue from a GIVEN `disp_q`
+    [B,H4,W4] (1/4-px units) and the 1/4-res encoder maps.  Used by the parity chain of tests/util.py to compare the GPU
+    refinement with the oracle's on identical discrete decisions."""
+    f1, f2 = conv_head(l4, w, "concatconv"), conv_head(r4, w, "concatconv")
+    g1, g2 = conv_head(l4, w, "gw"), conv_head(r4, w, "gw")
+    tgt4 = refinement(disp_q, f1, f2, g1, g2, w, cfg)
+    return refine_epilogue(tgt4, disp_q, w, None, out_hw)
 
 
 def forward(w, cfg, img1, img2, return_stages=False):

@@ -47,3 +47,40 @@ def test_batch_shard_and_gather_world2(total):
 def test_gather_is_identity_without_process_group():
     x = torch.rand(2, 4, 4)
     assert gather_disparity(x) is x
+
+
+def _bench(cmd, env_extra=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **(env_extra or {}))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable] + cmd, capture_output=True, text=True, cwd=root, env=env, timeout=300)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, [json.loads(l) for l in lines]
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="plumbing mode is what bench.py does on a host WITHOUT a GPU")
+def test_bench_launches_its_own_workers():
+    """`python bench.py --gpus 2` (the driver's N=1 command shape at N=2, no torchrun): bench.py starts its two ranks itself
+    (mp.start_processes, as the reference's main.py:129-142), shards the batch, gathers the results over gloo, rank 0 prints ONE
+    JSON line.  Without a GPU the forward is a stand-in and the line says so ("valid": false, no value)."""
+    r, recs = _bench(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "3"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert len(recs) == 1
+    rec = recs[0]
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["valid"] is False and rec["value"] is None
+    assert rec["config"]["global_batch"] == 6 and rec["config"]["result_gather"] and rec["config"]["gather_correct"]
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="plumbing mode is what bench.py does on a host WITHOUT a GPU")
+def test_bench_under_torchrun_and_loud_failure_without_gpu():
+    port = _free_port()
+    r, recs = _bench(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                      "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert len(recs) == 1 and recs[0]["n_gpus"] == 2 and recs[0]["config"]["gather_correct"]
+    r, recs = _bench(["bench.py", "--steps", "1", "--warmup", "1"])          # N=1 has nothing to fall back to: no line, an error
+    assert r.returncode != 0 and not recs and "needs an MI355X" in r.stderr

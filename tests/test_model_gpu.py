@@ -6,13 +6,26 @@ import pytest
 import torch
 
 from oracle import nmrf_oracle as O
-from tests.util import build_product, check_disp, golden, oracle_cfg, oracle_weights, report, t
+from tests.util import build_product, check_chain, golden, oracle_cfg, oracle_weights, report, t, unshuffle_heads
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-_check_disp = check_disp
+def _gpu_chain_side(model, fl, fr, out_hw):
+    """The GPU hot path with the tensors either side of its winner-take-all, in the layout check_chain wants."""
+    stages = {}
+    out = model.hot_path(fl, fr, out_hw, stages=stages)
+    b, _, h8, w8 = fl[0].shape
+    n = model.num_proposals
+    coarse, score = unshuffle_heads(stages["infer_delta"].cpu(), stages["infer_score"].cpu(),
+                                    out["proposal"].cpu().reshape(-1, n), (b, h8, w8, n))
+    return out, dict(score=score, coarse=coarse, disp_curr=stages["disp_curr"].cpu(), disp=out["disp"].cpu())
+
+
+def _oracle_chain_side(oout):
+    st = oout["stages"]
+    return dict(score=st["score"], coarse=st["coarse"], disp_curr=st["disp_curr"], disp=oout["disp"])
 
 
 def _oracle_features(g):
@@ -32,19 +45,32 @@ def test_hot_path_from_reference_features(name):
     w, cfg, oout, (fl, fr) = _oracle_features(g)
     model = build_product(int(g["max_disp"]), DEV)
     with torch.no_grad():
-        out = model.hot_path([f.to(DEV) for f in fl], [f.to(DEV) for f in fr], g["disp"].shape[-2:])
+        out, cand = _gpu_chain_side(model, [f.to(DEV) for f in fl], [f.to(DEV) for f in fr], g["disp"].shape[-2:])
     report("prob", out["prob"].cpu(), t(g["prob"]), 5e-6 if name != "e2e_d" else 1.5e-5)     # e2e_d: 17 x 129 x 2 pixels, measured 7e-6
     seeds = out["initial_proposal"].cpu().long()
     assert torch.equal(seeds, t(g["seeds"]).long()), \
         f"{int((seeds != t(g['seeds']).long()).any(-1).sum())} pixels with different label seeds"
     report("proposal", out["proposal"].cpu(), t(g["proposal"]), 2e-4)
-    _check_disp(name, out["disp"].cpu(), t(g["disp"]))
+    # the end-to-end contract as a chain around the winner-take-all (tests/util.py): against the REFERENCE's own captures of the
+    # score / candidate heads where the fixture holds them (e2e_a, e2e_b), against the pinned oracle's otherwise
+    base = _oracle_chain_side(oout)
+    if "infer_score" in g:
+        n = g["proposal"].shape[-1]
+        b, _, h8, w8 = fl[0].shape
+        coarse, score = unshuffle_heads(t(g["infer_delta"]), t(g["infer_score"]), t(g["proposal"]).reshape(-1, n), (b, h8, w8, n))
+        base.update(score=score, coarse=coarse)
+    base.update(disp_curr=t(g["disp_curr"]), disp=t(g["disp"]))
+    st4 = oout["stages"]
+    refine_from = lambda dq: O.refine_from(w, cfg, dq, st4["fmap4_l"], st4["fmap4_r"], g["disp"].shape[-2:])[0]
+    with torch.no_grad():
+        check_chain(name, cand, base, refine_from)
 
 
-def test_stages_from_reference_inputs():
-    """Each stage of the GPU path fed with the reference's own stage inputs (golden e2e_a), so the
-    ~1e3x Fourier amplification of upstream fp32 noise cannot mask or fake an error."""
-    g = golden("e2e_a")
+@pytest.mark.parametrize("name", ["e2e_a", "e2e_b"])
+def test_stages_from_reference_inputs(name):
+    """Each stage of the GPU path fed with the reference's own stage inputs (goldens e2e_a: D=16, e2e_b: D=40, the default
+    MAX_DISP), so the ~1e3x Fourier amplification of upstream fp32 noise cannot mask or fake an error."""
+    g = golden(name)
     w, cfg, oout, (fl, fr) = _oracle_features(g)
     model = build_product(int(g["max_disp"]), DEV)
     n = cfg.num_proposals
@@ -64,7 +90,13 @@ def test_stages_from_reference_inputs():
         tg = t(g["infer_tgt"]).to(DEV)
         from nmrf_amd import kernels as K
         b, _, h8, w8 = f1.shape
-        dq = K.wta_median(model.infer_head(tg), model.infer_score_head(tg), lab.reshape(-1).contiguous(), b, h8, w8, n)
+        delta = model.infer_head(tg)
+        report("infer_delta", delta.cpu(), t(g["infer_delta"]), 2e-5, 1e-5)
+        from nmrf_amd.models.nmp import _ChainLauncher                   # the score head as hot_path launches it
+        score = _ChainLauncher(3, (model.infer_score_head,), (128,), 64)(tg, 128)
+        report("infer_score", score.cpu(), t(g["infer_score"]), 2e-5, 1e-5)
+        # the winner-take-all on the REFERENCE's head outputs: identical decisions, so disp_curr must match everywhere
+        dq = K.wta_median(t(g["infer_delta"]).to(DEV), t(g["infer_score"]).to(DEV), lab.reshape(-1).contiguous(), b, h8, w8, n)
         report("disp_curr", dq.cpu(), t(g["disp_curr"]), 2e-5)
         # --- refinement from the reference's disp_curr
         f1, f2, g1, g2 = model.concatconv(l4), model.concatconv(r4), model.gw(l4), model.gw(r4)
@@ -116,23 +148,39 @@ def test_full_forward_vs_oracle_mid_size():
         got = build_product(320, DEV)({"img1": l[None], "img2": r[None]})
     report("prob", got["prob"].cpu(), want["prob"], 2e-4)
     mism = (got["initial_proposal"].cpu() != want["initial_proposal"]).any(-1).float().mean()
-    assert mism < 0.01, f"{float(mism) * 100:.2f}% of pixels got different seeds (MIOpen vs CPU conv noise at exact ties)"
-    _check_disp("full_forward_120x264", got["disp"].cpu(), want["disp"])
+    assert mism < 0.01, f"{float(mism) * 100:.2f}% of pixels got different seeds (GPU vs CPU conv noise at exact ties)"
     assert got["disp"].shape == (1, 120, 264) and got["disp_pred"].shape == (1, 120, 264)
+    # the encoder (N2 conv band) against the oracle's, then the hot path as a chain from the GPU's OWN features, so that a seed
+    # that moved with the conv noise cannot blur the comparison
+    model = build_product(320, DEV)
+    f4, f8 = _features(model, l[None], r[None])
+    with torch.no_grad():
+        o4, o8 = O.cnn_backbone(torch.cat(O.pad_images(l[None], r[None], 8)[:2], 0), w, "backbone")
+    report("encoder 1/4", f4.cpu(), o4, 2e-4, 1e-4)
+    report("encoder 1/8", f8.cpu(), o8, 2e-4, 1e-4)
+    out, _, _ = _hot_path_vs_oracle("full_forward_120x264 (hot path from the GPU encoder features)", model, (f4, f8), (120, 264), 320)
+    d = (out["disp"] - got["disp"]).abs()
+    assert float(d.median()) < 1e-3, "model(sample) and encoder + hot_path disagree"
 
 
 def test_driver_pipeline_matches_direct_calls():
-    """The double-buffered batched driver (N1) returns, per pair and in order, what model(sample) returns."""
+    """The pipelined batched driver (N1) returns, per pair and in order, what model(sample) returns: uint8 host images through
+    one captured hipGraph per shape (short final batch padded), float images, and eager launches all agree with direct calls."""
     from nmrf_amd.driver import StereoStream
     from nmrf_amd.utils.hashinit import synthetic_pair
     model = build_product(128, DEV)
     pairs = [(i,) + synthetic_pair(64, 104, seed=50 + i)[:2] for i in range(5)]
-    got = dict(StereoStream(model, DEV, batch=2).run(iter(pairs)))
+    assert all(torch.equal(p[1], p[1].round()) and torch.equal(p[2], p[2].round()) for p in pairs)      # integer-valued: uint8-exact
+    pairs_u8 = [(i, l.to(torch.uint8), r.to(torch.uint8)) for i, l, r in pairs]
+    got = dict(StereoStream(model, DEV, batch=2).run(iter(pairs_u8)))
     assert list(got) == [0, 1, 2, 3, 4]
-    # same batch composition -> same arithmetic in every hand-written kernel (tools/determinism_check.py: bit-identical
-    # run to run); MIOpen's solver for the tiny 8x13 coarse convs is not (1e-6 run-to-run noise on identical inputs,
-    # tools/determinism_trace.py), which the layers above amplify to ~1e-3 px and, at the odd pixel near a seed tie, to a
-    # good fraction of a pixel -- hence median / outlier-fraction bounds.  Different pairs differ by whole pixels on average.
+    got_f32 = dict(StereoStream(model, DEV, batch=2).run(iter(pairs)))
+    got_eager = dict(StereoStream(model, DEV, batch=2, graph=False).run(iter(pairs_u8)))
+    for i in got:
+        # the same kernels on the same values: uint8 staging, graph replay and eager launches may only differ where a library
+        # kernel (rocBLAS 1x1 shortcut) picks another reduction order for another batch size (the padded final batch)
+        assert float((got[i] - got_f32[i]).abs().median()) < 1e-3 and float((got[i] - got_eager[i]).abs().median()) < 1e-3
+    assert torch.equal(got[0], got_f32[0]) and torch.equal(got[0], got_eager[0])
     with torch.no_grad():
         for grp in ([0, 1], [2, 3], [4]):
             want = model({"img1": torch.stack([pairs[i][1] for i in grp]),
@@ -142,6 +190,31 @@ def test_driver_pipeline_matches_direct_calls():
                 assert float(d.median()) < 1e-3 and float((d > 0.1).float().mean()) < 0.01, \
                     (i, float(d.median()), float(d.mean()), float(d.max()))
                 assert all(float((got[i] - got[k]).abs().mean()) > 0.1 for k in got if k != i)
+    # a second shape through the same stream object: its own plan, the first one still valid
+    more = [(10 + i,) + tuple(t.to(torch.uint8) for t in synthetic_pair(48, 88, seed=70 + i)[:2]) for i in range(3)]
+    s2 = StereoStream(model, DEV, batch=2)
+    out = dict(s2.run(iter(pairs_u8[:2] + more + pairs_u8[2:4])))
+    assert list(out) == [0, 1, 10, 11, 12, 2, 3] and out[10].shape == (48, 88)
+    assert torch.equal(out[0], got[0]) and torch.equal(out[2], got[2])
+
+
+def test_mixed_sizes_with_equal_padded_grid_through_one_model():
+    """KITTI 2015 mixes 1242x375 and 1224x370 images; both pad to 48x156 cells, with different padding rows.
+    The persistent zero-padded token grids are keyed by geometry, so the second size must not see the first one's tokens as
+    non-zero padding: model(1242x375) then model(1224x370) == a fresh model on 1224x370 (same kernels, same values: bit-equal)."""
+    from nmrf_amd.utils.hashinit import synthetic_pair
+    a = synthetic_pair(375, 1242, seed=11)[:2]
+    b = synthetic_pair(370, 1224, seed=12)[:2]
+    used, fresh = build_product(320, DEV), build_product(320, DEV)
+    with torch.no_grad():
+        used({"img1": a[0][None], "img2": a[1][None]})
+        got = used({"img1": b[0][None], "img2": b[1][None]})["disp"]
+        want = fresh({"img1": b[0][None], "img2": b[1][None]})["disp"]
+        again = used({"img1": a[0][None], "img2": a[1][None]})["disp"]
+        first = build_product(320, DEV)({"img1": a[0][None], "img2": a[1][None]})["disp"]
+    for d in ((got - want).abs(), (again - first).abs()):
+        # same kernels on the same values; the bound leaves room only for a library kernel's run-to-run reduction order
+        assert float(d.median()) < 1e-5 and float((d > 0.1).float().mean()) < 1e-4, (float(d.median()), float(d.mean()), float(d.max()))
 
 
 def test_middlebury_half_res_size_runs():
@@ -258,17 +331,20 @@ def _hot_path_vs_oracle(tag, model, feats, out_hw, max_disp, opts=(), pick=0, pr
     divis = 32 if "swin" in opts else 8
     cfg = oracle_cfg(max_disp, divis_by=divis)
     with torch.no_grad():
-        got = model.hot_path([f8s[:1].contiguous(), f4s[:1].contiguous()], [f8s[1:].contiguous(), f4s[1:].contiguous()], out_hw)
-        want = O.hot_path(w, cfg, f8s.cpu(), f4s.cpu(), None, out_hw)
-    from tests.conftest import record_note
-    perr = float((got["prob"].cpu() - want["prob"]).abs().max())
-    mism = float((got["initial_proposal"].cpu() != want["initial_proposal"]).any(-1).float().mean())
-    record_note("%s: max|dprob| %.2e, %.4f%% of pixels with different seeds" % (tag, perr, mism * 100))
-    st = check_disp(tag, got["disp"].cpu(), want["disp"], **gate)
+        got, cand = _gpu_chain_side(model, [f8s[:1].contiguous(), f4s[:1].contiguous()], [f8s[1:].contiguous(), f4s[1:].contiguous()],
+                                    out_hw)
+        want = O.hot_path(w, cfg, f8s.cpu(), f4s.cpu(), None, out_hw, stages={})
+        l4, r4 = f4s[:1].cpu(), f4s[1:].cpu()
+        from tests.conftest import record_note
+        perr = float((got["prob"].cpu() - want["prob"]).abs().max())
+        mism = float((got["initial_proposal"].cpu() != want["initial_proposal"]).any(-1).float().mean())
+        record_note("%s: max|dprob| %.2e, %.4f%% of pixels with different seeds" % (tag, perr, mism * 100))
+        report(tag + " proposal", got["proposal"].cpu(), want["proposal"], 2e-4)
+        st = check_chain(tag, cand, _oracle_chain_side(want), lambda dq: O.refine_from(w, cfg, dq, l4, r4, out_hw)[0], **gate)
     # probabilities at full size: fp32 summation order of the 64-channel (Swin: 32) correlation means, amplified by the three
     # conv1d layers; measured on the MI355X 5e-6 ... 7e-6 (CNN features) and 1.8e-5 (Swin-T features, larger magnitudes)
     assert perr <= prob_tol, f"{tag}: max|dprob| {perr:.2e}"
-    assert mism <= 1e-3, f"{tag}: {mism * 100:.3f}% of the pixels got different label seeds from identical features"
+    assert mism == 0.0, f"{tag}: {mism * 100:.4f}% of the pixels got different label seeds from identical features"
     return got, st, mism
 
 
@@ -379,17 +455,22 @@ def test_split_linears_flip_rate_matches_fp32_path(monkeypatch):
     f4, f8 = _features(model, l[None], r[None])
     wts, cfg = oracle_weights(320), oracle_cfg(320)
     with torch.no_grad():
-        want = O.hot_path(wts, cfg, f8.cpu(), f4.cpu(), None, (h, w))["disp"]
+        oout = O.hot_path(wts, cfg, f8.cpu(), f4.cpu(), None, (h, w), stages={})
+        want, base = oout["disp"], _oracle_chain_side(oout)
+        l4, r4 = f4[:1].cpu(), f4[1:].cpu()
+        rf = lambda dq: O.refine_from(wts, cfg, dq, l4, r4, (h, w))[0]
         args = ([f8[:1].contiguous(), f4[:1].contiguous()], [f8[1:].contiguous(), f4[1:].contiguous()], (h, w))
-        split = model.hot_path(*args)["disp"].cpu()
+        _, c_split = _gpu_chain_side(model, *args)
         monkeypatch.setenv("NMRF_LINEAR", "fp32")
-        fp32 = model.hot_path(*args)["disp"].cpu()
+        _, c_fp32 = _gpu_chain_side(model, *args)
+        c1 = check_chain("KITTI hot path, split-fp16 linears vs oracle", c_split, base, rf)
+        c2 = check_chain("KITTI hot path, fp32-MFMA linears vs oracle", c_fp32, base, rf)
+    split, fp32 = c_split["disp"], c_fp32["disp"]
     s_split, s_fp32 = disp_stats(split, want), disp_stats(fp32, want)
-    record_disp_stats("KITTI hot path, split-fp16 linears vs oracle", s_split)
-    record_disp_stats("KITTI hot path, fp32-MFMA linears vs oracle", s_fp32)
     record_disp_stats("KITTI hot path, split vs fp32-MFMA linears", disp_stats(split, fp32))
     assert s_split["median"] <= 1.5 * s_fp32["median"] + 1e-5, (s_split, s_fp32)
-    assert s_split["frac_gt_0p5"] <= 3 * s_fp32["frac_gt_0p5"] + 64.0 / (h * w) + 1e-4, (s_split, s_fp32)
+    assert c1["wta_flips"] <= 3 * c2["wta_flips"] + 64, (c1, c2)
+    assert c1["score_maxdiff"] <= 2 * c2["score_maxdiff"] + 1e-4 and c1["cond_epe"] <= 2 * c2["cond_epe"] + 2e-5, (c1, c2)
 
 
 @pytest.mark.parametrize("h,w", [(8, 13), (10, 12)])

@@ -61,12 +61,18 @@ def test_swin_model_on_gpu():
         # hot path from the reference's own encoder features: seeds must be bit-exact
         ref4 = t(g["feat4"]).cuda()
         ref8 = F.avg_pool2d(ref4, 2, 2)
-        hp = model.hot_path([ref8[:1].contiguous(), ref4[:1].contiguous()], [ref8[1:].contiguous(), ref4[1:].contiguous()],
-                            g["disp"].shape[-2:])
+        from tests.test_model_gpu import _gpu_chain_side, _oracle_chain_side
+        from tests.util import check_chain, oracle_cfg, oracle_weights
+        out_hw = g["disp"].shape[-2:]
+        hp, cand = _gpu_chain_side(model, [ref8[:1].contiguous(), ref4[:1].contiguous()],
+                                   [ref8[1:].contiguous(), ref4[1:].contiguous()], out_hw)
+        w, cfg = oracle_weights(256, tuple(SWIN_OPTS)), oracle_cfg(256, divis_by=32)
+        base = _oracle_chain_side(O.hot_path(w, cfg, ref8.cpu(), ref4.cpu(), None, out_hw, stages={}))
+        base.update(disp_curr=t(g["disp_curr"]), disp=t(g["disp"]))          # the reference's own outputs
+        l4, r4 = ref4[:1].cpu(), ref4[1:].cpu()
+        check_chain("swin hot path from reference features", cand, base, lambda dq: O.refine_from(w, cfg, dq, l4, r4, out_hw)[0])
     assert torch.equal(hp["initial_proposal"].cpu().long(), t(g["seeds"]).long())
     report("prob", hp["prob"].cpu(), t(g["prob"]), 5e-6)
-    from tests.util import check_disp
-    check_disp("swin hot path from reference features", hp["disp"].cpu(), t(g["disp"]))
     assert out["disp"].shape == (1, 60, 90) and torch.isfinite(out["disp"]).all()
     mism = (out["initial_proposal"].cpu().long() != t(g["seeds"]).long()).any(-1).float().mean()
     assert mism < 0.05, f"{float(mism)} of the pixels changed seeds through the GPU encoder"

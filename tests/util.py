@@ -88,20 +88,107 @@ def disp_stats(got, want):
             "epe_inliers": float(inl.mean()) if inl.numel() else 0.0}
 
 
-def check_disp(tag, got, want, epe_inliers=1e-3, median=2e-4, frac=2e-3, p99=5e-2):
-    """End-to-end disparity agreement with the reference / oracle.  BASELINE.json asks for EPE within 1e-3 px.  With the hash
-    weights every Fourier band up to 2^14 carries O(1) weight, so fp32 summation-order noise of 1e-6 in the proposals becomes
-    ~1e-3 in the features and, at roughly one pixel in 10^4, flips a winner-take-all between candidates that lie tens of
-    pixels apart (measured on the MI355X against the reference goldens and the oracle, fp32-MFMA and split-fp16 linears alike:
-    1e-4 ... 1e-3 of the pixels, max |d| up to 190 px; the reference's own CPU and CUDA paths differ the same way -- DESIGN.md
-    section 3).  A mean over all pixels is then set by those few pixels (2e-4 x 100 px = 2e-2), not by the arithmetic, so the
-    gate is on what the arithmetic controls: the typical pixel (median <= 2e-4 px, measured 3e-5 ... 5e-5), the tail (99th
-    percentile <= 5e-2 px), the EPE over the pixels that did not flip (<= 1e-3 px, the contract; measured 5e-5 ... 3e-4) and
-    the flip rate itself (<= 0.2 % of the pixels off by more than 0.5 px).  All numbers, raw EPE included, are printed in the
-    pytest summary.  Per-stage parity with reference inputs (test_stages_from_reference_inputs) is the tight check."""
+# --------------------------------------------------------------------------------------------------------------------
+# The end-to-end contract (BASELINE.json: "disparity EPE within 1e-3"), accounted for pixel by pixel.
+#
+# The path holds exactly two discrete decisions: the label seeds (NMS + top-k, required BIT-EXACT everywhere) and the
+# winner-take-all over the 4 candidates of a pixel (NMRF.py:228), whose candidates lie tens of pixels apart.  Everything
+# else is continuous.  `tools/flip_floor.py` (table: profiles/r03a_flip_floor.md, measured on the MI355X box) shows what fp32
+# arithmetic itself does to that decision:
+#   * the REFERENCE's own fp32 output, against the same algorithm in fp64, picks another winner at 22 of 31 488 pixels of e2e_b
+#     (365 of 465 750 at KITTI size), 5.7e-3 of the pixels end up > 0.5 px away, raw EPE 0.16 ... 0.23 px, max 168 ... 243 px;
+#   * the CPU oracle (same ATen kernels as the reference) run on the GPU box's host instead of the build container differs from
+#     the reference golden at exactly the 2 pixels of e2e_b where the GPU does (margins 7.7e-6 and 8e-7): raw EPE 6.8e-2 for the
+#     reference's own arithmetic on another CPU;
+#   * the GPU path differs from the reference / oracle at 0 ... 19 decisions per image (<= 1.7e-5 of the pixels, reference
+#     margin <= 1.5e-5), i.e. 50 ... 100x more rarely than the reference differs from exact arithmetic, and on identical
+#     decisions agrees to 1.4e-6 px EPE (max 3.1e-5 px).
+# "EPE within 1e-3" therefore cannot be a mean of |gpu - reference| over all pixels -- the reference does not agree with itself
+# to that level on another host -- and the gate is the chain
+#   (1) seeds bit-exact, proposals within 2e-4                                   [asserted by the callers]
+#   (2) scores / candidates entering the winner-take-all within TAU_SCORE / TAU_COARSE of the reference's
+#   (3) every pixel whose winner differs has a REFERENCE score margin between the two winners <= 2 TAU_SCORE  (per pixel),
+#       and there are at most max(4, FLIP_RATE * pixels) of them
+#   (4) outside the 4x4 cells that contain such a pixel, disp_curr agrees within 4 TAU_COARSE (x2 units, x2 bound)
+#   (5) from the GPU's own disp_curr on, the GPU refinement agrees with the oracle's refinement of THAT disp_curr with
+#       raw EPE <= COND_EPE over ALL pixels and max |d| <= MAX_COND -- ten times tighter than the contract, on identical decisions
+#   (6) unconditional raw EPE vs the reference <= 1e-3 whenever (3) found no differing pixel; median <= 2e-4; pixels off by
+#       more than 0.5 px <= 2e-3 (the reference's own fp32-vs-fp64 rate is 5.7e-3).
+# Nothing is dropped: a pixel off by more than 0.5 px is either explained by a margin-limited decision of (3) or fails (5).
+# --------------------------------------------------------------------------------------------------------------------
+TAU_SCORE = 2e-4      # |0.25 * score head|: measured GPU vs reference <= 8.4e-5; the reference's own fp32-vs-fp64 distance is 4e-4 ... 7e-4
+TAU_COARSE = 2e-4     # candidate disparities, 1/8-px units: measured <= 7.1e-5 (reference fp32 vs fp64: 3e-4 ... 8e-4)
+COND_EPE = 1e-4       # px, EPE on identical decisions: measured 6e-7 ... 1.4e-6
+MAX_COND = 1e-3       # px, largest |gpu - oracle| on identical decisions: measured <= 3.1e-5
+FLIP_RATE = 1e-4      # differing winner-take-all decisions per pixel: measured <= 1.7e-5 (reference fp32 vs fp64: 7e-4 ... 8e-4)
+
+
+def unshuffle_heads(delta, score, labels, dims):
+    """[T,64] head outputs of the product (`hot_path(stages=...)`: infer_delta, infer_score without its 0.25) + labels [P,N]
+    -> (coarse, score) [B, 8H, 8W, N] exactly as oracle.coarse_heads lays them out (NMRF.py:218-223)."""
+    b, h, wd, n = dims
+    coarse = torch.relu(labels.reshape(-1, 1) + delta)
+    un = lambda x: x.reshape(b, h, wd, n, 8, 8).permute(0, 1, 4, 2, 5, 3).reshape(b, h * 8, wd * 8, n)
+    return un(coarse), un(0.25 * score)
+
+
+def check_chain(tag, cand, base, refine_from, tau_score=TAU_SCORE, tau_coarse=TAU_COARSE, max_cond=MAX_COND,
+                flip_rate=FLIP_RATE, epe=1e-3, median=2e-4, cond_epe=COND_EPE, frac=2e-3):
+    """cand / base: dicts with `score`, `coarse` [B,8H,8W,N] (full resolution, oracle layout), `disp_curr` [B,2H,2W], `disp`
+    [B,h0,w0] of the candidate (GPU) and of the reference (golden captures or the pinned oracle).  refine_from(disp_curr) ->
+    the oracle's final disparity from a given disp_curr.  Asserts steps (2)-(6) above (all statistics are recorded first, so a
+    failing run still prints them); returns the statistics."""
+    from oracle import nmrf_oracle as O
     from tests.conftest import record_disp_stats
-    stats = disp_stats(got, want)
-    record_disp_stats(tag, stats)
-    assert (stats["epe_inliers"] <= epe_inliers and stats["median"] <= median and stats["frac_gt_0p5"] <= frac
-            and stats["p99"] <= p99), (tag, stats)
-    return stats
+    sc, sb = cand["score"].double().cpu(), base["score"].double().cpu()
+    cc, cb = cand["coarse"].double().cpu(), base["coarse"].double().cpu()
+    st = {"score_maxdiff": float((sc - sb).abs().max()), "coarse_maxdiff": float((cc - cb).abs().max())}
+    # (3) decisions
+    ic, ib = sc.max(-1).indices, sb.max(-1).indices
+    flip = ic != ib
+    margin = (sb.gather(-1, ib[..., None]) - sb.gather(-1, ic[..., None]))[..., 0]
+    st["wta_flips"] = int(flip.sum())
+    st["wta_flip_rate"] = float(flip.double().mean())
+    st["wta_flip_margin_max"] = float(margin[flip].max()) if flip.any() else 0.0
+    # the candidate's disp_curr is its own decision applied to its own inputs (A12 kernel: exact)
+    got_q = cand["disp_curr"].double().cpu()
+    st["wta_self_consistency"] = float((O.wta_median(cc.float(), sc.float()).double() - got_q).abs().max())
+    # (4) cells without a differing pixel
+    b, hh, ww = flip.shape
+    cell = flip.view(b, hh // 4, 4, ww // 4, 4).any(4).any(2)
+    st["flipped_cells"] = int(cell.sum())
+    dcur = (got_q - base["disp_curr"].double().cpu()).abs()
+    st["disp_curr_maxdiff_unflipped"] = float(dcur[~cell].max()) if (~cell).any() else 0.0
+    # (5) the contract on identical decisions, (6) unconditional
+    cond = disp_stats(cand["disp"].cpu(), refine_from(cand["disp_curr"].float().cpu()))
+    raw = disp_stats(cand["disp"].cpu(), base["disp"].cpu())
+    st.update({"cond_" + k: v for k, v in cond.items()})
+    st.update({"raw_" + k: v for k, v in raw.items()})
+    record_disp_stats(tag + " | same decisions", cond)
+    record_disp_stats(tag, raw)
+    record_chain_stats(tag, st)
+    assert st["score_maxdiff"] <= tau_score and st["coarse_maxdiff"] <= tau_coarse, (tag, "stage tensors entering the WTA", st)
+    assert st["wta_flip_margin_max"] <= 2 * tau_score, \
+        (tag, "a winner changed at a pixel the reference decides by more than the noise bound", st)
+    assert st["wta_flips"] <= max(4, flip_rate * flip.numel()), (tag, st)
+    assert st["wta_self_consistency"] <= 1e-5, (tag, st)
+    assert st["disp_curr_maxdiff_unflipped"] <= 2 * 2 * tau_coarse, (tag, st)       # x2: disp_curr is in 1/4-px units
+    assert cond["epe"] <= cond_epe and cond["max"] <= max_cond, (tag, "refinement on identical decisions", cond)
+    if st["wta_flips"] == 0:
+        assert raw["epe"] <= epe, (tag, "no decision differs, raw EPE must meet the contract", raw)
+    assert raw["median"] <= median and raw["frac_gt_0p5"] <= frac, (tag, raw)
+    return st
+
+
+def record_chain_stats(tag, st):
+    from tests.conftest import record_note
+    record_note("%s: WTA decisions differing %d (%.1e of px, reference margin <= %.1e), score/coarse maxdiff %.1e / %.1e, "
+                "same-decision EPE %.2e max %.2e, raw EPE %.2e max %.2f" % (
+                    tag, st["wta_flips"], st["wta_flip_rate"], st["wta_flip_margin_max"], st["score_maxdiff"],
+                    st["coarse_maxdiff"], st["cond_epe"], st["cond_max"], st["raw_epe"], st["raw_max"]))
+    try:
+        import json
+        with open(os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out", "chain_stats.jsonl"), "a") as f:
+            f.write(json.dumps(dict(st, case=tag)) + "\n")
+    except OSError:
+        pass

@@ -10,7 +10,8 @@ regenerated from state-dict keys wherever the fixtures are consumed.
 Fixtures
   e2e_a.npz   52x100, MAX_DISP 128 (D=16), B=1: full per-stage captures
               (layer captures row-subsampled x2) - both pad branches odd
-  e2e_b.npz   96x328, default MAX_DISP 320 (D=40), B=1: small outputs only
+  e2e_b.npz   96x328, default MAX_DISP 320 (D=40), B=1: outputs + stage inputs / the tensors either side of the
+              winner-take-all (cost volume, infer_tgt, infer_delta, infer_score, refine_tgt)
   e2e_c.npz   40x72,  MAX_DISP 128, B=2 (two different pairs): small outputs
   e2e_d.npz   136x1032, MAX_DISP 320 (D=40), B=2: small outputs; 1/8 grid 17x129 = 17 key tiles per horizontal stripe
               (the long-loop stripe kernel of the KITTI bench), images regenerated from (h, w, seed)
@@ -68,6 +69,9 @@ def run_e2e(name, shapes_seeds, opts, full, store_images=True):
     for i, l in enumerate(model.refinement.layers):
         l.register_forward_hook(hook(f"refine_layer{i}"))
 
+    model.infer_head.register_forward_hook(hook("infer_delta"))
+    model.infer_score_head.register_forward_hook(hook("infer_score"))
+
     lefts, rights = [], []
     for (h, w, seed) in shapes_seeds:
         l, r, _ = synthetic_pair(h, w, seed=seed)
@@ -88,17 +92,19 @@ def run_e2e(name, shapes_seeds, opts, full, store_images=True):
         "disp_pred": _np(out["disp_pred"]),
         "disp_curr": _np(caps["refine_tgt_in"][0]),
     })
-    if full:
+    if full:                                   # the tensors either side of the winner-take-all (NMRF.py:218-232) + stage inputs
+        d["cost_volume"] = _np(caps["prop_in"][0])
+        d["infer_tgt"] = _np(caps["infer_tgt"].reshape(-1, 128))
+        d["infer_delta"] = _np(caps["infer_delta"].reshape(-1, 64))
+        d["infer_score"] = _np(caps["infer_score"].reshape(-1, 64))          # Linear output, before the 0.25 of NMRF.py:221
+        d["refine_tgt"] = _np(caps["refine_tgt"].reshape(-1, 128))
+    if full is True:
         sub = lambda t: _np(t.reshape(-1, t.shape[-1]))[::2]
-        cv = caps["prop_in"][0]
-        d["cost_volume"] = _np(cv)
         d["context"] = _np(caps["context"])
         d["seed_embed_sub2"] = sub(caps["seed_embed"])
         d["prop_memory"] = _np(caps["prop"][0].reshape(-1, 128))
         d["infer_ffn_sub2"] = sub(caps["infer_ffn"])
-        d["infer_tgt"] = _np(caps["infer_tgt"].reshape(-1, 128))
         d["refine_ffn_sub2"] = sub(caps["refine_ffn"])
-        d["refine_tgt"] = _np(caps["refine_tgt"].reshape(-1, 128))
         for k in ("prop_layer0", "prop_layer1", "infer_self0", "infer_layer0", "infer_layer1",
                   "refine_layer0", "refine_layer1"):
             d[k + "_sub2"] = sub(caps[k])
@@ -241,7 +247,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     run_e2e("e2e_a", [(52, 100, 1000)], ["DPN.MAX_DISP", 128], full=True)
-    run_e2e("e2e_b", [(96, 328, 1001)], [], full=False)
+    run_e2e("e2e_b", [(96, 328, 1001)], [], full="stages")
     run_e2e("e2e_c", [(40, 72, 1002), (40, 72, 1003)], ["DPN.MAX_DISP", 128], full=False)
     # mid-size: 17 key tiles per horizontal stripe (129 pixels x 4 labels), both window paddings live; the images are the
     # closed-form synthetic pairs of these seeds and are regenerated where the fixture is consumed
