@@ -14,6 +14,7 @@
 #ifndef NMRF_HIP_H
 #define NMRF_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -303,6 +304,13 @@ int nmrf_prep_images_s2d_f32(const float *img1, const float *img2, int B, int H,
 int nmrf_prep_images_s2d_u8(const uint8_t *img1, const uint8_t *img2, int B, int H, int W, int Hp, int Wp, float *out, void *stream);
 int nmrf_prep_images_u8(const uint8_t *img1, const uint8_t *img2, int B, int C, int H, int W, int Hp, int Wp, float *out,
                         void *stream);
+
+/* N1 host helper (no device work): memcpy into a pinned staging buffer with non-temporal stores, so that the H2D DMA that follows
+ * does not have to snoop freshly written lines out of the CPU cache.  Any alignment; returns after an sfence. */
+int nmrf_host_copy_nt(void *dst, const void *src, size_t bytes);
+/* ... and out of one: memcpy(dst, src) followed by a cache-line flush of [src, src + bytes), so that the next D2H DMA into that
+ * pinned buffer finds none of its lines in the CPU cache. */
+int nmrf_host_read_evict(void *dst, const void *src, size_t bytes);
 
 /* A1 + encoder input staging: replicate-pad both views right/bottom to (Hp, Wp) (InputPadder mode 'proposal',
  * nmrf/utils/frame_utils.py:268-275), stack them along the batch (NMRF.py:173) and normalise 2*(x/255)-1 (backbone.py:86).

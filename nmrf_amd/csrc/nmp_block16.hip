@@ -72,6 +72,7 @@ struct NmpBlock16Args {
     float eps2, epsq;
     int NQ;
     float inv_p, inv_1, inv_2, inv_q;
+    unsigned long long *stamps;  // debug build: s_memtime stamps of the first 64 blocks (DBG & 32)
 };
 
 // MLP: run fc1-GELU-fc2.  KQC: 32-deep k chunks of the q stage's operand [LNq(x2) | extra]: 0 none, 4 = LayerNorm only,
@@ -85,6 +86,8 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
     const int j = lane & 15, g = lane >> 4;
     float *Ot = reinterpret_cast<float *>(smem + B16_RING * B16_STAGE_U4 * 16) + wv * 16 * B16_OLD;     // wave-private [16][132]
     float *Par = reinterpret_cast<float *>(smem + B16_PAR_OFF);
+#define B16_STAMP(k) do { if constexpr ((DBG & 32) != 0) { if (lane == 0 && blockIdx.x < 64) a.stamps[(blockIdx.x * 8 + wv) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
+    B16_STAMP(0);
     {
         auto put = [&](int off, const float *src, int n) {
             for (int i = tid; i < n; i += B16_THR) Par[off + i] = src ? src[i] : 0.f;
@@ -173,6 +176,7 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < B16_PF; ++p) read_pair(cur, p, fqh[p], fql[p]);
+    B16_STAMP(1);
 
     // the 4 C/D registers of a 16-channel strip <-> columns [col0, col0 + 16) of the wave's tile (lane-private addresses)
     auto stage_strip = [&](const float *v, int col0) {
@@ -242,6 +246,7 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
                 const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
                 split8u(v, bmh[c], bml[c]);
             }
+            B16_STAMP(2);
             b16_static_for<4>([&](auto kk) {                                  // strips 2k, 2k+1 = one stage
                 constexpr int k = decltype(kk)::value;
 #pragma unroll
@@ -260,6 +265,7 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
                 for (int e = 0; e < 4; ++e) x1[4 * st + e] += fmaf(acc[st][e], a.inv_p, b4[e]);
             }
         }
+        B16_STAMP(3);
         // ---- stage M -----------------------------------------------------------------------------------------------------------
         if constexpr (MLP) {
             h16x8 bnh[4], bnl[4];
@@ -308,6 +314,7 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
                 });
                 stage_end();
             };
+            B16_STAMP(4);
             f32x4 fa0, fa1, fb0, fb1;
             fc1(fa0, fa1);
 #pragma unroll 1
@@ -325,11 +332,13 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
                 for (int e = 0; e < 4; ++e) x1[4 * st + e] += fmaf(acc[st][e], a.inv_2, b4[e]);
             }
         }
+        B16_STAMP(5);
         if (a.x_out) {
 #pragma unroll
             for (int st = 0; st < 8; ++st) stage_strip(&x1[4 * st], 16 * st);
             flush_rows(a.x_out, 128, 0, t0);
         }
+        B16_STAMP(6);
         // ---- stage Q -----------------------------------------------------------------------------------------------------------
         if constexpr (KQC > 0) {
             h16x8 bqh[KQC], bql[KQC];
@@ -353,6 +362,7 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
                     split8u(v, bqh[c], bql[c]);
                 }
             }
+            B16_STAMP(7);
             if (a.q_out) {
                 const int n_groups = a.NQ >> 7;
 #pragma unroll 1
@@ -379,8 +389,13 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
                         stage_strip(ov, 32 * sp + 16);
                     });
                     flush_rows(a.q_out, a.NQ, gq * 128, t0);
+                    if (gq < 3) B16_STAMP(8 + gq);
                 }
             }
+        }
+        if constexpr ((DBG & 32) != 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            B16_STAMP(11);
         }
     }
 }
@@ -420,13 +435,21 @@ extern "C" int nmrf_pack_split_weight16_f32(const float *w, int N, int K, int Kp
 
 #ifdef NMRF_DEBUG_PROBES
 static int g_b16_variant = 0;
+static unsigned long long *g_b16_stamps = nullptr;
 extern "C" int nmrf_debug_nmp_block16_variant(int v) { g_b16_variant = v; return NMRF_OK; }
+// stamps: device buffer of 64 blocks x 8 waves x 16 words, or NULL to switch the timing build off
+extern "C" int nmrf_debug_nmp_block16_timing(void *stamps) { g_b16_stamps = (unsigned long long *)stamps; return NMRF_OK; }
 #endif
 
 template <bool MLP, int KQC, int DBG = 0>
 static int launch_nmp_block16(const NmpBlock16Args &a, hipStream_t st) {
 #ifdef NMRF_DEBUG_PROBES
     if constexpr (DBG == 0) {
+        if (g_b16_stamps) {
+            NmpBlock16Args b = a;
+            b.stamps = g_b16_stamps;
+            return launch_nmp_block16<MLP, KQC, 32>(b, st);
+        }
         switch (g_b16_variant) {
             case 1: return launch_nmp_block16<MLP, KQC, 1>(a, st);
             case 2: return launch_nmp_block16<MLP, KQC, 2>(a, st);
@@ -478,7 +501,7 @@ extern "C" int nmrf_nmp_block16_f32(const float *x, const float *msg, const void
     if (total_stages != want || total_stages < 1) return NMRF_EINVAL;
     NmpBlock16Args a{x, msg, reinterpret_cast<const b16_u32x4 *>(stream_w), total_stages, bp, ln2_g, ln2_b, b1, b2, lnq_g, lnq_b, extra,
                      extra_ld, extra_div, bq, x_out, q_out, ln_out, ln_out_map, T, (int)ceil_div64(T, B16_TOK), eps2, epsq, NQ,
-                     inv_scales[0], inv_scales[1], inv_scales[2], inv_scales[3]};
+                     inv_scales[0], inv_scales[1], inv_scales[2], inv_scales[3], nullptr};
     hipStream_t st = (hipStream_t)stream;
     const int kqc = KQ / 32;
     if (has_mlp) {

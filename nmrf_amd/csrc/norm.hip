@@ -275,3 +275,43 @@ extern "C" int nmrf_bias_avgpool2_f32(const float *y, const float *bias, int64_t
                        pooled);
     return nmrf_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Host helper of the batched driver (N1): copy into a PINNED staging buffer with non-temporal stores.  A plain memcpy leaves the
+// last ~1-2 MB it wrote as dirty lines in the writing core's private cache, and the H2D DMA that follows has to snoop every one
+// of them out: measured on the MI355X host, ~20 ms per batch regardless of its size (31 pairs/s instead of 270 at KITTI
+// batch 1, tools/driver_probe3.py).  Streaming stores go to memory through the write-combining buffers and leave nothing behind.
+// ------------------------------------------------------------------------------------------------------------------
+#include <immintrin.h>
+#include <string.h>
+extern "C" int nmrf_host_copy_nt(void *dst, const void *src, size_t bytes) {
+    if (!dst || !src) return NMRF_ENULL;
+    unsigned char *d = static_cast<unsigned char *>(dst);
+    const unsigned char *s = static_cast<const unsigned char *>(src);
+    size_t head = (16 - (reinterpret_cast<uintptr_t>(d) & 15)) & 15;
+    if (head > bytes) head = bytes;
+    memcpy(d, s, head);
+    d += head; s += head; bytes -= head;
+    const size_t n16 = bytes / 16;
+    for (size_t i = 0; i < n16; ++i)
+        _mm_stream_si128(reinterpret_cast<__m128i *>(d) + i, _mm_loadu_si128(reinterpret_cast<const __m128i *>(s) + i));
+    memcpy(d + 16 * n16, s + 16 * n16, bytes - 16 * n16);
+    if (head || bytes != 16 * n16) {                         // the few bytes that went through the cache: push them out too
+        _mm_clflush(static_cast<unsigned char *>(dst));
+        _mm_clflush(d + bytes - 1);
+    }
+    _mm_sfence();
+    return NMRF_OK;
+}
+
+// The other direction: copy a finished result OUT of a pinned buffer and evict the lines the read pulled into the CPU cache, so
+// that the next D2H DMA into the same buffer does not have to invalidate them one by one (the same ~20 ms per batch).
+extern "C" int nmrf_host_read_evict(void *dst, const void *src, size_t bytes) {
+    if (!dst || !src) return NMRF_ENULL;
+    memcpy(dst, src, bytes);
+    const unsigned char *s = static_cast<const unsigned char *>(src);
+    const uintptr_t first = reinterpret_cast<uintptr_t>(s) & ~(uintptr_t)63, last = reinterpret_cast<uintptr_t>(s) + bytes;
+    for (uintptr_t a = first; a < last; a += 64) _mm_clflush(reinterpret_cast<const void *>(a));
+    _mm_sfence();
+    return NMRF_OK;
+}

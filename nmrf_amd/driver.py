@@ -17,6 +17,8 @@ import time
 import numpy as np
 import torch
 
+from . import kernels as K
+
 
 def encode_kitti_disp(disp):
     """float disparity [H,W] -> uint16 array, KITTI convention (0 = invalid is never produced here)."""
@@ -80,7 +82,10 @@ class StereoStream:
       batch is padded with copies of its last pair and the padding discarded): per batch the host issues two copies and a replay
       instead of ~150 kernel launches.  graph=False, a model that cannot be captured, or a CPU device -> eager calls.
     Results are yielded in input order as CPU tensors (`copy_out=False`: views into the pinned ring, valid until `depth` more
-    batches have been yielded)."""
+    batches have been yielded -- and every line of them the consumer reads stays in the CPU cache and slows the next D2H into that
+    slot down, see nmrf_host_read_evict; the default hands out pageable copies and evicts).
+    Host-side staging uses non-temporal stores (nmrf_host_copy_nt): a DMA that has to snoop freshly written lines out of a CPU
+    cache costs ~20 ms per batch on this platform, whatever the batch size (tools/driver_probe3.py)."""
 
     def __init__(self, model, device="cuda", batch=8, graph=True, depth=2, copy_out=True):
         self.model, self.device, self.batch = model, torch.device(device), batch
@@ -122,10 +127,11 @@ class StereoStream:
         pin = plan.pin_in[slot]
         plan.ev_in[slot].synchronize()                          # the slot's previous H2D has left the pinned buffer (long ago)
         for j, (_, left, right) in enumerate(group):
-            pin[0, j].copy_(left)
-            pin[1, j].copy_(right)
+            K.host_copy_nt(pin[0, j], left)
+            K.host_copy_nt(pin[1, j], right)
         for j in range(n, self.batch if self.use_graph else n): # pad a short batch for the fixed-size graph
-            pin[:, j].copy_(pin[:, n - 1])
+            K.host_copy_nt(pin[0, j], group[-1][1])
+            K.host_copy_nt(pin[1, j], group[-1][2])
         main = torch.cuda.current_stream(self.device)
         with torch.cuda.stream(self.h2d):
             if plan.ev_used[slot] is not None:
@@ -169,7 +175,7 @@ class StereoStream:
         if done is not None:
             done.synchronize()
         for k, d in zip(keys, host):
-            yield k, (d.clone() if self.copy_out and done is not None else d)
+            yield k, (K.host_read_evict(d) if self.copy_out and done is not None else d)
 
     def run(self, pairs):
         """pairs: iterable of (key, left [3,H,W], right [3,H,W]) (uint8 or float32, 0..255) -> yields (key, disparity [H,W] CPU

@@ -766,6 +766,26 @@ def prep_images(img1, img2, hp, wp):
     return out
 
 
+def host_copy_nt(dst, src):
+    """dst (pinned CPU tensor or a contiguous view of one) <- src (CPU tensor, same dtype and element count), written with
+    non-temporal stores (nmrf_host_copy_nt): what the driver stages its input images with."""
+    if dst.is_cuda or src.is_cuda or dst.dtype != src.dtype or dst.numel() != src.numel() or not dst.is_contiguous():
+        raise _lib.NmrfHipError("host_copy_nt: contiguous CPU tensors of one dtype and size")
+    src = src.contiguous()
+    _lib.check(_lib.load().nmrf_host_copy_nt(dst.data_ptr(), src.data_ptr(), dst.numel() * dst.element_size()), "host_copy_nt")
+    return dst
+
+
+def host_read_evict(src):
+    """A pageable copy of `src` (a contiguous view of a pinned CPU tensor); the lines of `src` are flushed from the CPU cache
+    afterwards (nmrf_host_read_evict): what the driver hands results out with."""
+    if src.is_cuda or not src.is_contiguous():
+        raise _lib.NmrfHipError("host_read_evict: a contiguous CPU tensor")
+    dst = torch.empty(src.shape, dtype=src.dtype)
+    _lib.check(_lib.load().nmrf_host_read_evict(dst.data_ptr(), src.data_ptr(), src.numel() * src.element_size()), "host_read_evict")
+    return dst
+
+
 @_on_device
 def bias_avgpool2(y, bias):
     """y [B,C,H,W] (bias-free conv output) -> (y + bias[c], its 2x2 average) in one pass."""

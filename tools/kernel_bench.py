@@ -111,7 +111,31 @@ if "block" in which:
         _l.nmrf_debug_nmp_block16_variant(var)
         timeit("nmp_block16 DBG " + tag, lambda: K.nmp_block(x, s16, st16, i16, msg, bp, (g, be, 1e-5, b1, b2), qd, tokens_per_wave=16))
     _l.nmrf_debug_nmp_block16_variant(0)
+    _l.nmrf_debug_nmp_block16_timing.restype = ctypes.c_int
+    def stamp16(tag, call):
+        st16s = torch.zeros(64 * 8 * 16, dtype=torch.int64, device=dev)
+        call(); call()
+        _l.nmrf_debug_nmp_block16_timing(ctypes.c_void_p(st16s.data_ptr()))
+        call()
+        torch.cuda.synchronize()
+        _l.nmrf_debug_nmp_block16_timing(None)
+        s_ = st16s.cpu().numpy().reshape(64, 8, 16).astype(np.int64)
+        nm = {1: "prologue: params + 2 stages to LDS + barrier", 2: "x / msg row loads + split", 3: "proj (4 stages, 96 MFMAs) + residual",
+              4: "LN2 + split + park x1", 5: "MLP (32 stages, 768 MFMAs, GELU)", 6: "x_out staging + row stores", 7: "LNq + extra + split",
+              8: "q group 0", 9: "q group 1", 10: "q group 2", 11: "drain (vmcnt 0)"}
+        print("nmp_block16 %s: per-wave phases in s_memtime ticks (100 MHz: 1 tick = 10 ns), median / min / max over 64 blocks x 8 waves" % tag)
+        prev = 0
+        for k in range(1, 12):
+            if (s_[:, :, k] == 0).all():
+                continue
+            d = (s_[:, :, k] - s_[:, :, prev]).reshape(-1)
+            print("   %-48s %7.0f %7.0f %7.0f" % (nm[k], np.median(d), d.min(), d.max()))
+            prev = k
+        print("   total per wave median %.0f ticks; first start to last end %.0f ticks" % (
+            np.median(s_[:, :, 11] - s_[:, :, 0]), s_[:, :, 11].max() - s_[:, :, 0].min()))
+    stamp16("proj+mlp+qkv", lambda: K.nmp_block(x, s16, st16, i16, msg, bp, (g, be, 1e-5, b1, b2), qd, tokens_per_wave=16))
     s16b, st16b, i16b = K.block_stream16(wp, None, None, wq, 160)
+    stamp16("proj+qkv (self block)", lambda: K.nmp_block(x, s16b, st16b, i16b, msg, bp, None, qd, tokens_per_wave=16))
     timeit("nmp_block16 proj+qkv (self block)", lambda: K.nmp_block(x, s16b, st16b, i16b, msg, bp, None, qd, tokens_per_wave=16))
     s16c, st16c, i16c = K.block_stream16(wp, w1, w2, None, 0)
     timeit("nmp_block16 proj+mlp", lambda: K.nmp_block(x, s16c, st16c, i16c, msg, bp, (g, be, 1e-5, b1, b2), None, tokens_per_wave=16))
