@@ -27,8 +27,17 @@ extern "C" {
 #define NMRF_ENULL -3       /* null pointer */
 
 const char *nmrf_strerror(int code);
+
+/* fp16 range of the split-operand kernels (csrc/split_mfma.h).  Every contraction of the path multiplies fp32 operands as fp16
+ * hi/lo pairs, so an ACTIVATION with |x| >= 65520 (or a NaN) cannot be represented; the reference's plain fp32 has no such limit
+ * (nmrf/models/NMP.py:54-66).  The limit is guarded: the entry points that split activations take `int *range_flag` -- a device
+ * int32 owned by the caller (may be NULL: no reporting) into which the kernel atomically ORs 1 when any activation it converted was
+ * out of range.  The flag is sticky; the caller reads and clears it at a point where it synchronises anyway
+ * (nmrf_amd.kernels.check_range -> NmrfHipError).  Weights are rescaled by a power of two when they are packed and have no limit.
+ * Below the range: absolute error <= 2^-25 per operand element (values below 2^-24 are flushed) -- one fp32 rounding of an O(1)
+ * accumulator. */
 /* ABI version of this header; bumps on any signature change. */
-int nmrf_abi_version(void);   /* currently 16 */
+int nmrf_abi_version(void);   /* currently 17 */
 
 /* A2  group-wise correlation volume.
  * replaces build_correlation_volume + the permute of DPN.forward
@@ -90,7 +99,7 @@ int nmrf_add_ln_concat_f32(const float *x, const float *y, float *x_out, const f
  * axes: bit 0 = run the vertical stripes (writes out[:, 0:C/2]), bit 1 = the horizontal ones (out[:, C/2:C]);
  * 3 = both (two kernel launches on `stream`). */
 int nmrf_stripe_attn_f32(const float *qkv, const float *lepe_v, const float *lepe_h, int B, int H, int W, int N,
-                         int C, int axes, float *out, void *stream);
+                         int C, int axes, float *out, int *range_flag, void *stream);
 
 /* A9  warp right maps at x-label, group correlation, concat.
  * replaces Inference.sample_fmap x2 + corr + cat (nmrf/models/NMP.py:683-741, 839-844).
@@ -112,7 +121,7 @@ int nmrf_self_attn_f32(const float *qkv, int64_t T, int N, int C, int heads, flo
  * Hp%win==0, Wp%win==0; shift in [0,win); sibling_mask!=0 forbids attention between different labels of one pixel.
  * -> out [B,Hp,Wp,N,C] (already un-rolled). heads*32==C. */
 int nmrf_window_attn_f32(const float *qkv, const float *table, int B, int Hp, int Wp, int N, int C, int heads,
-                         int win, int shift, int sibling_mask, float *out, void *stream);
+                         int win, int shift, int sibling_mask, float *out, int *range_flag, void *stream);
 
 /* A8/A11/A14  narrow prediction-head layers: out[T,N] = act(x[T,K] w[N,K]^T + bias), N <= 64, K % 4 == 0, K <= 512
  * (LDS: 32*(K+4) + 8*npt*K floats <= 64 KiB), act 0 = identity, 1 = ReLU; bias may be NULL.
@@ -120,34 +129,6 @@ int nmrf_window_attn_f32(const float *qkv, const float *table, int B, int Hp, in
  * (nmrf/models/NMP.py:54-66, nmrf/models/NMRF.py:82-83,105,218-220,238; nmrf/models/DPN.py:65,131). */
 int nmrf_linear_smalln_f32(const float *x, const float *w, const float *bias, int64_t T, int K, int N, int act,
                            float *out, void *stream);
-
-/* N3  token linear with fused prologue / epilogue on fp32 MFMA:
- *     out[T,N] = act( P(x) . W^T + bias ) + residual
- *     P(x)[t]  = [ LayerNorm_128(x[t] + y[t]) | extra[t / extra_div][0..E) ]   when ln_gamma != NULL  (Cx == 128, K == 128 + E)
- *              = x[t][0..K)                                                     otherwise              (Cx == K, K % 4 == 0)
- * replaces, per message-passing block, nn.LayerNorm + torch.cat + nn.Linear (+ nn.GELU) (+ the residual add):
- * BasicAttention.forward_pre (nmrf/models/NMP.py:90-108), SwinNMP.forward_pre/get_qkv_input (:343-364),
- * CSWinNMP.forward_pre/get_qkv (:544-574), the timm Mlp fc1-GELU-fc2 (:337,537,675) and the proj layers.
- * y (optional, with x_out): pending residual; x + y is what is normalised and x_out receives it.
- * w_packed: the [N,K] weight in MFMA fragment order from nmrf_pack_linear_weight_f32 (N % 32 == 0; K zero-padded to
- * 32*ceil(K/32), supported ceil(K/32): 4,5,6 with LayerNorm; 1,2,4,5,16 without).
- * act: 0 identity, 1 ReLU, 2 GELU(erf).  bias [N] / residual [T,N] may be NULL. */
-int nmrf_token_linear_f32(const float *x, const float *y, float *x_out, const float *ln_gamma, const float *ln_beta,
-                          float eps, const float *extra, int E, int extra_div, const float *w_packed, const float *bias,
-                          const float *residual, int act, int64_t T, int Cx, int K, int N, float *out, void *stream);
-/* w [N,K] row-major -> packed [N/32][ceil(K/32)][4][64][4] floats (one contiguous 1 KiB line per wave load) followed by
- * N/32 int32: per 32-column strip the number of leading 32-wide k chunks holding a non-zero weight (the kernels skip the
- * rest: the v rows of a fused q|k|v weight are zero on the side-input columns).  Size: N*32*ceil(K/32) + N/32 words. */
-int nmrf_pack_linear_weight_f32(const float *w, int N, int K, float *packed, void *stream);
-
-/* N2  3x3 / stride 1 / pad 1 / no bias convolution, NCHW fp32, as fused Winograd F(2x2,3x3) on fp32 MFMA.
- * replaces nn.Conv2d(Ci, Co, 3, 1, 1, bias=False) of the stock conv band: backbone residual blocks
- * (nmrf/models/backbone.py:38-46), concatconv / gw (nmrf/models/NMRF.py:56-65), dpn.proj (nmrf/models/DPN.py:45-49).
- * x [B,Ci,H,W]; u_packed from nmrf_wino_pack_filter_f32 (16*Ci*Co floats); Ci % 16 == 0, Co % 32 == 0 -> y [B,Co,H,W]. */
-int nmrf_conv3x3_wino_f32(const float *x, const float *u_packed, int B, int Ci, int H, int W, int Co, float *y,
-                          void *stream);
-/* w [Co,Ci,3,3] -> U = G w G^T in MFMA fragment order [Ci/16][Co/32][4][4][2][64][4]. */
-int nmrf_wino_pack_filter_f32(const float *w, int Co, int Ci, float *packed, void *stream);
 
 /* A16  superpixel-guided disparity downsample (evaluation only).  PARITY UNPINNED: the reference announces this operator
  * (README.md:48) but ships neither its source nor frame_utils.downsample_disp; semantics reconstructed from the call site
@@ -205,33 +186,21 @@ int nmrf_msda_backward_f64(const double *value, const int64_t *shapes, const int
  * msg NULL: no projection stage (x1 = x).  KQ = operand width of the q stage: 0 (none), 128, 160 (LayerNorm | 32 side columns:
  * Fourier31 + one zero), 192 (LayerNorm | 64 context columns); side rows extra[t / extra_div, 0..KQ-128) with row stride
  * extra_ld (multiple of 4, rows 16-byte aligned).
- * stream_w: the block's weights as split-fp16 MFMA fragments in consumption order -- pairs of nmrf_pack_split_weight_f32
- *   proj   (msg != NULL): Wp [128,128]   pairs (strip 0..3, chunk 0..7)                                   4 stages of 16 KB
- *   mlp    (has_mlp)    : W1 [512,128] strips and W2 [128,512] k-slices interleaved
- *                         W1[0] | W1[1], W2s[0] | W1[2], W2s[1] | ... | W1[15], W2s[14] | W2s[15],   W1[h] = pairs (h, 0..7),
- *                         W2s[h] = pairs (strip n, chunk 2h + c) for n = 0..3, c = 0..1                   32 stages
- *   q      (q_out)      : Wq [NQ,KQ] pairs (strip, chunk) in strip-major order                           NQ/128 * KQ/32 stages
+ * 16 tokens per wave on v_mfma_f32_16x16x32_f16, two waves per SIMD (csrc/nmp_block16.hip).
+ * stream_w: the block's weights as split-fp16 MFMA fragments in consumption order -- nmrf_pack_split_weight16_f32 pairs (16-row
+ * strips x 32-deep chunks), 8 pairs = one 16 KB stage: proj (4 stages) | W1g[0] | W1g[1], W2g[0] | ... | W2g[15] (32 stages) | q
+ * (NQ/128 * KQ/32 stages), where proj, every W1g[h] (strips 2h, 2h+1 of W1 [512,128]) and q list their strips two at a time,
+ * interleaved chunk by chunk -- (s, c0) (s+1, c0) (s, c1) (s+1, c1) ... -- and W2g[h] = pairs (strip 0..7, chunk h) of W2 [128,512]:
+ * the kernel feeds two adjacent pairs, which share their activation operand, to two accumulators with alternating MFMAs.
  * total_stages must equal the sum.  Biases / LayerNorm parameters are plain fp32 vectors.  inv_scales: HOST array of 4 floats,
- * 1 / scale the proj, fc1, fc2 and q weights were packed with (nmrf_pack_split_weight_f32; unused entries ignored).
+ * 1 / scale the proj, fc1, fc2 and q weights were packed with (unused entries ignored).
  * ln_out_map (optional, device int32 [T]): row of ln_out that token t is written to, negative = dropped (the crop of the padded
  * token grid, NMP.py:786-788, 888-890). */
-int nmrf_nmp_block_f32(const float *x, const float *msg, const void *stream_w, int total_stages, const float *bp,
-                       const float *ln2_g, const float *ln2_b, float eps2, const float *b1, const float *b2,
-                       const float *lnq_g, const float *lnq_b, float epsq, const float *extra, int extra_ld,
-                       int extra_div, const float *bq, int has_mlp, int KQ, int NQ, int64_t T, const float *inv_scales,
-                       float *x_out, float *q_out, float *ln_out, const int *ln_out_map, void *stream);
-
-/* Same operator as nmrf_nmp_block_f32 with 16 tokens per wave on v_mfma_f32_16x16x32_f16 (two waves per SIMD: one wave's loads,
- * LayerNorm, GELU and stores run under the other's MFMAs; csrc/nmp_block16.hip).  Identical arguments; the weight stream is built
- * from nmrf_pack_split_weight16_f32 pairs (16-row strips x 32-deep chunks) in the same consumption order: proj | W1g[0] | W1g[1],
- * W2g[0] | ... | W2g[15] | q, where proj, every W1g[h] (strips 2h, 2h+1) and q list their strips two at a time, interleaved chunk
- * by chunk -- (s, c0) (s+1, c0) (s, c1) (s+1, c1) ... -- and W2g[h] = pairs (strip 0..7, chunk h): the kernel feeds two adjacent
- * pairs, which share their activation operand, to two accumulators with alternating MFMAs.  KQ in {0, 128, 160, 192}. */
 int nmrf_nmp_block16_f32(const float *x, const float *msg, const void *stream_w, int total_stages, const float *bp,
                          const float *ln2_g, const float *ln2_b, float eps2, const float *b1, const float *b2,
                          const float *lnq_g, const float *lnq_b, float epsq, const float *extra, int extra_ld,
                          int extra_div, const float *bq, int has_mlp, int KQ, int NQ, int64_t T, const float *inv_scales,
-                         float *x_out, float *q_out, float *ln_out, const int *ln_out_map, void *stream);
+                         float *x_out, float *q_out, float *ln_out, const int *ln_out_map, int *range_flag, void *stream);
 
 /* Weight packing for nmrf_nmp_block16_f32: w [N,K] -> N/16 x Kp/32 pairs of 2 KB in [strip][chunk] order; lane (i = l & 15,
  * g = l >> 4) slot jj holds scale * w[16*strip + i][32*chunk + (jj&3) + 16*(jj>>2) + 4*g], zero beyond K; hi fragment then lo
@@ -253,9 +222,9 @@ int nmrf_selftest_mfma16x16_f16split(const float *A, const float *Bm, int K, flo
  * b1/b2/b3 may be NULL.  inv_scales: HOST array of 3 floats. */
 int nmrf_mlp_chain_f32(int kind, const float *in, int in_ld, int K1, const void *stream_w, int total_stages,
                        const float *b1, const float *b2, const float *b3, const float *extra, int extra_ld,
-                       const float *inv_scales, int64_t T, float *out, int out_ld, int n_out, const int *out_map, void *stream);
+                       const float *inv_scales, int64_t T, float *out, int out_ld, int n_out, const int *out_map, int *range_flag, void *stream);
 
-/* Weight packing for nmrf_nmp_block_f32: w [N,K] row-major fp32 (an nn.Linear weight) -> N/32 x Kp/16 pairs of 2 KB in
+/* Weight packing of the 32-row split-fp16 fragment streams (mlp_chain, conv kernels): w [N,K] row-major fp32 (an nn.Linear weight) -> N/32 x Kp/16 pairs of 2 KB in
  * [strip][chunk] order; a pair = [64 lanes][8 fp16] hi parts then the same for the lo parts (lo = fp16(w - hi), csrc/split_mfma.h);
  * lane (i = l & 31, h = l >> 5) slot jj holds scale * w[32*strip + i][16*chunk + (jj&3) + 8*(jj>>2) + 4*h], zero beyond K.
  * scale: a power of two that brings the largest |w| into [2^13, 2^14) (exact; the kernel multiplies the contraction by 1/scale):
@@ -274,7 +243,7 @@ int nmrf_instance_stats_f32(const float *x, int64_t planes, int64_t HW, float *w
  * pairs (strip-major), total_stages = N/32 * K/16 / 8, inv_scale = 1 / its scale.  Split-operand fp16 MFMA. */
 int nmrf_conv1x1_in_relu_f32(const float *x, int B, int Cx, int64_t HW, int c0, int K, const float *stats, int chunks, float eps,
                              const void *stream_w, int total_stages, float inv_scale, const float *bias, int N, float *out,
-                             void *stream);
+                             int *range_flag, void *stream);
 
 /* N2: 3x3 / stride 1 / pad 1 / no-bias convolution as a direct implicit GEMM on the split-operand fp16 MFMA, optionally with the
  * InstanceNorm + ReLU of its INPUT folded into the operand load (conv1 / conv2 of ResidualBlock, nmrf/models/backbone.py:38-46;
@@ -285,7 +254,7 @@ int nmrf_conv1x1_in_relu_f32(const float *x, int B, int Cx, int64_t HW, int c0, 
  * stream_w: nmrf_pack_split_weight_f32 of the matrix Wm[Co][9*Ci], Wm[co][((ci/16 * 3 + dy) * 3 + dx) * 16 + ci%16] = W[co,ci,dy,dx],
  * with its pairs reordered [group][chunk = 9*Ci/16][strip][512 x int32]; inv_scale = 1 / its scale. */
 int nmrf_conv3x3_split_f32(const float *x, int B, int Ci, int H, int W, const float *stats, int chunks, float eps,
-                           const void *stream_w, int strips, int groups, float inv_scale, int Co, float *out, void *stream);
+                           const void *stream_w, int strips, int groups, float inv_scale, int Co, float *out, int *range_flag, void *stream);
 
 /* N2: the same kernel for other tap counts / strides of the backbone (nmrf/models/backbone.py:70,74):
  *   kt = 3, stride = 2, pad = 1: the 3x3 / stride-2 convolution of layer2.0 (strips in {2,3});
@@ -294,7 +263,7 @@ int nmrf_conv3x3_split_f32(const float *x, int B, int Ci, int H, int W, const fl
  * x [B,Ci,H,W]; out [B,Co,Ho,Wo] with Ho = (H - 1) / stride + 1 (total padding kt - 1).  stream_w: as nmrf_conv3x3_split_f32 with
  * Wm[co][((ci/16 * kt + dy) * kt + dx) * 16 + ci%16] = W[co,ci,dy,dx] and 9 replaced by kt * kt. */
 int nmrf_conv_split_f32(const float *x, int B, int Ci, int H, int W, const float *stats, int chunks, float eps, const void *stream_w,
-                        int kt, int stride, int pad, int strips, int groups, float inv_scale, int Co, float *out, void *stream);
+                        int kt, int stride, int pad, int strips, int groups, float inv_scale, int Co, float *out, int *range_flag, void *stream);
 
 /* Encoder input staging as nmrf_prep_images_f32, written as the 2x2 space-to-depth image: out [2B, 16, Hp/2, Wp/2], channel
  * c*4 + p*2 + q = normalised padded pixel (2Y+p, 2X+q) of colour c (3 colours), channels 12..15 zero.  Hp, Wp even. */

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnmrf_hip.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -23,18 +23,14 @@ PROTOTYPES = {
     "nmrf_nms_topk_f32": [_P, _L, _I, _I, _F, _I, _P, _P],
     "nmrf_seed_features_f32": [_P, _P, _L, _I, _I, _I, _F, _P, _P, _I, _P],
     "nmrf_fourier_embed_f32": [_P, _L, _F, _P, _I, _P, _P],
-    "nmrf_mlp_chain_f32": [_I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _L, _P, _I, _I, _P, _P],
+    "nmrf_mlp_chain_f32": [_I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _L, _P, _I, _I, _P, _P, _P],
     "nmrf_ln_concat_f32": [_P, _P, _P, _F, _P, _I, _I, _L, _I, _P, _I, _P],
     "nmrf_add_ln_concat_f32": [_P, _P, _P, _P, _P, _F, _P, _I, _I, _L, _I, _P, _I, _P],
-    "nmrf_stripe_attn_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "nmrf_stripe_attn_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "nmrf_warp_corr_concat_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "nmrf_self_attn_f32": [_P, _L, _I, _I, _I, _P, _P],
-    "nmrf_window_attn_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    "nmrf_window_attn_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "nmrf_linear_smalln_f32": [_P, _P, _P, _L, _I, _I, _I, _P, _P],
-    "nmrf_token_linear_f32": [_P, _P, _P, _P, _P, _F, _P, _I, _I, _P, _P, _P, _I, _L, _I, _I, _I, _P, _P],
-    "nmrf_pack_linear_weight_f32": [_P, _I, _I, _P, _P],
-    "nmrf_conv3x3_wino_f32": [_P, _P, _I, _I, _I, _I, _I, _P, _P],
-    "nmrf_wino_pack_filter_f32": [_P, _I, _I, _P, _P],
     "nmrf_superpixel_downsample_f32": [_P, _P, _I, _I, _I, _I, _P, _P],
     "nmrf_wta_median_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "nmrf_refine_epilogue_f32": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
@@ -43,20 +39,19 @@ PROTOTYPES = {
     "nmrf_msda_forward_f64": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "nmrf_msda_backward_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "nmrf_msda_backward_f64": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
-    "nmrf_nmp_block_f32": [_P, _P, _P, _I, _P, _P, _P, _F, _P, _P, _P, _P, _F, _P, _I, _I, _P, _I, _I, _I, _L, _P, _P, _P, _P, _P, _P],
     "nmrf_pack_split_weight_f32": [_P, _I, _I, _I, _F, _P, _P],
-    "nmrf_nmp_block16_f32": [_P, _P, _P, _I, _P, _P, _P, _F, _P, _P, _P, _P, _F, _P, _I, _I, _P, _I, _I, _I, _L, _P, _P, _P, _P, _P, _P],
+    "nmrf_nmp_block16_f32": [_P, _P, _P, _I, _P, _P, _P, _F, _P, _P, _P, _P, _F, _P, _I, _I, _P, _I, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P],
     "nmrf_pack_split_weight16_f32": [_P, _I, _I, _I, _F, _P, _P],
     "nmrf_selftest_mfma16x16_f16split": [_P, _P, _I, _P, _P],
     "nmrf_instance_stats_f32": [_P, _L, _L, _P, _P],
-    "nmrf_conv_split_f32": [_P, _I, _I, _I, _I, _P, _I, _F, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P],
+    "nmrf_conv_split_f32": [_P, _I, _I, _I, _I, _P, _I, _F, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P],
     "nmrf_prep_images_s2d_f32": [_P, _P, _I, _I, _I, _I, _I, _P, _P],
     "nmrf_prep_images_s2d_u8": [_P, _P, _I, _I, _I, _I, _I, _P, _P],
     "nmrf_prep_images_u8": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "nmrf_host_copy_nt": [_P, _P, ctypes.c_size_t],
     "nmrf_host_read_evict": [_P, _P, ctypes.c_size_t],
-    "nmrf_conv3x3_split_f32": [_P, _I, _I, _I, _I, _P, _I, _F, _P, _I, _I, _F, _I, _P, _P],
-    "nmrf_conv1x1_in_relu_f32": [_P, _I, _I, _L, _I, _I, _P, _I, _F, _P, _I, _F, _P, _I, _P, _P],
+    "nmrf_conv3x3_split_f32": [_P, _I, _I, _I, _I, _P, _I, _F, _P, _I, _I, _F, _I, _P, _P, _P],
+    "nmrf_conv1x1_in_relu_f32": [_P, _I, _I, _L, _I, _I, _P, _I, _F, _P, _I, _F, _P, _I, _P, _P, _P],
     "nmrf_prep_images_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "nmrf_bias_avgpool2_f32": [_P, _P, _L, _I, _I, _I, _P, _P, _P],
     "nmrf_selftest_mfma_f32": [_P, _P, _I, _P, _P],
@@ -64,7 +59,18 @@ PROTOTYPES = {
     "nmrf_selftest_lds_dma": [_P, _P, _I, _P],
 }
 
+# exported only by libnmrf_hip_debug.so (include/nmrf_hip_debug.h): reference kernels for A/B runs, never launched by the product
+DEBUG_PROTOTYPES = {
+    "nmrf_token_linear_f32": [_P, _P, _P, _P, _P, _F, _P, _I, _I, _P, _P, _P, _I, _L, _I, _I, _I, _P, _P],
+    "nmrf_pack_linear_weight_f32": [_P, _I, _I, _P, _P],
+    "nmrf_conv3x3_wino_f32": [_P, _P, _I, _I, _I, _I, _I, _P, _P],
+    "nmrf_wino_pack_filter_f32": [_P, _I, _I, _P, _P],
+    "nmrf_nmp_block_f32": [_P, _P, _P, _I, _P, _P, _P, _F, _P, _P, _P, _P, _F, _P, _I, _I, _P, _I, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P],
+}
+DEBUG_LIB_PATH = os.path.join(_HERE, "lib", "libnmrf_hip_debug.so")
+
 _lib = None
+_dbg = None
 
 
 class NmrfHipError(RuntimeError):
@@ -91,6 +97,26 @@ def load():
     if ver != ABI_VERSION:
         raise NmrfHipError("libnmrf_hip.so ABI %d != binding ABI %d: rebuild" % (ver, ABI_VERSION))
     _lib = lib
+    return lib
+
+
+def load_debug():
+    """The tools / test build of the library (python -m nmrf_amd.build --debug): everything the product library exports plus the
+    reference kernels of include/nmrf_hip_debug.h.  Only NMRF_LINEAR=fp32 (A/B parity runs), tests and tools ask for it."""
+    global _dbg
+    if _dbg is not None:
+        return _dbg
+    if not os.path.exists(DEBUG_LIB_PATH):
+        raise NmrfHipError("libnmrf_hip_debug.so not found at %s: the fp32-MFMA reference kernels live in the tools build only "
+                           "(python -m nmrf_amd.build --debug)" % DEBUG_LIB_PATH)
+    lib = ctypes.CDLL(DEBUG_LIB_PATH)
+    for name, argtypes in list(PROTOTYPES.items()) + list(DEBUG_PROTOTYPES.items()):
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _I
+    if lib.nmrf_abi_version() != ABI_VERSION:
+        raise NmrfHipError("libnmrf_hip_debug.so ABI %d != binding ABI %d: rebuild" % (lib.nmrf_abi_version(), ABI_VERSION))
+    _dbg = lib
     return lib
 
 

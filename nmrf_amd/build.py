@@ -26,13 +26,19 @@ def _hipcc():
     raise RuntimeError("hipcc not found (need ROCm to build libnmrf_hip.so)")
 
 
-def _sources():
-    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+# kernels the product no longer launches: reference paths for A/B parity runs and micro-benchmarks, compiled into the tools / test
+# build only (include/nmrf_hip_debug.h)
+DEBUG_ONLY = ("token_linear.hip", "nmp_block.hip", "conv_wino.hip")
+
+
+def _sources(debug=False):
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip") and (debug or f not in DEBUG_ONLY))
 
 
 def _deps_mtime():
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "nmrf_hip.h"))
+    hdrs.append(os.path.join(os.path.dirname(HERE), "include", "nmrf_hip_debug.h"))
     return max(os.path.getmtime(h) for h in hdrs)
 
 
@@ -48,7 +54,7 @@ def build_library(force=False, verbose=True, debug=False):
     hdr_t = _deps_mtime()
     jobs = []
     objs = []
-    for src in _sources():
+    for src in _sources(debug):
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t)
@@ -66,7 +72,8 @@ def build_library(force=False, verbose=True, debug=False):
                     print("[nmrf_amd.build]", os.path.basename(cmd[-3]), "rc=%d" % rc)
                 if rc != 0:
                     raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), log))
-    if jobs or not os.path.exists(lib_path):
+    stale_lib = not os.path.exists(lib_path) or any(os.path.getmtime(o) > os.path.getmtime(lib_path) for o in objs)
+    if jobs or stale_lib:
         cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib_path] + objs
         cmd, rc, log = run(cmd)
         if rc != 0:

@@ -29,6 +29,7 @@ struct Conv1x1Args {
     int64_t HW;
     int tiles_per_image, n_tiles;
     float inv;
+    int *range_flag;             // sticky fp16-range flag of the split operands (split_mfma.h), may be NULL
 };
 
 template <int KC>                // 16-deep k chunks: 4 (K = 64) or 8 (K = 128)
@@ -42,6 +43,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1x1Args a) {
     SplitStream<C1_PF> ss;
     ss.init(a.stream, smem, a.total_stages, tid);
     const int n_strips = a.N >> 5;
+    float guard = 0.f;                                                       // fp16 range guard of the activation splits
 
 #pragma unroll 1
     for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1x1Args a) {
                     for (int e = 0; e < 4; ++e) v[4 * g + e] = fmaxf(fmaf(v[4 * g + e], sc[e], sh[e]), 0.f);
                 }
             }
-            split8u(v, bh[c], bl[c]);
+            split8u_g(v, bh[c], bl[c], guard);
         }
         // Output: a C/D register is 32 pixels of one channel = a 128-byte piece; written as such (8 strips x 16 pieces per wave,
         // 117 KB apart) the 1/4-resolution gw head ran at ~1 TB/s.  The four waves of the block stage each 32-channel strip in an
@@ -127,6 +129,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1x1Args a) {
             __syncthreads();                                                   // the tiles are rewritten by the next strip pair
         }
     }
+    split_guard_commit(guard, a.range_flag);
 }
 
 template <int KC>
@@ -154,7 +157,7 @@ static int launch_conv1x1(const Conv1x1Args &a, hipStream_t st) {
 
 extern "C" int nmrf_conv1x1_in_relu_f32(const float *x, int B, int Cx, int64_t HW, int c0, int K, const float *stats, int chunks,
                                         float eps, const void *stream_w, int total_stages, float inv_scale, const float *bias, int N,
-                                        float *out, void *stream) {
+                                        float *out, int *range_flag, void *stream) {
     if (!x || !stream_w || !out) return NMRF_ENULL;
     if (B < 1 || HW < 1 || (K != 64 && K != 128) || c0 < 0 || c0 + K > Cx || N < 64 || (N & 63) || (stats && chunks < 1))
         return NMRF_EINVAL;
@@ -162,7 +165,7 @@ extern "C" int nmrf_conv1x1_in_relu_f32(const float *x, int B, int Cx, int64_t H
     if (total_stages != (N / 32) * kc / 8) return NMRF_EINVAL;
     const int tpi = (int)ceil_div64(HW, C1_PIX);
     if ((int64_t)tpi * B > 0x7fffffff) return NMRF_EINVAL;
-    Conv1x1Args a{x, Cx, c0, K, stats, chunks, eps, stream_w, total_stages, bias, out, N, HW, tpi, tpi * B, inv_scale};
+    Conv1x1Args a{x, Cx, c0, K, stats, chunks, eps, stream_w, total_stages, bias, out, N, HW, tpi, tpi * B, inv_scale, range_flag};
     hipStream_t st = (hipStream_t)stream;
     switch (kc) {
         case 4: return launch_conv1x1<4>(a, st);

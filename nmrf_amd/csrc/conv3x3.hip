@@ -67,6 +67,7 @@ struct Conv3Args {
     float inv;
     int tiles_x, tiles_per_image, n_tiles, per_xcd;
     unsigned long long *stamps;  // debug build: s_memtime stamps of the first 128 tiles (DBG & 64)
+    int *range_flag;             // sticky fp16-range flag of the split operands (split_mfma.h), may be NULL
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads (and a workgroup fence, once LDS-DMA is outstanding) also drains
@@ -151,6 +152,7 @@ __global__ __launch_bounds__(256, STRIDE == 2 ? 1 : (STRIPS == 2 && KT == 3 ? 3 
     // version, which did all of it at the slab change: halo restaging 25 % of a wave's time, 1.9k cycles per slab for the load
     // issue alone, 1.3k for the conversion; profiles/r02o_conv_census.txt).  The compiler's scheduler sinks such side work below
     // the MFMAs of its block, so the order is written out and fenced (sched_barrier(0)) MFMA by MFMA.
+    float guard = 0.f;                 // fp16 range guard of the activation splits (split_mfma.h)
     float Rt[C3_IPT][8];               // raw fp32 channels of an item (slot jj <-> channel (jj & 3) + 8 (jj >> 2) + 4 h)
     unsigned Pk[C3_IPT][8];            // the same item converted: packed fp16 pairs, words 0..3 = hi, 4..7 = lo
     // part i (0..3) of an item = its slots 2i, 2i+1 = one packed word of hi and one of lo
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(256, STRIDE == 2 ? 1 : (STRIPS == 2 && KT == 3 ? 3 
         }
         if (loff[k] == C3_OUTSIDE) v = f32x2{0.f, 0.f};                          // zero padding applies AFTER the normalisation
         h16x2 h2, l2;
-        split2u(v, h2, l2);
+        split2u_g(v, h2, l2, guard);
         Pk[k][i] = *reinterpret_cast<const unsigned *>(&h2);
         Pk[k][4 + i] = *reinterpret_cast<const unsigned *>(&l2);
     };
@@ -349,6 +351,7 @@ __global__ __launch_bounds__(256, STRIDE == 2 ? 1 : (STRIPS == 2 && KT == 3 ? 3 
 #pragma unroll 1
     for (int slab = 0; slab < n_slabs; ++slab) ss_static_for<KT>([&](auto dd) { stage(dd, slab); });
     C3_STAMP(6);
+    split_guard_commit(guard, a.range_flag);
 
     // ---- epilogue: a C/D register is 32 consecutive pixels of one output channel ---------------------------------------------------
     const int co_base = grp * STRIPS * 32;
@@ -451,7 +454,7 @@ static int launch_conv3(const Conv3Args &a, int groups, hipStream_t st) {
 
 extern "C" int nmrf_conv_split_f32(const float *x, int B, int Ci, int H, int W, const float *stats, int chunks, float eps,
                                    const void *stream_w, int kt, int stride, int pad, int strips, int groups, float inv_scale,
-                                   int Co, float *out, void *stream) {
+                                   int Co, float *out, int *range_flag, void *stream) {
     if (!x || !stream_w || !out) return NMRF_ENULL;
     if (B < 1 || H < 1 || W < 1 || Ci < 16 || (Ci & 15) || strips < 2 || strips > 4 || groups < 1 || Co != strips * groups * 32 ||
         (stats && (chunks < 1 || Ci > C3_AFF)) || pad < 0 || pad >= kt)
@@ -467,7 +470,7 @@ extern "C" int nmrf_conv_split_f32(const float *x, int B, int Ci, int H, int W, 
     const int64_t n = (int64_t)tx * ty * B;
     if (n > 0x7ffffff) return NMRF_EINVAL;
     Conv3Args a{x, Ci, H, W, Ho, Wo, pad, stats, chunks, eps, reinterpret_cast<const ss_u32x4 *>(stream_w),
-                (int64_t)(Ci / 16) * kt * strips * kt * 128, out, Co, inv_scale, tx, tx * ty, (int)n, (int)((n + 7) / 8), nullptr};
+                (int64_t)(Ci / 16) * kt * strips * kt * 128, out, Co, inv_scale, tx, tx * ty, (int)n, (int)((n + 7) / 8), nullptr, range_flag};
     hipStream_t st = (hipStream_t)stream;
     const int key = kt * 100 + stride * 10 + strips;
     switch (key) {
@@ -483,8 +486,9 @@ extern "C" int nmrf_conv_split_f32(const float *x, int B, int Ci, int H, int W, 
 
 extern "C" int nmrf_conv3x3_split_f32(const float *x, int B, int Ci, int H, int W, const float *stats, int chunks, float eps,
                                       const void *stream_w, int strips, int groups, float inv_scale, int Co, float *out,
-                                      void *stream) {
-    return nmrf_conv_split_f32(x, B, Ci, H, W, stats, chunks, eps, stream_w, 3, 1, 1, strips, groups, inv_scale, Co, out, stream);
+                                      int *range_flag, void *stream) {
+    return nmrf_conv_split_f32(x, B, Ci, H, W, stats, chunks, eps, stream_w, 3, 1, 1, strips, groups, inv_scale, Co, out, range_flag,
+                               stream);
 }
 
 #ifdef NMRF_DEBUG_PROBES

@@ -16,6 +16,7 @@
 //   B operand  lane l : U_p[ci (same)][co = 16*strip + l%16]
 //   D          lane l, reg r : M_p[tile = 4*(l/16) + r][co = l%16]
 #include "common.h"
+#include "../../include/nmrf_hip_debug.h"      // tools / test build only (not in libnmrf_hip.so)
 
 #define WN_CK 8                  // input channels per chunk
 #define WN_RS 68                 // raw patch row stride (66 columns used)

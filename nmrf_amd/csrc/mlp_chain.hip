@@ -34,6 +34,7 @@ struct ChainArgs {
     int64_t T;
     int n_tiles;
     float inv1, inv2, inv3;
+    int *range_flag;             // sticky fp16-range flag of the split operands (split_mfma.h), may be NULL
 };
 
 template <int ACT>
@@ -64,6 +65,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     auto par4 = [&](int off) { return *reinterpret_cast<const f32x4 *>(Par + off); };
     SplitStream<MC_PF> ss;
     ss.init(a.stream, smem, a.total_stages, tid);
+    float guard = 0.f;                                                 // fp16 range guard of the activation splits
 
     constexpr int P1 = K1C * N1S, P2 = L2 ? 32 : 0, P3 = K3C * N3S;
     constexpr int PAIRS = P1 + P2 + P3, PADDED = (PAIRS + 7) / 8 * 8;
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             const float4 v0 = k0 < a.K1 ? ldg4(a.in + tc * a.in_ld + k0) : z, v1 = k1 < a.K1 ? ldg4(a.in + tc * a.in_ld + k1) : z;
             const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            split8u(v, bh[c], bl[c]);
+            split8u_g(v, bh[c], bl[c], guard);
         }
         float h[4][16];
         ss_static_for<N1S>([&](auto ss_) {
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // ---- layer 2 ---------------------------------------------------------------------------------------------------------------
         if constexpr (L2) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) split8u(&h[c >> 1][8 * (c & 1)], bh[c], bl[c]);
+            for (int c = 0; c < 8; ++c) split8u_g(&h[c >> 1][8 * (c & 1)], bh[c], bl[c], guard);
             ss_static_for<4>([&](auto ss_) {
                 constexpr int st = decltype(ss_)::value;
                 f32x16 acc;
@@ -125,14 +127,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // ---- layer 3 ---------------------------------------------------------------------------------------------------------------
         if constexpr (K3C > 0) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) split8u(&h[c >> 1][8 * (c & 1)], bh[c], bl[c]);
+            for (int c = 0; c < 8; ++c) split8u_g(&h[c >> 1][8 * (c & 1)], bh[c], bl[c], guard);
             if constexpr (K3C > 8) {
 #pragma unroll
                 for (int c = 8; c < K3C; ++c) {
                     const float *e = a.extra + tc * a.extra_ld + 16 * (c - 8) + 4 * hi;
                     const float4 v0 = ldg4(e), v1 = ldg4(e + 8);
                     const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                    split8u(v, bh[c], bl[c]);
+                    split8u_g(v, bh[c], bl[c], guard);
                 }
             }
             ss_static_for<N3S>([&](auto ss_) {
@@ -184,6 +186,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    split_guard_commit(guard, a.range_flag);
 }
 
 template <int K1C, int N1S, int ACT1, bool L2, int ACT2, int K3C, int N3S>
@@ -216,12 +219,12 @@ static int launch_chain(const ChainArgs &a, hipStream_t st) {
 extern "C" int nmrf_mlp_chain_f32(int kind, const float *in, int in_ld, int K1, const void *stream_w, int total_stages,
                                   const float *b1, const float *b2, const float *b3, const float *extra, int extra_ld,
                                   const float *inv_scales, int64_t T, float *out, int out_ld, int n_out, const int *out_map,
-                                  void *stream) {
+                                  int *range_flag, void *stream) {
     if (!in || !stream_w || !out || !inv_scales) return NMRF_ENULL;
     if (T < 1 || ceil_div64(T, MC_TOK) > 0x7fffffff || in_ld < K1 || (in_ld & 3) || (K1 & 3) || n_out < 1 || out_ld < n_out)
         return NMRF_EINVAL;
     ChainArgs a{in, in_ld, K1, stream_w, total_stages, b1, b2, b3, extra, extra_ld, out, out_ld, n_out, out_map, T,
-                (int)ceil_div64(T, MC_TOK), inv_scales[0], inv_scales[1], inv_scales[2]};
+                (int)ceil_div64(T, MC_TOK), inv_scales[0], inv_scales[1], inv_scales[2], range_flag};
     hipStream_t st = (hipStream_t)stream;
     switch (kind) {
         case 0:
@@ -239,3 +242,39 @@ extern "C" int nmrf_mlp_chain_f32(int kind, const float *in, int in_ld, int K1, 
         default: return NMRF_EINVAL;
     }
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// weight packing: W [N,K] row-major fp32 -> N/32 x Kp/16 pairs of 2 KB in [strip][chunk] order; pair = [64 lanes][8 fp16] hi
+// then the same for lo'; lane (i = l&31, h = l>>5) slot jj holds W[32*strip + i][16*chunk + split_kslot(jj, h)], 0 beyond K.
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_split_weight_kernel(const float *__restrict__ w, int N, int K, int KC, float scale,
+                                                               uint4 *__restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;           // one lane of one pair
+    const int64_t total = (int64_t)(N / 32) * KC * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const int64_t pair = idx >> 6;
+    const int c = (int)(pair % KC), s = (int)(pair / KC);
+    const int n = s * 32 + (lane & 31), h = lane >> 5;
+    float v[8];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const int k = 16 * c + split_kslot(jj, h);
+        v[jj] = k < K ? w[(int64_t)n * K + k] * scale : 0.f;
+    }
+    h16x8 vh, vl;
+    split8u(v, vh, vl);
+    out[pair * 128 + lane] = *reinterpret_cast<const uint4 *>(&vh);
+    out[pair * 128 + 64 + lane] = *reinterpret_cast<const uint4 *>(&vl);
+}
+
+extern "C" int nmrf_pack_split_weight_f32(const float *w, int N, int K, int Kp, float scale, void *out, void *stream) {
+    if (!w || !out) return NMRF_ENULL;
+    if (N < 32 || (N & 31) || K < 1 || Kp < K || (Kp & 15) || !(scale > 0.f)) return NMRF_EINVAL;
+    const int KC = Kp / 16;
+    const int64_t total = (int64_t)(N / 32) * KC * 64;
+    hipLaunchKernelGGL(pack_split_weight_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, w, N, K,
+                       KC, scale, reinterpret_cast<uint4 *>(out));
+    return nmrf_launch_status();
+}
+

@@ -22,6 +22,7 @@
 //
 // Outputs leave through a wave-private LDS tile as whole 512-byte rows (token-major fp32, same layouts as round 1).
 #include "common.h"
+#include "../../include/nmrf_hip_debug.h"      // tools / test build only (not in libnmrf_hip.so)
 #include "split_mfma.h"
 #include <type_traits>
 #include <utility>
@@ -456,41 +457,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
 }
 
-// ------------------------------------------------------------------------------------------------------------------------
-// weight packing: W [N,K] row-major fp32 -> N/32 x Kp/16 pairs of 2 KB in [strip][chunk] order; pair = [64 lanes][8 fp16] hi
-// then the same for lo'; lane (i = l&31, h = l>>5) slot jj holds W[32*strip + i][16*chunk + split_kslot(jj, h)], 0 beyond K.
-// ------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_split_weight_kernel(const float *__restrict__ w, int N, int K, int KC, float scale,
-                                                               uint4 *__restrict__ out) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;           // one lane of one pair
-    const int64_t total = (int64_t)(N / 32) * KC * 64;
-    if (idx >= total) return;
-    const int lane = (int)(idx & 63);
-    const int64_t pair = idx >> 6;
-    const int c = (int)(pair % KC), s = (int)(pair / KC);
-    const int n = s * 32 + (lane & 31), h = lane >> 5;
-    float v[8];
-#pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
-        const int k = 16 * c + split_kslot(jj, h);
-        v[jj] = k < K ? w[(int64_t)n * K + k] * scale : 0.f;
-    }
-    h16x8 vh, vl;
-    split8u(v, vh, vl);
-    out[pair * 128 + lane] = *reinterpret_cast<const uint4 *>(&vh);
-    out[pair * 128 + 64 + lane] = *reinterpret_cast<const uint4 *>(&vl);
-}
-
-extern "C" int nmrf_pack_split_weight_f32(const float *w, int N, int K, int Kp, float scale, void *out, void *stream) {
-    if (!w || !out) return NMRF_ENULL;
-    if (N < 32 || (N & 31) || K < 1 || Kp < K || (Kp & 15) || !(scale > 0.f)) return NMRF_EINVAL;
-    const int KC = Kp / 16;
-    const int64_t total = (int64_t)(N / 32) * KC * 64;
-    hipLaunchKernelGGL(pack_split_weight_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, (hipStream_t)stream, w, N, K,
-                       KC, scale, reinterpret_cast<uint4 *>(out));
-    return nmrf_launch_status();
-}
-
 #ifdef NMRF_DEBUG_PROBES
 // attainable v_mfma_f32_32x32x16_f16 rate: CHAINS independent accumulators per wave, iters x 24 MFMAs each, operands constant
 template <int CHAINS>
@@ -579,7 +545,7 @@ extern "C" int nmrf_nmp_block_f32(const float *x, const float *msg, const void *
                                   const float *ln2_g, const float *ln2_b, float eps2, const float *b1, const float *b2,
                                   const float *lnq_g, const float *lnq_b, float epsq, const float *extra, int extra_ld,
                                   int extra_div, const float *bq, int has_mlp, int KQ, int NQ, int64_t T, const float *inv_scales,
-                                  float *x_out, float *q_out, float *ln_out, const int *ln_out_map, void *stream) {
+                                  float *x_out, float *q_out, float *ln_out, const int *ln_out_map, int *range_flag, void *stream) {
     if (!x || !stream_w || !inv_scales) return NMRF_ENULL;
     if (T < 1 || ceil_div64(T, NB_TOK) > 0x7fffffff) return NMRF_EINVAL;
     if (has_mlp && (!ln2_g || !ln2_b || !b1 || !b2)) return NMRF_ENULL;

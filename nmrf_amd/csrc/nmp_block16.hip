@@ -73,6 +73,7 @@ struct NmpBlock16Args {
     int NQ;
     float inv_p, inv_1, inv_2, inv_q;
     unsigned long long *stamps;  // debug build: s_memtime stamps of the first 64 blocks (DBG & 32)
+    int *range_flag;             // sticky fp16-range flag of the split operands (split_mfma.h), may be NULL
 };
 
 // MLP: run fc1-GELU-fc2.  KQC: 32-deep k chunks of the q stage's operand [LNq(x2) | extra]: 0 none, 4 = LayerNorm only,
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
     float *Par = reinterpret_cast<float *>(smem + B16_PAR_OFF);
 #define B16_STAMP(k) do { if constexpr ((DBG & 32) != 0) { if (lane == 0 && blockIdx.x < 64) a.stamps[(blockIdx.x * 8 + wv) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
     B16_STAMP(0);
+    float guard = 0.f;                                                  // fp16 range guard of the activation splits (split_mfma.h)
     {
         auto put = [&](int off, const float *src, int n) {
             for (int i = tid; i < n; i += B16_THR) Par[off + i] = src ? src[i] : 0.f;
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
             for (int c = 0; c < 4; ++c) {
                 const float4 v0 = ldg4(a.msg + tc * 128 + 32 * c + 4 * g), v1 = ldg4(a.msg + tc * 128 + 32 * c + 16 + 4 * g);
                 const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                split8u(v, bmh[c], bml[c]);
+                split8u_g(v, bmh[c], bml[c], guard);
             }
             B16_STAMP(2);
             b16_static_for<4>([&](auto kk) {                                  // strips 2k, 2k+1 = one stage
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
                 float ln[32];
                 layer_norm(x1, B16P_G2, B16P_B2N, a.eps2, ln);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) split8u(&ln[8 * c], bnh[c], bnl[c]);
+                for (int c = 0; c < 4; ++c) split8u_g(&ln[8 * c], bnh[c], bnl[c], guard);
             }
 #pragma unroll
             for (int st = 0; st < 8; ++st) stage_strip(&x1[4 * st], 16 * st);     // x1 waits in LDS while the hidden layer runs
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
                     }
                 }
                 h16x8 hh, hl;
-                split8u(hv, hh, hl);
+                split8u_g(hv, hh, hl, guard);
                 stage_top();
                 b16_static_for<4>([&](auto cc) {
                     constexpr int p = 2 * decltype(cc)::value;
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
                     flush_rows(a.ln_out, 128, 0, t0, a.ln_out_map);
                 }
 #pragma unroll
-                for (int c = 0; c < 4; ++c) split8u(&ln[8 * c], bqh[c], bql[c]);
+                for (int c = 0; c < 4; ++c) split8u_g(&ln[8 * c], bqh[c], bql[c], guard);
             }
             if constexpr (KQC > 4) {
                 const float *e = a.extra + (tc / a.extra_div) * a.extra_ld;
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
                 for (int c = 4; c < KQC; ++c) {
                     const float4 v0 = ldg4(e + 32 * (c - 4) + 4 * g), v1 = ldg4(e + 32 * (c - 4) + 16 + 4 * g);
                     const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                    split8u(v, bqh[c], bql[c]);
+                    split8u_g(v, bqh[c], bql[c], guard);
                 }
             }
             B16_STAMP(7);
@@ -398,6 +400,7 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
             B16_STAMP(11);
         }
     }
+    split_guard_commit(guard, a.range_flag);
 }
 
 // w [N,K] fp32 -> N/16 x Kp/32 pairs in [strip][chunk] order: lane (i = l & 15, g = l >> 4) slot jj holds
@@ -487,7 +490,7 @@ extern "C" int nmrf_nmp_block16_f32(const float *x, const float *msg, const void
                                     const float *ln2_g, const float *ln2_b, float eps2, const float *b1, const float *b2,
                                     const float *lnq_g, const float *lnq_b, float epsq, const float *extra, int extra_ld,
                                     int extra_div, const float *bq, int has_mlp, int KQ, int NQ, int64_t T, const float *inv_scales,
-                                    float *x_out, float *q_out, float *ln_out, const int *ln_out_map, void *stream) {
+                                    float *x_out, float *q_out, float *ln_out, const int *ln_out_map, int *range_flag, void *stream) {
     if (!x || !stream_w || !inv_scales) return NMRF_ENULL;
     if (T < 1 || ceil_div64(T, B16_TOK) > 0x7fffffff) return NMRF_EINVAL;
     if (has_mlp && (!ln2_g || !ln2_b || !b1 || !b2)) return NMRF_ENULL;
@@ -501,7 +504,7 @@ extern "C" int nmrf_nmp_block16_f32(const float *x, const float *msg, const void
     if (total_stages != want || total_stages < 1) return NMRF_EINVAL;
     NmpBlock16Args a{x, msg, reinterpret_cast<const b16_u32x4 *>(stream_w), total_stages, bp, ln2_g, ln2_b, b1, b2, lnq_g, lnq_b, extra,
                      extra_ld, extra_div, bq, x_out, q_out, ln_out, ln_out_map, T, (int)ceil_div64(T, B16_TOK), eps2, epsq, NQ,
-                     inv_scales[0], inv_scales[1], inv_scales[2], inv_scales[3], nullptr};
+                     inv_scales[0], inv_scales[1], inv_scales[2], inv_scales[3], nullptr, range_flag};
     hipStream_t st = (hipStream_t)stream;
     const int kqc = KQ / 32;
     if (has_mlp) {

@@ -10,7 +10,11 @@
 // fp32 MFMA (v_mfma_f32_32x32x2_f32, 64 cycles per 2-deep step) costs 512 cycles: 5.3x more matrix-pipe time.
 // Error per product ~3 * 2^-24 * |a*b| (fp32 FMA: 2^-24): sums of 128...512 terms stay well inside the 2e-5 kernel tolerances
 // against fp64 that the fp32-MFMA kernels are held to (tests/test_hip_kernels.py).
-// Range: |a| must stay below 65504 (fp16 max); activations and weights of this network are O(1..100).
+// Range: |a| must stay below 65520 (fp16 max 65504); activations of this network are O(1..100), weights are rescaled by a power of
+// two at pack time.  The range is GUARDED, not assumed: every activation split feeds a per-lane guard accumulator (split2u_g,
+// one v_dot2c_f32_f16 per pair) that turns -inf / NaN forever once a value overflowed (or was NaN), and the kernel ORs a sticky
+// device flag at its end (split_guard_commit) -- nmrf_amd.kernels.check_range raises NmrfHipError from it.  Below the range the
+// error model is the one of the single-accumulator form further down: absolute 2^-25 per element.
 //
 // v_mfma_f32_32x32x16_f16 lane layout (gfx950; pinned by nmrf_selftest_mfma_f16split):
 //   A operand: lane l holds A[i = l&31][k = 8*(l>>5) + 0..7]    (8 fp16 = 4 VGPRs)
@@ -74,6 +78,28 @@ __device__ __forceinline__ void split8u(const float *v, h16x8 &hi, h16x8 &lo) {
         lo[2 * j] = l[0]; lo[2 * j + 1] = l[1];
     }
 }
+// ---- range guard --------------------------------------------------------------------------------------------------------------
+// g += hi . lo (v_dot2c_f32_f16).  While |a| < 65520: a finite number of no meaning (|hi * lo| <= 2^-11 * 65504^2, sums of 1e5 terms
+// stay below 1e12).  Once a value rounds to hi = +-inf, lo = a - hi = -+inf (or NaN): the product is -inf or NaN and g never
+// becomes finite again; a NaN activation does the same.  One VALU instruction per pair on top of the five of the split.
+__device__ __forceinline__ void split2u_g(f32x2 a, h16x2 &hi, h16x2 &lo, float &g) {
+    split2u(a, hi, lo);
+    g = __builtin_amdgcn_fdot2(hi, lo, g, false);
+}
+__device__ __forceinline__ void split8u_g(const float *v, h16x8 &hi, h16x8 &lo, float &g) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h16x2 h, l;
+        split2u_g(f32x2{v[2 * j], v[2 * j + 1]}, h, l, g);
+        hi[2 * j] = h[0]; hi[2 * j + 1] = h[1];
+        lo[2 * j] = l[0]; lo[2 * j + 1] = l[1];
+    }
+}
+// end of kernel: OR bit `bit` into the caller's sticky flag word if this lane saw an out-of-range / NaN activation
+__device__ __forceinline__ void split_guard_commit(float g, int *flag, int bit = 1) {
+    if (flag && !(__builtin_fabsf(g) <= 3.0e38f)) atomicOr(flag, bit);
+}
+
 // acc += Al*Bh + Ah*Bl + Ah*Bh (small terms first)
 __device__ __forceinline__ void split_mma1(h16x8 ah, h16x8 al, h16x8 bh, h16x8 bl, f32x16 &acc) {
     acc = mfma16h(al, bh, acc);
@@ -98,6 +124,29 @@ __device__ __forceinline__ void split_dot16(const float *a, const f32x16 &b, f32
 #pragma unroll
     for (int r = 0; r < 16; ++r) bv[r] = b[r];
     split_dot16(a, bv, acc);
+}
+// the same with the range guard on a (GB: on b as well -- b = softmax probabilities need none)
+template <bool GB>
+__device__ __forceinline__ void split_dot16_g(const float *a, const float *b, f32x16 &acc, float &g) {
+    h16x8 ah[2], al[2], bh[2], bl[2];
+    split8u_g(a, ah[0], al[0], g);
+    split8u_g(a + 8, ah[1], al[1], g);
+    if constexpr (GB) {
+        split8u_g(b, bh[0], bl[0], g);
+        split8u_g(b + 8, bh[1], bl[1], g);
+    } else {
+        split8u(b, bh[0], bl[0]);
+        split8u(b + 8, bh[1], bl[1]);
+    }
+    split_mma1(ah[0], al[0], bh[0], bl[0], acc);
+    split_mma1(ah[1], al[1], bh[1], bl[1], acc);
+}
+template <bool GB>
+__device__ __forceinline__ void split_dot16_g(const float *a, const f32x16 &b, f32x16 &acc, float &g) {
+    float bv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bv[r] = b[r];
+    split_dot16_g<GB>(a, bv, acc, g);
 }
 
 // k slot order of a B operand that is taken straight from a C/D result (and of every A operand contracted with it):

@@ -35,6 +35,7 @@ struct StripeGeom {
     int Ts;                // tokens per stripe = L*N
     int64_t pix_stride;    // token-pixel stride between consecutive stripe positions (W or 1)
     int gx, gy, gz;        // logical grid: query-tile groups x (stripe, head) x image
+    int *range_flag;       // sticky fp16-range flag of the split operands (split_mfma.h), may be NULL
 };
 
 // NSHIFT >= 0: N == 1<<NSHIFT at compile time (N=4 in every shipped config); NSHIFT < 0: runtime N
@@ -58,6 +59,7 @@ __global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__rest
                                                          StripeGeom g, float scale, float *__restrict__ out,
                                                          unsigned long long *__restrict__ census = nullptr) {
     constexpr int QPB = 4 / KSPLIT;                           // query tiles per block
+    float guard = 0.f;                                        // fp16 range guard of the q / k / v splits (split_mfma.h)
     // XCD-aware block order.  Workgroups go round-robin over the 8 XCDs (linear id % 8), each with a private 4 MB L2.
     // All query tiles of one (stripe, head) read the same K/V rows, so the logical work items are handed out in
     // contiguous runs per XCD: with the natural order every XCD streamed the whole K/V set (15 MB at KITTI) through
@@ -127,8 +129,8 @@ __global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__rest
         // both contractions run on the fp16 matrix pipe with split operands (split_mfma.h, single-accumulator form): chunk c,
         // slot jj of half hi <-> MFMA k-slot (step s = 8c + jj, half hi) of the fp32 formulation above, so every map stays
         h16x8 qh[2], ql[2];
-        split8u(qf, qh[0], ql[0]);
-        split8u(qf + 8, qh[1], ql[1]);
+        split8u_g(qf, qh[0], ql[0], guard);
+        split8u_g(qf + 8, qh[1], ql[1], guard);
         const int n_kt = (g.Ts + SA_TILE - 1) / SA_TILE;
         const int per = (n_kt + KSPLIT - 1) / KSPLIT;
         const int kt_begin = ks * per, kt_end = (kt_begin + per < n_kt) ? kt_begin + per : n_kt;
@@ -206,8 +208,8 @@ __global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__rest
             for (int r = 0; r < 16; ++r) st[r] = 0.f;
             {
                 h16x8 kh[2], kl[2];
-                split8u(kf, kh[0], kl[0]);
-                split8u(kf + 8, kh[1], kl[1]);
+                split8u_g(kf, kh[0], kl[0], guard);
+                split8u_g(kf + 8, kh[1], kl[1], guard);
                 split_mma1(kh[0], kl[0], qh[0], ql[0], st);
                 split_mma1(kh[1], kl[1], qh[1], ql[1], st);
             }
@@ -250,8 +252,8 @@ __global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__rest
                 h16x8 ph[2], pl[2], vh[2], vl[2];
                 split8u(pv, ph[0], pl[0]);
                 split8u(pv + 8, ph[1], pl[1]);
-                split8u(vf, vh[0], vl[0]);
-                split8u(vf + 8, vh[1], vl[1]);
+                split8u_g(vf, vh[0], vl[0], guard);
+                split8u_g(vf + 8, vh[1], vl[1], guard);
                 split_mma1(vh[0], vl[0], ph[0], pl[0], acc_o);
                 split_mma1(vh[1], vl[1], ph[1], pl[1], acc_o);
             }
@@ -331,6 +333,8 @@ __global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__rest
         SA_STAMP(9);
         __syncthreads();
         SA_STAMP(10);
+        split_guard_commit(guard, g.range_flag);
+        guard = 0.f;
         if (ks != 0) return;
 #pragma unroll
         for (int j = 1; j < KSPLIT; ++j) {
@@ -344,6 +348,7 @@ __global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__rest
             m_run = m_new;
         }
     }
+    split_guard_commit(guard, g.range_flag);
     if (!wave_on || !q_ok) return;
     const float inv_l = 1.0f / l_run;
 
@@ -397,7 +402,7 @@ static void launch_stripe(const float *qkv, const float *lepe, const StripeGeom 
 // Debug: census run of the horizontal N=4 KSPLIT=1 kernel (KITTI configuration); census[blocks*3] + stamps on device.
 extern "C" int nmrf_debug_stripe_census(const float *qkv, const float *lepe_h, int B, int H, int W, float *out,
                                         unsigned long long *census, int *grid_out, void *stream) {
-    StripeGeom g{H, W, 4, 128, W, W * 4, (int64_t)1, 0, 0, 0};
+    StripeGeom g{H, W, 4, 128, W, W * 4, (int64_t)1, 0, 0, 0, nullptr};
     const int n_qt = (g.Ts + SA_TILE - 1) / SA_TILE;
     g.gx = (n_qt + 3) / 4; g.gy = H * 2; g.gz = B;            // KSPLIT = 1 -> four query tiles per block
     dim3 grid((unsigned)(((int64_t)g.gx * g.gy * g.gz + 7) / 8 * 8));
@@ -409,19 +414,19 @@ extern "C" int nmrf_debug_stripe_census(const float *qkv, const float *lepe_h, i
 #endif  // NMRF_DEBUG_PROBES
 
 extern "C" int nmrf_stripe_attn_f32(const float *qkv, const float *lepe_v, const float *lepe_h, int B, int H, int W,
-                                    int N, int C, int axes, float *out, void *stream) {
+                                    int N, int C, int axes, float *out, int *range_flag, void *stream) {
     if (!qkv || !lepe_v || !lepe_h || !out) return NMRF_ENULL;
     if (B < 1 || H < 1 || W < 1 || N < 1 || C != 128 || axes < 1 || axes > 3) return NMRF_EINVAL;
     if (W * 2 > 65535 || H * 2 > 65535 || B > 65535) return NMRF_EINVAL;
     const float scale = 1.0f / sqrtf(32.0f);
     hipStream_t st = (hipStream_t)stream;
     if (axes & 1) {   // vertical stripes: one per column, H*N tokens each, channel half 0
-        StripeGeom g{H, W, N, C, H, H * N, (int64_t)W, 0, 0, 0};
+        StripeGeom g{H, W, N, C, H, H * N, (int64_t)W, 0, 0, 0, range_flag};
         if (N == 4) launch_stripe<0, 2>(qkv, lepe_v, g, W, B, scale, out, st);
         else launch_stripe<0, -1>(qkv, lepe_v, g, W, B, scale, out, st);
     }
     if (axes & 2) {   // horizontal stripes: one per row, W*N tokens each, channel half 1
-        StripeGeom g{H, W, N, C, W, W * N, (int64_t)1, 0, 0, 0};
+        StripeGeom g{H, W, N, C, W, W * N, (int64_t)1, 0, 0, 0, range_flag};
         if (N == 4) launch_stripe<1, 2>(qkv, lepe_h, g, H, B, scale, out, st);
         else launch_stripe<1, -1>(qkv, lepe_h, g, H, B, scale, out, st);
     }

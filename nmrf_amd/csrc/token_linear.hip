@@ -21,6 +21,7 @@
 // stride, every piece of a DRAM page arriving at a different time) the same tensor reached HBM at 1.5-3 TB/s and the
 // store phases took as long as the MFMAs; a plain fill of that tensor runs at 5-7 TB/s (tools/hbm_probe.py).
 #include "common.h"
+#include "../../include/nmrf_hip_debug.h"      // tools / test build only (not in libnmrf_hip.so)
 #include <type_traits>
 #include <utility>
 #include <stdlib.h>

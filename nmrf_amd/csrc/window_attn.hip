@@ -29,11 +29,13 @@ struct WinGeom {
     int Hp, Wp, N, C, heads, win, shift, sibling;
     int Tw;              // tokens per window = win*win*N
     int R;               // (2 win - 1)^2
+    int *range_flag;     // sticky fp16-range flag of the split operands (split_mfma.h), may be NULL
 };
 
 template <int NKT>
 __global__ __launch_bounds__(64 * NKT) void window_attn_kernel(const float *__restrict__ qkv,
         const float *__restrict__ table, WinGeom g, float scale, float *__restrict__ out) {
+    float guard = 0.f;                     // fp16 range guard of the activation splits (split_mfma.h)
     constexpr int TP = NKT * 32;                   // padded tokens per window
     constexpr int NTHR = 64 * NKT;
     const int win = g.win;
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(64 * NKT) void window_attn_kernel(const float *__re
         f32x16 st;
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[r] = 0.f;
-        split_dot16(kf, qf, st);                            // S^T = K . Q^T on split-fp16 MFMA (split_mfma.h)
+        split_dot16_g<true>(kf, qf, st, guard);                            // S^T = K . Q^T on split-fp16 MFMA (split_mfma.h)
         if (kt + 1 < NKT) load_k(kt + 1, kf);               // K fragment is dead: refill it for the next tile now,
         //                                                     in flight during this tile's softmax and P.V
         float m_tile = -INFINITY;
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(64 * NKT) void window_attn_kernel(const float *__re
 #pragma unroll
         for (int d = 0; d < 32; ++d) oe[d] *= alpha;
         // P.V on MFMA
-        split_dot16(vf, st, acc_o);                         // O^T += V^T . P^T on split-fp16 MFMA
+        split_dot16_g<false>(vf, st, acc_o, guard);                         // O^T += V^T . P^T on split-fp16 MFMA
         if (kt + 1 < NKT) load_v(kt + 1, vf);               // same for V: in flight during the ev term and the next S^T
         // value-embedding term on the VALU: sum over key PIXELS of (sum_n p) * ev[rel(pq,pk)]
 #pragma unroll
@@ -273,6 +275,7 @@ __global__ __launch_bounds__(64 * NKT) void window_attn_kernel(const float *__re
         half_swap(a, b);
         res[r] = (acc_o[r] + (a + b)) * inv_l;
     }
+    split_guard_commit(guard, g.range_flag);
     if (!q_ok) return;
     (void)qs;
     float *op = out + qrow * g.C + head * 32;
@@ -338,6 +341,7 @@ template <int NKT, int WIN, int NL, int WPB, int OCC, bool TIMED = false, int PK
 __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(const float *__restrict__ qkv,
         const float *__restrict__ table, WinGeom g, float scale, float *__restrict__ out,
         unsigned long long *__restrict__ stamps = nullptr) {
+    float guard = 0.f;                     // fp16 range guard of the activation splits (split_mfma.h)
     using L = WinFastLds<NKT, WIN, NL, WPB, PK>;
     constexpr int TP = L::TP, W2 = L::W2, R = L::R, Tw = L::Tw, TS = L::TS;
     constexpr int TwE = Tw * PK;                    // tokens of a wave's tile
@@ -562,7 +566,7 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
         f32x16 st;
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[r] = 0.f;
-        split_dot16(kf, qf, st);                            // S^T = K . Q^T on split-fp16 MFMA (split_mfma.h)
+        split_dot16_g<true>(kf, qf, st, guard);                            // S^T = K . Q^T on split-fp16 MFMA (split_mfma.h)
         if (kt + 1 < NKT) load_k(kt + 1, kf);
         // relative-position terms: one b128 of KR^T per key quad, QR^T per key pixel
 #pragma unroll
@@ -628,7 +632,7 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
         for (int r = 0; r < 16; ++r) acc_o[r] *= alpha;
 #pragma unroll
         for (int r = 0; r < 8; ++r) oe[r] *= alpha;
-        split_dot16(vf, st, acc_o);                         // O^T += V^T . P^T on split-fp16 MFMA
+        split_dot16_g<false>(vf, st, acc_o, guard);                         // O^T += V^T . P^T on split-fp16 MFMA
         // value-embedding term: sum over key PIXELS of (sum_n p) * ev[rel(pq,pk)].  The two half-lanes of a query
         // swap the probabilities of their pixels, then each accumulates BOTH pixels for its own 16 channels.
 #pragma unroll
@@ -668,6 +672,7 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
     for (int r = 0; r < 16; ++r) res[r] = (acc_o[r] + ((r & 1) ? oe[r >> 1].y : oe[r >> 1].x)) * inv_l;
     if (TIMED) asm volatile("" :: "v"(res[0]), "v"(res[15]));
     WA_STAMP(6 + NKT);
+    split_guard_commit(guard, g.range_flag);
     if (!tok_ok || !win_ok) return;
     float *op = out + (size_t)trow * g.C + head * 32;
 #pragma unroll
@@ -734,7 +739,7 @@ extern "C" int nmrf_debug_window_occupancy(int *blocks_infer, int *blocks_refine
 extern "C" int nmrf_debug_window_timing(const float *qkv, const float *table, int B, int Hp, int Wp, int shift, float *out,
                                         unsigned long long *stamps, void *stream) {
     using L = WinFastLds<5, 6, 4, 2>;
-    WinGeom g{Hp, Wp, 4, 128, 4, 6, shift, 1, 144, 121};
+    WinGeom g{Hp, Wp, 4, 128, 4, 6, shift, 1, 144, 121, nullptr};
     hipFuncSetAttribute((const void *)window_attn_fast_kernel<5, 6, 4, 2, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES);
     const int nwin = (Hp / 6) * (Wp / 6);
     dim3 grid((nwin + 1) / 2, 4, B);
@@ -750,12 +755,12 @@ extern "C" int nmrf_debug_window_pack1(int v) { g_window_pack1 = v; return NMRF_
 #endif
 
 extern "C" int nmrf_window_attn_f32(const float *qkv, const float *table, int B, int Hp, int Wp, int N, int C, int heads,
-                                    int win, int shift, int sibling_mask, float *out, void *stream) {
+                                    int win, int shift, int sibling_mask, float *out, int *range_flag, void *stream) {
     if (!qkv || !table || !out) return NMRF_ENULL;
     if (B < 1 || N < 1 || win < 1 || Hp % win || Wp % win || shift < 0 || shift >= win || heads * 32 != C || (C & 3))
         return NMRF_EINVAL;
     if ((int64_t)B * Hp * Wp * N >= (int64_t)1 << 31) return NMRF_EINVAL;
-    WinGeom g{Hp, Wp, N, C, heads, win, shift, sibling_mask ? 1 : 0, win * win * N, (2 * win - 1) * (2 * win - 1)};
+    WinGeom g{Hp, Wp, N, C, heads, win, shift, sibling_mask ? 1 : 0, win * win * N, (2 * win - 1) * (2 * win - 1), range_flag};
     const int nkt = (g.Tw + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
     if ((int64_t)B * Hp * Wp * N * 3 * C < ((int64_t)1 << 32)) {                            // 32-bit element offsets

@@ -61,6 +61,7 @@ class _Plan:
         self.static_in = torch.empty(2, b, c, h, w, dtype=dtype, device=dev)
         self.graph, self.static_out = None, None
         self.out_dev, self.pin_out = [None] * depth, [None] * depth
+        self.pin_flag = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(depth)]
         self.ev_in = [torch.cuda.Event() for _ in range(depth)]        # H2D of the slot finished
         self.ev_used = [None] * depth                                   # compute has consumed dev_in[slot]
         self.ev_out = [torch.cuda.Event() for _ in range(depth)]       # out_dev[slot] written
@@ -92,6 +93,10 @@ class StereoStream:
         self.on_gpu = self.device.type == "cuda"
         self.depth, self.copy_out, self.use_graph = max(2, depth), copy_out, graph and self.on_gpu
         self.plans = {}
+        # models of this package defer their fp16 range check to the driver (one flag read per drained batch)
+        self._range_model = model if (self.on_gpu and hasattr(model, "range_check")) else None
+        if self._range_model is not None:
+            self._range_model.range_check = False
         if self.on_gpu:
             self.h2d = torch.cuda.Stream(self.device)
             self.d2h = torch.cuda.Stream(self.device)
@@ -165,15 +170,19 @@ class StereoStream:
         with torch.cuda.stream(self.d2h):
             self.d2h.wait_event(plan.ev_out[slot])
             plan.pin_out[slot].copy_(plan.out_dev[slot], non_blocking=True)
+            if self._range_model is not None:               # the sticky fp16 range flag rides back with the results (4 bytes)
+                plan.pin_flag[slot].copy_(K.range_flag(self.device), non_blocking=True)
             done = torch.cuda.Event()
             done.record(self.d2h)
         plan.ev_d2h[slot] = done
-        return [g[0] for g in group], plan.pin_out[slot], done
+        return [g[0] for g in group], plan.pin_out[slot], done, plan.pin_flag[slot]
 
     def _drain(self, pending):
-        keys, host, done = pending
+        keys, host, done = pending[:3]
         if done is not None:
             done.synchronize()
+            if len(pending) > 3 and int(pending[3]) != 0:   # the fp16 range flag as it stood when this batch had finished
+                K.check_range(self.device)                  # raises NmrfHipError (and clears the flag)
         for k, d in zip(keys, host):
             yield k, (K.host_read_evict(d) if self.copy_out and done is not None else d)
 

@@ -37,6 +37,41 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+# ---- fp16 range guard of the split-operand kernels (include/nmrf_hip.h, "fp16 range"): one sticky int32 per device --------------
+_range_flags = {}
+
+
+def range_flag(device=None):
+    """The device int32 the guarded kernels OR their out-of-range bit into (allocated on first use, one per device)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    f = _range_flags.get(dev.index)
+    if f is None:
+        f = _range_flags[dev.index] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return f
+
+
+def _rf(t):
+    return range_flag(t.device).data_ptr()
+
+
+def check_range(device=None, reset=True):
+    """Synchronise with `device` and raise NmrfHipError if any guarded kernel since the last check converted an activation that does
+    not fit the fp16 range of the split-operand arithmetic (|x| >= 65520, or NaN).  The results of those launches are invalid (inf
+    / NaN or, downstream of a ReLU or a masked softmax, silently wrong).  The reference computes in plain fp32 and has no such
+    limit; weights have none here either (rescaled by a power of two at pack time)."""
+    f = range_flag(device)
+    v = int(f.item())
+    if v and reset:
+        f.zero_()
+    if v:
+        raise _lib.NmrfHipError("an activation left the fp16 range of the split-operand MFMA kernels (|x| >= 65520 or NaN): the "
+                                "outputs since the last check are invalid.  The reference's fp32 arithmetic has no such limit; "
+                                "rescale the inputs / checkpoint (csrc/split_mfma.h)")
+    return True
+
+
 def _on_device(fn):
     """Launch on the device the tensors live on (like the reference's device-guarded ATen ops): the stream handed to the C ABI
     is that device's current torch stream and the HIP current device is switched for the duration of the call."""
@@ -198,12 +233,12 @@ def stripe_attn(qkv, lepe_v, lepe_h, b, h, w, n):
     assert t == b * h * w * n
     out = torch.empty(t, c, device=qkv.device, dtype=torch.float32)
     fn = _lib.load().nmrf_stripe_attn_f32
-    _lib.check(fn(_p(qkv), _p(lepe_v), _p(lepe_h), b, h, w, n, c, 1, _p(out), _stream()), "stripe_attn(vertical)")
+    _lib.check(fn(_p(qkv), _p(lepe_v), _p(lepe_h), b, h, w, n, c, 1, _p(out), _rf(qkv), _stream()), "stripe_attn(vertical)")
     # per (row, head): QK^T and PV, 2*T^2*32 FLOPs each, T = W*N, 2 heads of 32 channels
     _hb("stripe_attn_horizontal", row="A7", bound="mfma", split=True, flops=b * h * 2 * 4.0 * 32 * (w * n) ** 2, bytes=4.0 * (qkv.numel() / 2 + t * c / 2),
         label="stripe_attn_kernel<1> (horizontal stripes, A7)",
         pmc=["stripe_attn_kernel<1, 2, 1, false>", "stripe_attn_kernel<1, 2, 2, false>"])
-    _lib.check(fn(_p(qkv), _p(lepe_v), _p(lepe_h), b, h, w, n, c, 2, _p(out), _stream()), "stripe_attn(horizontal)")
+    _lib.check(fn(_p(qkv), _p(lepe_v), _p(lepe_h), b, h, w, n, c, 2, _p(out), _rf(qkv), _stream()), "stripe_attn(horizontal)")
     _he("stripe_attn_horizontal")
     return out
 
@@ -255,7 +290,7 @@ def window_attn(qkv, table, b, hp, wp, n, heads, win, shift, sibling_mask):
         pmc=[fast.get((win, n), "window_attn_kernel<%d>" % ((tw + 31) // 32))] + (["window_attn_fast_kernel<1, 4, 1, 8, 2, false, 2>"]
                                                                                     if (win, n) == (4, 1) else []))
     _lib.check(_lib.load().nmrf_window_attn_f32(_p(qkv), _p(table), b, hp, wp, n, c, heads, win, shift,
-                                                int(bool(sibling_mask)), _p(out), _stream()), "window_attn")
+                                                int(bool(sibling_mask)), _p(out), _rf(qkv), _stream()), "window_attn")
     _he("window_attn_w%d_n%d" % (win, n))
     return out
 
@@ -274,17 +309,18 @@ def linear_smalln(x, weight, bias=None, relu=False):
 
 @_on_device
 def pack_linear_weight(weight):
-    """[N,K] nn.Linear weight -> MFMA fragment order for token_linear (N % 32 == 0)."""
+    """[N,K] nn.Linear weight -> MFMA fragment order for token_linear (N % 32 == 0).  Debug library (include/nmrf_hip_debug.h)."""
     _chk(weight)
     n, k = weight.shape
     packed = torch.empty(n * ((k + 31) // 32 * 32) + n // 32, device=weight.device, dtype=torch.float32)
-    _lib.check(_lib.load().nmrf_pack_linear_weight_f32(_p(weight.contiguous()), n, k, _p(packed), _stream()), "pack_linear_weight")
+    _lib.check(_lib.load_debug().nmrf_pack_linear_weight_f32(_p(weight.contiguous()), n, k, _p(packed), _stream()), "pack_linear_weight")
     return packed
 
 
 @_on_device
 def token_linear(x, packed_w, n, k, bias=None, ln=None, y=None, extra=None, extra_div=1, act=0, residual=None):
-    """out[T,n] = act(P(x) W^T + bias) + residual on the fused MFMA kernel.
+    """fp32-MFMA reference linear of the tools / test build (libnmrf_hip_debug.so; NMRF_LINEAR=fp32 A/B runs).
+    out[T,n] = act(P(x) W^T + bias) + residual on the fused MFMA kernel.
     ln = (gamma, beta, eps): P(x) = [LayerNorm(x + y) | extra[t // extra_div]]; returns (x + y, out) when y is given.
     ln = None: P(x) = x (k columns).  act: 0 / 'relu' / 'gelu'."""
     _chk(x, packed_w, bias, y, extra, residual)
@@ -309,7 +345,7 @@ def token_linear(x, packed_w, n, k, bias=None, ln=None, y=None, extra=None, extr
             label="token_linear%s_kernel<%d,%s,%s> (%s%d->%d%s)" % ("_pipe" if len(pmc) > 1 else "", kc, "LN" if ln is not None else "plain",
                                                                   "GELU" if act == 2 else "-", "LayerNorm+" if ln is not None else "", k, n,
                                                                   "+GELU" if act == 2 else ""), pmc=pmc)
-    _lib.check(_lib.load().nmrf_token_linear_f32(_p(x), _p(y), _p(x_out), _p(g), _p(bt), float(eps), _p(extra), e, extra_div,
+    _lib.check(_lib.load_debug().nmrf_token_linear_f32(_p(x), _p(y), _p(x_out), _p(g), _p(bt), float(eps), _p(extra), e, extra_div,
                                                  _p(packed_w), _p(bias), _p(residual), act, t, cx, k, n, _p(out), _stream()),
                "token_linear")
     if hook_name is not None:
@@ -440,7 +476,7 @@ def mlp_chain(kind, x, k1, stream, stages, inv_scales, biases, n_out, extra=None
             pmc=["mlp_chain_kernel"])
     _lib.check(_lib.load().nmrf_mlp_chain_f32(kind, _p(x), ld, k1, _p(stream), stages, _p(b[0]), _p(b[1]), _p(b[2]), _p(extra),
                                               0 if extra is None else extra.shape[-1], inv_scales, t, _p(out), out.shape[-1], n_out,
-                                              _p(out_map), _stream()), "mlp_chain")
+                                              _p(out_map), _rf(x), _stream()), "mlp_chain")
     if kernel_hook is not None:
         _he(name + "_n%d" % n_out)
     return out
@@ -448,8 +484,8 @@ def mlp_chain(kind, x, k1, stream, stages, inv_scales, biases, n_out, extra=None
 
 @_on_device
 def nmp_block(x, stream, stages, inv_scales, msg=None, bp=None, mlp=None, q=None, want_x=True, ln_out=None, ln_out_map=None,
-              tokens_per_wave=32):
-    """One fused message-passing block (nmrf_nmp_block_f32).
+              tokens_per_wave=16):
+    """One fused message-passing block (nmrf_nmp_block16_f32; tokens_per_wave=32: the debug library's 32-token form).
     mlp = (ln2_gamma, ln2_beta, eps, b1, b2) or None;  q = dict(g, b, eps, extra=None, extra_div=1, bias=None, kq=0|128|160|192,
     nq=0 -> no q_out, ln_out=False) or None.  Returns (x_out | None, q_out | None, ln_out | None)."""
     _chk(x, msg, bp)
@@ -488,11 +524,11 @@ def nmp_block(x, stream, stages, inv_scales, msg=None, bp=None, mlp=None, q=None
                 tokens_per_wave),
             pmc=["nmp_block_kernel<%s, %d, 1, 4, false, 0>" % ("true" if mlp is not None else "false", kq // 16) if tokens_per_wave == 32
                  else "nmp_block16_kernel<%s, %d, 0>" % ("true" if mlp is not None else "false", (kq + 31) // 32)])
-    fn = _lib.load().nmrf_nmp_block_f32 if tokens_per_wave == 32 else _lib.load().nmrf_nmp_block16_f32
+    fn = _lib.load_debug().nmrf_nmp_block_f32 if tokens_per_wave == 32 else _lib.load().nmrf_nmp_block16_f32
     _lib.check(fn(_p(x), _p(msg), _p(stream), stages, _p(bp), _p(ln2_g), _p(ln2_b), float(eps2), _p(b1),
                                               _p(b2), _p(lq_g), _p(lq_b), float(epsq), _p(extra), ld, div, _p(bq),
                                               int(mlp is not None), kq, nq, t, inv_scales, _p(x_out), _p(q_out), _p(ln_out),
-                                              _p(ln_out_map), _stream()),
+                                              _p(ln_out_map), _rf(x), _stream()),
                "nmp_block")
     if kernel_hook is not None:
         _he(name)
@@ -506,13 +542,14 @@ def wino_pack_filter(weight):
     co, ci, kh, kw = weight.shape
     assert kh == 3 and kw == 3
     packed = torch.empty(16 * co * ci, device=weight.device, dtype=torch.float32)
-    _lib.check(_lib.load().nmrf_wino_pack_filter_f32(_p(weight.contiguous()), co, ci, _p(packed), _stream()), "wino_pack_filter")
+    _lib.check(_lib.load_debug().nmrf_wino_pack_filter_f32(_p(weight.contiguous()), co, ci, _p(packed), _stream()), "wino_pack_filter")
     return packed
 
 
 @_on_device
 def conv3x3_wino(x, packed_u, co):
-    """3x3 / stride 1 / pad 1 / no-bias convolution (NCHW fp32) as fused Winograd F(2x2,3x3) on fp32 MFMA."""
+    """3x3 / stride 1 / pad 1 / no-bias convolution (NCHW fp32) as fused Winograd F(2x2,3x3) on fp32 MFMA: the round-1 kernel, kept
+    in the debug library as a reference (include/nmrf_hip_debug.h); the product runs conv3x3_split."""
     _chk(x, packed_u)
     b, ci, h, w = x.shape
     y = torch.empty(b, co, h, w, device=x.device, dtype=torch.float32)
@@ -521,7 +558,7 @@ def conv3x3_wino(x, packed_u, co):
     _hb("conv3x3_wino", row="N2", bound="mfma", flops=2.0 * 9 * b * ci * co * h * w / 2.25, direct_flops=2.0 * 9 * b * ci * co * h * w,
         bytes=4.0 * (x.numel() + y.numel()), label="conv3x3_wino_kernel (3x3 stride-1 convs of the backbone / conv heads, N2; "
         "mean over layers; Winograd-form FLOPs)", pmc=["conv3x3_wino_kernel"])
-    _lib.check(_lib.load().nmrf_conv3x3_wino_f32(_p(x), _p(packed_u), b, ci, h, w, co, _p(y), _stream()), "conv3x3_wino")
+    _lib.check(_lib.load_debug().nmrf_conv3x3_wino_f32(_p(x), _p(packed_u), b, ci, h, w, co, _p(y), _stream()), "conv3x3_wino")
     _he("conv3x3_wino")
     return y
 
@@ -532,9 +569,6 @@ def _conv3_plan(co, tiles):
     halo is then staged once for 128 channels instead of twice; measured at KITTI B=1: 128->256 at 1/4 res, 480 blocks of four
     strips 93 us vs 960 of two 103 us; 128->128 at 1/4 res, 240 vs 480 blocks: 56 vs 53 us; 128->256 at 1/8 res: 47 vs 34 us)."""
     k = co // 32
-    forced = os.environ.get("NMRF_CONV3_STRIPS")
-    if forced and k % int(forced) == 0:
-        return int(forced), k // int(forced)
     if k % 4 == 0 and tiles * (k // 4) >= 400:
         return 4, k // 4
     if k % 2 == 0:
@@ -576,7 +610,7 @@ def conv_split(x, packed, co, kt=3, stride=1, pad=1, stats=None, eps=1e-5):
     _hb(name, row="N2", bound="mfma", flops=2.0 * kt * kt * b * ci * co * ho * wo, bytes=4.0 * (x.numel() + y.numel()), split=True,
         label=label, pmc=["conv3x3_split_kernel<%d, %d, %d," % (strips, kt, stride)])
     _lib.check(_lib.load().nmrf_conv_split_f32(_p(x), b, ci, h, w, _p(stats), 0 if stats is None else stats.shape[1], float(eps),
-                                               _p(stream), kt, stride, pad, strips, groups, float(inv), co, _p(y), _stream()),
+                                               _p(stream), kt, stride, pad, strips, groups, float(inv), co, _p(y), _rf(x), _stream()),
                "conv_split")
     _he(name)
     return y
@@ -596,13 +630,12 @@ def _cached_pack(cache, key, make):
 
 
 def conv3x3_s2_auto(x, weight, cache):
-    """3x3 / stride 2 / pad 1 / no-bias convolution (layer2.0.conv1): split-fp16 MFMA kernel, or MIOpen (NMRF_CONV3 != split,
-    unsupported channel counts)."""
+    """3x3 / stride 2 / pad 1 / no-bias convolution (layer2.0.conv1): split-fp16 MFMA kernel; channel counts it is not built for
+    go to the stock torch convolution (MIOpen)."""
     co, ci = weight.shape[0], weight.shape[1]
     k = co // 32
     strips = 3 if k % 3 == 0 else (2 if k % 2 == 0 else 0)
-    if (not x.is_cuda or x.dtype != torch.float32 or ci % 16 or co % 32 or not strips
-            or os.environ.get("NMRF_CONV3", "split") != "split" or os.environ.get("NMRF_WINO", "1") == "0"):
+    if not x.is_cuda or x.dtype != torch.float32 or ci % 16 or co % 32 or not strips:
         return torch.nn.functional.conv2d(x, weight, None, 2, 1)
     groups = k // strips
     stream, inv = _cached_pack(cache, (weight.data_ptr(), weight._version, "s2"), lambda: pack_conv3x3(weight, strips, groups))
@@ -643,18 +676,14 @@ def stem_conv_s2d(x_s2d, weight, cache):
 
 
 def conv3x3_auto(x, weight, cache, stats=None):
-    """3x3 / stride 1 / pad 1 / no-bias convolution [of relu(InstanceNorm(x)) when `stats` = instance_stats(x) is given].
-    Default: the direct split-fp16 MFMA kernel (conv3x3.hip).  NMRF_CONV3=wino: the round-1 Winograd fp32-MFMA kernel where it has
-    enough blocks to fill the chip, MIOpen otherwise; NMRF_CONV3=miopen: always MIOpen.  Unsupported channel counts -> MIOpen.
+    """3x3 / stride 1 / pad 1 / no-bias convolution [of relu(InstanceNorm(x)) when `stats` = instance_stats(x) is given] on the
+    direct split-fp16 MFMA kernel (conv3x3.hip).  Channel counts the kernel is not built for (Ci % 16, Co % 32, or a normalised
+    input wider than the 256-channel affine table) go to the stock torch convolution (MIOpen).
     `cache`: a dict owned by the caller, holds the packed filter per weight version."""
     co, ci = weight.shape[0], weight.shape[1]
     b, _, h, w = x.shape
-    mode = os.environ.get("NMRF_CONV3", "split")
-    if os.environ.get("NMRF_WINO", "1") == "0":
-        mode = "miopen"
-    key = (weight.data_ptr(), weight._version, mode)
-    hip = x.is_cuda and x.dtype == torch.float32 and ci % 16 == 0 and co % 32 == 0
-    if hip and mode == "split" and (stats is None or ci <= 256):
+    key = (weight.data_ptr(), weight._version)
+    if x.is_cuda and x.dtype == torch.float32 and ci % 16 == 0 and co % 32 == 0 and (stats is None or ci <= 256):
         plan = _conv3_plan(co, b * ((h + 7) // 8) * ((w + 31) // 32))
         if plan is not None:
             if cache.get("key") != key + plan:
@@ -663,16 +692,9 @@ def conv3x3_auto(x, weight, cache, stats=None):
                 cache["key"] = key + plan
             stream, inv = cache["packed"]
             return conv3x3_split(x.contiguous(), (stream, plan[0], plan[1], inv), co, stats)
-    if stats is not None:                                  # the other paths take the normalised activation
+    if stats is not None:                                  # the stock path takes the normalised activation
         x = instance_norm(x.contiguous(), relu=True)
-    blocks = ((w + 1) // 2 + 31) // 32 * (((h + 1) // 2 + 1) // 2) * b * (co // 32)
-    if not hip or mode == "miopen" or blocks < 512:
-        return torch.nn.functional.conv2d(x, weight, None, 1, 1)
-    if cache.get("key") != key:
-        with torch.no_grad():
-            cache["packed"] = wino_pack_filter(weight)
-        cache["key"] = key
-    return conv3x3_wino(x.contiguous(), cache["packed"], co)
+    return torch.nn.functional.conv2d(x, weight, None, 1, 1)
 
 
 @_on_device
@@ -742,7 +764,7 @@ def conv1x1_in_relu(x, c0, k, stats, packed, bias=None, eps=1e-5):
     _hb("conv1x1_k%d_n%d" % (k, n), row="N2", bound="hbm", bytes=4.0 * b * h * w * (k + n), flops=2.0 * b * h * w * k * n, split=True,
         label="conv1x1_kernel (InstanceNorm + ReLU + 1x1 conv %d->%d of the conv heads, N2)" % (k, n), pmc=["conv1x1_kernel<%d>" % (k // 16)])
     _lib.check(_lib.load().nmrf_conv1x1_in_relu_f32(_p(x), b, cx, h * w, c0, k, _p(stats), 0 if stats is None else stats.shape[1],
-                                                    float(eps), _p(stream), stages, float(inv), _p(bias), n, _p(out), _stream()),
+                                                    float(eps), _p(stream), stages, float(inv), _p(bias), n, _p(out), _rf(x), _stream()),
                "conv1x1_in_relu")
     _he("conv1x1_k%d_n%d" % (k, n))
     return out

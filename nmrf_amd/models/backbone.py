@@ -6,7 +6,6 @@ Parameter names follow the reference's `Backbone` (nmrf/models/backbone.py:16-98
 checkpoints load with strict=True: conv1, layer{1,2,3}.{0,1}.{conv1,conv2,downsample.0}, conv2.
 """
 import logging
-import os
 
 import torch
 import torch.nn as nn
@@ -106,7 +105,7 @@ class Backbone(nn.Module):
             x = self.layer3(self.layer2(self.layer1(x)))
             if x.shape[-1] % 2 == 0 and x.shape[-2] % 2 == 0:
                 w2 = self.conv2.weight
-                if w2.shape[1] in (64, 128) and w2.shape[0] % 64 == 0 and os.environ.get("NMRF_CONV1X1", "1") != "0":
+                if w2.shape[1] in (64, 128) and w2.shape[0] % 64 == 0:
                     if not hasattr(self, "_c2"):
                         self._c2 = {}
                     key = (w2.data_ptr(), w2._version)

@@ -57,8 +57,7 @@ class DPN(nn.Module):
             self._c3 = {}
         raw = K.conv3x3_auto(fmap, self.proj[0].weight, self._c3).contiguous()
         w1 = self.proj[3].weight
-        import os
-        if os.environ.get("NMRF_CONV1X1", "1") != "0" and w1.shape[1] in (64, 128) and w1.shape[0] % 64 == 0:
+        if w1.shape[1] in (64, 128) and w1.shape[0] % 64 == 0:
             from .nmp import _FusedCache                    # IN + ReLU folded into the 1x1 conv's operand load (csrc/conv1x1.hip)
             if not hasattr(self, "_c1"):
                 self._c1 = _FusedCache()

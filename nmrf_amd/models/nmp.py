@@ -1,12 +1,12 @@
 """Neural message passing blocks of NMRF on the HIP kernels.
 
-The module tree and parameter names mirror nmrf/models/NMP.py so that reference checkpoints load
-with strict=True.  The arithmetic does not: every block is
-    [HIP] token_linear: (x + y) -> LayerNorm -> concat -> fused q|k|v GEMM on fp32 MFMA  ->  [HIP] attention kernel
-    ->  [HIP] token_linear proj  ->  [HIP] token_linear: add -> LayerNorm -> fc1 -> GELU  ->  [hipBLASLt] fc2
-on token-major fp32 buffers [T, C] with T = B*H*W*N.  q/k/v weights are fused and packed into MFMA fragment order
-once per parameter version.  NMRF_FUSED_LINEAR=0 switches the linears back to the round-1 path
-(ln_concat kernel + hipBLASLt GEMM + torch GELU) for A/B timing.
+The module tree and parameter names mirror nmrf/models/NMP.py so that reference checkpoints load with strict=True.  The arithmetic
+does not: on token-major fp32 buffers [T, C] (T = B*H*W*N) every block is
+    [HIP] attention kernel  ->  [HIP] nmp_block16: proj + residual + LayerNorm + fc1 + GELU + fc2 + residual + the NEXT block's
+                                 LayerNorm | side columns -> q|k|v                                     (ONE launch, split-fp16 MFMA)
+with the weights of a launch packed into one MFMA-fragment stream per parameter version.
+NMRF_LINEAR=fp32 (A/B parity runs, tests) switches the per-token linears to the round-1 chain of fp32-MFMA token_linear kernels
+(+ hipBLASLt fc2) of the tools / test library libnmrf_hip_debug.so; the product library does not contain them.
 There is no CPU path: the kernels raise on non-CUDA tensors.
 """
 import os
@@ -18,14 +18,10 @@ import torch.nn.functional as F
 from .. import kernels as K
 
 
-def _fused():
-    return os.environ.get("NMRF_FUSED_LINEAR", "1") != "0"
-
-
 def _split():
-    """Default: the per-token linears of a block run in ONE kernel on split-operand fp16 MFMA (csrc/nmp_block.hip, fp32-grade
-    products).  NMRF_LINEAR=fp32 keeps the round-1 chain of fp32-MFMA token_linear kernels + hipBLASLt fc2 for A/B runs."""
-    return _fused() and os.environ.get("NMRF_LINEAR", "split") != "fp32"
+    """Default: the per-token linears of a block run in ONE kernel on split-operand fp16 MFMA (csrc/nmp_block16.hip, fp32-grade
+    products).  NMRF_LINEAR=fp32: the reference chain of fp32-MFMA token_linear kernels + hipBLASLt fc2 (debug library)."""
+    return os.environ.get("NMRF_LINEAR", "split") != "fp32"
 
 FOURIER_DIM = 31        # 15 sin + 15 cos + the scaled coordinate (NMP.py:35-51)
 
@@ -48,7 +44,7 @@ class MLP(nn.Module):
             return self._chain(x.reshape(-1, 128).contiguous(), 128).view(*shp[:-1], self.layers[2].out_features)
         for i, layer in enumerate(self.layers):
             last = i == self.num_layers - 1
-            if (_fused() and x.is_cuda and layer.out_features % 32 == 0 and layer.out_features > 64
+            if (x.is_cuda and layer.out_features % 32 == 0 and layer.out_features > 64
                     and layer.in_features in (32, 64, 128, 160)):
                 if not hasattr(self, "_lin"):
                     self._lin = {}
@@ -78,7 +74,7 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden_features, out_features)
 
     def forward(self, x):
-        if _fused() and x.is_cuda and x.dim() == 2 and self.fc1.in_features in (64, 128, 160) and self.fc1.out_features % 32 == 0:
+        if x.is_cuda and x.dim() == 2 and self.fc1.in_features in (64, 128, 160) and self.fc1.out_features % 32 == 0:
             if not hasattr(self, "_lin1"):
                 self._lin1 = _Lin(self.fc1)
             return self.fc2(self._lin1(x.contiguous(), act="gelu"))
@@ -136,11 +132,6 @@ class _Lin:
         return K.token_linear(x, pw, n, k, b, act=act, **kw)
 
 
-def _block_tokens():
-    """Tokens per wave of the fused block kernel: 16 (csrc/nmp_block16.hip, two waves per SIMD; default) or 32 (csrc/nmp_block.hip)."""
-    return 32 if os.environ.get("NMRF_BLOCK_TOKENS", "16") == "32" else 16
-
-
 class _BlockLauncher:
     """One nmp_block launch site of a stage: x1 = x + proj(msg); x2 = x1 + mlp(norm2(x1)); then the NEXT block's q|k|v on
     [norm(x2) | side] or the stage's final norm.  The weight stream and the fused bias are rebuilt when a parameter changes."""
@@ -148,7 +139,6 @@ class _BlockLauncher:
     def __init__(self, proj=None, mlp=None, nxt_norm=None, nxt_linears=(), kq=0, ln_out=False):
         self.proj, self.mlp, self.nxt_norm, self.nxt_linears, self.kq, self.ln_out = proj, mlp, nxt_norm, tuple(nxt_linears), kq, ln_out
         self.cache = _FusedCache()
-        self.tokens = _block_tokens()
 
     def _params(self):
         ps = []
@@ -166,10 +156,9 @@ class _BlockLauncher:
             k = max(l.in_features for l in self.nxt_linears)
             wq = torch.cat([_pad_cols(l.weight, k) for l in self.nxt_linears], 0).contiguous()
             bq = torch.cat([l.bias for l in self.nxt_linears]).contiguous()
-        build = K.block_stream if self.tokens == 32 else K.block_stream16
-        stream, stages, inv = build(None if self.proj is None else self.proj.weight.contiguous(),
-                                    None if self.mlp is None else self.mlp[1].fc1.weight.contiguous(),
-                                    None if self.mlp is None else self.mlp[1].fc2.weight.contiguous(), wq, self.kq)
+        stream, stages, inv = K.block_stream16(None if self.proj is None else self.proj.weight.contiguous(),
+                                               None if self.mlp is None else self.mlp[1].fc1.weight.contiguous(),
+                                               None if self.mlp is None else self.mlp[1].fc2.weight.contiguous(), wq, self.kq)
         return stream, stages, inv, bq, (0 if wq is None else wq.shape[0])
 
     def __call__(self, x, msg=None, extra=None, extra_div=1, want_x=True, ln_out=None, ln_out_map=None):
@@ -183,7 +172,7 @@ class _BlockLauncher:
             q = dict(g=self.nxt_norm.weight, b=self.nxt_norm.bias, eps=self.nxt_norm.eps, extra=extra if self.kq > 128 else None,
                      extra_div=extra_div, bias=bq, kq=self.kq, nq=nq, ln_out=self.ln_out)
         return K.nmp_block(x, stream, stages, inv, msg, None if self.proj is None else self.proj.bias, mlp, q, want_x=want_x,
-                           ln_out=ln_out, ln_out_map=ln_out_map, tokens_per_wave=self.tokens)
+                           ln_out=ln_out, ln_out_map=ln_out_map)
 
 
 class _ChainLauncher:
@@ -253,30 +242,18 @@ class BasicAttention(nn.Module):
         self.norm1 = nn.LayerNorm(dim)
         self.q, self.k, self.v = nn.Linear(qk_dim, dim), nn.Linear(qk_dim, dim), nn.Linear(dim, dim)
         self.proj = nn.Linear(dim, dim)
-        self._fused = _FusedCache()
         self._packed_qkv = _FusedCache()
         self._proj = _Lin(self.proj)
 
-    def _weights(self):
-        def build():
-            kp = (self.q.in_features + 3) // 4 * 4
-            w = torch.cat((_pad_cols(self.q.weight, kp), _pad_cols(self.k.weight, kp), _pad_cols(self.v.weight, kp)), 0)
-            return w.contiguous(), torch.cat((self.q.bias, self.k.bias, self.v.bias)).contiguous(), kp
-        return self._fused.get((self.q.weight, self.k.weight, self.v.weight, self.q.bias, self.k.bias, self.v.bias), build)
-
     def forward_pair(self, x, y, abs_encoding, n):
-        """(x, y) = residual stream x + y; returns the next pair."""
-        if _fused():
-            pw, b, k, nn_ = _packed(self._packed_qkv, (self.q.weight, self.k.weight, self.v.weight),
-                                    (self.q.bias, self.k.bias, self.v.bias))
-            r = K.token_linear(x, pw, nn_, k, b, ln=(self.norm1.weight, self.norm1.bias, self.norm1.eps), y=y,
-                               extra=abs_encoding)
-            x, qkv = r if y is not None else (x, r)
-            return x, self._proj(K.self_attn(qkv, n, self.num_heads))
-        w, b, kp = self._weights()
-        x, a = _add_ln(x, y, self.norm1, abs_encoding, 1, kp)
-        msg = K.self_attn(F.linear(a, w, b), n, self.num_heads)
-        return x, self.proj(msg)
+        """(x, y) = residual stream x + y; returns the next pair.  (The fp32-MFMA reference chain; the default path runs the
+        whole stage through Inference._run_blocks.)"""
+        pw, b, k, nn_ = _packed(self._packed_qkv, (self.q.weight, self.k.weight, self.v.weight),
+                                (self.q.bias, self.k.bias, self.v.bias))
+        r = K.token_linear(x, pw, nn_, k, b, ln=(self.norm1.weight, self.norm1.bias, self.norm1.eps), y=y,
+                           extra=abs_encoding)
+        x, qkv = r if y is not None else (x, r)
+        return x, self._proj(K.self_attn(qkv, n, self.num_heads))
 
     def forward(self, label_rep, abs_encoding, n):
         """label_rep [T,C], abs_encoding [T,31] -> [T,C]; n = labels per pixel."""
@@ -319,26 +296,13 @@ class SwinNMP(nn.Module):
         self.proj = nn.Linear(dim, dim)
         self.norm2 = nn.LayerNorm(dim)
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
-        self._fused = _FusedCache()
         self._qkv = _Lin(self.qkv)
         self._proj = _Lin(self.proj)
 
-    def _weights(self):
-        def build():
-            kp = (self.qkv.in_features + 3) // 4 * 4
-            return _pad_cols(self.qkv.weight, kp).contiguous(), kp
-        return self._fused.get((self.qkv.weight,), build)
-
     def forward_pair(self, x, y, abs_encoding, dims, sibling_mask):
-        if _fused():
-            r = self._qkv(x, ln=(self.norm1.weight, self.norm1.bias, self.norm1.eps), y=y, extra=abs_encoding)
-            x, qkv = r if y is not None else (x, r)
-            return self.mlp.forward_ln(x, self._proj(self.attn(qkv, dims, sibling_mask)), self.norm2)
-        w, kp = self._weights()
-        x, a = _add_ln(x, y, self.norm1, abs_encoding, 1, kp)
-        msg = self.attn(F.linear(a, w, self.qkv.bias), dims, sibling_mask)
-        x, h = _add_ln(x, self.proj(msg), self.norm2)
-        return x, self.mlp(h)
+        r = self._qkv(x, ln=(self.norm1.weight, self.norm1.bias, self.norm1.eps), y=y, extra=abs_encoding)
+        x, qkv = r if y is not None else (x, r)
+        return self.mlp.forward_ln(x, self._proj(self.attn(qkv, dims, sibling_mask)), self.norm2)
 
     def forward(self, label_rep, abs_encoding, dims, sibling_mask):
         x, y = self.forward_pair(label_rep, None, abs_encoding, dims, sibling_mask)
@@ -373,16 +337,8 @@ class CSWinNMP(nn.Module):
         self.attns = nn.ModuleList(CSWinAttention(dim // 2, i, split_size, num_heads // 2) for i in range(2))
         self.mlp = Mlp(dim, int(dim * mlp_ratio), dim)
         self.norm2 = nn.LayerNorm(dim)
-        self._fused = _FusedCache()
         self._packed_qkv = _FusedCache()
         self._proj = _Lin(self.proj)
-
-    def _weights(self):
-        def build():
-            kp = (self.q.in_features + 3) // 4 * 4
-            w = torch.cat((_pad_cols(self.q.weight, kp), _pad_cols(self.k.weight, kp), _pad_cols(self.v.weight, kp)), 0)
-            return w.contiguous(), torch.cat((self.q.bias, self.k.bias, self.v.bias)).contiguous(), kp
-        return self._fused.get((self.q.weight, self.k.weight, self.v.weight, self.q.bias, self.k.bias, self.v.bias), build)
 
     def forward(self, seed_rep, context, dims):
         """seed_rep [T,C]; context [B*H*W, Cctx] (per pixel, shared by its N labels); dims=(B,H,W,N)."""
@@ -391,19 +347,13 @@ class CSWinNMP(nn.Module):
 
     def forward_pair(self, x, y, context, dims):
         b, h, wd, n = dims
-        if _fused():
-            pw, bias, k, nn_ = _packed(self._packed_qkv, (self.q.weight, self.k.weight, self.v.weight),
-                                       (self.q.bias, self.k.bias, self.v.bias))
-            r = K.token_linear(x, pw, nn_, k, bias, ln=(self.norm1.weight, self.norm1.bias, self.norm1.eps), y=y,
-                               extra=context, extra_div=n)
-            x, qkv = r if y is not None else (x, r)
-            msg = K.stripe_attn(qkv, self.attns[0].get_v.weight, self.attns[1].get_v.weight, b, h, wd, n)
-            return self.mlp.forward_ln(x, self._proj(msg), self.norm2)
-        w, bias, kp = self._weights()
-        x, a = _add_ln(x, y, self.norm1, context, n, kp)
-        msg = K.stripe_attn(F.linear(a, w, bias), self.attns[0].get_v.weight, self.attns[1].get_v.weight, b, h, wd, n)
-        x, hdn = _add_ln(x, self.proj(msg), self.norm2)
-        return x, self.mlp(hdn)
+        pw, bias, k, nn_ = _packed(self._packed_qkv, (self.q.weight, self.k.weight, self.v.weight),
+                                   (self.q.bias, self.k.bias, self.v.bias))
+        r = K.token_linear(x, pw, nn_, k, bias, ln=(self.norm1.weight, self.norm1.bias, self.norm1.eps), y=y,
+                           extra=context, extra_div=n)
+        x, qkv = r if y is not None else (x, r)
+        msg = K.stripe_attn(qkv, self.attns[0].get_v.weight, self.attns[1].get_v.weight, b, h, wd, n)
+        return self.mlp.forward_ln(x, self._proj(msg), self.norm2)
 
 
 class PropagationLayer(nn.Module):

@@ -68,6 +68,11 @@ class NMRF(nn.Module):
         self.register_buffer("device_indicator_tensor", torch.empty(0))
         self._head_cache8, self._head_cache4 = _FusedCache(), _FusedCache()
         self._side_stream = None
+        # fp16 range guard of the split-operand kernels (include/nmrf_hip.h): True = forward() ends with check_range() -- one
+        # 4-byte read-back and a device sync, like the .cpu() every caller of the reference does next (inference.py:74) -- so that
+        # an out-of-range activation raises instead of returning inf / NaN.  False: the caller checks itself where it synchronises
+        # anyway (nmrf_amd.driver, bench.py); never checked inside a hipGraph capture.
+        self.range_check = True
 
     @classmethod
     def from_config(cls, cfg):
@@ -119,8 +124,7 @@ class NMRF(nn.Module):
             b = image1.shape[0]
             hp, wp = h0 + (-h0) % self.divis_by, w0 + (-w0) % self.divis_by
             stem = enc.conv1
-            if (enc.fused and os.environ.get("NMRF_CONV3", "split") == "split" and os.environ.get("NMRF_WINO", "1") != "0"
-                    and image1.shape[1] == 3 and hp % 2 == 0 and wp % 2 == 0 and stem.weight.shape[0] % 64 == 0
+            if (enc.fused and image1.shape[1] == 3 and hp % 2 == 0 and wp % 2 == 0 and stem.weight.shape[0] % 64 == 0
                     and tuple(stem.weight.shape[1:]) == (3, 7, 7) and stem.stride == (2, 2) and stem.padding == (3, 3)):
                 # the stem (7x7 / stride 2) runs as a 4x4 convolution over the 2x2 space-to-depth image: staged in that layout
                 feats = enc(K.prep_images_s2d(image1.contiguous(), image2.contiguous(), hp, wp), normalized="s2d")[::-1]
@@ -133,9 +137,16 @@ class NMRF(nn.Module):
             image1, image2 = padder.pad(image1.float(), image2.float())
             fmap1_list, fmap2_list = self.extract_feature(image1, image2)
         try:
-            return self.hot_path(fmap1_list, fmap2_list, (h0, w0))
+            out = self.hot_path(fmap1_list, fmap2_list, (h0, w0))
         finally:
             self._joint_feats = None
+        if self.range_check and not torch.cuda.is_current_stream_capturing():
+            K.check_range(self.device)
+        return out
+
+    def check_range(self):
+        """Raise NmrfHipError if an activation left the fp16 range of the split-operand kernels since the last check (syncs)."""
+        return K.check_range(self.device)
 
     def _match_heads(self, left, right, cache):
         """concatconv / gw on both views as ONE stock 3x3 convolution: the two heads share their input, so their
@@ -156,8 +167,7 @@ class NMRF(nn.Module):
             both = torch.cat((left, right), 0)
         raw = K.conv3x3_auto(both, w3, cache.wino).contiguous()
         wf, wg = self.concatconv[3].weight, self.gw[3].weight
-        if (os.environ.get("NMRF_CONV1X1", "1") != "0" and wf.shape[1] == 128 and wg.shape[1] == 128 and wf.shape[0] % 64 == 0
-                and wg.shape[0] % 64 == 0):
+        if wf.shape[1] == 128 and wg.shape[1] == 128 and wf.shape[0] % 64 == 0 and wg.shape[0] % 64 == 0:
             # InstanceNorm + ReLU + the two 1x1 convs read the 3x3 output once: statistics pass, then one fused kernel per head
             if not hasattr(cache, "c1"):
                 cache.c1 = (_FusedCache(), _FusedCache())
@@ -193,7 +203,7 @@ class NMRF(nn.Module):
             side.wait_stream(main)
         context, ctx_ready = None, None
         with torch.cuda.stream(side):
-            if overlap and os.environ.get("NMRF_CTX_SIDE", "1") != "0":
+            if overlap:
                 # the DPN context convs first: the seed stage (cost volume, conv1d + softmax, NMS: latency-bound) runs beside them
                 context = self.dpn.context(fmap1_list[0])
                 ctx_ready = torch.cuda.Event()

@@ -612,18 +612,21 @@ def test_stem_space_to_depth(b, h, w, hp, wp):
     report("stem", got, ref, 3e-5, 1e-5)
 
 
-def test_conv3x3_auto_paths_agree(monkeypatch):
-    """The dispatcher: split kernel (default) vs the Winograd / MIOpen paths on the same input, with and without folded stats."""
+def test_conv3x3_auto_paths_agree():
+    """The product's convolution (direct split-fp16 MFMA kernel behind conv3x3_auto) against the two paths it replaced -- the
+    round-1 Winograd fp32-MFMA kernel (debug library, include/nmrf_hip_debug.h) and the stock torch convolution (MIOpen) -- on
+    the same input, with and without the folded InstanceNorm + ReLU."""
     kk = K()
     x = (rnd(2, 64, 40, 200, seed=5, scale=1.5) + 0.2).to(DEV)
     wt = rnd(96, 64, 3, 3, seed=6, scale=0.1).to(DEV)
-    outs = {}
-    for mode in ("split", "wino", "miopen"):
-        monkeypatch.setenv("NMRF_CONV3", mode)
-        outs[mode] = (kk.conv3x3_auto(x, wt, {}).cpu(), kk.conv3x3_auto(x, wt, {}, stats=kk.instance_stats(x)).cpu())
-    for mode in ("wino", "miopen"):
+    xn = kk.instance_norm(x, relu=True)
+    ours = (kk.conv3x3_auto(x, wt, {}).cpu(), kk.conv3x3_auto(x, wt, {}, stats=kk.instance_stats(x)).cpu())
+    pu = kk.wino_pack_filter(wt)
+    others = {"wino": (kk.conv3x3_wino(x, pu, 96).cpu(), kk.conv3x3_wino(xn, pu, 96).cpu()),
+              "miopen": (F.conv2d(x, wt, None, 1, 1).cpu(), F.conv2d(xn, wt, None, 1, 1).cpu())}
+    for mode, outs in others.items():
         for i in range(2):
-            report("conv3x3_auto %s[%d]" % (mode, i), outs["split"][i], outs[mode][i].double(), 2e-4, 1e-5)
+            report("conv3x3_auto vs %s[%d]" % (mode, i), ours[i], outs[i].double(), 2e-4, 1e-5)
 
 
 @pytest.mark.parametrize("b,h,w,k,nlab", [(1, 16, 24, 4, 3), (2, 37, 53, 4, 40), (1, 64, 64, 2, 1000), (1, 8, 8, 8, 2)])
@@ -676,3 +679,88 @@ def test_ops_functions_api_forward_backward():
     with pytest.raises(RuntimeError, match="CPU"):
         MSDA.ms_deform_attn_forward(torch.zeros(1, 4, 1, 4), torch.tensor([[2, 2]]), torch.tensor([0]),
                                     torch.zeros(1, 1, 1, 1, 1, 2), torch.zeros(1, 1, 1, 1, 1), 64)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# fp16 range of the split-operand kernels (include/nmrf_hip.h, "fp16 range"; csrc/split_mfma.h): guarded, never silent
+# --------------------------------------------------------------------------------------------------------------------
+def _range_cases():
+    """(name, launcher(scale_of_activations, scale_of_weights) -> (got, fp64 reference)) for every kernel family that splits."""
+    kk = K()
+    d = lambda v: None if v is None else v.to(DEV)
+
+    def linear(sa, sw):                                   # mlp_chain kind 3: x [T,128] . W^T + b
+        x, w, b = rnd(777, 128, seed=1) * sa, rnd(64, 128, seed=2, scale=0.1) * sw, rnd(64, seed=3, scale=0.3)
+        stream, stages, inv = kk.chain_stream([d(w)], (128,))
+        return kk.mlp_chain(3, d(x), 128, stream, stages, inv, [d(b)], 64), x.double() @ w.double().t() + b.double()
+
+    def block(sa, sw):                                    # nmp_block16: x + proj(msg), no MLP, no q stage
+        x, msg = rnd(300, 128, seed=4), rnd(300, 128, seed=5) * sa
+        wp, bp = rnd(128, 128, seed=6, scale=0.1) * sw, rnd(128, seed=7, scale=0.2)
+        stream, stages, inv = kk.block_stream16(d(wp), None, None, None, 0)
+        xo, _, _ = kk.nmp_block(d(x), stream, stages, inv, d(msg), d(bp), None, None, want_x=True)
+        return xo, x.double() + msg.double() @ wp.double().t() + bp.double()
+
+    def conv3(sa, sw):
+        x, w = rnd(1, 32, 9, 70, seed=8) * sa, rnd(64, 32, 3, 3, seed=9, scale=0.1) * sw
+        return kk.conv3x3_auto(d(x), d(w), {}), F.conv2d(x.double(), w.double(), None, 1, 1)
+
+    def conv1(sa, sw):
+        x, w = rnd(1, 64, 7, 40, seed=10) * sa, rnd(64, 64, 1, 1, seed=11, scale=0.1) * sw
+        return (kk.conv1x1_in_relu(d(x), 0, 64, None, kk.pack_conv1x1(d(w))), F.conv2d(x.double(), w.double()))
+
+    return [("mlp_chain", linear), ("nmp_block16", block), ("conv3x3_split", conv3), ("conv1x1", conv1)]
+
+
+@pytest.mark.parametrize("idx", range(4))
+def test_split_operand_range_is_guarded(idx):
+    """Activations at 3e4 (inside the fp16 range): fp32-grade results, flag clear.  At 7e4: the kernel raises the sticky device
+    flag and check_range() turns it into NmrfHipError -- no silent inf.  At 1e-6 (fp16 subnormals / flushed low parts): the
+    documented ABSOLUTE error floor (2^-25 per operand element times the weight magnitude), nothing non-finite.  Weights at 1e-4
+    and 1e3 times their usual size: rescaled by a power of two at pack time, same relative accuracy."""
+    from nmrf_amd._lib import NmrfHipError
+    kk = K()
+    name, run = _range_cases()[idx]
+    kk.check_range()                                                        # start from a clear flag
+    got, ref = run(3e4, 1.0)
+    report(name + " |x| ~ 3e4", got.cpu().double().reshape(ref.shape), ref, 2e-5 * 3e4, 1e-5)
+    assert kk.check_range()
+    got, ref = run(7e4, 1.0)
+    with pytest.raises(NmrfHipError, match="fp16 range"):
+        kk.check_range()
+    assert kk.check_range()                                                 # the flag was cleared by the failing check
+    got, ref = run(1e-6, 1.0)
+    assert torch.isfinite(got).all() and kk.check_range()
+    report(name + " |x| ~ 1e-6", got.cpu().double().reshape(ref.shape), ref, 2e-7, 1e-5)      # ~K * 2^-25 * |w| absolute
+    for sw in (1e-4, 1e3):
+        got, ref = run(1.0, sw)
+        report(name + " weights x %g" % sw, got.cpu().double().reshape(ref.shape), ref, 2e-5 * sw, 1e-5)
+    assert kk.check_range()
+
+
+def test_attention_range_is_guarded():
+    """The q | k | v operands of the stripe and window attention kernels: in range -> flag clear; one value of 7e4 -> flagged."""
+    from nmrf_amd._lib import NmrfHipError
+    kk = K()
+    kk.check_range()
+    b, h, w, n = 1, 6, 12, 4
+    qkv = rnd(b * h * w * n, 384, seed=21).to(DEV)
+    lv, lh = rnd(64, 1, 3, 3, seed=22).to(DEV), rnd(64, 1, 3, 3, seed=23).to(DEV)
+    table = rnd(121, 384, seed=24).to(DEV)
+    kk.stripe_attn(qkv, lv, lh, b, h, w, n)
+    kk.window_attn(qkv, table, b, h, w, n, 4, 6, 0, True)
+    assert kk.check_range()
+    for col in (5, 128 + 70, 256 + 130):                                     # a q, a k and a v element
+        bad = qkv.clone()
+        bad[37, col] = 7e4
+        kk.stripe_attn(bad, lv, lh, b, h, w, n)
+        with pytest.raises(NmrfHipError, match="fp16 range"):
+            kk.check_range()
+        kk.window_attn(bad, table, b, h, w, n, 4, 6, 0, True)
+        with pytest.raises(NmrfHipError, match="fp16 range"):
+            kk.check_range()
+    bad = qkv.clone()
+    bad[0, 0] = float("nan")
+    kk.window_attn(bad, table, b, h, w, n, 4, 6, 0, True)
+    with pytest.raises(NmrfHipError):
+        kk.check_range()

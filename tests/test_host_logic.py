@@ -36,6 +36,30 @@ def test_every_declared_symbol_is_exported_and_bound():
     lib = _lib.load()
     assert lib.nmrf_abi_version() == _lib.ABI_VERSION
     assert lib.nmrf_strerror(-1).decode().startswith("invalid")
+    # the reference kernels of the tools / test build (round-1 fp32-MFMA linears, Winograd convolution, 32-token block kernel) are
+    # NOT part of the product library: declared in include/nmrf_hip_debug.h, exported by libnmrf_hip_debug.so only
+    dbg_hdr = open(os.path.join(ROOT, "include", "nmrf_hip_debug.h")).read()
+    dbg_declared = set(re.findall(r"^int\s+(nmrf_\w+)\s*\(", dbg_hdr, re.M))
+    assert dbg_declared == set(_lib.DEBUG_PROTOTYPES) and not (dbg_declared & declared)
+    for name in dbg_declared:
+        assert not hasattr(raw, name), f"{name} is a debug-library entry point but libnmrf_hip.so exports it"
+    if os.path.exists(_lib.DEBUG_LIB_PATH):
+        dbg = ctypes.CDLL(_lib.DEBUG_LIB_PATH)
+        for name in dbg_declared | declared:
+            assert hasattr(dbg, name), f"{name} missing from libnmrf_hip_debug.so"
+
+
+def test_product_reads_two_environment_switches_only():
+    """NMRF_LINEAR (split | fp32: A/B runs on the debug library's fp32-MFMA linears) and NMRF_OVERLAP (side stream on / off for
+    profiling) -- nothing else in the product tree changes the arithmetic or the launch structure from the environment."""
+    names = set()
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "nmrf_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                names |= set(re.findall(r"(?:environ(?:\.get)?\s*[\(\[]\s*|getenv\s*\(\s*)\"(\w+)\"", txt))
+    # (HIPCC: the build script's compiler override; the two getenvs are tuning overrides of the debug build, under NMRF_DEBUG_PROBES)
+    assert names <= {"NMRF_LINEAR", "NMRF_OVERLAP", "HIPCC", "NMRF_TL_NOPIPE", "NMRF_STRIPE_KSPLIT"}, names
 
 
 def test_entry_points_validate_arguments_without_touching_the_gpu():
@@ -44,8 +68,8 @@ def test_entry_points_validate_arguments_without_touching_the_gpu():
     one = ctypes.c_void_p(16)
     assert lib.nmrf_cost_volume_f32(one, one, 1, 255, 4, 4, 40, 4, one, None) == -1           # C % G != 0
     assert lib.nmrf_nms_topk_f32(one, 10, 300, 4, 1e-3, 1, one, None) == -1                   # D > 64
-    assert lib.nmrf_window_attn_f32(one, one, 1, 13, 12, 4, 128, 4, 6, 0, 1, one, None) == -1 # Hp % win
-    assert lib.nmrf_stripe_attn_f32(one, one, one, 1, 4, 4, 4, 128, 0, one, None) == -1       # axes == 0
+    assert lib.nmrf_window_attn_f32(one, one, 1, 13, 12, 4, 128, 4, 6, 0, 1, one, None, None) == -1 # Hp % win
+    assert lib.nmrf_stripe_attn_f32(one, one, one, 1, 4, 4, 4, 128, 0, one, None, None) == -1       # axes == 0
 
 
 def test_missing_library_fails_loudly(monkeypatch):
@@ -146,15 +170,21 @@ def test_relative_position_index_formula():
 
 
 def test_fused_weight_cache_tracks_parameter_updates():
+    """Packed weight streams are derived tensors: _FusedCache rebuilds them when (and only when) a source parameter changes."""
+    from nmrf_amd.models.nmp import _FusedCache
     m = build_product(128)
     blk = m.inference.layers[0].self_nmp
-    w1, b1, kp = blk._weights()
-    assert w1.shape == (384, 160) and kp == 160 and torch.equal(w1[:128, :159], blk.q.weight)
-    assert torch.equal(w1[256:, :128], blk.v.weight) and (w1[256:, 128:] == 0).all() and (w1[:, 159] == 0).all()
-    assert blk._weights()[0] is w1
+    cache, calls = _FusedCache(), []
+
+    def build():
+        calls.append(1)
+        return torch.cat((blk.q.weight, blk.k.weight), 0).clone()
+    w1 = cache.get((blk.q.weight, blk.k.weight), build)
+    assert cache.get((blk.q.weight, blk.k.weight), build) is w1 and len(calls) == 1
     with torch.no_grad():
         blk.q.weight.add_(1.0)
-    assert blk._weights()[0] is not w1 and torch.equal(blk._weights()[0][:128, :159], blk.q.weight)
+    w2 = cache.get((blk.q.weight, blk.k.weight), build)
+    assert w2 is not w1 and len(calls) == 2 and torch.equal(w2[:128], blk.q.weight)
 
 
 def test_shard_range_partitions_exactly():

@@ -139,7 +139,7 @@ def test_individual_layers_vs_oracle():
 
 
 def test_full_forward_vs_oracle_mid_size():
-    """Whole model(sample) on the GPU (MIOpen backbone) vs the whole oracle on CPU, 120x264."""
+    """Whole model(sample) on the GPU (encoder and hot path on this library's kernels) vs the whole oracle on CPU, 120x264."""
     from nmrf_amd.utils.hashinit import synthetic_pair
     l, r, _ = synthetic_pair(120, 264, seed=1234)
     w, cfg = oracle_weights(320), oracle_cfg(320)
@@ -234,10 +234,10 @@ def test_middlebury_half_res_size_runs():
 def test_full_size_properties(h, w):
     """BASELINE sizes (KITTI, SceneFlow): properties that hold at any size.
     * per-image independence of the whole model: a batch of two different pairs ~= the two pairs run alone,
-      in either order.  Not bit-exact end to end: hipBLASLt / MIOpen pick batch-size-dependent reduction
-      orders, and that fp32 noise is amplified by the 2^14 Fourier band; seeds must agree on >= 99.9 % of
-      pixels and the disparity on average to 1e-2 px.  (The hand-written kernels ARE bit-exact under
-      batching: test_hip_kernels_are_batch_invariant.)
+      in either order.  Not required bit-exact end to end: the two 1x1 down-sampling shortcuts of the encoder still run on
+      rocBLAS, which may pick a batch-size-dependent reduction order, and that fp32 noise is amplified by the 2^14
+      Fourier band; seeds must agree on >= 99.9 % of pixels and the disparity on average to 1e-2 px.  (The
+      hand-written kernels ARE bit-exact under batching: test_hip_kernels_are_batch_invariant.)
     * probabilities sum to 1, seeds are distinct in-range bins, strong seeds are local maxima of prob
     * outputs are finite, non-negative, and of the un-padded size."""
     from nmrf_amd.utils.hashinit import synthetic_pair
@@ -270,26 +270,27 @@ def test_full_size_properties(h, w):
     assert ((p[:, 0] >= left[:, 0]) & (p[:, 0] >= right[:, 0]))[strong].all()
 
 
-def test_library_paths_agree_with_hand_written_paths_at_kitti_size(monkeypatch):
-    """N2 / N3 in the model: the Winograd MFMA convolution and the fused token linears against the stock MIOpen / hipBLASLt
-    paths they replace (NMRF_WINO=0, NMRF_FUSED_LINEAR=0), same weights, one KITTI-size pair.  The two sides differ by
-    fp32 rounding only (different summation orders); seeds must agree on >= 99.5 % of pixels, the disparity to a median
-    of 2e-3 px with < 1 % of the pixels moving by more than 0.1 px (ties in seeds / winner-take-all)."""
-    import os
+def test_conv_band_agrees_with_stock_torch_modules_at_kitti_size():
+    """N2 in the model: the encoder on the hand-written kernels (staging, stem, 3x3 convs with folded InstanceNorm, 1x1 + pooling)
+    against the SAME modules run as stock torch ops (MIOpen convolutions, torch InstanceNorm: the reference's own arithmetic,
+    nmrf/models/backbone.py:38-98) on one KITTI-size pair.  fp32 rounding only: features within 2e-4 + 1e-4 |ref|."""
     from nmrf_amd.utils.hashinit import synthetic_pair
     model = build_product(320, DEV)
     l, r, _ = synthetic_pair(375, 1242, seed=1002)
-    sample = {"img1": l[None], "img2": r[None]}
     with torch.no_grad():
-        ours = model(sample)
-        monkeypatch.setenv("NMRF_WINO", "0")
-        monkeypatch.setenv("NMRF_FUSED_LINEAR", "0")
-        stock = model(sample)
-    assert os.environ["NMRF_WINO"] == "0"
-    mism = (ours["initial_proposal"] != stock["initial_proposal"]).any(-1).float().mean()
-    assert float(mism) < 5e-3, float(mism)
-    d = (ours["disp"] - stock["disp"]).abs()
-    assert float(d.median()) < 2e-3 and float((d > 0.1).float().mean()) < 0.01, (float(d.median()), float(d.mean()))
+        ours4, ours8 = _features(model, l[None], r[None])
+        enc = model.backbone
+        flags = [(m, m.fused) for m in enc.modules() if hasattr(m, "fused")]
+        for m, _ in flags:
+            m.fused = False                                        # the stock branch of every block
+        try:
+            stock4, stock8 = _features(model, l[None], r[None])
+        finally:
+            for m, f in flags:
+                m.fused = f
+    assert len(flags) == 7
+    report("encoder 1/4 vs stock modules", ours4.cpu(), stock4.cpu(), 2e-4, 1e-4)
+    report("encoder 1/8 vs stock modules", ours8.cpu(), stock8.cpu(), 2e-4, 1e-4)
 
 
 def test_hip_kernels_are_batch_invariant():
@@ -491,3 +492,25 @@ def test_padded_grid_row_maps_match_reference_padding(h, w):
     back = xp[(to_d >= 0).nonzero().squeeze(1)]
     assert torch.equal(back, nmp._crop_grid(xp_ref.contiguous(), pdims, dims, off).contiguous()) and torch.equal(back, x)
     assert torch.equal(to_d[to_p.long()].cpu(), torch.arange(t_, dtype=torch.int32))
+
+
+def test_model_raises_on_out_of_range_activations_instead_of_returning_garbage():
+    """Whole model: a checkpoint whose score-head input blows past the fp16 range (final LayerNorm gain x 1e6) must raise
+    NmrfHipError from forward() (range_check on by default); with the check deferred (range_check = False, the driver's mode) the
+    flag stays sticky until check_range() is called; the intact model runs clean."""
+    from nmrf_amd._lib import NmrfHipError
+    from nmrf_amd.utils.hashinit import synthetic_pair
+    l, r, _ = synthetic_pair(64, 104, seed=5)
+    sample = {"img1": l[None], "img2": r[None]}
+    model = build_product(128, DEV)
+    with torch.no_grad():
+        out = model(sample)
+        assert torch.isfinite(out["disp"]).all() and model.check_range()
+        model.inference.norm.weight.mul_(1e6)
+        with pytest.raises(NmrfHipError, match="fp16 range"):
+            model(sample)
+        model.range_check = False
+        model(sample)                                                        # no exception: deferred
+        with pytest.raises(NmrfHipError, match="fp16 range"):
+            model.check_range()
+        assert model.check_range()

@@ -80,13 +80,13 @@ if "block" in which:
                      (10, "DBG no barrier"), (11, "DBG no commit/fetch"), (12, "DBG no LDS fragment reads"), (13, "DBG no MFMA"),
                      (14, "DBG no barrier, no commit/fetch"), (15, "DBG no barrier/commit/fetch/fragment reads")):
         _l.nmrf_debug_nmp_block_variant(var)
-        timeit("nmp_block proj+mlp+qkv " + tag, lambda: K.nmp_block(x, stream, stages, inv, msg, bp, (g, be, 1e-5, b1, b2), qd))
+        timeit("nmp_block proj+mlp+qkv " + tag, lambda: K.nmp_block(x, stream, stages, inv, msg, bp, (g, be, 1e-5, b1, b2), qd, tokens_per_wave=32))
     _l.nmrf_debug_nmp_block_variant(0)
     import numpy as np
     stamps = torch.zeros(64 * 4 * 16, dtype=torch.int64, device=dev)
     _l.nmrf_debug_nmp_block_timing.restype = ctypes.c_int
     _l.nmrf_debug_nmp_block_timing(ctypes.c_void_p(stamps.data_ptr()))
-    K.nmp_block(x, stream, stages, inv, msg, bp, (g, be, 1e-5, b1, b2), qd)
+    K.nmp_block(x, stream, stages, inv, msg, bp, (g, be, 1e-5, b1, b2), qd, tokens_per_wave=32)
     torch.cuda.synchronize()
     _l.nmrf_debug_nmp_block_timing(None)
     st = stamps.cpu().numpy().reshape(64, 4, 16).astype(np.int64)
@@ -140,11 +140,11 @@ if "block" in which:
     s16c, st16c, i16c = K.block_stream16(wp, w1, w2, None, 0)
     timeit("nmp_block16 proj+mlp", lambda: K.nmp_block(x, s16c, st16c, i16c, msg, bp, (g, be, 1e-5, b1, b2), None, tokens_per_wave=16))
     s2, st2, i2 = K.block_stream(wp, None, None, wq, 160)
-    timeit("nmp_block proj+qkv (self block)", lambda: K.nmp_block(x, s2, st2, i2, msg, bp, None, qd))
+    timeit("nmp_block proj+qkv (self block)", lambda: K.nmp_block(x, s2, st2, i2, msg, bp, None, qd, tokens_per_wave=32))
     s3, st3, i3 = K.block_stream(None, None, None, wq, 160)
-    timeit("nmp_block qkv only", lambda: K.nmp_block(x, s3, st3, i3, None, None, None, qd, want_x=False))
+    timeit("nmp_block qkv only", lambda: K.nmp_block(x, s3, st3, i3, None, None, None, qd, want_x=False, tokens_per_wave=32))
     s4, st4, i4 = K.block_stream(wp, w1, w2, None, 0)
-    timeit("nmp_block proj+mlp", lambda: K.nmp_block(x, s4, st4, i4, msg, bp, (g, be, 1e-5, b1, b2), None))
+    timeit("nmp_block proj+mlp", lambda: K.nmp_block(x, s4, st4, i4, msg, bp, (g, be, 1e-5, b1, b2), None, tokens_per_wave=32))
     pwp, pw1, pwq = (K.pack_linear_weight(v.contiguous()) for v in (wp, w1, wq))
     enc31 = enc[:, :31].contiguous()
 
@@ -167,7 +167,7 @@ if "stripe" in which:
     for ax, nm in ((1, "vertical"), (2, "horizontal")):
         timeit("stripe_attn %s only" % nm, lambda: _l.nmrf_stripe_attn_f32(
             ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(lv.data_ptr()), ctypes.c_void_p(lh.data_ptr()), b, h, w, n, 128, ax,
-            ctypes.c_void_p(so.data_ptr()), None))
+            ctypes.c_void_p(so.data_ptr()), None, None))
 if "refine" in which:
     hp, wp = 96, 312
     qkv, table = mk("q3", b * hp * wp, 384), mk("t3", 49, 384)
