@@ -35,7 +35,10 @@ const char *nmrf_strerror(int code);
  * out of range.  The flag is sticky; the caller reads and clears it at a point where it synchronises anyway
  * (nmrf_amd.kernels.check_range -> NmrfHipError).  Weights are rescaled by a power of two when they are packed and have no limit.
  * Below the range: absolute error <= 2^-25 per operand element (values below 2^-24 are flushed) -- one fp32 rounding of an O(1)
- * accumulator. */
+ * accumulator.
+ * The two window-attention kernels run at their VGPR cap and carry no guard of their own: nmrf_window_attn_f32 scans its qkv operand
+ * in a separate pass when range_flag != NULL; pass NULL when qkv was produced by nmrf_nmp_block16_f32, which range-checks its q_out. */
+int nmrf_range_scan_f32(const float *x, int64_t n, int *range_flag, void *stream);   /* n % 4 == 0, x 16-byte aligned */
 /* ABI version of this header; bumps on any signature change. */
 int nmrf_abi_version(void);   /* currently 17 */
 

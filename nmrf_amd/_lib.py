@@ -48,6 +48,7 @@ PROTOTYPES = {
     "nmrf_prep_images_s2d_f32": [_P, _P, _I, _I, _I, _I, _I, _P, _P],
     "nmrf_prep_images_s2d_u8": [_P, _P, _I, _I, _I, _I, _I, _P, _P],
     "nmrf_prep_images_u8": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "nmrf_range_scan_f32": [_P, _L, _P, _P],
     "nmrf_host_copy_nt": [_P, _P, ctypes.c_size_t],
     "nmrf_host_read_evict": [_P, _P, ctypes.c_size_t],
     "nmrf_conv3x3_split_f32": [_P, _I, _I, _I, _I, _P, _I, _F, _P, _I, _I, _F, _I, _P, _P, _P],

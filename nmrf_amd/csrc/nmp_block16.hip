@@ -90,6 +90,7 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
 #define B16_STAMP(k) do { if constexpr ((DBG & 32) != 0) { if (lane == 0 && blockIdx.x < 64) a.stamps[(blockIdx.x * 8 + wv) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
     B16_STAMP(0);
     float guard = 0.f;                                                  // fp16 range guard of the activation splits (split_mfma.h)
+    float qmax = 0.f;                       // ... and of q_out: the attention kernels split it without a guard of their own (window_attn.hip)
     {
         auto put = [&](int off, const float *src, int n) {
             for (int i = tid; i < n; i += B16_THR) Par[off + i] = src ? src[i] : 0.f;
@@ -385,9 +386,11 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
                         float ov[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) ov[e] = fmaf(qh0[e], a.inv_q, ba[e]);
+                        qmax = fmaxf(fmaxf(qmax, fmaxf(fabsf(ov[0]), fabsf(ov[1]))), fmaxf(fabsf(ov[2]), fabsf(ov[3])));
                         stage_strip(ov, 32 * sp);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) ov[e] = fmaf(qh1[e], a.inv_q, bb[e]);
+                        qmax = fmaxf(fmaxf(qmax, fmaxf(fabsf(ov[0]), fabsf(ov[1]))), fmaxf(fabsf(ov[2]), fabsf(ov[3])));
                         stage_strip(ov, 32 * sp + 16);
                     });
                     flush_rows(a.q_out, a.NQ, gq * 128, t0);
@@ -401,6 +404,7 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
         }
     }
     split_guard_commit(guard, a.range_flag);
+    if (a.range_flag && !(qmax < 65520.0f)) atomicOr(a.range_flag, 1);   // (a NaN in q_out has a NaN operand upstream: caught by `guard`)
 }
 
 // w [N,K] fp32 -> N/16 x Kp/32 pairs in [strip][chunk] order: lane (i = l & 15, g = l >> 4) slot jj holds

@@ -161,12 +161,13 @@ __device__ __forceinline__ WarpTaps make_taps(float label, int x, int y, int H, 
     return t;
 }
 
-__device__ __forceinline__ float warp_fetch(const float *__restrict__ plane, const WarpTaps &t) {
-    // nw*v + ne*v + sw*v + se*v in ATen's order; zero-weight taps are skipped (0*finite adds exactly 0)
+// nw*v + ne*v + sw*v + se*v in ATen's order.  All four taps are ALWAYS loaded (their offsets are clamped into the map; a
+// zero-weight tap contributes 0 * finite = exactly 0): unconditional loads let the compiler issue a whole channel batch as one
+// clause -- with the former `if (w != 0) load` every tap was its own branch + wait and the kernel sat at 88 % SQ_WAIT_ANY.
+__device__ __forceinline__ float warp_combine(const float (&v)[4], const WarpTaps &t) {
     float r = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (t.w[k] != 0.f) r += plane[t.off[k]] * t.w[k];
+    for (int k = 0; k < 4; ++k) r += v[k] * t.w[k];
     return r;
 }
 
@@ -174,7 +175,7 @@ __device__ __forceinline__ float warp_fetch(const float *__restrict__ plane, con
 // WC_CHUNKS threads (8 feature channels + 4 correlation groups each at the default 64/256/32 sizes), so a KITTI
 // pair launches ~3.7k waves instead of ~460 and every thread issues ~100 independent loads.
 #define WC_CHUNKS 8
-__global__ __launch_bounds__(256) void warp_corr_concat_kernel(const float *__restrict__ labels,
+__global__ __launch_bounds__(256, 5) void warp_corr_concat_kernel(const float *__restrict__ labels,
         const float *__restrict__ f1, const float *__restrict__ f2, const float *__restrict__ g1,
         const float *__restrict__ g2, int H, int W, int N, int Cf, int Cg, int groups, float *__restrict__ out, int ld) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -200,13 +201,20 @@ __global__ __launch_bounds__(256) void warp_corr_concat_kernel(const float *__re
     float *o = out + t * ld;
     const float *pf1 = f1 + (size_t)b * Cf * plane, *pf2 = f2 + (size_t)b * Cf * plane;
     const int fc = Cf / WC_CHUNKS;                          // feature channels per chunk (multiple of 4, host-checked)
+    // Loads first, arithmetic after, in batches of 4 channels = 4 + 16 independent loads in flight per batch and thread; a
+    // channel row is `plane` floats from the next, the lane part of every address is one of five 32-bit offsets.
     for (int c = chunk * fc; c < (chunk + 1) * fc; c += 4) {
-        float a[4], w[4];
+        float a[4], v[4][4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            a[k] = pf1[(size_t)(c + k) * plane + pix];
-            w[k] = warp_fetch(pf2 + (size_t)(c + k) * plane, tp);
+            const float *p1 = pf1 + (size_t)(c + k) * plane, *p2 = pf2 + (size_t)(c + k) * plane;      // uniform
+            a[k] = p1[pix];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[k][q] = p2[tp.off[q]];
         }
+        float w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] = warp_combine(v[k], tp);
         stg4(o + c, make_float4(a[0], a[1], a[2], a[3]));
         stg4(o + Cf + c, make_float4(w[0], w[1], w[2], w[3]));
     }
@@ -218,9 +226,25 @@ __global__ __launch_bounds__(256) void warp_corr_concat_kernel(const float *__re
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float s = 0.f;
-            for (int c = 0; c < cpg; ++c) {
-                size_t ch = (size_t)((g + k) * cpg + c) * plane;
-                s = fmaf(pg1[ch + pix], warp_fetch(pg2 + ch, tp), s);
+            if (cpg == 8) {                                 // every shipped config: 256 channels in 32 groups -- 8 + 32 loads per group
+                float a[8], v[8][4];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const size_t ch = (size_t)((g + k) * 8 + c) * plane;
+                    a[c] = pg1[ch + pix];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[c][q] = (pg2 + ch)[tp.off[q]];
+                }
+#pragma unroll
+                for (int c = 0; c < 8; ++c) s = fmaf(a[c], warp_combine(v[c], tp), s);
+            } else {
+                for (int c = 0; c < cpg; ++c) {
+                    const size_t ch = (size_t)((g + k) * cpg + c) * plane;
+                    float v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = (pg2 + ch)[tp.off[q]];
+                    s = fmaf(pg1[ch + pix], warp_combine(v, tp), s);
+                }
             }
             r[k] = s * inv;
         }

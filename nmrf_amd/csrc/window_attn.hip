@@ -29,13 +29,11 @@ struct WinGeom {
     int Hp, Wp, N, C, heads, win, shift, sibling;
     int Tw;              // tokens per window = win*win*N
     int R;               // (2 win - 1)^2
-    int *range_flag;     // sticky fp16-range flag of the split operands (split_mfma.h), may be NULL
 };
 
 template <int NKT>
 __global__ __launch_bounds__(64 * NKT) void window_attn_kernel(const float *__restrict__ qkv,
         const float *__restrict__ table, WinGeom g, float scale, float *__restrict__ out) {
-    float guard = 0.f;                     // fp16 range guard of the activation splits (split_mfma.h)
     constexpr int TP = NKT * 32;                   // padded tokens per window
     constexpr int NTHR = 64 * NKT;
     const int win = g.win;
@@ -194,7 +192,7 @@ __global__ __launch_bounds__(64 * NKT) void window_attn_kernel(const float *__re
         f32x16 st;
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[r] = 0.f;
-        split_dot16_g<true>(kf, qf, st, guard);                            // S^T = K . Q^T on split-fp16 MFMA (split_mfma.h)
+        split_dot16(kf, qf, st);                            // S^T = K . Q^T on split-fp16 MFMA (split_mfma.h)
         if (kt + 1 < NKT) load_k(kt + 1, kf);               // K fragment is dead: refill it for the next tile now,
         //                                                     in flight during this tile's softmax and P.V
         float m_tile = -INFINITY;
@@ -237,7 +235,7 @@ __global__ __launch_bounds__(64 * NKT) void window_attn_kernel(const float *__re
 #pragma unroll
         for (int d = 0; d < 32; ++d) oe[d] *= alpha;
         // P.V on MFMA
-        split_dot16_g<false>(vf, st, acc_o, guard);                         // O^T += V^T . P^T on split-fp16 MFMA
+        split_dot16(vf, st, acc_o);                         // O^T += V^T . P^T on split-fp16 MFMA
         if (kt + 1 < NKT) load_v(kt + 1, vf);               // same for V: in flight during the ev term and the next S^T
         // value-embedding term on the VALU: sum over key PIXELS of (sum_n p) * ev[rel(pq,pk)]
 #pragma unroll
@@ -275,7 +273,6 @@ __global__ __launch_bounds__(64 * NKT) void window_attn_kernel(const float *__re
         half_swap(a, b);
         res[r] = (acc_o[r] + (a + b)) * inv_l;
     }
-    split_guard_commit(guard, g.range_flag);
     if (!q_ok) return;
     (void)qs;
     float *op = out + qrow * g.C + head * 32;
@@ -341,7 +338,6 @@ template <int NKT, int WIN, int NL, int WPB, int OCC, bool TIMED = false, int PK
 __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(const float *__restrict__ qkv,
         const float *__restrict__ table, WinGeom g, float scale, float *__restrict__ out,
         unsigned long long *__restrict__ stamps = nullptr) {
-    float guard = 0.f;                     // fp16 range guard of the activation splits (split_mfma.h)
     using L = WinFastLds<NKT, WIN, NL, WPB, PK>;
     constexpr int TP = L::TP, W2 = L::W2, R = L::R, Tw = L::Tw, TS = L::TS;
     constexpr int TwE = Tw * PK;                    // tokens of a wave's tile
@@ -566,7 +562,7 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
         f32x16 st;
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[r] = 0.f;
-        split_dot16_g<true>(kf, qf, st, guard);                            // S^T = K . Q^T on split-fp16 MFMA (split_mfma.h)
+        split_dot16(kf, qf, st);                            // S^T = K . Q^T on split-fp16 MFMA (split_mfma.h)
         if (kt + 1 < NKT) load_k(kt + 1, kf);
         // relative-position terms: one b128 of KR^T per key quad, QR^T per key pixel
 #pragma unroll
@@ -632,7 +628,7 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
         for (int r = 0; r < 16; ++r) acc_o[r] *= alpha;
 #pragma unroll
         for (int r = 0; r < 8; ++r) oe[r] *= alpha;
-        split_dot16_g<false>(vf, st, acc_o, guard);                         // O^T += V^T . P^T on split-fp16 MFMA
+        split_dot16(vf, st, acc_o);                         // O^T += V^T . P^T on split-fp16 MFMA
         // value-embedding term: sum over key PIXELS of (sum_n p) * ev[rel(pq,pk)].  The two half-lanes of a query
         // swap the probabilities of their pixels, then each accumulates BOTH pixels for its own 16 channels.
 #pragma unroll
@@ -672,7 +668,6 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
     for (int r = 0; r < 16; ++r) res[r] = (acc_o[r] + ((r & 1) ? oe[r >> 1].y : oe[r >> 1].x)) * inv_l;
     if (TIMED) asm volatile("" :: "v"(res[0]), "v"(res[15]));
     WA_STAMP(6 + NKT);
-    split_guard_commit(guard, g.range_flag);
     if (!tok_ok || !win_ok) return;
     float *op = out + (size_t)trow * g.C + head * 32;
 #pragma unroll
@@ -739,7 +734,7 @@ extern "C" int nmrf_debug_window_occupancy(int *blocks_infer, int *blocks_refine
 extern "C" int nmrf_debug_window_timing(const float *qkv, const float *table, int B, int Hp, int Wp, int shift, float *out,
                                         unsigned long long *stamps, void *stream) {
     using L = WinFastLds<5, 6, 4, 2>;
-    WinGeom g{Hp, Wp, 4, 128, 4, 6, shift, 1, 144, 121, nullptr};
+    WinGeom g{Hp, Wp, 4, 128, 4, 6, shift, 1, 144, 121};
     hipFuncSetAttribute((const void *)window_attn_fast_kernel<5, 6, 4, 2, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES);
     const int nwin = (Hp / 6) * (Wp / 6);
     dim3 grid((nwin + 1) / 2, 4, B);
@@ -754,15 +749,44 @@ static int g_window_pack1 = 0;      // tools: run the refinement windows one per
 extern "C" int nmrf_debug_window_pack1(int v) { g_window_pack1 = v; return NMRF_OK; }
 #endif
 
+// fp16 range of the q | k | v operand (include/nmrf_hip.h).  The two fast kernels sit at their VGPR cap (164-167 of 168: ONE more
+// live value spills 258 registers and the refinement kernel runs 6x slower -- measured), so they carry no guard accumulator.  The
+// product's qkv comes from nmrf_nmp_block16_f32, which range-checks its q_out; for any other producer the entry point scans the
+// operand in a pass of its own (one extra read of qkv) when a flag is given.
+__global__ __launch_bounds__(256) void range_scan_kernel(const float4 *__restrict__ v, int64_t n4, int *__restrict__ flag) {
+    float m = 0.f, z = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 t = v[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(t.x), fabsf(t.y))), fmaxf(fabsf(t.z), fabsf(t.w)));
+        z += (t.x + t.y + t.z + t.w) * 0.f;                          // NaN / inf anywhere -> NaN (fmax drops NaN operands)
+    }
+    if (!(m < 65520.0f) || z != 0.f) atomicOr(flag, 1);
+}
+
+extern "C" int nmrf_range_scan_f32(const float *x, int64_t n, int *range_flag, void *stream) {
+    if (!x || !range_flag) return NMRF_ENULL;
+    if (n < 0 || (n & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return NMRF_EINVAL;
+    if (n == 0) return NMRF_OK;
+    int64_t blocks = ceil_div64(n / 4, 256 * 8);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(range_scan_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4 *>(x), n / 4, range_flag);
+    return nmrf_launch_status();
+}
+
 extern "C" int nmrf_window_attn_f32(const float *qkv, const float *table, int B, int Hp, int Wp, int N, int C, int heads,
                                     int win, int shift, int sibling_mask, float *out, int *range_flag, void *stream) {
     if (!qkv || !table || !out) return NMRF_ENULL;
     if (B < 1 || N < 1 || win < 1 || Hp % win || Wp % win || shift < 0 || shift >= win || heads * 32 != C || (C & 3))
         return NMRF_EINVAL;
     if ((int64_t)B * Hp * Wp * N >= (int64_t)1 << 31) return NMRF_EINVAL;
-    WinGeom g{Hp, Wp, N, C, heads, win, shift, sibling_mask ? 1 : 0, win * win * N, (2 * win - 1) * (2 * win - 1), range_flag};
+    WinGeom g{Hp, Wp, N, C, heads, win, shift, sibling_mask ? 1 : 0, win * win * N, (2 * win - 1) * (2 * win - 1)};
     const int nkt = (g.Tw + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
+    if (range_flag) {
+        const int rc = nmrf_range_scan_f32(qkv, (int64_t)B * Hp * Wp * N * 3 * C, range_flag, stream);
+        if (rc != NMRF_OK) return rc;
+    }
     if ((int64_t)B * Hp * Wp * N * 3 * C < ((int64_t)1 << 32)) {                            // 32-bit element offsets
         if (win == 6 && N == 4) return launch_window_fast<5, 6, 4, 2, 3>(qkv, table, g, B, out, st);   // inference windows
 #ifdef NMRF_DEBUG_PROBES

@@ -274,7 +274,7 @@ def self_attn(qkv, n, heads):
 
 
 @_on_device
-def window_attn(qkv, table, b, hp, wp, n, heads, win, shift, sibling_mask):
+def window_attn(qkv, table, b, hp, wp, n, heads, win, shift, sibling_mask, checked=False):
     _chk(qkv, table)
     t, c3 = qkv.shape
     c = c3 // 3
@@ -290,7 +290,8 @@ def window_attn(qkv, table, b, hp, wp, n, heads, win, shift, sibling_mask):
         pmc=[fast.get((win, n), "window_attn_kernel<%d>" % ((tw + 31) // 32))] + (["window_attn_fast_kernel<1, 4, 1, 8, 2, false, 2>"]
                                                                                     if (win, n) == (4, 1) else []))
     _lib.check(_lib.load().nmrf_window_attn_f32(_p(qkv), _p(table), b, hp, wp, n, c, heads, win, shift,
-                                                int(bool(sibling_mask)), _p(out), _rf(qkv), _stream()), "window_attn")
+                                                int(bool(sibling_mask)), _p(out), None if checked else _rf(qkv), _stream()),
+               "window_attn")
     _he("window_attn_w%d_n%d" % (win, n))
     return out
 

@@ -276,11 +276,12 @@ class WindowAttention(nn.Module):
         idx = (rel[0] + wh - 1) * (2 * ww - 1) + (rel[1] + ww - 1)
         self.register_buffer("relative_position_index", idx)      # state-dict parity; the kernel derives it itself
 
-    def forward(self, qkv, dims, sibling_mask):
-        """qkv [T,3C] token-major on the padded grid dims=(B,Hp,Wp,N) -> [T,C]."""
+    def forward(self, qkv, dims, sibling_mask, checked=False):
+        """qkv [T,3C] token-major on the padded grid dims=(B,Hp,Wp,N) -> [T,C].  checked: qkv comes from nmp_block16, which has
+        range-checked it (include/nmrf_hip.h, "fp16 range"); otherwise the entry point scans it first."""
         b, hp, wp, n = dims
         return K.window_attn(qkv, self.relative_position_enc_table, b, hp, wp, n, self.num_heads,
-                             self.window_size[0], self.shift_size, sibling_mask)
+                             self.window_size[0], self.shift_size, sibling_mask, checked=checked)
 
 
 class SwinNMP(nn.Module):
@@ -571,7 +572,7 @@ class Inference(nn.Module):
             if kind == "self":
                 msg = K.self_attn(qkv, n, m.num_heads)
             else:
-                msg = m.attn(qkv, pdims, n > 1)                         # sibling mask for N > 1 (inference), none for refinement
+                msg = m.attn(qkv, pdims, n > 1, checked=True)           # sibling mask for N > 1 (inference), none for refinement
             last = i + 1 == len(self._sites)
             if last and self.norm is not None and to_dense is not None:       # final norm, cropped to the dense grid on the way out
                 ln = torch.empty(t_dense, self.dim, device=x.device)

@@ -734,7 +734,8 @@ def test_split_operand_range_is_guarded(idx):
     report(name + " |x| ~ 1e-6", got.cpu().double().reshape(ref.shape), ref, 2e-7, 1e-5)      # ~K * 2^-25 * |w| absolute
     for sw in (1e-4, 1e3):
         got, ref = run(1.0, sw)
-        report(name + " weights x %g" % sw, got.cpu().double().reshape(ref.shape), ref, 2e-5 * sw, 1e-5)
+        # (+3e-7: one fp32 rounding of the O(1) residual stream the block kernel adds the projection to)
+        report(name + " weights x %g" % sw, got.cpu().double().reshape(ref.shape), ref, 2e-5 * sw + 3e-7, 1e-5)
     assert kk.check_range()
 
 
@@ -750,9 +751,11 @@ def test_attention_range_is_guarded():
     kk.stripe_attn(qkv, lv, lh, b, h, w, n)
     kk.window_attn(qkv, table, b, h, w, n, 4, 6, 0, True)
     assert kk.check_range()
-    for col in (5, 128 + 70, 256 + 130):                                     # a q, a k and a v element
+    # a q, a k and a v element (both channel halves: vertical and horizontal stripes).  q is multiplied by head_dim^-0.5 * log2(e)
+    # = 0.255 before it is split, so it overflows later than k and v -- 3e5 does for every kernel
+    for col, val in ((5, 3e5), (70, 3e5), (128 + 70, 7e4), (128 + 5, 7e4), (256 + 70, 7e4), (256 + 3, 7e4)):
         bad = qkv.clone()
-        bad[37, col] = 7e4
+        bad[37, col] = val
         kk.stripe_attn(bad, lv, lh, b, h, w, n)
         with pytest.raises(NmrfHipError, match="fp16 range"):
             kk.check_range()
