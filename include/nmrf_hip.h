@@ -247,6 +247,14 @@ int nmrf_instance_stats_f32(const float *x, int64_t planes, int64_t HW, float *w
 int nmrf_conv1x1_in_relu_f32(const float *x, int B, int Cx, int64_t HW, int c0, int K, const float *stats, int chunks, float eps,
                              const void *stream_w, int total_stages, float inv_scale, const float *bias, int N, float *out,
                              int *range_flag, void *stream);
+/* The same kernel as a plain strided 1x1 convolution over [B,Cx,H,W] (the down-sampling shortcuts of the encoder,
+ * nmrf/models/backbone.py:33-35: Conv2d(64, 96, 1, stride 2), Conv2d(96, 128, 1)): out[b,co,y,x] = sum_ci W[co,ci] x[b,c0+ci,y*s,x*s]
+ * (+ bias) -> [B,N,Ho,Wo], Ho = (H-1)/s + 1.  K in {16..128} (multiple of 16), any N: stream_w = nmrf_pack_split_weight_f32 of W
+ * zero-padded to [64*ceil(N/64), Kp] with Kp = 64 (K <= 64) or 128; total_stages = 2*ceil(N/64) * Kp/16 / 8.  stats (stride 1 only)
+ * as in nmrf_conv1x1_in_relu_f32, which is this entry point with H*W = HW, stride 1. */
+int nmrf_conv1x1_f32(const float *x, int B, int Cx, int H, int W, int stride, int c0, int K, const float *stats, int chunks,
+                     float eps, const void *stream_w, int total_stages, float inv_scale, const float *bias, int N, float *out,
+                     int *range_flag, void *stream);
 
 /* N2: 3x3 / stride 1 / pad 1 / no-bias convolution as a direct implicit GEMM on the split-operand fp16 MFMA, optionally with the
  * InstanceNorm + ReLU of its INPUT folded into the operand load (conv1 / conv2 of ResidualBlock, nmrf/models/backbone.py:38-46;

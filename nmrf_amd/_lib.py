@@ -53,6 +53,7 @@ PROTOTYPES = {
     "nmrf_host_read_evict": [_P, _P, ctypes.c_size_t],
     "nmrf_conv3x3_split_f32": [_P, _I, _I, _I, _I, _P, _I, _F, _P, _I, _I, _F, _I, _P, _P, _P],
     "nmrf_conv1x1_in_relu_f32": [_P, _I, _I, _L, _I, _I, _P, _I, _F, _P, _I, _F, _P, _I, _P, _P, _P],
+    "nmrf_conv1x1_f32": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _F, _P, _I, _F, _P, _I, _P, _P, _P],
     "nmrf_prep_images_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "nmrf_bias_avgpool2_f32": [_P, _P, _L, _I, _I, _I, _P, _P, _P],
     "nmrf_selftest_mfma_f32": [_P, _P, _I, _P, _P],

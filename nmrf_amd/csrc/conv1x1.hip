@@ -17,7 +17,8 @@
 
 struct Conv1x1Args {
     const float *x;              // [B, Cx, HW]
-    int Cx, c0, K;               // channels of x, first input channel of this conv, its input channels (<= 128, multiple of 16)
+    int Cx, c0, K;               // channels of x, first input channel of this conv, its input channels (<= 16 * KC, multiple of 16;
+                                 // the weight stream is zero-padded to 16 * KC columns)
     const float *stats;          // in_stats workspace of x ([B*Cx][chunks][2] = per-chunk mean, M2) or NULL (no norm, no ReLU)
     int chunks;
     float eps;
@@ -30,6 +31,8 @@ struct Conv1x1Args {
     int tiles_per_image, n_tiles;
     float inv;
     int *range_flag;             // sticky fp16-range flag of the split operands (split_mfma.h), may be NULL
+    int stride, Wo, Win;         // stride > 1: output pixel (y, x) of a Wo-wide map reads input pixel (y * stride, x * stride) of a Win-wide one
+    int64_t HWin;                // pixels of an input plane (== HW when stride == 1)
 };
 
 template <int KC>                // 16-deep k chunks: 4 (K = 64) or 8 (K = 128)
@@ -42,7 +45,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1x1Args a) {
     float *Ot = Aff + 256;                                                   // [64 co][C1_OLD] output staging
     SplitStream<C1_PF> ss;
     ss.init(a.stream, smem, a.total_stages, tid);
-    const int n_strips = a.N >> 5;
+    const int n_strips = ((a.N + 63) >> 6) << 1;                             // strip pairs; rows beyond N are zero in the stream, never stored
     float guard = 0.f;                                                       // fp16 range guard of the activation splits
 
 #pragma unroll 1
@@ -63,8 +66,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1x1Args a) {
         // B operand: lane (pixel j, half hi), chunk c, slot jj <-> channel 16c + split_kslot(jj, hi)
         // Addresses as (uniform channel-row pointer) + (32-bit lane offset): the 64 loads of a lane then share ONE offset register
         // (global_load saddr form) instead of 64 precomputed 64-bit addresses, which had pushed the kernel into scratch.
-        const float *xu = a.x + ((size_t)b * a.Cx + a.c0) * a.HW;             // uniform
-        const unsigned loff = (unsigned)(pc + (int64_t)(4 * hi) * a.HW);      // pixel + the lane half's 4 channels
+        const float *xu = a.x + ((size_t)b * a.Cx + a.c0) * a.HWin;           // uniform
+        int64_t pin = pc;
+        if (a.stride > 1) {
+            const int64_t yo = pc / a.Wo;
+            pin = yo * a.stride * a.Win + (pc - yo * a.Wo) * a.stride;
+        }
+        const unsigned loff = (unsigned)(pin + (int64_t)(4 * hi) * a.HWin);   // pixel + the lane half's 4 channels
         const float *affl = Aff + 4 * hi;
         h16x8 bh[KC], bl[KC];
 #pragma unroll
@@ -72,8 +80,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1x1Args a) {
             float v[8];
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
-                const float *row = xu + (size_t)(16 * c + (jj & 3) + 8 * (jj >> 2)) * a.HW;   // uniform
-                v[jj] = row[loff];
+                const float *row = xu + (size_t)(16 * c + (jj & 3) + 8 * (jj >> 2)) * a.HWin;   // uniform
+                v[jj] = 16 * c < a.K ? row[loff] : 0.f;                       // (whole chunks of the zero-padded k range: nothing to load)
             }
             if (a.stats) {
 #pragma unroll
@@ -158,14 +166,27 @@ static int launch_conv1x1(const Conv1x1Args &a, hipStream_t st) {
 extern "C" int nmrf_conv1x1_in_relu_f32(const float *x, int B, int Cx, int64_t HW, int c0, int K, const float *stats, int chunks,
                                         float eps, const void *stream_w, int total_stages, float inv_scale, const float *bias, int N,
                                         float *out, int *range_flag, void *stream) {
+    return nmrf_conv1x1_f32(x, B, Cx, (int)HW, 1, 1, c0, K, stats, chunks, eps, stream_w, total_stages, inv_scale, bias, N, out,
+                            range_flag, stream);
+}
+
+extern "C" int nmrf_conv1x1_f32(const float *x, int B, int Cx, int H, int W, int stride, int c0, int K, const float *stats, int chunks,
+                                float eps, const void *stream_w, int total_stages, float inv_scale, const float *bias, int N,
+                                float *out, int *range_flag, void *stream) {
     if (!x || !stream_w || !out) return NMRF_ENULL;
-    if (B < 1 || HW < 1 || (K != 64 && K != 128) || c0 < 0 || c0 + K > Cx || N < 64 || (N & 63) || (stats && chunks < 1))
+    if (B < 1 || H < 1 || W < 1 || stride < 1 || stride > 4 || K < 16 || K > 128 || (K & 15) || c0 < 0 || c0 + K > Cx || N < 1 ||
+        (stats && (chunks < 1 || stride != 1)))
         return NMRF_EINVAL;
-    const int kc = K / 16;
-    if (total_stages != (N / 32) * kc / 8) return NMRF_EINVAL;
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const int64_t HW = (int64_t)Ho * Wo, HWin = (int64_t)H * W;
+    if ((int64_t)Cx * HWin >= ((int64_t)1 << 32)) return NMRF_EINVAL;         // 32-bit lane offsets
+    const int kc = K <= 64 ? 4 : 8;                                          // k chunks of the (zero-padded) stream
+    const int n_pad = (N + 63) / 64 * 64;
+    if (total_stages != (n_pad / 32) * kc / 8) return NMRF_EINVAL;
     const int tpi = (int)ceil_div64(HW, C1_PIX);
     if ((int64_t)tpi * B > 0x7fffffff) return NMRF_EINVAL;
-    Conv1x1Args a{x, Cx, c0, K, stats, chunks, eps, stream_w, total_stages, bias, out, N, HW, tpi, tpi * B, inv_scale, range_flag};
+    Conv1x1Args a{x, Cx, c0, K, stats, chunks, eps, stream_w, total_stages, bias, out, N, HW, tpi, tpi * B, inv_scale, range_flag,
+                  stride, Wo, W, HWin};
     hipStream_t st = (hipStream_t)stream;
     switch (kc) {
         case 4: return launch_conv1x1<4>(a, st);

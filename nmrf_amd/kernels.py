@@ -772,10 +772,33 @@ def conv1x1_in_relu(x, c0, k, stats, packed, bias=None, eps=1e-5):
 
 
 def pack_conv1x1(weight):
-    """[N,K,1,1] conv weight -> (stream, stages, 1/scale, N) for conv1x1_in_relu."""
+    """[N,K,1,1] conv weight -> (stream, stages, 1/scale, N) for conv1x1_in_relu / conv1x1: rows zero-padded to a multiple of 64,
+    columns to 64 (K <= 64) or 128."""
     n, k = weight.shape[0], weight.shape[1]
-    pk, inv = pack_split_weight(weight.reshape(n, k).contiguous(), k)
+    kp, npad = (64 if k <= 64 else 128), (n + 63) // 64 * 64
+    w = weight.reshape(n, k)
+    if npad != n:
+        w = torch.nn.functional.pad(w, (0, 0, 0, npad - n))
+    pk, inv = pack_split_weight(w.contiguous(), kp)
     return pk.view(-1, 512).contiguous(), pk.shape[0] * pk.shape[1] // 8, inv, n
+
+
+@_on_device
+def conv1x1(x, packed, k, stride=1, bias=None):
+    """Plain (strided) 1x1 convolution [B,Cx,H,W] -> [B,N,Ho,Wo] on the conv1x1 kernel (the encoder's down-sampling shortcuts)."""
+    _chk(x, bias)
+    stream, stages, inv, n = packed
+    _chk(stream, dtype=torch.int32)
+    b, cx, h, w = x.shape
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    out = torch.empty(b, n, ho, wo, device=x.device, dtype=torch.float32)
+    _hb("conv1x1_s%d_k%d_n%d" % (stride, k, n), row="N2", bound="hbm", bytes=4.0 * b * ho * wo * (k + n), flops=2.0 * b * ho * wo * k * n,
+        split=True, label="conv1x1_kernel (1x1 stride-%d shortcut %d->%d of the encoder, N2)" % (stride, k, n),
+        pmc=["conv1x1_kernel<%d>" % (4 if k <= 64 else 8)])
+    _lib.check(_lib.load().nmrf_conv1x1_f32(_p(x), b, cx, h, w, stride, 0, k, None, 0, 1e-5, _p(stream), stages, float(inv), _p(bias), n,
+                                            _p(out), _rf(x), _stream()), "conv1x1")
+    _he("conv1x1_s%d_k%d_n%d" % (stride, k, n))
+    return out
 
 
 @_on_device

@@ -39,7 +39,7 @@ class ResidualBlock(nn.Module):
         self.norm1 = _norm(norm, cout)
         self.norm2 = _norm(norm, cout)
         self.fused = norm == "instance"
-        self._wino1, self._wino2 = {}, {}
+        self._wino1, self._wino2, self._ds = {}, {}, {}
         self.downsample = None
         if stride != 1 or cin != cout:
             self.norm3 = _norm(norm, cout)
@@ -59,7 +59,13 @@ class ResidualBlock(nn.Module):
             if self.downsample is not None:
                 # (the 1x1 conv's bias is a per-channel constant: InstanceNorm removes it, so the add is skipped)
                 d = self.downsample[0]
-                x = K.instance_norm(F.conv2d(x, d.weight, None, d.stride).contiguous())
+                if d.weight.shape[1] % 16 == 0 and d.weight.shape[1] <= 128 and d.stride[0] == d.stride[1] and x.dtype == torch.float32:
+                    key = (d.weight.data_ptr(), d.weight._version)
+                    if self._ds.get("key") != key:
+                        self._ds = {"key": key, "packed": K.pack_conv1x1(d.weight)}
+                    x = K.instance_norm(K.conv1x1(x.contiguous(), self._ds["packed"], d.weight.shape[1], d.stride[0]))
+                else:
+                    x = K.instance_norm(F.conv2d(x, d.weight, None, d.stride).contiguous())
             # norm1 + ReLU live only inside conv2's operand load: statistics pass, then the conv reads the raw conv1 output
             c2 = K.conv3x3_auto(c1, self.conv2.weight, self._wino2, stats=K.instance_stats(c1))
             return K.instance_norm(c2.contiguous(), relu=True, residual=x.contiguous(), relu_out=True)

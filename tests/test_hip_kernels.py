@@ -767,3 +767,18 @@ def test_attention_range_is_guarded():
     kk.window_attn(bad, table, b, h, w, n, 4, 6, 0, True)
     with pytest.raises(NmrfHipError):
         kk.check_range()
+
+
+@pytest.mark.parametrize("b,ci,co,h,w,stride,bias", [(2, 64, 96, 37, 70, 2, False), (1, 96, 128, 23, 70, 1, True), (1, 32, 40, 9, 11, 3, True),
+                                                     (2, 64, 96, 188, 624, 2, False), (2, 96, 128, 94, 312, 1, False)])
+def test_conv1x1_strided_shortcut(b, ci, co, h, w, stride, bias):
+    """The encoder's down-sampling shortcuts (nmrf/models/backbone.py:33-35: Conv2d(64, 96, 1, stride 2), Conv2d(96, 128, 1)) on the
+    conv1x1 kernel -- input channels zero-padded to 64 / 128 in the weight stream, output rows to a multiple of 64, strided pixel
+    gather -- against torch fp64, incl. the two KITTI layer shapes."""
+    kk = K()
+    x = rnd(b, ci, h, w, seed=3, scale=1.3)
+    wt = rnd(co, ci, 1, 1, seed=4, scale=0.1)
+    bs = rnd(co, seed=5, scale=0.3) if bias else None
+    got = kk.conv1x1(x.to(DEV), kk.pack_conv1x1(wt.to(DEV)), ci, stride, None if bs is None else bs.to(DEV)).cpu()
+    ref = F.conv2d(x.double(), wt.double(), None if bs is None else bs.double(), stride)
+    report("conv1x1 stride %d" % stride, got, ref, 2e-5, 1e-5)
