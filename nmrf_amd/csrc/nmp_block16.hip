@@ -529,6 +529,38 @@ extern "C" int nmrf_nmp_block16_f32(const float *x, const float *msg, const void
     return NMRF_EINVAL;
 }
 
+#ifdef NMRF_DEBUG_PROBES
+// attainable v_mfma_f32_16x16x32_f16 rate: CHAINS independent accumulators per wave, iters x 24 MFMAs each, constant operands;
+// THREADS = 256 (one wave per SIMD) or 512 (two)
+template <int CHAINS, int THREADS>
+__global__ __launch_bounds__(THREADS) void mfma16x16_peak_kernel(int iters, float *__restrict__ out) {
+    f32x4 acc[CHAINS];
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    h16x8 a, b;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { a[k] = (_Float16)(0.001f * (threadIdx.x + k)); b[k] = (_Float16)(0.002f * (threadIdx.x ^ k)); }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 24 / CHAINS; ++k)
+#pragma unroll
+            for (int c = 0; c < CHAINS; ++c) acc[c] = mfma16x16h(a, b, acc[c]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) sum += acc[c][0] + acc[c][3];
+    out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = sum;
+}
+extern "C" int nmrf_debug_mfma16x16_peak(int chains, int threads, int iters, int blocks, float *out, void *stream) {
+    if (!out) return NMRF_ENULL;
+    hipStream_t st = (hipStream_t)stream;
+#define PK(C, T) if (chains == C && threads == T) { hipLaunchKernelGGL((mfma16x16_peak_kernel<C, T>), dim3(blocks), dim3(T), 0, st, iters, out); return nmrf_launch_status(); }
+    PK(1, 256) PK(2, 256) PK(4, 256) PK(8, 256) PK(1, 512) PK(2, 512) PK(4, 512) PK(8, 512)
+#undef PK
+    return NMRF_EINVAL;
+}
+#endif
+
 // self-test of the 16x16x32 form: out[16x16] = A[16,K] . B[K,16] (row-major fp32, K % 32 == 0) on one wave, split operands with
 // the k slots in split_kslot16 order on both sides
 __global__ __launch_bounds__(64) void selftest_mfma16x16_kernel(const float *__restrict__ A, const float *__restrict__ Bm, int K,

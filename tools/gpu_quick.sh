@@ -1,5 +1,5 @@
 #!/bin/bash
-# quick GPU check: selected tests + bench.  PYTEST_K='range or warp' tools/gpu_quick.sh
+# quick GPU check: selected tests + bench (+ kernel micro-bench).  PYTEST_K='range or warp' KB=block tools/gpu_quick.sh
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 ( timeout 900 python -m pytest tests -m gpu -q --tb=short -rf -p no:cacheprovider -k "${PYTEST_K:-range}" 2>&1 | tail -40 ) > gpurun_out/pytest_quick.log
@@ -17,3 +17,4 @@ if l:
 else:
     print(open('gpurun_out/bench_quick.log').read()[-2000:])
 PY
+if [ -n "$KB" ]; then ( timeout 600 python tools/kernel_bench.py --iters 20 --which $KB 2>&1 | grep -v stamp | tail -${KBTAIL:-60} ) > gpurun_out/kernel_bench_quick.log; cat gpurun_out/kernel_bench_quick.log; fi

@@ -66,6 +66,20 @@ if "mfma16" in which:
         n_mfma = 256 * 4 * iters * (24 // chains) * chains
         print("mfma 32x32x16 f16, %d chain(s) per wave, 1 wave/SIMD: %.1f TFLOP/s, %.1f cycles/MFMA at 2.4 GHz" % (
             chains, n_mfma * 32768 / ms / 1e9, ms * 1e-3 * 2.4e9 / (iters * (24 // chains) * chains)), flush=True)
+if "mfma16x16" in which:
+    out = torch.empty(256 * 512, device=dev)
+    _l.nmrf_debug_mfma16x16_peak.restype = ctypes.c_int
+    for threads in (256, 512):
+        for chains in (1, 2, 4, 8):
+            iters = 2000
+            fn = lambda: _l.nmrf_debug_mfma16x16_peak(chains, threads, iters, 256, ctypes.c_void_p(out.data_ptr()), None)
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1)
+            per_simd = iters * 24 * (threads // 256)
+            print("mfma 16x16x32 f16, %d chain(s) per wave, %d wave(s)/SIMD: %.1f TFLOP/s, %.1f cycles per MFMA slot of a SIMD at 2.4 GHz" % (
+                chains, threads // 256, 256 * 4 * per_simd * 16384 / ms / 1e9, ms * 1e-3 * 2.4e9 / per_simd), flush=True)
 if "block" in which:
     # the fused block kernel against the four launches it replaces (KITTI padded inference grid, batch b)
     import torch.nn.functional as F
