@@ -248,11 +248,11 @@ def run(args):
     def forward():
         return model(sample)["disp"]
 
-    overlapped = OverlappedGather()                           # the gather rides a side stream behind the next step's compute
+    overlapped = OverlappedGather(single_rank_too=args.force_dist)      # the gather rides a side stream behind the next step's compute
 
     def gather(disp):
         if use_dist and not args.no_gather:
-            if world == 1:                                    # --force-dist smoke: the collective on a 1-rank group
+            if world == 1 and args.sync_gather:               # --force-dist smoke: the collective on a 1-rank group
                 g = torch.empty_like(disp)
                 dist.all_gather_into_tensor(g, disp.contiguous())
                 return g
@@ -304,14 +304,16 @@ def run(args):
             elapsed = float(tt.item())
         # the collective alone ("report the gather time separately"): 10 back-to-back all-gathers of one step's output
         gather_ms = None
-        if use_dist and world > 1 and not args.no_gather:
+        if use_dist and not args.no_gather:
             d0 = static_out if graph is not None else forward()
-            gather_disparity(d0)
+            alone = (lambda t: overlapped.submit(t)) if world == 1 else gather_disparity      # (1-rank group: same RCCL call)
+            alone(d0)
             torch.cuda.synchronize()
             g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             g0.record()
             for _ in range(10):
-                gather_disparity(d0)
+                alone(d0)
+            overlapped.finish()
             g1.record()
             torch.cuda.synchronize()
             gather_ms = g0.elapsed_time(g1) / 10

@@ -52,9 +52,10 @@ class OverlappedGather:
     `finish()` makes the calling stream wait for everything in flight.  Without a process group (or world 1) it is the identity.
     On CPU / gloo there are no streams: the gather runs synchronously (tests, launcher plumbing)."""
 
-    def __init__(self, depth=2, group=None):
+    def __init__(self, depth=2, group=None, single_rank_too=False):
         self.depth, self.group = depth, group
-        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        # (single_rank_too: run the collective on a 1-rank group as well -- the RCCL smoke path of bench.py --force-dist)
+        self.active = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or single_rank_too)
         self.slots = [None] * depth
         self.i = 0
         self.side = None
