@@ -95,9 +95,23 @@ class Backbone(nn.Module):
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
+    def stem_s2d_ok(self, x):
+        """The 7x7 / stride-2 stem can run as a 4x4 convolution over the 2x2 space-to-depth image (csrc/conv3x3.hip, KT = 4)."""
+        stem = self.conv1
+        return (x.dim() == 4 and x.shape[0] % 2 == 0 and x.shape[1] == 3 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+                and x.dtype in (torch.float32, torch.uint8) and stem.weight.shape[0] % 64 == 0
+                and tuple(stem.weight.shape[1:]) == (3, 7, 7) and stem.stride == (2, 2) and stem.padding == (3, 3))
+
     def forward(self, x, normalized=False):
         """x [B,3,H,W] in 0..255 (or already in [-1,1] with normalized=True: NMRF.forward stages pad + stack + normalise in
         one HIP pass; normalized="s2d": that pass wrote the 2x2 space-to-depth image [B,16,H/2,W/2] the stem kernel consumes)."""
+        if self.fused and _hip_ok(self, x) and normalized is False and self.stem_s2d_ok(x):
+            # raw 0..255 images (extract_feature of the reference API, NMRF.py:172-187): normalise + space-to-depth in the staging
+            # kernel, so that the stem runs on this library's kernel here as well (no MIOpen call)
+            from .. import kernels as K
+            n = x.shape[0] // 2
+            x = K.prep_images_s2d(x[:n].contiguous(), x[n:].contiguous(), x.shape[2], x.shape[3])
+            normalized = "s2d"
         if not normalized:
             x = 2 * (x / 255.0) - 1.0
         if self.fused and _hip_ok(self, x):
