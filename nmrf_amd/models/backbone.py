@@ -6,6 +6,7 @@ Parameter names follow the reference's `Backbone` (nmrf/models/backbone.py:16-98
 checkpoints load with strict=True: conv1, layer{1,2,3}.{0,1}.{conv1,conv2,downsample.0}, conv2.
 """
 import logging
+import os
 
 import torch
 import torch.nn as nn
@@ -40,6 +41,7 @@ class ResidualBlock(nn.Module):
         self.norm2 = _norm(norm, cout)
         self.fused = norm == "instance"
         self._wino1, self._wino2, self._ds = {}, {}, {}
+        self._side = None
         self.downsample = None
         if stride != 1 or cin != cout:
             self.norm3 = _norm(norm, cout)
@@ -56,18 +58,36 @@ class ResidualBlock(nn.Module):
             else:
                 c1 = self.conv1(x)
             c1 = c1.contiguous()
+            joined = None
             if self.downsample is not None:
+                # The shortcut (1x1 conv + InstanceNorm) depends on x only: it runs on a side stream beside conv1's statistics pass and
+                # conv2 (a parallel branch of the captured hipGraph), joined before the residual add.  NMRF_OVERLAP=0: same stream.
                 # (the 1x1 conv's bias is a per-channel constant: InstanceNorm removes it, so the add is skipped)
                 d = self.downsample[0]
-                if d.weight.shape[1] % 16 == 0 and d.weight.shape[1] <= 128 and d.stride[0] == d.stride[1] and x.dtype == torch.float32:
-                    key = (d.weight.data_ptr(), d.weight._version)
-                    if self._ds.get("key") != key:
-                        self._ds = {"key": key, "packed": K.pack_conv1x1(d.weight)}
-                    x = K.instance_norm(K.conv1x1(x.contiguous(), self._ds["packed"], d.weight.shape[1], d.stride[0]))
-                else:
-                    x = K.instance_norm(F.conv2d(x, d.weight, None, d.stride).contiguous())
+                main = torch.cuda.current_stream(x.device)
+                side = main
+                if os.environ.get("NMRF_OVERLAP", "1") != "0":
+                    if self._side is None or self._side.device != x.device:
+                        self._side = torch.cuda.Stream(device=x.device)
+                    side = self._side
+                    side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    if d.weight.shape[1] % 16 == 0 and d.weight.shape[1] <= 128 and d.stride[0] == d.stride[1] and x.dtype == torch.float32:
+                        key = (d.weight.data_ptr(), d.weight._version)
+                        if self._ds.get("key") != key:
+                            self._ds = {"key": key, "packed": K.pack_conv1x1(d.weight)}
+                        xs = K.instance_norm(K.conv1x1(x.contiguous(), self._ds["packed"], d.weight.shape[1], d.stride[0]))
+                    else:
+                        xs = K.instance_norm(F.conv2d(x, d.weight, None, d.stride).contiguous())
+                if side is not main:
+                    x.record_stream(side)
+                    xs.record_stream(main)
+                    joined = side
+                x = xs
             # norm1 + ReLU live only inside conv2's operand load: statistics pass, then the conv reads the raw conv1 output
             c2 = K.conv3x3_auto(c1, self.conv2.weight, self._wino2, stats=K.instance_stats(c1))
+            if joined is not None:
+                torch.cuda.current_stream(c2.device).wait_stream(joined)
             return K.instance_norm(c2.contiguous(), relu=True, residual=x.contiguous(), relu_out=True)
         y = self.relu(self.norm1(self.conv1(x)))
         y = self.relu(self.norm2(self.conv2(y)))
