@@ -120,15 +120,27 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
         l = *reinterpret_cast<const h16x8 *>(base + p * 128 + 64 + lane);
     };
     bool have_barrier = true;
+    unsigned long long tk_bar = 0, tk_use = 0, tk_commit = 0, tk_t = 0;     // DBG & 32: ticks inside barriers / consume / commit+fetch
+#define B16_NOW() (((DBG & 32) != 0) ? __builtin_amdgcn_s_memtime() : 0ull)
     auto stage_top = [&]() {
+        const unsigned long long t0 = B16_NOW();
         if (!have_barrier && !(DBG & 1)) __syncthreads();
         have_barrier = false;
+        tk_t = B16_NOW();
+        tk_bar += tk_t - t0;
     };
     auto stage_end = [&]() {
+        unsigned long long t1 = 0;
+        if constexpr ((DBG & 32) != 0) {
+            asm volatile("s_nop 0" ::: "memory");
+            t1 = B16_NOW();
+            tk_use += t1 - tk_t;
+        }
         if constexpr (!(DBG & 2)) {
             commit();
             fetch();
         }
+        if constexpr ((DBG & 32) != 0) tk_commit += B16_NOW() - t1;
         rd_slot = (rd_slot == B16_RING - 1) ? 0 : rd_slot + 1;
         cur = nxt;
         nxt = ring + ((rd_slot == B16_RING - 1) ? 0 : rd_slot + 1) * B16_STAGE_U4;
@@ -401,6 +413,10 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
         if constexpr ((DBG & 32) != 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             B16_STAMP(11);
+            if (lane == 0 && blockIdx.x < 64) {
+                unsigned long long *o = a.stamps + ((size_t)blockIdx.x * 8 + wv) * 16;
+                o[12] = tk_bar; o[13] = tk_use; o[14] = tk_commit;
+            }
         }
     }
     split_guard_commit(guard, a.range_flag);

@@ -145,6 +145,9 @@ if "block" in which:
             d = (s_[:, :, k] - s_[:, :, prev]).reshape(-1)
             print("   %-48s %7.0f %7.0f %7.0f" % (nm[k], np.median(d), d.min(), d.max()))
             prev = k
+        for k, nm_ in ((12, "sum over stages: barrier wait"), (13, "sum over stages: consume (LDS reads + MFMAs + VALU between)"), (14, "sum over stages: commit + fetch issue")):
+            d = s_[:, :, k].reshape(-1)
+            print("   %-48s %7.0f %7.0f %7.0f" % (nm_, np.median(d), d.min(), d.max()))
         print("   total per wave median %.0f ticks; first start to last end %.0f ticks" % (
             np.median(s_[:, :, 11] - s_[:, :, 0]), s_[:, :, 11].max() - s_[:, :, 0].min()))
     stamp16("proj+mlp+qkv", lambda: K.nmp_block(x, s16, st16, i16, msg, bp, (g, be, 1e-5, b1, b2), qd, tokens_per_wave=16))
