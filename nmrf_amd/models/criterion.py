@@ -1,0 +1,120 @@
+"""Training criterion of NMRF-Stereo: the loss terms of nmrf/models/NMRF.py:276-429 on the output dictionary of
+`NMRF.forward`, restated in this build's own formulation.  Plain PyTorch (the losses are a few elementwise passes over the
+outputs, nothing for a hand-written kernel); works on CPU and on the MI355X, differentiable through torch autograd.
+
+Inference build: `NMRF.forward` produces the eval-mode dictionary only (no `aux_outputs`: the HIP kernels are forward-only), so
+what this module gives a caller of the reference's drivers is the loss / EPE logging of an evaluation pass and the criterion object
+`build_model(cfg)` is expected to return (nmrf/models/__init__.py:9-10); `aux_outputs`, when a caller supplies them, are honoured.
+
+Terms (names and reductions as the reference's training loop reads them, main.py:413-420):
+  loss_prop   smooth-L1 between every valid ground-truth pixel of an 8x8 cell and the NEAREST of the cell's N proposals (x8 px),
+              summed, divided by the number of valid pixels (NMRF.py:301-320)
+  init        cross-entropy between the initial cost-volume distribution `prob` [B*h*w, D] and a soft target histogram per cell:
+              every valid pixel spreads unit mass linearly over the two bins around gt/8 (bins clamped to D-1), the histogram is
+              normalised, -sum(label * log clamp(prob, 1e-6)) / number of cells with a valid pixel (NMRF.py:322-365)
+  loss_disp   L1 (or smooth-L1) of the refined disparity `disp_pred * 4` over valid pixels (NMRF.py:378-384)
+  loss_coarse_disp_i / loss_disp_i   the same on intermediate predictions, score-weighted for the coarse ones (NMRF.py:367-376)
+  epe_train   mean |disp - gt| over valid pixels (logging)
+A pixel is valid for the proposal / init terms if 0 < gt < 320 (the network's own range, hard-coded in the reference), for the
+disparity terms if 0 < gt < SOLVER.MAX_DISP.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _cells(x, c=8):
+    """[B, c*h, c*w] -> [B, h*w, c*c]: the pixels of every c x c cell, row-major inside the cell."""
+    b, hh, ww = x.shape
+    return x.reshape(b, hh // c, c, ww // c, c).permute(0, 1, 3, 2, 4).reshape(b, (hh // c) * (ww // c), c * c)
+
+
+class Criterion(nn.Module):
+    def __init__(self, weight_dict, cfg):
+        super().__init__()
+        if cfg.SOLVER.LOSS_TYPE not in ("L1", "SMOOTH_L1"):
+            raise AssertionError(f"unrecognized loss type {cfg.SOLVER.LOSS_TYPE}")
+        self.weight_dict = weight_dict
+        self.max_disp = cfg.SOLVER.MAX_DISP
+        self.loss_fn = F.smooth_l1_loss if cfg.SOLVER.LOSS_TYPE == "SMOOTH_L1" else F.l1_loss
+
+    # ---- proposals ---------------------------------------------------------------------------------------------------------
+    def loss_prop(self, disp_prop, gt_disp):
+        """disp_prop [B, h*w, N] in pixels; gt_disp [B, 8h, 8w]."""
+        tgt = _cells(torch.where(gt_disp >= 320, torch.zeros_like(gt_disp), gt_disp))           # [B, hw, 64]
+        nearest = (tgt.unsqueeze(-1) - disp_prop.unsqueeze(-2)).abs().argmin(-1)                # first minimum, like torch.min
+        matched = disp_prop.gather(-1, nearest)
+        valid = (tgt > 0) & (tgt < self.max_disp)
+        total = F.smooth_l1_loss(matched[valid], tgt[valid], reduction="sum")
+        return {"loss_prop": total / (valid.sum() + 1e-6)}
+
+    # ---- initial distribution ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def loss_init(prob, gt_disp):
+        """prob [B*h*w, D]; gt_disp [B, 8h, 8w]."""
+        nd = prob.shape[-1]
+        gt = gt_disp.clamp(min=0)
+        xs = torch.arange(gt.shape[-1], device=prob.device).view(1, 1, -1)
+        valid = (gt > 0) & (gt < 320) & (xs - gt >= 0)                   # the match must lie inside the right view
+        t = _cells(gt / 8).reshape(-1, 64)                                # target in bins
+        wgt = _cells(valid.to(gt.dtype)).reshape(-1, 64)
+        lo = t.floor()
+        frac = t - lo
+        lo = lo.long()
+        label = torch.zeros_like(prob)
+        label.scatter_add_(-1, lo.clamp(max=nd - 1), (1 - frac) * wgt)
+        label.scatter_add_(-1, (lo + 1).clamp(max=nd - 1), frac * wgt)
+        label = label / label.sum(-1, keepdim=True).clamp(min=1e-3)
+        hit = label > 0
+        nll = -(prob[hit].clamp(min=1e-6).log() * label[hit]).sum()
+        cells = (wgt.sum(-1) > 0).sum()
+        loss = nll / (cells + 1e-6)
+        assert not torch.isnan(loss).any()
+        return {"init": loss}
+
+    # ---- disparities --------------------------------------------------------------------------------------------------------------
+    def loss_coarse(self, disp_pred, logits_pred, disp_gt):
+        valid = (disp_gt > 0) & (disp_gt < self.max_disp)
+        if not valid.any():                     # keeps the graph alive with a zero loss (NMRF.py:374-375)
+            return {"loss_coarse_disp": F.smooth_l1_loss(disp_pred, disp_pred.detach()) + F.smooth_l1_loss(logits_pred, logits_pred.detach())}
+        err = self.loss_fn(disp_pred, disp_gt.unsqueeze(-1).expand_as(disp_pred), reduction="none")
+        return {"loss_coarse_disp": (F.softmax(logits_pred, -1) * err).sum(-1)[valid].mean()}
+
+    def loss_disp(self, disp_pred, disp_gt):
+        valid = (disp_gt > 0) & (disp_gt < self.max_disp)
+        if not valid.any():
+            return {"loss_disp": F.smooth_l1_loss(disp_pred, disp_pred.detach())}
+        return {"loss_disp": self.loss_fn(disp_pred[valid], disp_gt[valid], reduction="mean")}
+
+    def forward(self, outputs, targets, log=True):
+        """outputs: the dictionary of NMRF.forward; targets: {'disp' [B,H,W], 'valid' bool [B,H,W]} -> dict of scalar losses."""
+        disp = outputs["disp"]
+        gt = targets["disp"].to(disp.device)
+        gt[~targets["valid"].to(disp.device)] = 0            # (in place, as the reference does: callers see the masked target)
+        losses = self.loss_prop(outputs["proposal"] * 8, gt)
+        losses.update(self.loss_init(outputs["prob"], gt))
+        if "disp_pred" in outputs:
+            losses.update(self.loss_disp(outputs["disp_pred"] * 4, gt))
+        if log:
+            valid = (gt > 0) & (gt < self.max_disp)
+            losses["epe_train"] = (disp - gt).abs()[valid].mean()
+        for i, aux in enumerate(outputs.get("aux_outputs", ())):
+            if "logits_pred" in aux:
+                part = self.loss_coarse(aux["disp_pred"] * 8, aux["logits_pred"], gt)
+            else:
+                part = self.loss_disp(aux["disp_pred"] * 4, gt)
+            losses.update({f"{k}_{i}": v for k, v in part.items()})
+        return losses
+
+
+def build_criterion(cfg):
+    """The weight dictionary of nmrf/models/NMRF.py:432-447."""
+    n_inf, n_ref = cfg.NMP.NUM_INFER_LAYERS, cfg.NMP.NUM_REFINE_LAYERS
+    lw = cfg.SOLVER.LOSS_WEIGHTS
+    assert len(lw) == n_inf + n_ref
+    weights = {"proposal_disp": 1, "init": 1}
+    if cfg.SOLVER.AUX_LOSS:
+        for i in range(n_inf + n_ref - 1):
+            weights[(f"loss_coarse_disp_{i}" if i < n_inf else f"loss_disp_{i}")] = lw[i]
+    weights["loss_disp"] = lw[-1]
+    return Criterion(weights, cfg)

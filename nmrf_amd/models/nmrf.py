@@ -1,6 +1,6 @@
 """NMRF top module: same constructor arguments, forward API and state-dict names as
-nmrf/models/NMRF.py:21-262, with the hot path on libnmrf_hip.so.  Inference only: the `Criterion`
-and the aux-loss outputs of the reference are training-side and out of scope.
+nmrf/models/NMRF.py:21-262, with the hot path on libnmrf_hip.so.  Inference only: the aux-loss outputs of the
+reference's training mode are not produced (forward-only kernels); the `Criterion` lives in models/criterion.py.
 """
 import os
 
@@ -250,6 +250,8 @@ class NMRF(nn.Module):
 
 
 def build(cfg):
-    """(model, criterion) like nmrf/models/NMRF.py:432-447; the training criterion is not part of this build."""
+    """(model, criterion) like nmrf/models/NMRF.py:432-447.  The model is the inference build (forward-only HIP kernels); the
+    criterion (models/criterion.py, plain PyTorch) evaluates the reference's loss terms on its output dictionary."""
+    from .criterion import build_criterion
     kwargs = NMRF.from_config(cfg)
-    return NMRF(**kwargs), None
+    return NMRF(**kwargs), build_criterion(cfg)

@@ -135,7 +135,7 @@ print("frame_utils", fu.__file__, hasattr(fu, "InputPadder"), fu.downsample_disp
 cfg = ns["get_cfg"]() if "get_cfg" in ns else nmrf.config.get_cfg()
 cfg.freeze()
 model, criterion = ns["build_model"](cfg)
-print("model", type(model).__module__, criterion, sum(p.numel() for p in model.parameters()))
+print("model", type(model).__module__, type(criterion).__module__, sorted(criterion.weight_dict)[-1], sum(p.numel() for p in model.parameters()))
 import nmrf_amd.models.nmp as nmp, importlib
 print("identity", nmp.__spec__.name, nmp.__package__)
 importlib.reload(nmp)
@@ -158,5 +158,5 @@ def test_real_checkout_import_lines_resolve_through_the_hook():
     assert out["inference.py"] == "nmrf_amd.models" and out["main.py"] == "nmrf_amd.models"
     assert out["config"] == os.path.join(REAL_CHECKOUT, "nmrf", "config", "__init__.py")
     assert out["frame_utils"] == "%s True nmrf_amd.frame_utils" % os.path.join(REAL_CHECKOUT, "nmrf", "utils", "frame_utils.py")
-    assert out["model"] == "nmrf_amd.models.nmrf None 6113210"
+    assert out["model"] == "nmrf_amd.models.nmrf nmrf_amd.models.criterion proposal_disp 6113210"
     assert out["identity"] == "nmrf_amd.models.nmp nmrf_amd.models"

@@ -88,7 +88,7 @@ def test_shipped_swint_yaml_keys_build_verbatim():
                          "BACKBONE.DROP_PATH", 0.4, "BACKBONE.COMPAT", False])
     cfg.freeze()
     model, criterion = build_model(cfg)
-    assert criterion is None and hasattr(model, "image_encoder") and model.divis_by == 32
+    assert criterion.weight_dict["loss_disp"] == cfg.SOLVER.LOSS_WEIGHTS[-1] and hasattr(model, "image_encoder") and model.divis_by == 32
     model.eval()
     with pytest.raises(NotImplementedError):
         model.train()({"img1": torch.zeros(1, 3, 32, 32), "img2": torch.zeros(1, 3, 32, 32)})
