@@ -89,6 +89,13 @@ class KernelTimer:
         return sum(vals) / len(vals) if vals else None
 
 
+def _set_infer_layers(cfg, n):
+    """NMP.NUM_INFER_LAYERS with SOLVER.LOSS_WEIGHTS kept one-per-layer: build() asserts that, as nmrf/models/NMRF.py:434 does."""
+    lw, n0 = list(cfg.SOLVER.LOSS_WEIGHTS), cfg.NMP.NUM_INFER_LAYERS
+    cfg.NMP.NUM_INFER_LAYERS = n
+    cfg.SOLVER.LOSS_WEIGHTS = lw[n0 - n:] if n <= n0 else [lw[0]] * (n - n0) + lw
+
+
 def cpu_baseline(height, width, infer_layers, max_disp=320):
     """The CPU oracle (a plain-PyTorch port of the reference path, pinned to the reference by tests/test_oracle_golden.py) on
     the host cores, same synthetic pair, batch 1: 1 warm-up + median of 3 forwards on up to 16 threads, and one
@@ -101,7 +108,7 @@ def cpu_baseline(height, width, infer_layers, max_disp=320):
     nthr = min(cores, 16)                     # the op-by-op CPU path stops scaling (and collapses) beyond ~16 threads
     torch.set_num_threads(nthr)
     cfg = get_cfg()
-    cfg.NMP.NUM_INFER_LAYERS = infer_layers
+    _set_infer_layers(cfg, infer_layers)
     cfg.DPN.MAX_DISP = max_disp
     w = hash_state_dict(build_model(cfg)[0].state_dict())
     ocfg = O.OracleCfg(num_infer_layers=infer_layers, max_disp=max_disp)
@@ -231,7 +238,7 @@ def run(args):
     from nmrf_amd.utils.hashinit import apply_hash_weights, synthetic_pair
 
     cfg = get_cfg()
-    cfg.NMP.NUM_INFER_LAYERS = args.infer_layers
+    _set_infer_layers(cfg, args.infer_layers)
     cfg.DPN.MAX_DISP = args.max_disp
     if args.backbone == "swin":                                   # configs/sceneflow_swint.yaml
         cfg.merge_from_list(["BACKBONE.MODEL_TYPE", "swin", "BACKBONE.OUT_CHANNELS", 128, "DATASETS.DIVIS_BY", 32,

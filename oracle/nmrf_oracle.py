@@ -646,8 +646,11 @@ def msda_core(value, shapes, loc, wgt):
 # --------------------------------------------------------------------------- #
 # full forward (NMRF.py:189-262), CNN backbone
 # --------------------------------------------------------------------------- #
-def hot_path(w, cfg, feats8, feats4, pad_hw, out_hw, stages=None):
-    """Everything after the backbone (NMRF.py:207-262).  feats8 / feats4: [2B,C,H,W] maps, left views first."""
+def hot_path(w, cfg, feats8, feats4, pad_hw, out_hw, stages=None, seeds=None):
+    """Everything after the backbone (NMRF.py:207-262).  feats8 / feats4: [2B,C,H,W] maps, left views first.
+    seeds: [P,N] int64 label seeds to continue from instead of the oracle's own NMS + top-k (test infrastructure: at a pixel
+    whose candidates tie within the fp32 noise of `prob`, the checker continues from the candidate's choice -- tests/util.py
+    seeds_explained_by_prob_noise -- so that everything downstream is compared on identical seeds)."""
     b = feats8.shape[0] // 2
     l8, r8 = feats8[:b], feats8[b:]
     l4, r4 = feats4[:b], feats4[b:]
@@ -658,7 +661,7 @@ def hot_path(w, cfg, feats8, feats4, pad_hw, out_hw, stages=None):
 
     cv = cost_volume(l8, r8, num_disp, cfg.cost_group)
     prob = dpn_filter_softmax(cv, w)
-    seeds = nms_topk(prob, n, cfg.eps)
+    seeds = nms_topk(prob, n, cfg.eps) if seeds is None else seeds.long().reshape(-1, n)
     ctx = conv_head(l8, w, "dpn.proj").permute(0, 2, 3, 1)
     mem = propagation(cv, seeds, ctx, w, cfg, dims8, stages)
     labels = F.relu(_relu_mlp(mem, w, "dpn.prop_head").view(-1, n) + seeds.to(mem.dtype))

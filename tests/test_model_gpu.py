@@ -6,7 +6,8 @@ import pytest
 import torch
 
 from oracle import nmrf_oracle as O
-from tests.util import build_product, check_chain, golden, oracle_cfg, oracle_weights, report, t, unshuffle_heads
+from tests.util import (build_product, check_chain, golden, oracle_cfg, oracle_weights, report, seeds_explained_by_prob_noise, t,
+                        unshuffle_heads)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -336,16 +337,13 @@ def _hot_path_vs_oracle(tag, model, feats, out_hw, max_disp, opts=(), pick=0, pr
                                     out_hw)
         want = O.hot_path(w, cfg, f8s.cpu(), f4s.cpu(), None, out_hw, stages={})
         l4, r4 = f4s[:1].cpu(), f4s[1:].cpu()
-        from tests.conftest import record_note
-        perr = float((got["prob"].cpu() - want["prob"]).abs().max())
-        mism = float((got["initial_proposal"].cpu() != want["initial_proposal"]).any(-1).float().mean())
-        record_note("%s: max|dprob| %.2e, %.4f%% of pixels with different seeds" % (tag, perr, mism * 100))
+        # probabilities at full size: fp32 summation order of the 64-channel (Swin: 32) correlation means, amplified by the three
+        # conv1d layers; measured on the MI355X 5e-6 ... 7e-6 (CNN features) and 1.8e-5 (Swin-T features, larger magnitudes)
+        mism = seeds_explained_by_prob_noise(tag, got, want, cfg.eps, prob_tol)
+        if mism:            # candidates tied within the noise of prob: the oracle continues from the GPU's choice there
+            want = O.hot_path(w, cfg, f8s.cpu(), f4s.cpu(), None, out_hw, stages={}, seeds=got["initial_proposal"].cpu().long())
         report(tag + " proposal", got["proposal"].cpu(), want["proposal"], 2e-4)
         st = check_chain(tag, cand, _oracle_chain_side(want), lambda dq: O.refine_from(w, cfg, dq, l4, r4, out_hw)[0], **gate)
-    # probabilities at full size: fp32 summation order of the 64-channel (Swin: 32) correlation means, amplified by the three
-    # conv1d layers; measured on the MI355X 5e-6 ... 7e-6 (CNN features) and 1.8e-5 (Swin-T features, larger magnitudes)
-    assert perr <= prob_tol, f"{tag}: max|dprob| {perr:.2e}"
-    assert mism == 0.0, f"{tag}: {mism * 100:.4f}% of the pixels got different label seeds from identical features"
     return got, st, mism
 
 

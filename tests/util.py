@@ -180,6 +180,35 @@ def check_chain(tag, cand, base, refine_from, tau_score=TAU_SCORE, tau_coarse=TA
     return st
 
 
+def seeds_explained_by_prob_noise(tag, got, want, eps, prob_tol, budget=1e-4):
+    """Label seeds of the GPU hot path vs the oracle's from the SAME features.  The NMS + top-k kernel is bit-exact on a given
+    `prob` (tests/test_hip_kernels.py: every crafted tie / plateau row and the reference's golden rows); end to end its input
+    differs from the oracle's by the fp32 summation order of the correlation means (<= prob_tol, asserted here), so two
+    candidates closer than that can swap ranks or trade the k-th place.  Returns the number of pixels whose seeds differ, after
+    asserting for EVERY such pixel that the candidate's seeds are exactly torch.topk(nms(candidate's own prob)) -- i.e. the
+    difference is the perturbation of `prob`, not the selection -- and that there are at most max(2, budget * pixels) of them.
+    The caller then continues the oracle from the candidate's seeds (oracle.hot_path(seeds=...))."""
+    from oracle import nmrf_oracle as O
+    from tests.conftest import record_note
+    n = got["initial_proposal"].shape[-1]
+    pg, pw = got["prob"].cpu(), want["prob"].cpu()
+    perr = float((pg - pw).abs().max())
+    assert perr <= prob_tol, f"{tag}: max|dprob| {perr:.2e}"
+    sg, sw = got["initial_proposal"].cpu().long().reshape(-1, n), want["initial_proposal"].cpu().long().reshape(-1, n)
+    differ = (sg != sw).any(-1)
+    nd = int(differ.sum())
+    record_note("%s: max|dprob| %.2e, %d of %d pixels with different seeds" % (tag, perr, nd, differ.numel()))
+    if nd:
+        own = O.nms_topk(pg[differ], n, eps)
+        assert torch.equal(own, sg[differ]), f"{tag}: seeds are not the top-k of the candidate's own probabilities"
+        # the two selections are both exact on inputs <= prob_tol apart: the candidates involved tie within 2 * prob_tol
+        sup = O.nms_suppress(pw[differ], eps)
+        gap = (sup.gather(1, sw[differ]) - sup.gather(1, sg[differ])).abs().max(-1).values
+        record_note("%s: seed differences at near-ties of the oracle's suppressed prob, largest gap %.2e" % (tag, float(gap.max())))
+        assert nd <= max(2, budget * differ.numel()), f"{tag}: {nd} pixels with different seeds"
+    return nd
+
+
 def record_chain_stats(tag, st):
     from tests.conftest import record_note
     record_note("%s: WTA decisions differing %d (%.1e of px, reference margin <= %.1e), score/coarse maxdiff %.1e / %.1e, "
