@@ -42,10 +42,16 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1x1Args a) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, hi = lane >> 5;
     float *Aff = reinterpret_cast<float *>(smem + SS_RING_BYTES);           // [2][128]: scale, shift of the block's image
-    float *Ot = Aff + 256;                                                   // [64 co][C1_OLD] output staging
+    float *Ot = Aff + 256;                                                   // [32 co][C1_OLD] output staging (one strip: 66 KB of LDS
+    //                                                                          per block, TWO blocks per CU -- with a tile per strip PAIR
+    //                                                                          it was 83 KB: one block, one wave per SIMD)
+    // blockIdx.y = group of output-channel strip pairs (maps with fewer pixel tiles than CUs split their channels over blocks: every
+    // block then re-reads the input tile, which is small, and walks 1 / gridDim.y of the weight stream)
+    const int pairs_all = (a.N + 63) >> 6, pairs_blk = pairs_all / (int)gridDim.y;
+    const int stages_blk = a.total_stages / (int)gridDim.y;
     SplitStream<C1_PF> ss;
-    ss.init(a.stream, smem, a.total_stages, tid);
-    const int n_strips = ((a.N + 63) >> 6) << 1;                             // strip pairs; rows beyond N are zero in the stream, never stored
+    ss.init(reinterpret_cast<const ss_u32x4 *>(a.stream) + (size_t)blockIdx.y * stages_blk * SS_STAGE_U4, smem, stages_blk, tid);
+    const int s_first = 2 * pairs_blk * (int)blockIdx.y, n_strips = s_first + 2 * pairs_blk;    // rows beyond N are zero in the stream, never stored
     float guard = 0.f;                                                       // fp16 range guard of the activation splits
 
 #pragma unroll 1
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1x1Args a) {
         float *obase = a.out + (size_t)b * a.N * a.HW;
         const bool vec_ok = (a.HW & 3) == 0;
 #pragma unroll 1
-        for (int s = 0; s < n_strips; s += 2) {                              // two strips = 2*KC pairs per iteration (whole stages)
+        for (int s = s_first; s < n_strips; s += 2) {                        // two strips = 2*KC pairs per iteration (whole stages)
             ss_static_for<2>([&](auto hh) {
                 constexpr int half = decltype(hh)::value;
                 f32x16 acc;
@@ -112,29 +118,28 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1x1Args a) {
                     ss_pair<half * KC + c>(ss, bh[c], bl[c], acc);
                 });
                 const int co0 = 32 * (s + half);
-                float *ot = Ot + half * 32 * C1_OLD;                          // one tile per strip of the pair: no barrier in between
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = mfma_row(r, hi);
-                    ot[row * C1_OLD + 32 * wv + j] = fmaf(acc[r], a.inv, a.bias ? a.bias[co0 + row] : 0.f);
+                    Ot[row * C1_OLD + 32 * wv + j] = fmaf(acc[r], a.inv, a.bias ? a.bias[co0 + row] : 0.f);
                 }
-            });
-            __syncthreads();
-            // 64 rows (2 strips x 32 channels) of 128 pixels: thread = (row = tid / 32 + 8 * pass, 4 pixels)
+                __syncthreads();
+                // 32 rows (channels) of 128 pixels: thread = (row = tid / 32 + 8 * pass, 4 pixels)
 #pragma unroll
-            for (int pass = 0; pass < 8; ++pass) {
-                const int row = (tid >> 5) + 8 * pass, px = (tid & 31) * 4;
-                const int co = 32 * s + row;
-                const int64_t pp = pb + px;
-                if (co < a.N && pp < a.HW) {
-                    const f32x4 v = *reinterpret_cast<const f32x4 *>(Ot + row * C1_OLD + px);
-                    float *dst = obase + (size_t)co * a.HW + pp;
-                    if (vec_ok && pp + 3 < a.HW) *reinterpret_cast<f32x4 *>(dst) = v;
-                    else
-                        for (int e = 0; e < 4 && pp + e < a.HW; ++e) dst[e] = v[e];
+                for (int pass = 0; pass < 4; ++pass) {
+                    const int row = (tid >> 5) + 8 * pass, px = (tid & 31) * 4;
+                    const int co = co0 + row;
+                    const int64_t pp = pb + px;
+                    if (co < a.N && pp < a.HW) {
+                        const f32x4 v = *reinterpret_cast<const f32x4 *>(Ot + row * C1_OLD + px);
+                        float *dst = obase + (size_t)co * a.HW + pp;
+                        if (vec_ok && pp + 3 < a.HW) *reinterpret_cast<f32x4 *>(dst) = v;
+                        else
+                            for (int e = 0; e < 4 && pp + e < a.HW; ++e) dst[e] = v[e];
+                    }
                 }
-            }
-            __syncthreads();                                                   // the tiles are rewritten by the next strip pair
+                __syncthreads();                                               // the tile is rewritten by the next strip
+            });
         }
     }
     split_guard_commit(guard, a.range_flag);
@@ -146,7 +151,7 @@ static int launch_conv1x1(const Conv1x1Args &a, hipStream_t st) {
     static int n_cu_dev[NMRF_MAX_DEV] = {};
     const int dev = nmrf_cur_device();
     if (dev < 0) return NMRF_ELAUNCH;
-    const size_t lds = (size_t)SS_RING_BYTES + (256 + 64 * C1_OLD) * sizeof(float);
+    const size_t lds = (size_t)SS_RING_BYTES + (256 + 32 * C1_OLD) * sizeof(float);
     if (!attr_set_dev[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv1x1_kernel<KC>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess)
@@ -158,8 +163,15 @@ static int launch_conv1x1(const Conv1x1Args &a, hipStream_t st) {
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return NMRF_ELAUNCH;
         n_cu_dev[dev] = prop.multiProcessorCount;
     }
-    const int grid = a.n_tiles < 2 * n_cu_dev[dev] ? a.n_tiles : 2 * n_cu_dev[dev];
-    hipLaunchKernelGGL((conv1x1_kernel<KC>), dim3(grid), dim3(256), lds, st, a);
+    const int slots = 2 * n_cu_dev[dev];
+    const int grid = a.n_tiles < slots ? a.n_tiles : slots;
+    // fewer pixel tiles than block slots: split the output channels (strip pairs; whole stages each) over blockIdx.y
+    const int pairs = (a.N + 63) >> 6;
+    int split = 1;
+    while (split * 2 <= pairs && pairs % (split * 2) == 0 && a.n_tiles * split * 2 <= slots &&
+           (a.total_stages % (split * 2)) == 0)
+        split *= 2;
+    hipLaunchKernelGGL((conv1x1_kernel<KC>), dim3(grid, split), dim3(256), lds, st, a);
     return nmrf_launch_status();
 }
 

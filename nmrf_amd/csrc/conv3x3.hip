@@ -464,7 +464,11 @@ extern "C" int nmrf_conv_split_f32(const float *x, int B, int Ci, int H, int W, 
     if (HW * 8 + HW > 0xffffffffLL) return NMRF_EINVAL;                         // 32-bit lane offsets
     // small maps: one output row per wave (4-row tiles) when the 8-row tiling leaves most of the chip idle
     const int tx = (Wo + C3_TC - 1) / C3_TC;
-    const bool small = stride == 1 && kt == 3 && strips == 2 && (int64_t)tx * ((Ho + 7) / 8) * B * groups <= 256;
+    bool small = stride == 1 && kt == 3 && strips == 2 && (int64_t)tx * ((Ho + 7) / 8) * B * groups <= 256;
+#ifdef NMRF_DEBUG_PROBES
+    if (g_conv3_variant == 100 && stride == 1 && kt == 3 && strips == 2) small = true;       // A/B: 4-row tiles regardless of size
+    if (g_conv3_variant == 101) small = false;
+#endif
     const int tr = stride == 1 && !small ? 8 : 4;
     const int ty = (Ho + tr - 1) / tr;
     const int64_t n = (int64_t)tx * ty * B;

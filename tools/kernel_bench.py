@@ -382,6 +382,13 @@ if "conv" in which:
                 packed = (pk[0], strips, co // 32 // strips, pk[1])
                 cands.append(("split%d" % strips, lambda packed=packed: K.conv3x3_split(xx, packed, co)))
                 cands.append(("split%d+IN" % strips, lambda packed=packed: K.conv3x3_split(xx, packed, co, st)))
+                if strips == 2:
+                    def rows1(packed=packed):
+                        _l.nmrf_debug_conv3_variant(100)
+                        r = K.conv3x3_split(xx, packed, co, st)
+                        _l.nmrf_debug_conv3_variant(0)
+                        return r
+                    cands.append(("split2+IN 4-row tiles", rows1))
         line = "conv3x3 %3d->%3d @%dx%dx%d :" % (ci, co, bb * args.batch, hh, ww)
         for nm, fn in cands:
             fn(); fn(); torch.cuda.synchronize()
