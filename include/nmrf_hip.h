@@ -40,7 +40,7 @@ const char *nmrf_strerror(int code);
  * in a separate pass when range_flag != NULL; pass NULL when qkv was produced by nmrf_nmp_block16_f32, which range-checks its q_out. */
 int nmrf_range_scan_f32(const float *x, int64_t n, int *range_flag, void *stream);   /* n % 4 == 0, x 16-byte aligned */
 /* ABI version of this header; bumps on any signature change. */
-int nmrf_abi_version(void);   /* currently 17 */
+int nmrf_abi_version(void);   /* currently 18 */
 
 /* A2  group-wise correlation volume.
  * replaces build_correlation_volume + the permute of DPN.forward
@@ -71,6 +71,14 @@ int nmrf_nms_topk_f32(const float *prob, int64_t P, int D, int K, float eps, int
  * enc rows of enc_ld >= 31 floats = [sin(c*2^i) i<15 | cos(c*2^i) | c | 0 ...], c = seed*normalizer.  enc may be NULL. */
 int nmrf_seed_features_f32(const float *vol, const int64_t *seeds, int64_t P, int G, int D, int N,
                            float normalizer, float *cost, float *enc, int enc_ld, void *stream);
+
+/* A4 + A6 in one launch: NMS + top-k (semantics and tie order of nmrf_nms_topk_f32, bit-exact) on one wave per pixel with the
+ * row in registers, followed at once by the seed features of nmrf_seed_features_f32 and the float copy of the seeds that
+ * Propagation.forward hands on (nmrf/models/DPN.py:120-125; NMP.py:619-634,35-51,646-647).
+ * prob [P,D], vol [P,G,D] (may be NULL when cost is) -> seeds [P,K] int64, seeds_f [P,K] float (may be NULL),
+ * cost [P*K, G*9] (may be NULL), enc rows of enc_ld >= 31 floats (may be NULL).  D<=64, K<=8, K*64>D. */
+int nmrf_seed_select_f32(const float *prob, const float *vol, int64_t P, int G, int D, int K, float eps, int do_nms,
+                         float normalizer, int64_t *seeds, float *seeds_f, float *cost, float *enc, int enc_ld, void *stream);
 
 /* Fourier(31) of arbitrary fp32 coordinates (labels / refined disparity).
  * replaces fourier_coord_embed call sites nmrf/models/NMP.py:743,846.

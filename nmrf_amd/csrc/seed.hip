@@ -368,6 +368,188 @@ __device__ __forceinline__ void fourier_pad(int f, float *row, int ld) {
     if (f == 15) for (int k = 31; k < ld; ++k) row[k] = 0.f;
 }
 
+// ------------------------------------------------------------------------------------------------
+// A4 + A6 in one launch, one WAVE per pixel, the row in REGISTERS: lane j holds bin j as an order-preserving integer key and its
+// index; the NMS is three shuffles, and the introselect + insertion sort above (same steps, same comparator, same swaps, hence
+// the same tie order as ATen's CPU top-k) runs on the SCALAR unit: every index is wave-uniform, so element j is read with
+// v_readlane / written with v_writelane and compared with s_cmp -- no LDS round trip per step (the LDS form above spends ~30 us
+// on 7 332 rows of 40 bins: a serial chain of dependent LDS accesses on one lane per wave).  The K winners are then used at once
+// by all 64 lanes for the seed features (A6: 9 taps x G groups of the cost volume, Fourier(31) of the seed) and the float copy of
+// the seeds that the propagation consumes (NMP.py:619-649) -- the separate gather launch and the int64 -> float pass disappear.
+//   key(x): tk_gt(x, y) <=> key(x) > key(y) as unsigned integers: NaN -> 0xffffffff (all NaNs tie, above +inf), -0 -> +0,
+//           sign-magnitude -> biased two's complement.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned tk_key(float x) {
+    if (isnan(x)) return 0xffffffffu;
+    const unsigned b = __float_as_uint(x + 0.0f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+struct TkR {                                   // the row: lane j <-> element j (uniform j only)
+    unsigned key;
+    int idx;
+    __device__ __forceinline__ unsigned K(int j) const { return (unsigned)__builtin_amdgcn_readlane((int)key, j); }
+    __device__ __forceinline__ int I(int j) const { return __builtin_amdgcn_readlane(idx, j); }
+    __device__ __forceinline__ void put(int j, unsigned k, int i) {       // (this clang has no writelane builtin: a select on the lane id)
+        const bool me = (int)(threadIdx.x & 63) == j;
+        key = me ? k : key;
+        idx = me ? i : idx;
+    }
+    __device__ __forceinline__ void move(int dst, int src) { put(dst, K(src), I(src)); }
+    __device__ __forceinline__ void swap(int a, int b) {
+        const unsigned ka = K(a), kb = K(b);
+        const int ia = I(a), ib = I(b);
+        put(a, kb, ib);
+        put(b, ka, ia);
+    }
+};
+
+__device__ __forceinline__ void tkr_insertion_sort(TkR &q, int first, int last) {
+    if (first == last) return;
+    for (int i = first + 1; i < last; ++i) {
+        const unsigned vk = q.K(i);
+        const int vi = q.I(i);
+        if (vk > q.K(first)) {
+            for (int j = i; j > first; --j) q.move(j, j - 1);
+            q.put(first, vk, vi);
+        } else {
+            int j = i;
+            while (vk > q.K(j - 1)) { q.move(j, j - 1); --j; }
+            q.put(j, vk, vi);
+        }
+    }
+}
+
+__device__ __forceinline__ void tkr_adjust_heap(TkR &q, int start, int hole, int len, unsigned vk, int vi) {
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (q.K(start + child) > q.K(start + child - 1)) child--;
+        q.move(start + hole, start + child);
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        q.move(start + hole, start + child - 1);
+        hole = child - 1;
+    }
+    int parent = (hole - 1) / 2;
+    while (hole > top && q.K(start + parent) > vk) {
+        q.move(start + hole, start + parent);
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    q.put(start + hole, vk, vi);
+}
+
+__device__ __forceinline__ void tkr_heap_select(TkR &q, int first, int middle, int last) {
+    const int len = middle - first;
+    if (len >= 2) {
+        for (int parent = (len - 2) / 2;; --parent) {
+            tkr_adjust_heap(q, first, parent, len, q.K(first + parent), q.I(first + parent));
+            if (parent == 0) break;
+        }
+    }
+    for (int i = middle; i < last; ++i)
+        if (q.K(i) > q.K(first)) {
+            const unsigned vk = q.K(i);
+            const int vi = q.I(i);
+            q.move(i, first);
+            tkr_adjust_heap(q, first, 0, len, vk, vi);
+        }
+}
+
+__device__ __forceinline__ void tkr_nth_element(TkR &q, int n, int nth) {
+    int first = 0, last = n;
+    if (first == last || nth == last) return;
+    int depth = 2 * (31 - __clz(n));
+    while (last - first > 3) {
+        if (depth == 0) {
+            tkr_heap_select(q, first, nth + 1, last);
+            q.swap(first, nth);
+            return;
+        }
+        --depth;
+        const int a = first + 1, b = first + (last - first) / 2, c = last - 1;
+        int m;
+        const unsigned va = q.K(a), vb = q.K(b), vc = q.K(c);
+        if (va > vb) m = vb > vc ? b : (va > vc ? c : a);
+        else         m = va > vc ? a : (vb > vc ? c : b);
+        q.swap(first, m);
+        const unsigned pv = q.K(first);
+        int lo = first + 1, hi = last;
+        for (;;) {
+            while (q.K(lo) > pv) ++lo;
+            --hi;
+            while (pv > q.K(hi)) --hi;
+            if (!(lo < hi)) break;
+            q.swap(lo, hi);
+            ++lo;
+        }
+        if (lo <= nth) first = lo; else last = lo;
+    }
+    tkr_insertion_sort(q, first, last);
+}
+
+#define SS_ROWS 4                                // rows (waves) per block
+__global__ __launch_bounds__(64 * SS_ROWS) void seed_select_kernel(const float *__restrict__ prob, const float *__restrict__ vol,
+        int64_t P, int G, int D, int K, float eps, int do_nms, float normalizer, int64_t *__restrict__ seeds,
+        float *__restrict__ seeds_f, float *__restrict__ cost, float *__restrict__ enc, int enc_ld) {
+    const int lane = threadIdx.x & 63;
+    const int64_t p = (int64_t)blockIdx.x * SS_ROWS + (threadIdx.x >> 6);
+    if (p >= P) return;                                                     // (wave-uniform; no barriers below)
+    const bool in = lane < D;
+    float cur = in ? prob[(size_t)p * D + lane] : -INFINITY;
+    if (do_nms) {
+        float prev = __shfl_up(cur, 1), nxt = __shfl_down(cur, 1);
+        if (lane == 0) prev = -INFINITY;
+        if (lane >= D - 1) nxt = -INFINITY;
+        const bool any_nan = isnan(prev) || isnan(cur) || isnan(nxt);
+        const float m = any_nan ? NAN : fmaxf(fmaxf(prev, nxt), cur);       // max_pool1d(k=3,p=1), NaN-propagating
+        cur = (cur != m && cur > eps) ? eps : cur;                          // DPN.py:121-124
+    }
+    TkR q{tk_key(cur), lane};
+    tkr_nth_element(q, D, K - 1);
+    tkr_insertion_sort(q, 0, K - 1);
+    // lanes 0 .. K-1 now hold the winners in top-k order
+    if (lane < K) {
+        seeds[(size_t)p * K + lane] = (int64_t)q.idx;
+        if (seeds_f) seeds_f[(size_t)p * K + lane] = (float)q.idx;
+    }
+    if (cost) {
+        const int per = G * 9;
+        for (int i = lane; i < K * per; i += 64) {
+            const int k = i / per, j = i - k * per;
+            const int g = j / 9, tap = j - g * 9;
+            int d = __shfl(q.idx, k) + tap - 4;
+            d = d < 0 ? 0 : (d > D - 1 ? D - 1 : d);
+            cost[((size_t)p * K + k) * per + j] = vol[((size_t)p * G + g) * D + d];
+        }
+    }
+    if (enc) {
+        for (int i = lane; i < K * 16; i += 64) {
+            const int k = i >> 4;
+            float *row = enc + ((size_t)p * K + k) * enc_ld;
+            fourier_write((float)__shfl(q.idx, k), normalizer, i & 15, row);
+            fourier_pad(i & 15, row, enc_ld);
+        }
+    }
+}
+
+extern "C" int nmrf_seed_select_f32(const float *prob, const float *vol, int64_t P, int G, int D, int K, float eps, int do_nms,
+                                    float normalizer, int64_t *seeds, float *seeds_f, float *cost, float *enc, int enc_ld,
+                                    void *stream) {
+    if (!prob || !seeds) return NMRF_ENULL;
+    if (cost && !vol) return NMRF_ENULL;
+    if (P < 1 || D < 1 || D > TK_MAXD || K < 1 || K > 8 || K > D || K * 64 <= D || (cost && G < 1) || (enc && enc_ld < 31))
+        return NMRF_EINVAL;
+    if (ceil_div64(P, SS_ROWS) > 0x7fffffff) return NMRF_EINVAL;
+    hipLaunchKernelGGL(seed_select_kernel, dim3((unsigned)ceil_div64(P, SS_ROWS)), dim3(64 * SS_ROWS), 0, (hipStream_t)stream, prob,
+                       vol, P, G, D, K, eps, do_nms, normalizer, seeds, seeds_f, cost, enc, enc_ld);
+    return nmrf_launch_status();
+}
+
 __global__ __launch_bounds__(256) void seed_features_kernel(const float *__restrict__ vol, const int64_t *__restrict__ seeds,
         int64_t P, int G, int D, int N, float normalizer, float *__restrict__ cost, float *__restrict__ enc, int enc_ld) {
     const int per = G * 9;

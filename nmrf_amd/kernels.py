@@ -155,6 +155,22 @@ def nms_topk(prob, k, eps, do_nms=True):
 
 
 @_on_device
+def seed_select(prob, vol, k, eps, normalizer, enc_ld=31, do_nms=True):
+    """NMS + top-k and the seed features in one launch (csrc/seed.hip seed_select_kernel): -> (seeds [P,k] int64, seeds as
+    float [P,k], cost [P*k, G*9], enc [P*k, enc_ld]).  Same seeds, bit for bit, as nms_topk; same features as seed_features."""
+    _chk(prob, vol)
+    p, d = prob.shape
+    g = vol.shape[1]
+    seeds = torch.empty(p, k, device=prob.device, dtype=torch.int64)
+    seeds_f = torch.empty(p, k, device=prob.device, dtype=torch.float32)
+    cost = torch.empty(p * k, g * 9, device=prob.device, dtype=torch.float32)
+    enc = torch.empty(p * k, enc_ld, device=prob.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_seed_select_f32(_p(prob), _p(vol), p, g, d, k, float(eps), int(do_nms), float(normalizer), _p(seeds),
+                                                _p(seeds_f), _p(cost), _p(enc), enc_ld, _stream()), "seed_select")
+    return seeds, seeds_f, cost, enc
+
+
+@_on_device
 def seed_features(vol, seeds, normalizer, enc_ld=31):
     _chk(vol)
     _chk(seeds, dtype=torch.int64)

@@ -43,11 +43,22 @@ class DPN(nn.Module):
                    mlp_ratio=cfg.NMP.MLP_RATIO, split_size=cfg.NMP.SPLIT_SIZE, prop_n_heads=cfg.NMP.PROP_N_HEADS,
                    normalize_before=cfg.NMP.NORMALIZE_BEFORE)
 
-    def seeds(self, cost_volume):
-        """cost_volume [P,G,D] -> (prob [P,D], label_seeds [P,K] int64)   (DPN.py:117-125)"""
+    # one wave per pixel with the row in registers (+ the seed features in the same launch) up to this many pixels: 22 us against
+    # 34 + 10 + 5 us of the three launches it replaces at KITTI batch 1 (7 332 pixels); it is bound by the scalar unit (one row per
+    # wave), so from ~50 000 pixels on the LDS form with 16 / 64 rows per wave catches up (109 vs 103 us at KITTI batch 8)
+    SELECT_MAX_PIXELS = 1 << 15
+
+    def seeds(self, cost_volume, features=None):
+        """cost_volume [P,G,D] -> (prob [P,D], label_seeds [P,K] int64)   (DPN.py:117-125).
+        features = (Fourier normalizer, row stride of the encoding): also hand back, in the third slot, what
+        Propagation.forward would gather from these seeds (seeds as float, cost taps, Fourier encoding: K.seed_select)."""
         m = self.mlp
         prob = K.dpn_filter_softmax(cost_volume, m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias)
-        return prob, K.nms_topk(prob, self.num_proposals, self.eps)
+        if features is not None and prob.shape[0] <= self.SELECT_MAX_PIXELS:
+            seeds, seeds_f, cost, enc = K.seed_select(prob, cost_volume, self.num_proposals, self.eps, *features)
+            return prob, seeds, (seeds_f, cost, enc)
+        seeds = K.nms_topk(prob, self.num_proposals, self.eps)
+        return (prob, seeds) if features is None else (prob, seeds, None)
 
     def context(self, fmap):
         """proj (Conv3x3 - IN - ReLU - Conv1x1, DPN.py:45-49) of the 1/8-resolution left feature map -> [B,Cctx,H,W]."""
@@ -71,13 +82,13 @@ class DPN(nn.Module):
         if cost_volume.dim() == 5:
             b, g, d, h, w = cost_volume.shape
             cost_volume = cost_volume.permute(0, 3, 4, 1, 2).reshape(b * h * w, g, d).contiguous()
-        prob, seeds = self.seeds(cost_volume)
+        prob, seeds, feats = self.seeds(cost_volume, features=self.propagation.seed_feature_args(context))
         if context is None:
             context = self.context(fmap1_list[0])
         elif context_ready is not None:
             torch.cuda.current_stream().wait_event(context_ready)
         context = context.permute(0, 2, 3, 1).contiguous()
-        memory, seeds_f = self.propagation(cost_volume, seeds, context)
+        memory, seeds_f = self.propagation(cost_volume, seeds, context, feats=feats)
         outputs = self.prop_head(memory).view(-1, *seeds_f.shape)
         labels = F.relu(outputs + seeds_f[None])
         return cost_volume, prob, seeds_f, labels

@@ -432,24 +432,42 @@ class Propagation(nn.Module):
         self.proj = nn.Linear(embed_dim + FOURIER_DIM, embed_dim, bias=False)
         self.embed_dim, self.layers, self.norm = embed_dim, layers, norm
 
-    def forward(self, cost_volume, label_seed, context):
-        """cost_volume [P,G,D]; label_seed [P,N] int64; context [B,H,W,Cctx] -> ([1,P*N,C], seeds.float())"""
+    def _split_ok(self, cc):
+        return (_split() and cc == 64 and self.embed_dim == 128 and self.cost_encoder[0].in_features <= 48
+                and self.cost_encoder[0].in_features % 4 == 0 and all(_block_ok(l.nmp.proj, l.nmp.mlp) for l in self.layers))
+
+    def seed_feature_args(self, context):
+        """(Fourier normalizer, encoding row stride) of the seed features this module consumes (NMP.py:646-647), for the producer of
+        the seeds to gather them in its own launch (DPN.seeds / K.seed_select)."""
+        cc = context.shape[1] if context is not None else self.layers[0].nmp.q.in_features - self.embed_dim
+        return (3.14 / 64, 32 if self._split_ok(cc) else 31)
+
+    def forward(self, cost_volume, label_seed, context, feats=None):
+        """cost_volume [P,G,D]; label_seed [P,N] int64; context [B,H,W,Cctx] -> ([1,P*N,C], seeds.float()).
+        feats: (seeds as float, cost taps, Fourier encoding) already gathered by the seed kernel, or None."""
         b, h, wd, cc = context.shape
         n = label_seed.shape[-1]
         dims = (b, h, wd, n)
-        split = (_split() and cc == 64 and self.embed_dim == 128 and self.cost_encoder[0].in_features <= 48
-                 and self.cost_encoder[0].in_features % 4 == 0 and all(_block_ok(l.nmp.proj, l.nmp.mlp) for l in self.layers))
+        split = self._split_ok(cc)
         ctx = context.reshape(b * h * wd, cc)
+        seeds_f = None
+        if feats is not None:
+            seeds_f, cost, enc = feats
+            if enc.shape[1] != (32 if split else 31):
+                feats = None
         if split:
-            cost, enc = K.seed_features(cost_volume, label_seed, 3.14 / 64, 32)
+            if feats is None:
+                cost, enc = K.seed_features(cost_volume, label_seed, 3.14 / 64, 32)
             if not hasattr(self, "_embed"):
                 self._embed = _ChainLauncher(1, (self.cost_encoder[0], self.cost_encoder[2], self.proj), (48, 128, 160), 128)
             x = self._embed(cost, cost.shape[1], extra=enc)
-            return self._forward_blocks(x, ctx, dims).unsqueeze(0), label_seed.float()
-        cost, enc = K.seed_features(cost_volume, label_seed, 3.14 / 64)
+            return self._forward_blocks(x, ctx, dims).unsqueeze(0), (label_seed.float() if seeds_f is None else seeds_f)
+        if feats is None:
+            cost, enc = K.seed_features(cost_volume, label_seed, 3.14 / 64)
+        seeds_f = label_seed.float() if seeds_f is None else seeds_f
         x = self.proj(torch.cat((self.cost_encoder(cost), enc), -1))
         if _split() and cc == 64 and self.embed_dim == 128 and all(_block_ok(l.nmp.proj, l.nmp.mlp) for l in self.layers):
-            return self._forward_blocks(x.contiguous(), ctx, dims).unsqueeze(0), label_seed.float()
+            return self._forward_blocks(x.contiguous(), ctx, dims).unsqueeze(0), seeds_f
         y = None
         for layer in self.layers:
             x, y = layer.forward_pair(x, y, ctx, dims)
@@ -457,7 +475,7 @@ class Propagation(nn.Module):
             x = _add_ln(x, y, self.norm)[1]
         elif y is not None:
             x = x + y
-        return x.unsqueeze(0), label_seed.float()
+        return x.unsqueeze(0), seeds_f
 
 
 def _qkv_of(nmp):

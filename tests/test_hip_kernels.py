@@ -168,6 +168,59 @@ def test_nms_topk_on_reference_prob_gives_reference_seeds():
         assert torch.equal(got, t(g["seeds"]).long().reshape(-1, 4)), name
 
 
+def _select_seeds(prob, k=4, eps=1e-3, do_nms=True):
+    """seeds of the one-wave-per-row register kernel (seed_select) on a dummy one-group volume"""
+    vol = torch.zeros(prob.shape[0], 1, prob.shape[1], device=DEV)
+    return K().seed_select(prob.to(DEV), vol, k, eps, 3.14 / 64, 31, do_nms=do_nms)[0].cpu()
+
+
+@pytest.mark.parametrize("d", [24, 32, 40])
+def test_seed_select_crafted_cases_bit_exact(d):
+    """The register / scalar-unit form of NMS + top-k (csrc/seed.hip seed_select_kernel) on every crafted row of the reference
+    fixture: plateaus, all-tied rows, values at eps, NaN, signed zeros -- same indices in the same order as ATen's CPU top-k."""
+    g = golden("nms_cases")
+    got = _select_seeds(t(g[f"prob_{d}"])).numpy()
+    want = g[f"seeds_{d}"].astype(np.int64)
+    bad = np.nonzero((got != want).any(1))[0]
+    assert bad.size == 0, f"D={d}: {bad.size} rows differ, first row {bad[:5]}: got {got[bad[:3]]} want {want[bad[:3]]}"
+
+
+def test_seed_select_ties_denormals_and_specials_match_aten_cpu():
+    gen = torch.Generator().manual_seed(12)
+    for n in (5, 24, 40, 48, 64):
+        x = torch.randint(0, 4, (5000, n), generator=gen).float()
+        x[::3] = torch.rand(x[::3].shape, generator=gen)
+        x[1::7] *= 1e-41                                                  # denormals (ATen on the CPU compares them as they are)
+        x[2::11, ::3] = -0.0
+        x[3::13, 1::4] = float("nan")
+        x[4::17, ::5] = float("inf")
+        x[5::19] = -x[5::19]
+        want = torch.topk(x, 4, dim=-1).indices
+        got = _select_seeds(x, eps=0.0, do_nms=False)
+        assert torch.equal(got, want), f"n={n}: {(got != want).any(1).sum()} rows differ"
+        assert torch.equal(got, K().nms_topk(x.to(DEV), 4, 0.0, do_nms=False).cpu()), n
+    p = torch.softmax(rnd(3000, 40, seed=5, scale=6.0), -1)
+    assert torch.equal(_select_seeds(p), O.nms_topk(p, 4, 1e-3))
+    for k in (1, 2, 8):
+        assert torch.equal(_select_seeds(p, k=k), O.nms_topk(p, k, 1e-3)), k
+
+
+def test_seed_select_features_equal_the_two_kernel_path():
+    """seeds, float seeds, cost taps and Fourier rows of the fused launch against nms_topk + seed_features (bit for bit), at the
+    KITTI seed-stage size and on the reference's golden probabilities."""
+    for p_, g_, d_, ld in ((7332, 4, 40, 32), (3001, 4, 32, 31), (517, 2, 24, 31)):
+        vol = rnd(p_, g_, d_, seed=p_)
+        prob = torch.softmax(rnd(p_, d_, seed=p_ + 1, scale=4.0), -1)
+        seeds, seeds_f, cost, enc = (x.cpu() for x in K().seed_select(prob.to(DEV), vol.to(DEV), 4, 1e-3, 3.14 / 64, ld))
+        want = K().nms_topk(prob.to(DEV), 4, 1e-3)
+        wc, we = K().seed_features(vol.to(DEV), want, 3.14 / 64, ld)
+        assert torch.equal(seeds, want.cpu()) and torch.equal(seeds_f, want.cpu().float())
+        assert torch.equal(cost, wc.cpu()) and torch.equal(enc, we.cpu())
+    for name in ("e2e_a", "e2e_b", "e2e_c"):
+        g = golden(name)
+        assert torch.equal(_select_seeds(t(g["prob"])), t(g["seeds"]).long().reshape(-1, 4)), name
+
+
 def test_seed_features_and_fourier():
     p, g, d, n = 500, 4, 40, 4
     cv = rnd(p, g, d, seed=3)

@@ -366,6 +366,15 @@ if "linear_timing" in which:
             prev = idx
         print("  %-26s" % "total", " ".join("%7.0f" % v for v in (st[:, :, 11] - st[:, :, 0]).mean(0)))
 
+if "seed" in which:
+    for pp in (7332, 8160, 58656, 261120):
+        prob = torch.softmax(mk("sp%d" % pp, pp, 40) * 4.0, -1)
+        vol = mk("sv%d" % pp, pp, 4, 40)
+        timeit("nms_topk (LDS rows) P=%d" % pp, lambda: K.nms_topk(prob, 4, 1e-3))
+        sd = K.nms_topk(prob, 4, 1e-3)
+        timeit("  + seed_features + seeds.float() P=%d" % pp, lambda: (K.seed_features(vol, sd, 3.14 / 64, 32), sd.float()))
+        timeit("seed_select (one wave per row, registers; features fused) P=%d" % pp, lambda: K.seed_select(prob, vol, 4, 1e-3, 3.14 / 64, 32))
+        assert torch.equal(K.seed_select(prob, vol, 4, 1e-3, 3.14 / 64, 32)[0], sd)
 if "conv" in which:
     import torch.nn.functional as F
     for (bb, ci, co, hh, ww) in ((2, 64, 64, 192, 624), (2, 96, 96, 96, 312), (2, 96, 128, 96, 312), (2, 128, 128, 96, 312),
