@@ -206,8 +206,12 @@ int nmrf_msda_backward_f64(const double *value, const int64_t *shapes, const int
  * total_stages must equal the sum.  Biases / LayerNorm parameters are plain fp32 vectors.  inv_scales: HOST array of 4 floats,
  * 1 / scale the proj, fc1, fc2 and q weights were packed with (unused entries ignored).
  * ln_out_map (optional, device int32 [T]): row of ln_out that token t is written to, negative = dropped (the crop of the padded
- * token grid, NMP.py:786-788, 888-890). */
-int nmrf_nmp_block16_f32(const float *x, const float *msg, const void *stream_w, int total_stages, const float *bp,
+ * token grid, NMP.py:786-788, 888-890).
+ * attn_qkv (instead of msg; proj-only blocks, attn_n == 4, T % 4 == 0): [T, 384] q | k | v of the self-edge attention among the
+ * attn_n sibling labels of a pixel (4 heads of 32, BasicAttention, NMP.py:90-108); the message softmax(q k^T / sqrt(32)) v is
+ * computed on the way in (same arithmetic as nmrf_self_attn_f32). */
+int nmrf_nmp_block16_f32(const float *x, const float *msg, const float *attn_qkv, int attn_n, const void *stream_w,
+                         int total_stages, const float *bp,
                          const float *ln2_g, const float *ln2_b, float eps2, const float *b1, const float *b2,
                          const float *lnq_g, const float *lnq_b, float epsq, const float *extra, int extra_ld,
                          int extra_div, const float *bq, int has_mlp, int KQ, int NQ, int64_t T, const float *inv_scales,

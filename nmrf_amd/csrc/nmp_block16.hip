@@ -58,8 +58,16 @@ __device__ __forceinline__ void b16_static_for(F &&f) {
     b16_static_for_impl(static_cast<F &&>(f), std::make_integer_sequence<int, N>{});
 }
 
+// value of quad lane N (lanes 4p .. 4p+3 = the sibling tokens of one pixel) in every lane of the quad
+template <int N>
+__device__ __forceinline__ float b16_quad(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), N * 0x55, 0xf, 0xf, false));
+}
+
 struct NmpBlock16Args {
     const float *x, *msg;
+    const float *attn_qkv;       // MLP == false: [T, 384] q | k | v of the self-edge attention (4 sibling tokens per pixel, 4 heads of 32);
+                                 // the message is then computed here instead of being read from `msg`
     const b16_u32x4 *stream;
     int total_stages;
     const float *bp, *ln2_g, *ln2_b, *b1, *b2, *lnq_g, *lnq_b, *extra;
@@ -253,13 +261,68 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
         }
         f32x4 acc[8];
         // ---- stage P -----------------------------------------------------------------------------------------------------------
-        if (a.msg) {
+        bool have_msg = a.msg != nullptr;
+        if constexpr (!MLP) have_msg = have_msg || a.attn_qkv != nullptr;
+        if (have_msg) {
             h16x8 bmh[4], bml[4];
+            bool from_attn = false;
+            if constexpr (!MLP) from_attn = a.attn_qkv != nullptr;
+            if (from_attn) {
+                // Self-edge attention of BasicAttention (NMP.py:90-108) on the way in: the 16 tokens of a wave are 4 pixels x 4 sibling
+                // labels, the siblings of a token sit in its lane quad, head c of a token is k chunk c of the message operand, of
+                // which this lane holds 8 channels (the other 24 in lanes j + 16, j + 32, j + 48).  softmax_j(q_i . k_j / sqrt(32)) v_j
+                // with the arithmetic of self_attn_kernel (token.hip); replaces that launch and the [T,128] round trip of its output.
+                const float *qp = a.attn_qkv + tc * 384;
+                const float sc = 0.17677669529663687f;                       // 32^-0.5
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float4 v0 = ldg4(a.msg + tc * 128 + 32 * c + 4 * g), v1 = ldg4(a.msg + tc * 128 + 32 * c + 16 + 4 * g);
-                const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                split8u_g(v, bmh[c], bml[c], guard);
+                for (int c = 0; c < 4; ++c) {
+                    float q[8], k[8], vv[8];
+                    {
+                        const float4 q0 = ldg4(qp + 32 * c + 4 * g), q1 = ldg4(qp + 32 * c + 16 + 4 * g);
+                        const float4 k0 = ldg4(qp + 128 + 32 * c + 4 * g), k1 = ldg4(qp + 128 + 32 * c + 16 + 4 * g);
+                        const float4 v0 = ldg4(qp + 256 + 32 * c + 4 * g), v1 = ldg4(qp + 256 + 32 * c + 16 + 4 * g);
+                        q[0] = q0.x; q[1] = q0.y; q[2] = q0.z; q[3] = q0.w; q[4] = q1.x; q[5] = q1.y; q[6] = q1.z; q[7] = q1.w;
+                        k[0] = k0.x; k[1] = k0.y; k[2] = k0.z; k[3] = k0.w; k[4] = k1.x; k[5] = k1.y; k[6] = k1.z; k[7] = k1.w;
+                        vv[0] = v0.x; vv[1] = v0.y; vv[2] = v0.z; vv[3] = v0.w; vv[4] = v1.x; vv[5] = v1.y; vv[6] = v1.z; vv[7] = v1.w;
+                    }
+                    float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        s[0] = fmaf(q[e], b16_quad<0>(k[e]), s[0]);
+                        s[1] = fmaf(q[e], b16_quad<1>(k[e]), s[1]);
+                        s[2] = fmaf(q[e], b16_quad<2>(k[e]), s[2]);
+                        s[3] = fmaf(q[e], b16_quad<3>(k[e]), s[3]);
+                    }
+                    float m = -INFINITY;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        s[n] += __shfl_xor(s[n], 16);
+                        s[n] += __shfl_xor(s[n], 32);
+                        s[n] *= sc;
+                        m = fmaxf(m, s[n]);
+                    }
+                    float z = 0.f;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) { s[n] = expf(s[n] - m); z += s[n]; }
+                    const float rz = 1.0f / z;
+                    float o[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float acc_o = (s[0] * rz) * b16_quad<0>(vv[e]);
+                        acc_o = fmaf(s[1] * rz, b16_quad<1>(vv[e]), acc_o);
+                        acc_o = fmaf(s[2] * rz, b16_quad<2>(vv[e]), acc_o);
+                        acc_o = fmaf(s[3] * rz, b16_quad<3>(vv[e]), acc_o);
+                        o[e] = acc_o;
+                    }
+                    split8u_g(o, bmh[c], bml[c], guard);
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float4 v0 = ldg4(a.msg + tc * 128 + 32 * c + 4 * g), v1 = ldg4(a.msg + tc * 128 + 32 * c + 16 + 4 * g);
+                    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    split8u_g(v, bmh[c], bml[c], guard);
+                }
             }
             B16_STAMP(2);
             b16_static_for<4>([&](auto kk) {                                  // strips 2k, 2k+1 = one stage
@@ -506,7 +569,8 @@ static int launch_nmp_block16(const NmpBlock16Args &a, hipStream_t st) {
     return nmrf_launch_status();
 }
 
-extern "C" int nmrf_nmp_block16_f32(const float *x, const float *msg, const void *stream_w, int total_stages, const float *bp,
+extern "C" int nmrf_nmp_block16_f32(const float *x, const float *msg, const float *attn_qkv, int attn_n, const void *stream_w,
+                                    int total_stages, const float *bp,
                                     const float *ln2_g, const float *ln2_b, float eps2, const float *b1, const float *b2,
                                     const float *lnq_g, const float *lnq_b, float epsq, const float *extra, int extra_ld,
                                     int extra_div, const float *bq, int has_mlp, int KQ, int NQ, int64_t T, const float *inv_scales,
@@ -514,15 +578,16 @@ extern "C" int nmrf_nmp_block16_f32(const float *x, const float *msg, const void
     if (!x || !stream_w || !inv_scales) return NMRF_ENULL;
     if (T < 1 || ceil_div64(T, B16_TOK) > 0x7fffffff) return NMRF_EINVAL;
     if (has_mlp && (!ln2_g || !ln2_b || !b1 || !b2)) return NMRF_ENULL;
+    if (attn_qkv && (msg || has_mlp || attn_n != 4 || (T & 3))) return NMRF_EINVAL;     // self-edge attention: 4 siblings, proj-only blocks
     if (KQ != 0 && KQ != 128 && KQ != 160 && KQ != 192) return NMRF_EINVAL;
     if (KQ && (!lnq_g || !lnq_b)) return NMRF_ENULL;
     if (KQ > 128 && (!extra || extra_ld < KQ - 128 || (extra_ld & 3) || extra_div < 1)) return NMRF_EINVAL;
     if (q_out && (KQ == 0 || NQ < 128 || (NQ & 127) || NQ > 512)) return NMRF_EINVAL;
     if (ln_out && KQ == 0) return NMRF_EINVAL;
     if (!q_out && !ln_out && !x_out) return NMRF_ENULL;
-    const int want = (msg ? 4 : 0) + (has_mlp ? 32 : 0) + (q_out ? (NQ / 128) * (KQ / 32) : 0);
+    const int want = ((msg || attn_qkv) ? 4 : 0) + (has_mlp ? 32 : 0) + (q_out ? (NQ / 128) * (KQ / 32) : 0);
     if (total_stages != want || total_stages < 1) return NMRF_EINVAL;
-    NmpBlock16Args a{x, msg, reinterpret_cast<const b16_u32x4 *>(stream_w), total_stages, bp, ln2_g, ln2_b, b1, b2, lnq_g, lnq_b, extra,
+    NmpBlock16Args a{x, msg, attn_qkv, reinterpret_cast<const b16_u32x4 *>(stream_w), total_stages, bp, ln2_g, ln2_b, b1, b2, lnq_g, lnq_b, extra,
                      extra_ld, extra_div, bq, x_out, q_out, ln_out, ln_out_map, T, (int)ceil_div64(T, B16_TOK), eps2, epsq, NQ,
                      inv_scales[0], inv_scales[1], inv_scales[2], inv_scales[3], nullptr, range_flag};
     hipStream_t st = (hipStream_t)stream;

@@ -501,11 +501,12 @@ def mlp_chain(kind, x, k1, stream, stages, inv_scales, biases, n_out, extra=None
 
 @_on_device
 def nmp_block(x, stream, stages, inv_scales, msg=None, bp=None, mlp=None, q=None, want_x=True, ln_out=None, ln_out_map=None,
-              tokens_per_wave=16):
+              tokens_per_wave=16, attn_qkv=None):
     """One fused message-passing block (nmrf_nmp_block16_f32; tokens_per_wave=32: the debug library's 32-token form).
     mlp = (ln2_gamma, ln2_beta, eps, b1, b2) or None;  q = dict(g, b, eps, extra=None, extra_div=1, bias=None, kq=0|128|160|192,
-    nq=0 -> no q_out, ln_out=False) or None.  Returns (x_out | None, q_out | None, ln_out | None)."""
-    _chk(x, msg, bp)
+    nq=0 -> no q_out, ln_out=False) or None.  attn_qkv [T,384] (instead of msg, proj-only blocks): q | k | v of the self-edge
+    attention among the 4 sibling labels of a pixel, evaluated on the way in.  Returns (x_out | None, q_out | None, ln_out | None)."""
+    _chk(x, msg, bp, attn_qkv)
     _chk(stream, dtype=torch.int32)
     t = x.shape[0]
     ln2_g = ln2_b = b1 = b2 = None
@@ -529,24 +530,28 @@ def nmp_block(x, stream, stages, inv_scales, msg=None, bp=None, mlp=None, q=None
     _chk(ln_out)
     _chk(ln_out_map, dtype=torch.int32)
     if kernel_hook is not None:
-        flops = 2.0 * t * ((128 * 128 if msg is not None else 0) + (2 * 128 * 512 if mlp is not None else 0) + kq * nq)
-        nbytes = 4.0 * t * (128 * (1 + (msg is not None) + bool(want_x) + bool(want_ln)) + nq) + (4.0 * extra.numel() if extra is not None else 0)
-        name = "nmp_block_p%d_m%d_q%dx%d" % (msg is not None, mlp is not None, kq, nq)
+        has_msg = msg is not None or attn_qkv is not None
+        flops = 2.0 * t * ((128 * 128 if has_msg else 0) + (2 * 128 * 512 if mlp is not None else 0) + kq * nq)
+        nbytes = 4.0 * t * (128 * (1 + (msg is not None) + 3 * (attn_qkv is not None) + bool(want_x) + bool(want_ln)) + nq) + (
+            4.0 * extra.numel() if extra is not None else 0)
+        name = "nmp_block_p%d_m%d_q%dx%d" % (1 if msg is not None else (2 if attn_qkv is not None else 0), mlp is not None, kq, nq)
         _hb(name, row="A7/A10/A13 (N3)", bound="mfma", flops=flops, bytes=nbytes, split=True,
             label="%s<%s,%d> (%s%s%s fused, split-fp16 MFMA, %d tokens per wave)" % (
                 "nmp_block_kernel" if tokens_per_wave == 32 else "nmp_block16_kernel",
                 "true" if mlp is not None else "false", kq // 16 if tokens_per_wave == 32 else (kq + 31) // 32,
-                "proj+residual " if msg is not None else "",
+                "proj+residual " if msg is not None else ("self-edge attention+proj+residual " if attn_qkv is not None else ""),
                 "LN+fc1+GELU+fc2 " if mlp is not None else "", ("LN+%d->%d" % (kq, nq)) if nq else ("final LN" if want_ln else ""),
                 tokens_per_wave),
             pmc=["nmp_block_kernel<%s, %d, 1, 4, false, 0>" % ("true" if mlp is not None else "false", kq // 16) if tokens_per_wave == 32
                  else "nmp_block16_kernel<%s, %d, 0>" % ("true" if mlp is not None else "false", (kq + 31) // 32)])
-    fn = _lib.load_debug().nmrf_nmp_block_f32 if tokens_per_wave == 32 else _lib.load().nmrf_nmp_block16_f32
-    _lib.check(fn(_p(x), _p(msg), _p(stream), stages, _p(bp), _p(ln2_g), _p(ln2_b), float(eps2), _p(b1),
-                                              _p(b2), _p(lq_g), _p(lq_b), float(epsq), _p(extra), ld, div, _p(bq),
-                                              int(mlp is not None), kq, nq, t, inv_scales, _p(x_out), _p(q_out), _p(ln_out),
-                                              _p(ln_out_map), _rf(x), _stream()),
-               "nmp_block")
+    tail = (_p(stream), stages, _p(bp), _p(ln2_g), _p(ln2_b), float(eps2), _p(b1), _p(b2), _p(lq_g), _p(lq_b), float(epsq), _p(extra), ld,
+            div, _p(bq), int(mlp is not None), kq, nq, t, inv_scales, _p(x_out), _p(q_out), _p(ln_out), _p(ln_out_map), _rf(x), _stream())
+    if tokens_per_wave == 32:
+        if attn_qkv is not None:
+            raise ValueError("the 32-token debug form takes the message as a tensor")
+        _lib.check(_lib.load_debug().nmrf_nmp_block_f32(_p(x), _p(msg), *tail), "nmp_block")
+    else:
+        _lib.check(_lib.load().nmrf_nmp_block16_f32(_p(x), _p(msg), _p(attn_qkv), 4 if attn_qkv is not None else 0, *tail), "nmp_block")
     if kernel_hook is not None:
         _he(name)
     return x_out, q_out, ln_out

@@ -161,7 +161,7 @@ class _BlockLauncher:
                                                None if self.mlp is None else self.mlp[1].fc2.weight.contiguous(), wq, self.kq)
         return stream, stages, inv, bq, (0 if wq is None else wq.shape[0])
 
-    def __call__(self, x, msg=None, extra=None, extra_div=1, want_x=True, ln_out=None, ln_out_map=None):
+    def __call__(self, x, msg=None, extra=None, extra_div=1, want_x=True, ln_out=None, ln_out_map=None, attn_qkv=None):
         stream, stages, inv, bq, nq = self.cache.get(self._params(), self._build)
         mlp = None
         if self.mlp is not None:
@@ -172,7 +172,7 @@ class _BlockLauncher:
             q = dict(g=self.nxt_norm.weight, b=self.nxt_norm.bias, eps=self.nxt_norm.eps, extra=extra if self.kq > 128 else None,
                      extra_div=extra_div, bias=bq, kq=self.kq, nq=nq, ln_out=self.ln_out)
         return K.nmp_block(x, stream, stages, inv, msg, None if self.proj is None else self.proj.bias, mlp, q, want_x=want_x,
-                           ln_out=ln_out, ln_out_map=ln_out_map)
+                           ln_out=ln_out, ln_out_map=ln_out_map, attn_qkv=attn_qkv)
 
 
 class _ChainLauncher:
@@ -587,7 +587,10 @@ class Inference(nn.Module):
         _, qkv, _ = self._launch[0](x, None, enc, 1, want_x=False)
         ln = None
         for i, (kind, m) in enumerate(self._sites):
-            if kind == "self":
+            attn_qkv = None
+            if kind == "self" and n == 4 and m.num_heads == 4 and qkv.shape[1] == 384 and i + 1 < len(self._sites):
+                msg, attn_qkv = None, qkv               # the 4 x 4 self-edge attention is evaluated inside the block kernel
+            elif kind == "self":
                 msg = K.self_attn(qkv, n, m.num_heads)
             else:
                 msg = m.attn(qkv, pdims, n > 1, checked=True)           # sibling mask for N > 1 (inference), none for refinement
@@ -596,7 +599,7 @@ class Inference(nn.Module):
                 ln = torch.empty(t_dense, self.dim, device=x.device)
                 self._launch[i + 1](x, msg, enc, 1, want_x=False, ln_out=ln, ln_out_map=to_dense)
                 return ln
-            x, qkv, ln = self._launch[i + 1](x, msg, enc, 1, want_x=not last or self.norm is None)
+            x, qkv, ln = self._launch[i + 1](x, msg, enc, 1, want_x=not last or self.norm is None, attn_qkv=attn_qkv)
         if to_dense is not None:
             keep = (to_dense >= 0).nonzero().squeeze(1)
             return (ln if self.norm is not None else x).index_select(0, keep)

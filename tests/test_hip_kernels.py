@@ -504,6 +504,36 @@ def test_nmp_block_fused(t_, proj, mlp, kq, nq, div, ln_out, tokens):
         report("block ln_out", lo.cpu(), rl, 1e-5, 1e-5)
 
 
+@pytest.mark.parametrize("t_", [64, 516, 29952, 40004])
+def test_nmp_block_with_self_edge_attention_on_the_way_in(t_):
+    """The self-edge block (BasicAttention, NMP.py:90-108) with the 4 x 4 sibling attention evaluated inside the block kernel
+    (attn_qkv) against fp64 softmax attention + projection + residual + LayerNorm + the window q|k|v, and against the two-launch
+    path (self_attn_kernel -> msg) it replaces."""
+    kk = K()
+    d = lambda v: None if v is None else v.to(DEV)
+    x = rnd(t_, 128, seed=1, scale=2.0)
+    qkv = rnd(t_, 384, seed=2, scale=1.5)
+    wp, bp = rnd(128, 128, seed=3, scale=0.1), rnd(128, seed=4, scale=0.2)
+    gq, bqn = 1.0 + 0.1 * rnd(128, seed=11), 0.1 * rnd(128, seed=12)
+    extra = rnd(t_, 32, seed=13)
+    extra[:, 31] = 0.0
+    wq, bq = rnd(384, 159, seed=14, scale=0.1), rnd(384, seed=15)
+    stream, stages, inv = kk.block_stream16(d(wp), None, None, d(wq), 160)
+    q = dict(g=d(gq), b=d(bqn), eps=1e-5, extra=d(extra), extra_div=1, bias=d(bq), kq=160, nq=384, ln_out=False)
+    xo, qo, _ = kk.nmp_block(d(x), stream, stages, inv, None, d(bp), None, q, want_x=True, attn_qkv=d(qkv))
+    # fp64 reference: per pixel (4 consecutive tokens), 4 heads of 32
+    qq, kk_, vv = (qkv[:, i * 128:(i + 1) * 128].double().view(t_ // 4, 4, 4, 32).transpose(1, 2) for i in range(3))     # [pix, head, tok, 32]
+    att = torch.softmax(qq @ kk_.transpose(-1, -2) / 32 ** 0.5, -1) @ vv
+    msg = att.transpose(1, 2).reshape(t_, 128)
+    rx, rq, _ = _block_ref(x, msg, wp, bp, None, dict(g=gq, b=bqn, w=wq, bias=bq, extra=extra, div=1))
+    report("attn block x_out", xo.cpu(), rx, 2e-5, 1e-5)
+    report("attn block q_out", qo.cpu(), rq, 2e-5, 1e-5)
+    m2 = kk.self_attn(d(qkv), 4, 4)
+    xo2, qo2, _ = kk.nmp_block(d(x), stream, stages, inv, m2, d(bp), None, q, want_x=True)
+    report("attn block vs two launches", xo.cpu(), xo2.cpu().double(), 2e-6, 1e-6)
+    report("attn block vs two launches (q)", qo.cpu(), qo2.cpu().double(), 5e-6, 1e-6)
+
+
 @pytest.mark.parametrize("kind,t_,n_out", [(0, 300, 128), (0, 29328, 128), (1, 1000, 128), (2, 517, 64), (2, 300, 16), (2, 4097, 1),
                                            (3, 777, 64), (3, 40001, 64)])
 def test_mlp_chain_fused(kind, t_, n_out):
