@@ -68,7 +68,7 @@ def test_swin_model_on_gpu():
                                    [ref8[1:].contiguous(), ref4[1:].contiguous()], out_hw)
         w, cfg = oracle_weights(256, tuple(SWIN_OPTS)), oracle_cfg(256, divis_by=32)
         base = _oracle_chain_side(O.hot_path(w, cfg, ref8.cpu(), ref4.cpu(), None, out_hw, stages={}))
-        base.update(disp_curr=t(g["disp_curr"]), disp=t(g["disp"]))          # the reference's own outputs
+        # (one consistent chain: scores, decisions and disparities of the same oracle run on this host -- tests/test_model_gpu.py)
         l4, r4 = ref4[:1].cpu(), ref4[1:].cpu()
         check_chain("swin hot path from reference features", cand, base, lambda dq: O.refine_from(w, cfg, dq, l4, r4, out_hw)[0])
     assert torch.equal(hp["initial_proposal"].cpu().long(), t(g["seeds"]).long())
