@@ -249,6 +249,12 @@ int nmrf_pack_split_weight_f32(const float *w, int N, int K, int Kp, float scale
 
 /* N2: statistics pass of InstanceNorm2d alone: ws [planes][ceil(HW/8192)][2] = per-chunk (mean, M2) of x [planes, HW]. */
 int nmrf_instance_stats_f32(const float *x, int64_t planes, int64_t HW, float *ws, void *stream);
+/* Apply pass alone on given statistics: y = [relu_out]( [relu_mid] IN(x; ws) + f(residual) ), f = identity or, with res_ws (the
+ * statistics workspace of `residual`), IN(residual; res_ws) [+ ReLU if res_relu]: the residual operand may be a RAW convolution
+ * output whose own InstanceNorm (+ ReLU) is still pending -- the stem output entering layer1.0, the 1x1 shortcut of a downsampling
+ * block (nmrf/models/backbone.py:40-46, 70-72, 85) -- so that its own apply pass never runs.  x, residual, y: same 16-byte phase. */
+int nmrf_instance_apply_f32(const float *x, const float *ws, const float *residual, const float *res_ws, int res_relu,
+                            int64_t planes, int64_t HW, float eps, int relu_mid, int relu_out, float *y, void *stream);
 
 /* N2: 1x1 convolution of a conv head with the InstanceNorm + ReLU in front of it folded into its operand load
  * (nmrf/models/NMRF.py:56-65 `concatconv` / `gw`, DPN.py:45-49 `proj`: Conv3x3 - IN - ReLU - Conv1x1):

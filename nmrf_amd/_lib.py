@@ -45,6 +45,7 @@ PROTOTYPES = {
     "nmrf_pack_split_weight16_f32": [_P, _I, _I, _I, _F, _P, _P],
     "nmrf_selftest_mfma16x16_f16split": [_P, _P, _I, _P, _P],
     "nmrf_instance_stats_f32": [_P, _L, _L, _P, _P],
+    "nmrf_instance_apply_f32": [_P, _P, _P, _P, _I, _L, _L, _F, _I, _I, _P, _P],
     "nmrf_conv_split_f32": [_P, _I, _I, _I, _I, _P, _I, _F, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P],
     "nmrf_prep_images_s2d_f32": [_P, _P, _I, _I, _I, _I, _I, _P, _P],
     "nmrf_prep_images_s2d_u8": [_P, _P, _I, _I, _I, _I, _I, _P, _P],

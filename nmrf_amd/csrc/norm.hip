@@ -79,14 +79,9 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const float *__restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void in_apply_kernel(const float *__restrict__ x, const float *__restrict__ res,
-        int64_t HW, int chunks, float eps, int relu_mid, int relu_out, const float *__restrict__ ws,
-        float *__restrict__ y) {
-    const int64_t plane = blockIdx.y;
-    const int chunk = blockIdx.x;
-    // merge the chunk statistics of this plane (every thread redundantly: chunks <= a few dozen, scalar loads)
-    const float *w = ws + plane * chunks * 2;
-    float mean = 0.f;
+// merge the chunk statistics of one plane (every thread redundantly: chunks <= a few dozen, scalar loads)
+__device__ __forceinline__ void in_merge_chunks(const float *w, int chunks, int64_t HW, float eps, float &mean, float &rstd) {
+    mean = 0.f;
     for (int c = 0; c < chunks; ++c) {
         const int64_t nb = (int64_t)c * IN_CHUNK;
         const float nc = (float)((nb + IN_CHUNK < HW ? nb + IN_CHUNK : HW) - nb);
@@ -100,7 +95,22 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const float *__restrict__
         const float d = w[2 * c] - mean;
         m2 += w[2 * c + 1] + nc * d * d;
     }
-    const float rstd = 1.0f / sqrtf(m2 / (float)HW + eps);
+    rstd = 1.0f / sqrtf(m2 / (float)HW + eps);
+}
+
+// res_ws != NULL: the residual operand is itself a RAW convolution output whose InstanceNorm (+ ReLU if res_relu) has not been
+// applied yet -- the stem output entering layer1.0, the 1x1 shortcut of layer2.0 / layer3.0 (nmrf/models/backbone.py:40-46, 85):
+// it is normalised on the way in, so that its own apply pass (a read and a write of the whole map) never runs.
+__global__ __launch_bounds__(256) void in_apply_kernel(const float *__restrict__ x, const float *__restrict__ res,
+        int64_t HW, int chunks, float eps, int relu_mid, int relu_out, const float *__restrict__ ws,
+        float *__restrict__ y, const float *__restrict__ res_ws = nullptr, int res_relu = 0) {
+    const int64_t plane = blockIdx.y;
+    const int chunk = blockIdx.x;
+    float mean, rstd;
+    in_merge_chunks(ws + plane * chunks * 2, chunks, HW, eps, mean, rstd);
+    float rmean = 0.f, rrstd = 1.f;
+    const bool rnorm = res && res_ws;
+    if (rnorm) in_merge_chunks(res_ws + plane * chunks * 2, chunks, HW, eps, rmean, rrstd);
     const ChunkView cv = chunk_view(x + plane * HW, HW, chunk);
     const int64_t off = cv.p - x;                               // same element offset (and alignment) in res / y
     const float *r = res ? res + off : nullptr;
@@ -108,6 +118,10 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const float *__restrict__
     auto f = [&](float xv, float rv) {
         float t = (xv - mean) * rstd;
         if (relu_mid) t = fmaxf(t, 0.f);
+        if (rnorm) {
+            rv = (rv - rmean) * rrstd;
+            if (res_relu) rv = fmaxf(rv, 0.f);
+        }
         t += rv;
         if (relu_out) t = fmaxf(t, 0.f);
         return t;
@@ -131,6 +145,19 @@ __global__ __launch_bounds__(256) void in_apply_kernel(const float *__restrict__
     }
 }
 
+// apply pass alone, statistics given: y = [relu_out]( [relu_mid] IN(x; ws) + f(residual) ),  f = identity, or IN(.; res_ws) [+ ReLU]
+extern "C" int nmrf_instance_apply_f32(const float *x, const float *ws, const float *residual, const float *res_ws, int res_relu,
+                                       int64_t planes, int64_t HW, float eps, int relu_mid, int relu_out, float *y, void *stream) {
+    if (!x || !ws || !y) return NMRF_ENULL;
+    if (res_ws && !residual) return NMRF_ENULL;
+    if (planes < 1 || planes > 65535 || HW < 1) return NMRF_EINVAL;
+    if ((((uintptr_t)x ^ (uintptr_t)y) & 15) || (residual && (((uintptr_t)x ^ (uintptr_t)residual) & 15))) return NMRF_EINVAL;
+    const int chunks = (int)ceil_div64(HW, IN_CHUNK);
+    hipLaunchKernelGGL(in_apply_kernel, dim3(chunks, (unsigned)planes), dim3(256), 0, (hipStream_t)stream, x, residual, HW, chunks, eps,
+                       relu_mid, relu_out, ws, y, res_ws, res_relu);
+    return nmrf_launch_status();
+}
+
 // statistics pass alone: ws [planes][ceil(HW / 8192)][2] = per-chunk (mean, M2), merged by the consumer (in_apply_kernel or the
 // fused 1x1 convolution of conv1x1.hip)
 extern "C" int nmrf_instance_stats_f32(const float *x, int64_t planes, int64_t HW, float *ws, void *stream) {
@@ -151,7 +178,7 @@ extern "C" int nmrf_instance_norm_f32(const float *x, const float *residual, int
     dim3 grid(chunks, (unsigned)planes);
     hipLaunchKernelGGL(in_stats_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, HW, chunks, ws);
     hipLaunchKernelGGL(in_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, residual, HW, chunks, eps, relu_mid,
-                       relu_out, ws, y);
+                       relu_out, ws, y, (const float *)nullptr, 0);
     return nmrf_launch_status();
 }
 

@@ -766,6 +766,18 @@ def instance_norm(x, relu=False, residual=None, relu_out=False, eps=1e-5):
 
 
 @_on_device
+def instance_apply(x, stats, relu=False, residual=None, relu_out=False, residual_stats=None, residual_relu=False, eps=1e-5):
+    """The apply pass of instance_norm on given statistics (instance_stats(x)); with residual_stats the residual operand is a raw
+    convolution output that is normalised (+ ReLU) on the way in: y = [relu_out]([relu] IN(x) + [relu] IN(residual))."""
+    _chk(x, residual, stats, residual_stats)
+    b, c, h, w = x.shape
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().nmrf_instance_apply_f32(_p(x), _p(stats), _p(residual), _p(residual_stats), int(residual_relu), b * c, h * w,
+                                                   float(eps), int(relu), int(relu_out), _p(y), _stream()), "instance_apply")
+    return y
+
+
+@_on_device
 def instance_stats(x):
     """Statistics pass of InstanceNorm2d: x [B,C,H,W] -> per-chunk (mean, M2) workspace for conv1x1_in_relu."""
     _chk(x)

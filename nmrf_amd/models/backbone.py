@@ -47,22 +47,29 @@ class ResidualBlock(nn.Module):
             self.norm3 = _norm(norm, cout)
             self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride), self.norm3)
 
-    def forward(self, x):
+    def forward(self, x, x_stats=None):
+        """x_stats (HIP path only): x is a RAW convolution output whose InstanceNorm + ReLU is still pending (the stem's, statistics
+        x_stats): conv1 normalises it in its operand load and the residual add normalises it on the way in -- the apply pass of
+        the stem (a read and a write of the largest map of the encoder) never runs."""
         if self.fused and _hip_ok(self, x):
             # InstanceNorm + ReLU (+ residual add + ReLU) in two HIP passes instead of 4-6 torch kernels
             from .. import kernels as K
+            if x_stats is not None and (self.conv1.stride != (1, 1) or self.downsample is not None):
+                x, x_stats = K.instance_apply(x, x_stats, relu=True), None       # (not the shape of any shipped layer1.0)
             if self.conv1.stride == (1, 1):
-                c1 = K.conv3x3_auto(x, self.conv1.weight, self._wino1)
+                c1 = K.conv3x3_auto(x, self.conv1.weight, self._wino1, stats=x_stats)
             elif self.conv1.stride == (2, 2):
                 c1 = K.conv3x3_s2_auto(x, self.conv1.weight, self._wino1)
             else:
                 c1 = self.conv1(x)
             c1 = c1.contiguous()
             joined = None
+            res, res_stats, res_relu = x, x_stats, x_stats is not None
             if self.downsample is not None:
                 # The shortcut (1x1 conv + InstanceNorm) depends on x only: it runs on a side stream beside conv1's statistics pass and
                 # conv2 (a parallel branch of the captured hipGraph), joined before the residual add.  NMRF_OVERLAP=0: same stream.
                 # (the 1x1 conv's bias is a per-channel constant: InstanceNorm removes it, so the add is skipped)
+                # Only its statistics pass runs here: the normalisation itself is folded into the residual add below.
                 d = self.downsample[0]
                 main = torch.cuda.current_stream(x.device)
                 side = main
@@ -76,19 +83,23 @@ class ResidualBlock(nn.Module):
                         key = (d.weight.data_ptr(), d.weight._version)
                         if self._ds.get("key") != key:
                             self._ds = {"key": key, "packed": K.pack_conv1x1(d.weight)}
-                        xs = K.instance_norm(K.conv1x1(x.contiguous(), self._ds["packed"], d.weight.shape[1], d.stride[0]))
+                        xs = K.conv1x1(x.contiguous(), self._ds["packed"], d.weight.shape[1], d.stride[0])
                     else:
-                        xs = K.instance_norm(F.conv2d(x, d.weight, None, d.stride).contiguous())
+                        xs = F.conv2d(x, d.weight, None, d.stride).contiguous()
+                    xs_stats = K.instance_stats(xs)
                 if side is not main:
                     x.record_stream(side)
                     xs.record_stream(main)
+                    xs_stats.record_stream(main)
                     joined = side
-                x = xs
+                res, res_stats, res_relu = xs, xs_stats, False
             # norm1 + ReLU live only inside conv2's operand load: statistics pass, then the conv reads the raw conv1 output
-            c2 = K.conv3x3_auto(c1, self.conv2.weight, self._wino2, stats=K.instance_stats(c1))
+            c2 = K.conv3x3_auto(c1, self.conv2.weight, self._wino2, stats=K.instance_stats(c1)).contiguous()
+            c2_stats = K.instance_stats(c2)
             if joined is not None:
                 torch.cuda.current_stream(c2.device).wait_stream(joined)
-            return K.instance_norm(c2.contiguous(), relu=True, residual=x.contiguous(), relu_out=True)
+            return K.instance_apply(c2, c2_stats, relu=True, residual=res.contiguous(), relu_out=True, residual_stats=res_stats,
+                                    residual_relu=res_relu)
         y = self.relu(self.norm1(self.conv1(x)))
         y = self.relu(self.norm2(self.conv2(y)))
         if self.downsample is not None:
@@ -139,10 +150,12 @@ class Backbone(nn.Module):
             if normalized == "s2d":
                 if not hasattr(self, "_stem"):
                     self._stem = {}
-                x = K.instance_norm(K.stem_conv_s2d(x, self.conv1.weight, self._stem), relu=True)
+                x = K.stem_conv_s2d(x, self.conv1.weight, self._stem).contiguous()
             else:
-                x = K.instance_norm(self.conv1(x).contiguous(), relu=True)
-            x = self.layer3(self.layer2(self.layer1(x)))
+                x = self.conv1(x).contiguous()
+            # the stem's InstanceNorm + ReLU stays pending: layer1.0 applies it in its conv1 operand load and in its residual add
+            x = self.layer1[1](self.layer1[0](x, x_stats=K.instance_stats(x)))
+            x = self.layer3(self.layer2(x))
             if x.shape[-1] % 2 == 0 and x.shape[-2] % 2 == 0:
                 w2 = self.conv2.weight
                 if w2.shape[1] in (64, 128) and w2.shape[0] % 64 == 0:

@@ -626,6 +626,16 @@ def test_instance_norm_fused(b, c, h, w):
     report("in+relu", K().instance_norm(x.to(DEV), relu=True).cpu(), F.relu(ref), 5e-6)
     got = K().instance_norm(x.to(DEV), relu=True, residual=res.to(DEV), relu_out=True).cpu()
     report("in+relu+res+relu", got, F.relu(F.relu(ref) + res.double()), 5e-6)
+    # apply pass on given statistics, the residual a raw map whose own InstanceNorm (+ ReLU) is still pending
+    kk = K()
+    raw = rnd(b, c, h, w, seed=h + 2, scale=2.0) - 0.7
+    rref = F.instance_norm(raw.double(), eps=1e-5)
+    sx, sr = kk.instance_stats(x.to(DEV)), kk.instance_stats(raw.to(DEV))
+    got = kk.instance_apply(x.to(DEV), sx, relu=True, residual=raw.to(DEV), relu_out=True, residual_stats=sr, residual_relu=True).cpu()
+    report("in+relu + relu(in(res)) +relu", got, F.relu(F.relu(ref) + F.relu(rref)), 5e-6)
+    got = kk.instance_apply(x.to(DEV), sx, relu=True, residual=raw.to(DEV), relu_out=True, residual_stats=sr).cpu()
+    report("in+relu + in(res) +relu", got, F.relu(F.relu(ref) + rref), 5e-6)
+    assert torch.equal(kk.instance_apply(x.to(DEV), sx, relu=True).cpu(), kk.instance_norm(x.to(DEV), relu=True).cpu())
 
 
 @pytest.mark.parametrize("b,ci,co,h,w", [(1, 16, 32, 4, 64), (2, 32, 32, 7, 9), (1, 64, 64, 47, 156), (2, 96, 128, 23, 70),
