@@ -88,10 +88,16 @@ class StereoStream:
     Host-side staging uses non-temporal stores (nmrf_host_copy_nt): a DMA that has to snoop freshly written lines out of a CPU
     cache costs ~20 ms per batch on this platform, whatever the batch size (tools/driver_probe3.py)."""
 
-    def __init__(self, model, device="cuda", batch=8, graph=True, depth=2, copy_out=True):
+    def __init__(self, model, device="cuda", batch=8, graph=True, depth=2, copy_out=True, threaded=True):
         self.model, self.device, self.batch = model, torch.device(device), batch
         self.on_gpu = self.device.type == "cuda"
         self.depth, self.copy_out, self.use_graph = max(2, depth), copy_out, graph and self.on_gpu
+        # threaded: staging + launches of batch i+1 / i+2 on a producer thread while the caller's thread drains batch i (the staging
+        # copies and the evicting read-out run outside the GIL).  Needs a third slot (see _run_threaded) and handed-out COPIES.
+        self.threaded = bool(threaded) and self.on_gpu and copy_out
+        if self.threaded:
+            self.depth = max(3, self.depth)
+            self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.plans = {}
         # models of this package defer their fp16 range check to the driver (one flag read per drained batch)
         self._range_model = model if (self.on_gpu and hasattr(model, "range_check")) else None
@@ -186,9 +192,54 @@ class StereoStream:
         for k, d in zip(keys, host):
             yield k, (K.host_read_evict(d) if self.copy_out and done is not None else d)
 
+    def _run_threaded(self, pairs):
+        """Producer thread: decode (the `pairs` iterator), stage, enqueue.  Caller's thread: wait, read out, yield.  One-element queue:
+        while the caller drains batch j the producer may have enqueued j+1 (queued) and be working on j+2 -- never on j+3, which
+        shares batch j's slot in the three-slot ring, before batch j+1 has been taken, i.e. before batch j is fully read out."""
+        import queue
+        import threading
+        q, stop = queue.Queue(maxsize=1), threading.Event()
+
+        def put(item):
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.05)
+                    return True
+                except queue.Full:
+                    pass
+            return False
+
+        def produce():
+            try:
+                torch.cuda.set_device(self._dev_index)
+                for i, group in enumerate(batches(pairs, self.batch)):
+                    if stop.is_set() or not put(self._enqueue(self._plan(group), group, i % self.depth)):
+                        return
+                put(None)
+            except BaseException as e:                          # surfaces in the caller's thread
+                put(e)
+
+        th = threading.Thread(target=produce, name="nmrf-stage", daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                yield from self._drain(item)
+        finally:
+            stop.set()
+            th.join()
+            torch.cuda.synchronize(self.device)                 # nothing of an abandoned batch stays in flight over the rings
+
     def run(self, pairs):
         """pairs: iterable of (key, left [3,H,W], right [3,H,W]) (uint8 or float32, 0..255) -> yields (key, disparity [H,W] CPU
         tensor) in input order."""
+        if self.threaded:
+            yield from self._run_threaded(pairs)
+            return
         pending, i = None, 0
         for group in batches(pairs, self.batch):
             if self.on_gpu:

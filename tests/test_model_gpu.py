@@ -199,6 +199,24 @@ def test_driver_pipeline_matches_direct_calls():
     out = dict(s2.run(iter(pairs_u8[:2] + more + pairs_u8[2:4])))
     assert list(out) == [0, 1, 10, 11, 12, 2, 3] and out[10].shape == (48, 88)
     assert torch.equal(out[0], got[0]) and torch.equal(out[2], got[2])
+    # the producer thread (staging + launches beside the read-out) changes nothing: same values as the single-threaded pipeline,
+    # a long run through the three-slot ring stays in order, and a consumer that walks away early leaves nothing hanging
+    plain = dict(StereoStream(model, DEV, batch=2, threaded=False).run(iter(pairs_u8)))
+    assert all(torch.equal(plain[i], got[i]) for i in got)
+    many = [(k, pairs_u8[k % 5][1], pairs_u8[k % 5][2]) for k in range(23)]
+    longrun = list(StereoStream(model, DEV, batch=2).run(iter(many)))
+    assert [k for k, _ in longrun] == list(range(23)) and all(torch.equal(d, got[k % 5]) for k, d in longrun)
+    gen = StereoStream(model, DEV, batch=2).run(iter(many))
+    k0, d0 = next(gen)
+    gen.close()
+    assert k0 == 0 and torch.equal(d0, got[0])
+
+    def broken():
+        yield many[0]
+        yield many[1]
+        raise OSError("decode failed")
+    with pytest.raises(OSError, match="decode failed"):
+        list(StereoStream(model, DEV, batch=2).run(broken()))
 
 
 def test_mixed_sizes_with_equal_padded_grid_through_one_model():
