@@ -99,6 +99,24 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
     B16_STAMP(0);
     float guard = 0.f;                                                  // fp16 range guard of the activation splits (split_mfma.h)
     float qmax = 0.f;                       // ... and of q_out: the attention kernels split it without a guard of their own (window_attn.hip)
+    // The x / msg rows of the block's FIRST tile are requested before the prologue (parameter table, first weight stages, barrier):
+    // their latency then runs under it instead of behind it (census: 5.5k cycles of a wave's life were this phase, and at batch 1
+    // the first tile is the only one).
+    constexpr bool HOIST = !(DBG & 256);
+    float4 xpre[8], mpre[8];
+    if constexpr (HOIST) {
+        const int64_t tq0 = (int64_t)blockIdx.x * B16_TOK + wv * 16 + j;
+        const int64_t tc0 = tq0 < a.T ? tq0 : a.T - 1;
+#pragma unroll
+        for (int st = 0; st < 8; ++st) xpre[st] = ldg4(a.x + tc0 * 128 + 16 * st + 4 * g);
+        if (a.msg) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                mpre[2 * c] = ldg4(a.msg + tc0 * 128 + 32 * c + 4 * g);
+                mpre[2 * c + 1] = ldg4(a.msg + tc0 * 128 + 32 * c + 16 + 4 * g);
+            }
+        }
+    }
     {
         auto put = [&](int off, const float *src, int n) {
             for (int i = tid; i < n; i += B16_THR) Par[off + i] = src ? src[i] : 0.f;
@@ -193,9 +211,23 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
             acc1[P0 & 3] += (float)ah1[0] + (float)bl[1];
         }
     };
-    fetch(); commit();
-    fetch(); commit();
-    fetch();
+    {
+        // the first three stages are requested TOGETHER (two extra register pairs, free here): one L2 round trip instead of three
+        // serial fetch -> commit pairs (the prologue was ~5k cycles of a wave's life, 27 launches per forward)
+        b16_u32x4 Ra[2], Rb[2];
+        auto fetch_into = [&](b16_u32x4 (&Rx)[2]) {
+            const b16_u32x4 *p = a.stream + (size_t)src_stage * B16_STAGE_U4 + tid;
+            Rx[0] = p[0]; Rx[1] = p[B16_THR];
+            src_stage = (src_stage + 1 == a.total_stages) ? 0 : src_stage + 1;
+        };
+        auto commit_from = [&](const b16_u32x4 (&Rx)[2]) {
+            b16_u32x4 *d = ring + wr_slot * B16_STAGE_U4 + tid;
+            d[0] = Rx[0]; d[B16_THR] = Rx[1];
+            wr_slot = (wr_slot == B16_RING - 1) ? 0 : wr_slot + 1;
+        };
+        fetch_into(Ra); fetch_into(Rb); fetch();
+        commit_from(Ra); commit_from(Rb);
+    }
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < B16_PF; ++p) read_pair(cur, p, fqh[p], fql[p]);
@@ -248,23 +280,26 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
         }
     };
 
-#pragma unroll 1
-    for (int tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    // the body of one tile; PRE: its x / msg rows are the ones requested before the prologue (first tile of the block)
+    auto tile_body = [&](const int tile, auto pre_c) {
+        constexpr bool first = decltype(pre_c)::value;
         const int64_t t0 = (int64_t)tile * B16_TOK + wv * 16;
         const int64_t tq = t0 + j;
         const int64_t tc = tq < a.T ? tq : a.T - 1;
         float x1[32];                                                          // channel 16*(i >> 2) + 4g + (i & 3)
 #pragma unroll
         for (int st = 0; st < 8; ++st) {
-            const float4 v = ldg4(a.x + tc * 128 + 16 * st + 4 * g);
+            float4 v;
+            if constexpr (first) v = xpre[st];
+            else v = ldg4(a.x + tc * 128 + 16 * st + 4 * g);
             x1[4 * st] = v.x; x1[4 * st + 1] = v.y; x1[4 * st + 2] = v.z; x1[4 * st + 3] = v.w;
         }
+        h16x8 bmh[4], bml[4];
         f32x4 acc[8];
         // ---- stage P -----------------------------------------------------------------------------------------------------------
         bool have_msg = a.msg != nullptr;
         if constexpr (!MLP) have_msg = have_msg || a.attn_qkv != nullptr;
         if (have_msg) {
-            h16x8 bmh[4], bml[4];
             bool from_attn = false;
             if constexpr (!MLP) from_attn = a.attn_qkv != nullptr;
             if (from_attn) {
@@ -319,7 +354,9 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
             } else {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float4 v0 = ldg4(a.msg + tc * 128 + 32 * c + 4 * g), v1 = ldg4(a.msg + tc * 128 + 32 * c + 16 + 4 * g);
+                    float4 v0, v1;
+                    if constexpr (first) { v0 = mpre[2 * c]; v1 = mpre[2 * c + 1]; }
+                    else { v0 = ldg4(a.msg + tc * 128 + 32 * c + 4 * g); v1 = ldg4(a.msg + tc * 128 + 32 * c + 16 + 4 * g); }
                     const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
                     split8u_g(v, bmh[c], bml[c], guard);
                 }
@@ -481,7 +518,14 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
                 o[12] = tk_bar; o[13] = tk_use; o[14] = tk_commit;
             }
         }
+    };
+    int tile = blockIdx.x;
+    if constexpr (HOIST) {
+        tile_body(tile, std::true_type{});
+        tile += gridDim.x;
     }
+#pragma unroll 1
+    for (; tile < a.n_tiles; tile += gridDim.x) tile_body(tile, std::false_type{});
     split_guard_commit(guard, a.range_flag);
     if (a.range_flag && !(qmax < 65520.0f)) atomicOr(a.range_flag, 1);   // (a NaN in q_out has a NaN operand upstream: caught by `guard`)
 }
@@ -534,6 +578,7 @@ static int launch_nmp_block16(const NmpBlock16Args &a, hipStream_t st) {
         if (g_b16_stamps) {
             NmpBlock16Args b = a;
             b.stamps = g_b16_stamps;
+            if (g_b16_variant == 256) return launch_nmp_block16<MLP, KQC, 288>(b, st);
             return launch_nmp_block16<MLP, KQC, 32>(b, st);
         }
         switch (g_b16_variant) {
@@ -544,6 +589,7 @@ static int launch_nmp_block16(const NmpBlock16Args &a, hipStream_t st) {
             case 7: return launch_nmp_block16<MLP, KQC, 7>(a, st);
             case 16: return launch_nmp_block16<MLP, KQC, 16>(a, st);
             case 24: return launch_nmp_block16<MLP, KQC, 24>(a, st);
+            case 256: return launch_nmp_block16<MLP, KQC, 256>(a, st);
             default: break;
         }
     }

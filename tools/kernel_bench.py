@@ -151,6 +151,18 @@ if "block" in which:
         print("   total per wave median %.0f ticks; first start to last end %.0f ticks" % (
             np.median(s_[:, :, 11] - s_[:, :, 0]), s_[:, :, 11].max() - s_[:, :, 0].min()))
     stamp16("proj+mlp+qkv", lambda: K.nmp_block(x, s16, st16, i16, msg, bp, (g, be, 1e-5, b1, b2), qd, tokens_per_wave=16))
+    # A/B inside this process: the first tile's rows requested before the prologue (product) vs behind it (variant 256)
+    ref_out = [t.clone() for t in K.nmp_block(x, s16, st16, i16, msg, bp, (g, be, 1e-5, b1, b2), qd, tokens_per_wave=16) if t is not None]
+    for rep in range(2):
+        _l.nmrf_debug_nmp_block16_variant(256)
+        alt_out = [t.clone() for t in K.nmp_block(x, s16, st16, i16, msg, bp, (g, be, 1e-5, b1, b2), qd, tokens_per_wave=16) if t is not None]
+        timeit("nmp_block16 proj+mlp+qkv, rows loaded behind the prologue (variant 256)", lambda: K.nmp_block(x, s16, st16, i16, msg, bp, (g, be, 1e-5, b1, b2), qd, tokens_per_wave=16))
+        _l.nmrf_debug_nmp_block16_variant(0)
+        timeit("nmp_block16 proj+mlp+qkv, product (rows requested before the prologue)", lambda: K.nmp_block(x, s16, st16, i16, msg, bp, (g, be, 1e-5, b1, b2), qd, tokens_per_wave=16))
+    print("variant 256 vs product: max |diff|", [float((p_ - q_).abs().max()) for p_, q_ in zip(ref_out, alt_out)])
+    _l.nmrf_debug_nmp_block16_variant(256)
+    stamp16("proj+mlp+qkv, rows behind the prologue", lambda: K.nmp_block(x, s16, st16, i16, msg, bp, (g, be, 1e-5, b1, b2), qd, tokens_per_wave=16))
+    _l.nmrf_debug_nmp_block16_variant(0)
     s16b, st16b, i16b = K.block_stream16(wp, None, None, wq, 160)
     stamp16("proj+qkv (self block)", lambda: K.nmp_block(x, s16b, st16b, i16b, msg, bp, None, qd, tokens_per_wave=16))
     timeit("nmp_block16 proj+qkv (self block)", lambda: K.nmp_block(x, s16b, st16b, i16b, msg, bp, None, qd, tokens_per_wave=16))
