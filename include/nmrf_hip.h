@@ -110,7 +110,9 @@ int nmrf_add_ln_concat_f32(const float *x, const float *y, float *x_out, const f
  * axes: bit 0 = run the vertical stripes (writes out[:, 0:C/2]), bit 1 = the horizontal ones (out[:, C/2:C]);
  * 3 = both (two kernel launches on `stream`). */
 int nmrf_stripe_attn_f32(const float *qkv, const float *lepe_v, const float *lepe_h, int B, int H, int W, int N,
-                         int C, int axes, float *out, int *range_flag, void *stream);
+                         int C, int axes, int kv16, float *out, int *range_flag, void *stream);
+/* (kv16 != 0: the k | v thirds of qkv hold split fp16 operand pairs, see nmrf_nmp_block16_f32; N == 4.  Same results, bit for bit,
+ *  as on the fp32 rows they were split from; the range of k and v is then the producer's to check.) */
 
 /* A9  warp right maps at x-label, group correlation, concat.
  * replaces Inference.sample_fmap x2 + corr + cat (nmrf/models/NMP.py:683-741, 839-844).
@@ -215,7 +217,14 @@ int nmrf_nmp_block16_f32(const float *x, const float *msg, const float *attn_qkv
                          const float *ln2_g, const float *ln2_b, float eps2, const float *b1, const float *b2,
                          const float *lnq_g, const float *lnq_b, float epsq, const float *extra, int extra_ld,
                          int extra_div, const float *bq, int has_mlp, int KQ, int NQ, int64_t T, const float *inv_scales,
-                         float *x_out, float *q_out, float *ln_out, const int *ln_out_map, int *range_flag, void *stream);
+                         float *x_out, float *q_out, float *ln_out, const int *ln_out_map, int kv16, int *range_flag, void *stream);
+/* kv16 != 0 (NQ == 384, q_out = q | k | v for nmrf_stripe_attn_f32 / nmrf_window_attn_f32 called with kv16 != 0): the k and v
+ * thirds of a q_out row carry the split fp16 operand pairs the attention kernels contract (csrc/split_mfma.h: hi = rn_f16(x),
+ * lo = rn_f16(x - hi)) instead of the floats -- the same 4 bytes per value, split once by the producer instead of by every query
+ * tile that reads the row:
+ *   floats 128 .. 255 (k): per 32-channel head h, bytes [128 h, 128 h + 64) = hi of channels 0 .. 31 (fp16), the next 64 = lo;
+ *   floats 256 .. 383 (v): value c as the 32-bit word  hi | lo << 16.
+ * q (floats 0 .. 127) stays fp32. */
 
 /* Weight packing for nmrf_nmp_block16_f32: w [N,K] -> N/16 x Kp/32 pairs of 2 KB in [strip][chunk] order; lane (i = l & 15,
  * g = l >> 4) slot jj holds scale * w[16*strip + i][32*chunk + (jj&3) + 16*(jj>>2) + 4*g], zero beyond K; hi fragment then lo

@@ -27,7 +27,7 @@ PROTOTYPES = {
     "nmrf_mlp_chain_f32": [_I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _L, _P, _I, _I, _P, _P, _P],
     "nmrf_ln_concat_f32": [_P, _P, _P, _F, _P, _I, _I, _L, _I, _P, _I, _P],
     "nmrf_add_ln_concat_f32": [_P, _P, _P, _P, _P, _F, _P, _I, _I, _L, _I, _P, _I, _P],
-    "nmrf_stripe_attn_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "nmrf_stripe_attn_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "nmrf_warp_corr_concat_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     "nmrf_self_attn_f32": [_P, _L, _I, _I, _I, _P, _P],
     "nmrf_window_attn_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
@@ -41,7 +41,7 @@ PROTOTYPES = {
     "nmrf_msda_backward_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "nmrf_msda_backward_f64": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "nmrf_pack_split_weight_f32": [_P, _I, _I, _I, _F, _P, _P],
-    "nmrf_nmp_block16_f32": [_P, _P, _P, _I, _P, _I, _P, _P, _P, _F, _P, _P, _P, _P, _F, _P, _I, _I, _P, _I, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P],
+    "nmrf_nmp_block16_f32": [_P, _P, _P, _I, _P, _I, _P, _P, _P, _F, _P, _P, _P, _P, _F, _P, _I, _I, _P, _I, _I, _I, _L, _P, _P, _P, _P, _P, _I, _P, _P],
     "nmrf_pack_split_weight16_f32": [_P, _I, _I, _I, _F, _P, _P],
     "nmrf_selftest_mfma16x16_f16split": [_P, _P, _I, _P, _P],
     "nmrf_instance_stats_f32": [_P, _L, _L, _P, _P],

@@ -82,6 +82,8 @@ struct NmpBlock16Args {
     float inv_p, inv_1, inv_2, inv_q;
     unsigned long long *stamps;  // debug build: s_memtime stamps of the first 64 blocks (DBG & 32)
     int *range_flag;             // sticky fp16-range flag of the split operands (split_mfma.h), may be NULL
+    int kv16;                    // q_out is q | k | v for an attention kernel (NQ == 384): write k and v as the split fp16 operand
+                                 // pairs those kernels would otherwise make of them on every key tile (format: include/nmrf_hip.h)
 };
 
 // MLP: run fc1-GELU-fc2.  KQC: 32-deep k chunks of the q stage's operand [LNq(x2) | extra]: 0 none, 4 = LayerNorm only,
@@ -495,15 +497,37 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
                             if constexpr (pg % 8 == 6) stage_end();
                         });
                         const f32x4 ba = par4(B16P_BQ + gq * 128 + 32 * sp + 4 * g), bb = par4(B16P_BQ + gq * 128 + 32 * sp + 16 + 4 * g);
+                        // kv16: the k group leaves as [hi fp16 x 32 | lo fp16 x 32] per 32-channel head, the v group as (hi, lo)
+                        // half pairs in place of the floats -- the same 4 bytes per value, split ONCE here (split2u, bit for bit what
+                        // the attention kernels' split8u would produce) instead of by every query tile that reads the row
+                        const int kvmode = (a.kv16 && n_groups == 3) ? gq : 0;        // 0: floats, 1: k, 2: v
+                        auto put_strip = [&](const float (&v)[4], int col0) {
+                            if (kvmode == 0) { stage_strip(v, col0); return; }
+                            h16x2 h01, l01, h23, l23;
+                            split2u(f32x2{v[0], v[1]}, h01, l01);
+                            split2u(f32x2{v[2], v[3]}, h23, l23);
+                            const unsigned uh01 = __builtin_bit_cast(unsigned, h01), ul01 = __builtin_bit_cast(unsigned, l01);
+                            const unsigned uh23 = __builtin_bit_cast(unsigned, h23), ul23 = __builtin_bit_cast(unsigned, l23);
+                            float *row = Ot + j * B16_OLD;
+                            if (kvmode == 1) {                            // channels c0 .. c0+3 of head col0 / 32, c0 = col0 % 32 + 4g
+                                const int hb = col0 & ~31, c0 = (col0 & 31) + 4 * g;
+                                *reinterpret_cast<uint2 *>(row + hb + (c0 >> 1)) = make_uint2(uh01, uh23);
+                                *reinterpret_cast<uint2 *>(row + hb + 16 + (c0 >> 1)) = make_uint2(ul01, ul23);
+                            } else {                                      // element e -> hi | lo << 16
+                                const uint4 pk = make_uint4(__builtin_amdgcn_perm(ul01, uh01, 0x05040100u), __builtin_amdgcn_perm(ul01, uh01, 0x07060302u),
+                                                            __builtin_amdgcn_perm(ul23, uh23, 0x05040100u), __builtin_amdgcn_perm(ul23, uh23, 0x07060302u));
+                                *reinterpret_cast<uint4 *>(row + col0 + 4 * g) = pk;
+                            }
+                        };
                         float ov[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) ov[e] = fmaf(qh0[e], a.inv_q, ba[e]);
                         qmax = fmaxf(fmaxf(qmax, fmaxf(fabsf(ov[0]), fabsf(ov[1]))), fmaxf(fabsf(ov[2]), fabsf(ov[3])));
-                        stage_strip(ov, 32 * sp);
+                        put_strip(ov, 32 * sp);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) ov[e] = fmaf(qh1[e], a.inv_q, bb[e]);
                         qmax = fmaxf(fmaxf(qmax, fmaxf(fabsf(ov[0]), fabsf(ov[1]))), fmaxf(fabsf(ov[2]), fabsf(ov[3])));
-                        stage_strip(ov, 32 * sp + 16);
+                        put_strip(ov, 32 * sp + 16);
                     });
                     flush_rows(a.q_out, a.NQ, gq * 128, t0);
                     if (gq < 3) B16_STAMP(8 + gq);
@@ -620,8 +644,10 @@ extern "C" int nmrf_nmp_block16_f32(const float *x, const float *msg, const floa
                                     const float *ln2_g, const float *ln2_b, float eps2, const float *b1, const float *b2,
                                     const float *lnq_g, const float *lnq_b, float epsq, const float *extra, int extra_ld,
                                     int extra_div, const float *bq, int has_mlp, int KQ, int NQ, int64_t T, const float *inv_scales,
-                                    float *x_out, float *q_out, float *ln_out, const int *ln_out_map, int *range_flag, void *stream) {
+                                    float *x_out, float *q_out, float *ln_out, const int *ln_out_map, int kv16, int *range_flag,
+                                    void *stream) {
     if (!x || !stream_w || !inv_scales) return NMRF_ENULL;
+    if (kv16 && (!q_out || NQ != 384)) return NMRF_EINVAL;
     if (T < 1 || ceil_div64(T, B16_TOK) > 0x7fffffff) return NMRF_EINVAL;
     if (has_mlp && (!ln2_g || !ln2_b || !b1 || !b2)) return NMRF_ENULL;
     if (attn_qkv && (msg || has_mlp || attn_n != 4 || (T & 3))) return NMRF_EINVAL;     // self-edge attention: 4 siblings, proj-only blocks
@@ -635,7 +661,7 @@ extern "C" int nmrf_nmp_block16_f32(const float *x, const float *msg, const floa
     if (total_stages != want || total_stages < 1) return NMRF_EINVAL;
     NmpBlock16Args a{x, msg, attn_qkv, reinterpret_cast<const b16_u32x4 *>(stream_w), total_stages, bp, ln2_g, ln2_b, b1, b2, lnq_g, lnq_b, extra,
                      extra_ld, extra_div, bq, x_out, q_out, ln_out, ln_out_map, T, (int)ceil_div64(T, B16_TOK), eps2, epsq, NQ,
-                     inv_scales[0], inv_scales[1], inv_scales[2], inv_scales[3], nullptr, range_flag};
+                     inv_scales[0], inv_scales[1], inv_scales[2], inv_scales[3], nullptr, range_flag, kv16 ? 1 : 0};
     hipStream_t st = (hipStream_t)stream;
     const int kqc = KQ / 32;
     if (has_mlp) {

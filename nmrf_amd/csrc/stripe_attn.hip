@@ -54,7 +54,32 @@ __device__ __forceinline__ int64_t stripe_row(const StripeGeom &g, int64_t base_
 // __launch_bounds__(256, 3): with a register budget <= 256 the compiler keeps the MFMA accumulators in VGPRs; without the
 // occupancy hint it parks them in AGPRs and every `acc *= alpha` / softmax pass pays v_accvgpr_read/write round trips
 // (112 of them per key tile in the first version of this kernel).
-template <int AXIS, int NSHIFT, int KSPLIT, bool CENSUS = false>
+// value c of a kv16 row's v third: hi | lo << 16 (include/nmrf_hip.h) -> the float it was split from (up to 2^-22 relative)
+__device__ __forceinline__ float kv16_value(float w) {
+    const unsigned u = __builtin_bit_cast(unsigned, w);
+    return (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu)) + (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16));
+}
+// 16 such words (MFMA k-slot order s = 8c + jj) -> the hi / lo operand chunks: two v_perm_b32 per pair of values, no arithmetic
+__device__ __forceinline__ void kv16_chunks(const float *w, h16x8 (&vh)[2], h16x8 (&vl)[2]) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned e0 = __builtin_bit_cast(unsigned, w[8 * c + 2 * k]), e1 = __builtin_bit_cast(unsigned, w[8 * c + 2 * k + 1]);
+            h[k] = __builtin_amdgcn_perm(e1, e0, 0x05040100u);
+            l[k] = __builtin_amdgcn_perm(e1, e0, 0x07060302u);
+        }
+        const uint4 hv = make_uint4(h[0], h[1], h[2], h[3]), lv = make_uint4(l[0], l[1], l[2], l[3]);
+        vh[c] = __builtin_bit_cast(h16x8, hv);
+        vl[c] = __builtin_bit_cast(h16x8, lv);
+    }
+}
+
+// KV16: the k and v thirds of a qkv row hold split fp16 operand pairs (the producing block kernel wrote them so: kv16 of
+// nmrf_nmp_block16_f32, include/nmrf_hip.h) -- the K fragment is four 16-byte loads that ARE the MFMA operands, the V fragment
+// 16 words and 16 v_perm_b32; without it each key tile pays 2 x 48 VALU instructions to split them (of ~250 in a tile).
+template <int AXIS, int NSHIFT, int KSPLIT, bool CENSUS = false, bool KV16 = false>
 __global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__restrict__ qkv, const float *__restrict__ lepe,
                                                          StripeGeom g, float scale, float *__restrict__ out,
                                                          unsigned long long *__restrict__ census = nullptr) {
@@ -109,9 +134,10 @@ __global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__rest
     const int64_t qrow = stripe_row<NSHIFT>(g, base_pix, wave_on ? qsc : 0);
     const int q_pix = div_n<NSHIFT>(g, qsc);
 
-    f32x16 acc_o;
+    constexpr bool DUAL = false;                // (two MFMA chains per contraction, accumulators summed afterwards: measured 37.4 vs 37.1 us -- nothing)
+    f32x16 acc_o, acc_o2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc_o[r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc_o[r] = acc_o2[r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
     if (wave_on) {
@@ -134,8 +160,11 @@ __global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__rest
         const int n_kt = (g.Ts + SA_TILE - 1) / SA_TILE;
         const int per = (n_kt + KSPLIT - 1) / KSPLIT;
         const int kt_begin = ks * per, kt_end = (kt_begin + per < n_kt) ? kt_begin + per : n_kt;
-        const float *kbase = qkv + g.C + coff + 16 * hi;
+        // K fragment of lane (key, hi): 16 channels of the head -- 16 floats, or (KV16) 16 hi halves at float offset 8 hi of the head's
+        // 32-float block and the 16 lo halves 16 floats further; kd[0..7] then hold the hi chunks, kd[8..15] the lo chunks
+        const float *kbase = qkv + g.C + coff + (KV16 ? 8 : 16) * hi;
         const float *vbase = qkv + 2 * g.C + coff + qi;
+        constexpr int KO2 = KV16 ? 16 : 8, KO3 = KV16 ? 20 : 12;     // float offsets of the 3rd / 4th 16-byte piece
         // N == 4: a key tile is 8 whole pixels, so the rows of a FULL tile sit at fixed offsets from one per-lane
         // pointer that advances by `tile_step` per tile (the generic row arithmetic cost 68 v_mul_lo_u32 + 34
         // v_mad_u64_u32 per tile -- more VALU issue than the softmax).  Only a ragged last tile takes the clamped path.
@@ -150,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__rest
             const float *p = kfast + (int64_t)kt * tile_step;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                float4 v = ldg4(p + 4 * c);
+                float4 v = ldg4(p + (c < 2 ? 4 * c : (c == 2 ? KO2 : KO3)));
                 kd[4 * c + 0] = v.x; kd[4 * c + 1] = v.y; kd[4 * c + 2] = v.z; kd[4 * c + 3] = v.w;
             }
         };
@@ -172,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__rest
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                float4 v = ldg4(p + 4 * c);
+                float4 v = ldg4(p + (c < 2 ? 4 * c : (c == 2 ? KO2 : KO3)));
                 kd[4 * c + 0] = v.x; kd[4 * c + 1] = v.y; kd[4 * c + 2] = v.z; kd[4 * c + 3] = v.w;
             }
         };
@@ -208,10 +237,33 @@ __global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__rest
             for (int r = 0; r < 16; ++r) st[r] = 0.f;
             {
                 h16x8 kh[2], kl[2];
-                split8u_g(kf, kh[0], kl[0], guard);
-                split8u_g(kf + 8, kh[1], kl[1], guard);
-                split_mma1(kh[0], kl[0], qh[0], ql[0], st);
-                split_mma1(kh[1], kl[1], qh[1], ql[1], st);
+                if constexpr (KV16) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const f32x4 hv = {kf[4 * c], kf[4 * c + 1], kf[4 * c + 2], kf[4 * c + 3]};
+                        const f32x4 lv = {kf[8 + 4 * c], kf[8 + 4 * c + 1], kf[8 + 4 * c + 2], kf[8 + 4 * c + 3]};
+                        kh[c] = __builtin_bit_cast(h16x8, hv);
+                        kl[c] = __builtin_bit_cast(h16x8, lv);
+                    }
+                } else {
+                    split8u_g(kf, kh[0], kl[0], guard);
+                    split8u_g(kf + 8, kh[1], kl[1], guard);
+                }
+                if constexpr (DUAL) {
+                    // the two k chunks into two accumulators, their MFMAs interleaved: a dependent MFMA then issues behind an
+                    // independent one instead of waiting out its predecessor (six chained on one accumulator stall on each other)
+                    f32x16 st2;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st2[r] = 0.f;
+                    st = mfma16h(kl[0], qh[0], st);   st2 = mfma16h(kl[1], qh[1], st2);
+                    st = mfma16h(kh[0], ql[0], st);   st2 = mfma16h(kh[1], ql[1], st2);
+                    st = mfma16h(kh[0], qh[0], st);   st2 = mfma16h(kh[1], qh[1], st2);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st[r] += st2[r];
+                } else {
+                    split_mma1(kh[0], kl[0], qh[0], ql[0], st);
+                    split_mma1(kh[1], kl[1], qh[1], ql[1], st);
+                }
             }
             if (STEADY) load_k_fast(kt + 2, kf);                // K fragment is dead: refill now
             else if (kt + 2 < kt_end) load_k(kt + 2, kf);
@@ -245,6 +297,10 @@ __global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__rest
             m_run = m_new;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc_o[r] *= alpha;
+            if constexpr (DUAL) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_o2[r] *= alpha;
+            }
             {
                 float pv[16];
 #pragma unroll
@@ -252,10 +308,20 @@ __global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__rest
                 h16x8 ph[2], pl[2], vh[2], vl[2];
                 split8u(pv, ph[0], pl[0]);
                 split8u(pv + 8, ph[1], pl[1]);
-                split8u_g(vf, vh[0], vl[0], guard);
-                split8u_g(vf + 8, vh[1], vl[1], guard);
-                split_mma1(vh[0], vl[0], ph[0], pl[0], acc_o);
-                split_mma1(vh[1], vl[1], ph[1], pl[1], acc_o);
+                if constexpr (KV16) {
+                    kv16_chunks(vf, vh, vl);
+                } else {
+                    split8u_g(vf, vh[0], vl[0], guard);
+                    split8u_g(vf + 8, vh[1], vl[1], guard);
+                }
+                if constexpr (DUAL) {
+                    acc_o = mfma16h(vl[0], ph[0], acc_o);   acc_o2 = mfma16h(vl[1], ph[1], acc_o2);
+                    acc_o = mfma16h(vh[0], pl[0], acc_o);   acc_o2 = mfma16h(vh[1], pl[1], acc_o2);
+                    acc_o = mfma16h(vh[0], ph[0], acc_o);   acc_o2 = mfma16h(vh[1], ph[1], acc_o2);
+                } else {
+                    split_mma1(vh[0], vl[0], ph[0], pl[0], acc_o);
+                    split_mma1(vh[1], vl[1], ph[1], pl[1], acc_o);
+                }
             }
             if (STEADY) load_v_fast(kt + 2, vf);                // V fragment likewise
             else if (kt + 2 < kt_end) load_v(kt + 2, vf);
@@ -278,6 +344,10 @@ __global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__rest
         }
         SA_STAMP(7);
         l_run = half_sum(l_run);                        // both halves now hold the range's full (m, l)
+        if constexpr (DUAL) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_o[r] += acc_o2[r];
+        }
     }
 
     // ---- LePE for width-1 stripes (NMP.py:433-449 / SURVEY H3), independent of the attention itself:
@@ -298,13 +368,18 @@ __global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__rest
         for (int j = 0; j < RB_PER; ++j) {
             const int rb = ks * RB_PER + j;
             const int d0 = 8 * rb + 4 * hi;                        // == mfma_row(4*rb, hi)
-            float4 vq = ldg4(vb + qrow * ld + d0);
+            auto vrow4 = [&](int64_t row) {                       // four consecutive channels of a token's v
+                float4 t = ldg4(vb + row * ld + d0);
+                if constexpr (KV16) t = make_float4(kv16_value(t.x), kv16_value(t.y), kv16_value(t.z), kv16_value(t.w));
+                return t;
+            };
+            float4 vq = vrow4(qrow);
             float4 sp = make_float4(0.f, 0.f, 0.f, 0.f), sn = sp;
             if (wave_on)
                 for (int n = 0; n < nlab; ++n) {
-                    float4 t = ldg4(vb + (prev_row + n) * ld + d0);
+                    float4 t = vrow4(prev_row + n);
                     sp.x += t.x; sp.y += t.y; sp.z += t.z; sp.w += t.w;
-                    float4 u = ldg4(vb + (next_row + n) * ld + d0);
+                    float4 u = vrow4(next_row + n);
                     sn.x += u.x; sn.y += u.y; sn.z += u.z; sn.w += u.w;
                 }
             const float fp = has_prev ? 1.f : 0.f, fn = has_next ? 1.f : 0.f;
@@ -371,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__rest
     SA_STAMP(11);
 }
 
-template <int AXIS, int NSHIFT>
+template <int AXIS, int NSHIFT, bool KV16 = false>
 static void launch_stripe(const float *qkv, const float *lepe, const StripeGeom &g_in, int stripes, int B, float scale,
                           float *out, hipStream_t st) {
     // key split, decided per image and NOT per batch so that results do not depend on the batch size.  Measured on MI355X
@@ -390,11 +465,11 @@ static void launch_stripe(const float *qkv, const float *lepe, const StripeGeom 
     StripeGeom g = g_in;
     g.gx = (n_qt + qpb - 1) / qpb; g.gy = stripes * 2; g.gz = B;
     dim3 grid((unsigned)(((int64_t)g.gx * g.gy * g.gz + 7) / 8 * 8));
-    if (ksplit == 1) hipLaunchKernelGGL((stripe_attn_kernel<AXIS, NSHIFT, 1>), grid, dim3(256), 0, st, qkv, lepe, g, scale, out,
+    if (ksplit == 1) hipLaunchKernelGGL((stripe_attn_kernel<AXIS, NSHIFT, 1, false, KV16>), grid, dim3(256), 0, st, qkv, lepe, g, scale, out,
                                           (unsigned long long *)nullptr);
-    else if (ksplit == 2) hipLaunchKernelGGL((stripe_attn_kernel<AXIS, NSHIFT, 2>), grid, dim3(256), 0, st, qkv, lepe, g, scale, out,
+    else if (ksplit == 2) hipLaunchKernelGGL((stripe_attn_kernel<AXIS, NSHIFT, 2, false, KV16>), grid, dim3(256), 0, st, qkv, lepe, g, scale, out,
                                           (unsigned long long *)nullptr);
-    else hipLaunchKernelGGL((stripe_attn_kernel<AXIS, NSHIFT, 4>), grid, dim3(256), 0, st, qkv, lepe, g, scale, out,
+    else hipLaunchKernelGGL((stripe_attn_kernel<AXIS, NSHIFT, 4, false, KV16>), grid, dim3(256), 0, st, qkv, lepe, g, scale, out,
                                           (unsigned long long *)nullptr);
 }
 
@@ -414,20 +489,23 @@ extern "C" int nmrf_debug_stripe_census(const float *qkv, const float *lepe_h, i
 #endif  // NMRF_DEBUG_PROBES
 
 extern "C" int nmrf_stripe_attn_f32(const float *qkv, const float *lepe_v, const float *lepe_h, int B, int H, int W,
-                                    int N, int C, int axes, float *out, int *range_flag, void *stream) {
+                                    int N, int C, int axes, int kv16, float *out, int *range_flag, void *stream) {
     if (!qkv || !lepe_v || !lepe_h || !out) return NMRF_ENULL;
     if (B < 1 || H < 1 || W < 1 || N < 1 || C != 128 || axes < 1 || axes > 3) return NMRF_EINVAL;
+    if (kv16 && N != 4) return NMRF_EINVAL;                     // (the pre-split form is built for the shipped four labels per pixel)
     if (W * 2 > 65535 || H * 2 > 65535 || B > 65535) return NMRF_EINVAL;
     const float scale = 1.0f / sqrtf(32.0f);
     hipStream_t st = (hipStream_t)stream;
     if (axes & 1) {   // vertical stripes: one per column, H*N tokens each, channel half 0
         StripeGeom g{H, W, N, C, H, H * N, (int64_t)W, 0, 0, 0, range_flag};
-        if (N == 4) launch_stripe<0, 2>(qkv, lepe_v, g, W, B, scale, out, st);
+        if (N == 4 && kv16) launch_stripe<0, 2, true>(qkv, lepe_v, g, W, B, scale, out, st);
+        else if (N == 4) launch_stripe<0, 2>(qkv, lepe_v, g, W, B, scale, out, st);
         else launch_stripe<0, -1>(qkv, lepe_v, g, W, B, scale, out, st);
     }
     if (axes & 2) {   // horizontal stripes: one per row, W*N tokens each, channel half 1
         StripeGeom g{H, W, N, C, W, W * N, (int64_t)1, 0, 0, 0, range_flag};
-        if (N == 4) launch_stripe<1, 2>(qkv, lepe_h, g, H, B, scale, out, st);
+        if (N == 4 && kv16) launch_stripe<1, 2, true>(qkv, lepe_h, g, H, B, scale, out, st);
+        else if (N == 4) launch_stripe<1, 2>(qkv, lepe_h, g, H, B, scale, out, st);
         else launch_stripe<1, -1>(qkv, lepe_h, g, H, B, scale, out, st);
     }
     return nmrf_launch_status();

@@ -242,19 +242,21 @@ def _he(name):
 
 
 @_on_device
-def stripe_attn(qkv, lepe_v, lepe_h, b, h, w, n):
+def stripe_attn(qkv, lepe_v, lepe_h, b, h, w, n, kv16=False):
+    """kv16: the k | v thirds of qkv are split fp16 operand pairs (nmp_block(q=dict(kv16=True)) / to_kv16)."""
     _chk(qkv, lepe_v, lepe_h)
     t, c3 = qkv.shape
     c = c3 // 3
     assert t == b * h * w * n
     out = torch.empty(t, c, device=qkv.device, dtype=torch.float32)
     fn = _lib.load().nmrf_stripe_attn_f32
-    _lib.check(fn(_p(qkv), _p(lepe_v), _p(lepe_h), b, h, w, n, c, 1, _p(out), _rf(qkv), _stream()), "stripe_attn(vertical)")
+    rf = None if kv16 else _rf(qkv)                      # (pre-split operands were range-checked by their producer)
+    _lib.check(fn(_p(qkv), _p(lepe_v), _p(lepe_h), b, h, w, n, c, 1, int(kv16), _p(out), rf, _stream()), "stripe_attn(vertical)")
     # per (row, head): QK^T and PV, 2*T^2*32 FLOPs each, T = W*N, 2 heads of 32 channels
     _hb("stripe_attn_horizontal", row="A7", bound="mfma", split=True, flops=b * h * 2 * 4.0 * 32 * (w * n) ** 2, bytes=4.0 * (qkv.numel() / 2 + t * c / 2),
         label="stripe_attn_kernel<1> (horizontal stripes, A7)",
-        pmc=["stripe_attn_kernel<1, 2, 1, false>", "stripe_attn_kernel<1, 2, 2, false>"])
-    _lib.check(fn(_p(qkv), _p(lepe_v), _p(lepe_h), b, h, w, n, c, 2, _p(out), _rf(qkv), _stream()), "stripe_attn(horizontal)")
+        pmc=["stripe_attn_kernel<1, 2, 1, false", "stripe_attn_kernel<1, 2, 2, false"])
+    _lib.check(fn(_p(qkv), _p(lepe_v), _p(lepe_h), b, h, w, n, c, 2, int(kv16), _p(out), rf, _stream()), "stripe_attn(horizontal)")
     _he("stripe_attn_horizontal")
     return out
 
@@ -276,6 +278,25 @@ def warp_corr_concat(labels, f1, f2, g1, g2, n, groups=32, ld=None):
     _lib.check(_lib.load().nmrf_warp_corr_concat_f32(_p(labels), _p(f1), _p(f2), _p(g1), _p(g2), b, h, w, n, cf, cg,
                                                      groups, _p(out), ld, _stream()), "warp_corr_concat")
     _he("warp_corr_concat_n%d" % n)
+    return out
+
+
+def to_kv16(qkv):
+    """[T, 384] fp32 q | k | v -> the same tensor with k and v as split fp16 operand pairs (the kv16 format of include/nmrf_hip.h;
+    torch restatement of what nmrf_nmp_block16_f32 writes with kv16 != 0: tests and tools)."""
+    t = qkv.shape[0]
+    out = qkv.clone()
+    words = out.view(torch.int32)
+
+    def split(x):
+        hi = x.half()
+        lo = (x - hi.float()).half()
+        return hi.view(torch.int16).int() & 0xffff, lo.view(torch.int16).int() & 0xffff
+    kh, kl = split(qkv[:, 128:256].reshape(t, 4, 32))
+    pack2 = lambda a: a[..., 0::2] | (a[..., 1::2] << 16)                         # two fp16 per 32-bit word, little endian
+    words[:, 128:256] = torch.cat((pack2(kh), pack2(kl)), -1).reshape(t, 128)     # per head: 16 words of hi, 16 words of lo
+    vh, vl = split(qkv[:, 256:384])
+    words[:, 256:384] = vh | (vl << 16)
     return out
 
 
@@ -504,7 +525,7 @@ def nmp_block(x, stream, stages, inv_scales, msg=None, bp=None, mlp=None, q=None
               tokens_per_wave=16, attn_qkv=None):
     """One fused message-passing block (nmrf_nmp_block16_f32; tokens_per_wave=32: the debug library's 32-token form).
     mlp = (ln2_gamma, ln2_beta, eps, b1, b2) or None;  q = dict(g, b, eps, extra=None, extra_div=1, bias=None, kq=0|128|160|192,
-    nq=0 -> no q_out, ln_out=False) or None.  attn_qkv [T,384] (instead of msg, proj-only blocks): q | k | v of the self-edge
+    nq=0 -> no q_out, ln_out=False, kv16=False: k | v of q_out as split fp16 pairs, include/nmrf_hip.h) or None.  attn_qkv [T,384] (instead of msg, proj-only blocks): q | k | v of the self-edge
     attention among the 4 sibling labels of a pixel, evaluated on the way in.  Returns (x_out | None, q_out | None, ln_out | None)."""
     _chk(x, msg, bp, attn_qkv)
     _chk(stream, dtype=torch.int32)
@@ -544,14 +565,16 @@ def nmp_block(x, stream, stages, inv_scales, msg=None, bp=None, mlp=None, q=None
                 tokens_per_wave),
             pmc=["nmp_block_kernel<%s, %d, 1, 4, false, 0>" % ("true" if mlp is not None else "false", kq // 16) if tokens_per_wave == 32
                  else "nmp_block16_kernel<%s, %d, 0>" % ("true" if mlp is not None else "false", (kq + 31) // 32)])
-    tail = (_p(stream), stages, _p(bp), _p(ln2_g), _p(ln2_b), float(eps2), _p(b1), _p(b2), _p(lq_g), _p(lq_b), float(epsq), _p(extra), ld,
-            div, _p(bq), int(mlp is not None), kq, nq, t, inv_scales, _p(x_out), _p(q_out), _p(ln_out), _p(ln_out_map), _rf(x), _stream())
+    head = (_p(stream), stages, _p(bp), _p(ln2_g), _p(ln2_b), float(eps2), _p(b1), _p(b2), _p(lq_g), _p(lq_b), float(epsq), _p(extra), ld,
+            div, _p(bq), int(mlp is not None), kq, nq, t, inv_scales, _p(x_out), _p(q_out), _p(ln_out), _p(ln_out_map))
+    kv16 = int(bool(q is not None and q.get("kv16", False)))
     if tokens_per_wave == 32:
-        if attn_qkv is not None:
-            raise ValueError("the 32-token debug form takes the message as a tensor")
-        _lib.check(_lib.load_debug().nmrf_nmp_block_f32(_p(x), _p(msg), *tail), "nmp_block")
+        if attn_qkv is not None or kv16:
+            raise ValueError("the 32-token debug form takes the message as a tensor and writes fp32 q | k | v")
+        _lib.check(_lib.load_debug().nmrf_nmp_block_f32(_p(x), _p(msg), *head, _rf(x), _stream()), "nmp_block")
     else:
-        _lib.check(_lib.load().nmrf_nmp_block16_f32(_p(x), _p(msg), _p(attn_qkv), 4 if attn_qkv is not None else 0, *tail), "nmp_block")
+        _lib.check(_lib.load().nmrf_nmp_block16_f32(_p(x), _p(msg), _p(attn_qkv), 4 if attn_qkv is not None else 0, *head, kv16, _rf(x),
+                                                    _stream()), "nmp_block")
     if kernel_hook is not None:
         _he(name)
     return x_out, q_out, ln_out

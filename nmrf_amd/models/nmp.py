@@ -136,8 +136,9 @@ class _BlockLauncher:
     """One nmp_block launch site of a stage: x1 = x + proj(msg); x2 = x1 + mlp(norm2(x1)); then the NEXT block's q|k|v on
     [norm(x2) | side] or the stage's final norm.  The weight stream and the fused bias are rebuilt when a parameter changes."""
 
-    def __init__(self, proj=None, mlp=None, nxt_norm=None, nxt_linears=(), kq=0, ln_out=False):
+    def __init__(self, proj=None, mlp=None, nxt_norm=None, nxt_linears=(), kq=0, ln_out=False, kv16=False):
         self.proj, self.mlp, self.nxt_norm, self.nxt_linears, self.kq, self.ln_out = proj, mlp, nxt_norm, tuple(nxt_linears), kq, ln_out
+        self.kv16 = kv16        # the q|k|v it produces goes to an attention kernel that takes k | v as split fp16 pairs (include/nmrf_hip.h)
         self.cache = _FusedCache()
 
     def _params(self):
@@ -170,7 +171,7 @@ class _BlockLauncher:
         q = None
         if self.nxt_norm is not None:
             q = dict(g=self.nxt_norm.weight, b=self.nxt_norm.bias, eps=self.nxt_norm.eps, extra=extra if self.kq > 128 else None,
-                     extra_div=extra_div, bias=bq, kq=self.kq, nq=nq, ln_out=self.ln_out)
+                     extra_div=extra_div, bias=bq, kq=self.kq, nq=nq, ln_out=self.ln_out, kv16=self.kv16 and nq == 384)
         return K.nmp_block(x, stream, stages, inv, msg, None if self.proj is None else self.proj.bias, mlp, q, want_x=want_x,
                            ln_out=ln_out, ln_out_map=ln_out_map, attn_qkv=attn_qkv)
 
@@ -410,18 +411,20 @@ class Propagation(nn.Module):
         """5 x [stripe attention -> one fused block kernel]; the block of layer i also produces layer i+1's q|k|v."""
         b, h, wd, n = dims
         L = [l.nmp for l in self.layers]
-        if not hasattr(self, "_launch"):
-            self._launch = [_BlockLauncher(nxt_norm=L[0].norm1, nxt_linears=_qkv_of(L[0]), kq=192)]
+        kv16 = n == 4            # the stripe kernels take k | v pre-split at four labels per pixel (every shipped config)
+        if not hasattr(self, "_launch") or self._launch_kv16 != kv16:
+            self._launch_kv16 = kv16
+            self._launch = [_BlockLauncher(nxt_norm=L[0].norm1, nxt_linears=_qkv_of(L[0]), kq=192, kv16=kv16)]
             for i, m in enumerate(L):
                 if i + 1 < len(L):
-                    self._launch.append(_BlockLauncher(m.proj, (m.norm2, m.mlp), L[i + 1].norm1, _qkv_of(L[i + 1]), 192))
+                    self._launch.append(_BlockLauncher(m.proj, (m.norm2, m.mlp), L[i + 1].norm1, _qkv_of(L[i + 1]), 192, kv16=kv16))
                 elif self.norm is not None:
                     self._launch.append(_BlockLauncher(m.proj, (m.norm2, m.mlp), self.norm, (), 128, ln_out=True))
                 else:
                     self._launch.append(_BlockLauncher(m.proj, (m.norm2, m.mlp)))
         _, qkv, _ = self._launch[0](x, None, ctx, n, want_x=False)
         for i, m in enumerate(L):
-            msg = K.stripe_attn(qkv, m.attns[0].get_v.weight, m.attns[1].get_v.weight, b, h, wd, n)
+            msg = K.stripe_attn(qkv, m.attns[0].get_v.weight, m.attns[1].get_v.weight, b, h, wd, n, kv16=kv16)
             last = i + 1 == len(L)
             x, qkv, ln = self._launch[i + 1](x, msg, ctx, n, want_x=not last or self.norm is None)
         return ln if self.norm is not None else x

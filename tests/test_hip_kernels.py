@@ -504,6 +504,37 @@ def test_nmp_block_fused(t_, proj, mlp, kq, nq, div, ln_out, tokens):
         report("block ln_out", lo.cpu(), rl, 1e-5, 1e-5)
 
 
+def test_kv16_format_producer_and_stripe_consumer_bit_exact():
+    """k | v of an attention operand as split fp16 pairs (kv16, include/nmrf_hip.h): the block kernel writes exactly what
+    kernels.to_kv16 (a torch restatement of the format) makes of its fp32 output, and the stripe kernels return, bit for bit, what
+    they return on the fp32 rows -- the split moved, the arithmetic did not."""
+    kk = K()
+    d = lambda v: None if v is None else v.to(DEV)
+    t_ = 47 * 12 * 4
+    x = rnd(t_, 128, seed=1, scale=2.0)
+    msg = rnd(t_, 128, seed=2, scale=1.5)
+    wp, bp = rnd(128, 128, seed=3, scale=0.1), rnd(128, seed=4, scale=0.2)
+    gq, bqn = 1.0 + 0.1 * rnd(128, seed=11), 0.1 * rnd(128, seed=12)
+    ctx = rnd(t_ // 4, 64, seed=13)
+    wq, bq = rnd(384, 192, seed=14, scale=0.1), rnd(384, seed=15)
+    stream, stages, inv = kk.block_stream16(d(wp), None, None, d(wq), 192)
+    q = dict(g=d(gq), b=d(bqn), eps=1e-5, extra=d(ctx), extra_div=4, bias=d(bq), kq=192, nq=384, ln_out=False)
+    _, q32, _ = kk.nmp_block(d(x), stream, stages, inv, d(msg), d(bp), None, q)
+    _, q16, _ = kk.nmp_block(d(x), stream, stages, inv, d(msg), d(bp), None, dict(q, kv16=True))
+    want = kk.to_kv16(q32)
+    assert torch.equal(q16[:, :128], q32[:, :128])
+    assert torch.equal(q16.view(torch.int32), want.view(torch.int32)), "kv16 rows of the block kernel differ from the format's restatement"
+    lv, lh = rnd(64, 1, 3, 3, seed=21, scale=0.3), rnd(64, 1, 3, 3, seed=22, scale=0.3)
+    for (b, h, w) in ((1, 47, 12), (2, 6, 47)):
+        a = kk.stripe_attn(q32, d(lv), d(lh), b, h, w, 4)
+        c = kk.stripe_attn(q16, d(lv), d(lh), b, h, w, 4, kv16=True)
+        # attention: identical operands -> identical bits; LePE reads v back as hi + lo (2^-22 relative)
+        report("stripe attention on kv16 rows", c.cpu(), a.cpu().double(), 2e-6, 1e-6)
+    # the value-independent part bit for bit: zero LePE weights
+    z = torch.zeros_like(lv)
+    assert torch.equal(kk.stripe_attn(q32, d(z), d(z), 1, 47, 12, 4), kk.stripe_attn(q16, d(z), d(z), 1, 47, 12, 4, kv16=True))
+
+
 @pytest.mark.parametrize("t_", [64, 516, 29952, 40004])
 def test_nmp_block_with_self_edge_attention_on_the_way_in(t_):
     """The self-edge block (BasicAttention, NMP.py:90-108) with the 4 x 4 sibling attention evaluated inside the block kernel

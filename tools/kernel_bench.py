@@ -193,10 +193,13 @@ if "stripe" in which:
     lv, lh = mk("lv", 64, 1, 3, 3), mk("lh", 64, 1, 3, 3)
     timeit("stripe_attn (both axes)", lambda: K.stripe_attn(qkv, lv, lh, b, h, w, n))
     so = torch.empty(b * h * w * n, 128, device=dev)
-    for ax, nm in ((1, "vertical"), (2, "horizontal")):
-        timeit("stripe_attn %s only" % nm, lambda: _l.nmrf_stripe_attn_f32(
-            ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(lv.data_ptr()), ctypes.c_void_p(lh.data_ptr()), b, h, w, n, 128, ax,
-            ctypes.c_void_p(so.data_ptr()), None, None))
+    q16 = K.to_kv16(qkv)
+    for rep in range(2):
+        for ax, nm in ((1, "vertical"), (2, "horizontal")):
+            for fmt, src in ((0, qkv), (1, q16)):
+                timeit("stripe_attn %s only, %s" % (nm, "k | v pre-split (kv16)" if fmt else "fp32 rows"), lambda: _l.nmrf_stripe_attn_f32(
+                    ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(lv.data_ptr()), ctypes.c_void_p(lh.data_ptr()), b, h, w, n, 128, ax,
+                    fmt, ctypes.c_void_p(so.data_ptr()), None, None))
 if "refine" in which:
     hp, wp = 96, 312
     qkv, table = mk("q3", b * hp * wp, 384), mk("t3", 49, 384)
