@@ -112,6 +112,15 @@ __global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__rest
     __shared__ float s_ml[KSPLIT > 1 ? 4 : 1][2][64];          // their (m, l)
     constexpr int RB_PER = 4 / KSPLIT;                        // LePE channel blocks computed by each key-range wave
     __shared__ float s_rpe[KSPLIT > 1 ? 4 : 1][4 * RB_PER][64];
+    // SHARED (four-label stripes with pre-split k | v, one key range): the four query tiles of a block walk the same key tiles, so
+    // the block stages each K and V tile ONCE in LDS -- every thread one 16-byte load of a row's 128 contiguous bytes -- instead of
+    // every wave fetching its own fragments, where a K load instruction has each lane on a different row: 64 cache lines per
+    // instruction, four such per tile and wave, and the L1 address path (not the matrix pipe, not the VALU: cutting a third of a
+    // tile's VALU work bought 8 %) set the pace.  Rows are padded to 36 floats: the b128 fragment reads are conflict-free.
+    constexpr bool SHARED = KV16 && KSPLIT == 1 && NSHIFT == 2;
+    constexpr int SROW = 36;
+    __shared__ __attribute__((aligned(16))) float s_k[SHARED ? 2 : 1][SHARED ? 32 * SROW : 4];
+    __shared__ __attribute__((aligned(16))) float s_v[SHARED ? 2 : 1][SHARED ? 32 * SROW : 4];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: key loop + addresses on the SALU
     const int qi = lane & 31, hi = lane >> 5;
@@ -140,7 +149,104 @@ __global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__rest
     for (int r = 0; r < 16; ++r) acc_o[r] = acc_o2[r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    if (wave_on) {
+    if constexpr (SHARED) {
+        // ---- Q fragment (B operand), as below ---------------------------------------------------------------
+        h16x8 qh[2], ql[2];
+        {
+            float qf[16];
+            const float sc2 = scale * SA_LOG2E;
+            const float *p = qkv + qrow * ld + coff + 16 * hi;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float4 v = ldg4(p + 4 * c);
+                qf[4 * c + 0] = v.x * sc2; qf[4 * c + 1] = v.y * sc2; qf[4 * c + 2] = v.z * sc2; qf[4 * c + 3] = v.w * sc2;
+            }
+            split8u_g(qf, qh[0], ql[0], guard);
+            split8u_g(qf + 8, qh[1], ql[1], guard);
+        }
+        const int n_kt = (g.Ts + SA_TILE - 1) / SA_TILE;
+        // staging role of this thread: row (key) tid / 8 of the tile, 16-byte piece tid % 8 of its 128-byte head block
+        const int srow = threadIdx.x >> 3, spc = threadIdx.x & 7;
+        const int64_t ps = (AXIS == 1) ? (int64_t)1 : g.pix_stride;
+        auto stage_ptr = [&](int kt) -> const float * {
+            int kk = kt * SA_TILE + srow;
+            kk = kk < g.Ts ? kk : g.Ts - 1;                       // rows beyond the stripe shadow its last token (masked below)
+            return qkv + stripe_row<NSHIFT>(g, base_pix, kk) * ld + coff + 4 * spc;
+        };
+        float4 rk, rv;
+        auto fetch_tile = [&](int kt) { const float *p = stage_ptr(kt); rk = ldg4(p + g.C); rv = ldg4(p + 2 * g.C); };
+        auto store_tile = [&](int buf) {
+            stg4(&s_k[buf][srow * SROW + 4 * spc], rk);
+            stg4(&s_v[buf][srow * SROW + 4 * spc], rv);
+        };
+        fetch_tile(0);
+        store_tile(0);
+        __syncthreads();
+#pragma unroll 1
+        for (int kt = 0; kt < n_kt; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < n_kt) fetch_tile(kt + 1);                // in flight under this tile's arithmetic
+            if (wave_on) {
+                const int k0 = kt * SA_TILE;
+                h16x8 kh[2], kl[2], vh[2], vl[2];
+                {
+                    const float *kr = &s_k[buf][qi * SROW + 8 * hi];            // hi halves of channels 16 hi .. +15, lo 16 floats on
+                    kh[0] = *reinterpret_cast<const h16x8 *>(kr);      kh[1] = *reinterpret_cast<const h16x8 *>(kr + 4);
+                    kl[0] = *reinterpret_cast<const h16x8 *>(kr + 16); kl[1] = *reinterpret_cast<const h16x8 *>(kr + 20);
+                    float vw[16];
+#pragma unroll
+                    for (int s2 = 0; s2 < 16; ++s2) vw[s2] = s_v[buf][mfma_row(s2, hi) * SROW + qi];
+                    kv16_chunks(vw, vh, vl);
+                }
+                f32x16 st;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[r] = 0.f;
+                split_mma1(kh[0], kl[0], qh[0], ql[0], st);
+                split_mma1(kh[1], kl[1], qh[1], ql[1], st);
+                if (kt == n_kt - 1) {                             // keys beyond the stripe (last tile only)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (k0 + mfma_row(r, hi) >= g.Ts) st[r] = -INFINITY;
+                }
+                if (kt == qt && nlab > 1) {                       // sibling labels of the query's own pixel (diagonal tile)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kk = k0 + mfma_row(r, hi);
+                        if (div_n<NSHIFT>(g, kk) == q_pix && kk != qsc) st[r] = -INFINITY;
+                    }
+                }
+                float m_tile = st[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) m_tile = fmaxf(m_tile, st[r]);
+                m_tile = half_max(m_tile);
+                const float m_new = fmaxf(m_run, m_tile);
+                const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+                float psum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    st[r] = __builtin_amdgcn_exp2f(st[r] - m_use);
+                    psum += st[r];
+                }
+                l_run = l_run * alpha + psum;
+                m_run = m_new;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc_o[r] *= alpha;
+                float pv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pv[r] = st[r];
+                h16x8 ph[2], pl[2];
+                split8u(pv, ph[0], pl[0]);
+                split8u(pv + 8, ph[1], pl[1]);
+                split_mma1(vh[0], vl[0], ph[0], pl[0], acc_o);
+                split_mma1(vh[1], vl[1], ph[1], pl[1], acc_o);
+            }
+            if (kt + 1 < n_kt) store_tile(buf ^ 1);               // (last read during tile kt - 1: every wave is past that barrier)
+            __syncthreads();
+        }
+        l_run = half_sum(l_run);
+    }
+    if (!SHARED && wave_on) {
         // ---- Q fragment (B operand): lane (qi,hi) holds Q[q0+qi][16*hi + s], pre-scaled by s*log2(e) ------
         float qf[16];
         {
@@ -457,6 +563,9 @@ static void launch_stripe(const float *qkv, const float *lepe, const StripeGeom 
     const int n_qt = (g_in.Ts + SA_TILE - 1) / SA_TILE;
     int ksplit = 1;
     if (n_qt >= 4 && n_qt < 16) ksplit = 2;
+    // pre-split rows: the block stages each key tile once for its four query tiles (SHARED), which needs them on one key range --
+    // vertical KITTI stripes 20.4 us against 22.2 for two key ranges with per-wave fragments (and 27.3 for fp32 rows unsplit)
+    if (KV16 && NSHIFT == 2) ksplit = 1;
 #ifdef NMRF_DEBUG_PROBES
     static const char *force = getenv("NMRF_STRIPE_KSPLIT");   // tuning override (tools/kernel_bench.py), debug library only
     if (force && (force[0] == '1' || force[0] == '2' || force[0] == '4')) ksplit = force[0] - '0';
