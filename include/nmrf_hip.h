@@ -134,7 +134,9 @@ int nmrf_self_attn_f32(const float *qkv, int64_t T, int N, int C, int heads, flo
  * Hp%win==0, Wp%win==0; shift in [0,win); sibling_mask!=0 forbids attention between different labels of one pixel.
  * -> out [B,Hp,Wp,N,C] (already un-rolled). heads*32==C. */
 int nmrf_window_attn_f32(const float *qkv, const float *table, int B, int Hp, int Wp, int N, int C, int heads,
-                         int win, int shift, int sibling_mask, float *out, int *range_flag, void *stream);
+                         int win, int shift, int sibling_mask, int kv16, float *out, int *range_flag, void *stream);
+/* (kv16 != 0: the k | v thirds of qkv hold split fp16 operand pairs, see nmrf_nmp_block16_f32; win == 6, N == 4, range_flag == NULL:
+ *  the range of such rows was checked by their producer.) */
 
 /* A8/A11/A14  narrow prediction-head layers: out[T,N] = act(x[T,K] w[N,K]^T + bias), N <= 64, K % 4 == 0, K <= 512
  * (LDS: 32*(K+4) + 8*npt*K floats <= 64 KiB), act 0 = identity, 1 = ReLU; bias may be NULL.

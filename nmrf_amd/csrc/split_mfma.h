@@ -149,6 +149,29 @@ __device__ __forceinline__ void split_dot16_g(const float *a, const f32x16 &b, f
     split_dot16_g<GB>(a, bv, acc, g);
 }
 
+// ---- kv16: k | v of an attention operand stored as split pairs by their producer (include/nmrf_hip.h, nmrf_nmp_block16_f32) ----------
+// value c of a kv16 row's v third: hi | lo << 16 (include/nmrf_hip.h) -> the float it was split from (up to 2^-22 relative)
+__device__ __forceinline__ float kv16_value(float w) {
+    const unsigned u = __builtin_bit_cast(unsigned, w);
+    return (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu)) + (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16));
+}
+// 16 such words (MFMA k-slot order s = 8c + jj) -> the hi / lo operand chunks: two v_perm_b32 per pair of values, no arithmetic
+__device__ __forceinline__ void kv16_chunks(const float *w, h16x8 (&vh)[2], h16x8 (&vl)[2]) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned e0 = __builtin_bit_cast(unsigned, w[8 * c + 2 * k]), e1 = __builtin_bit_cast(unsigned, w[8 * c + 2 * k + 1]);
+            h[k] = __builtin_amdgcn_perm(e1, e0, 0x05040100u);
+            l[k] = __builtin_amdgcn_perm(e1, e0, 0x07060302u);
+        }
+        const uint4 hv = make_uint4(h[0], h[1], h[2], h[3]), lv = make_uint4(l[0], l[1], l[2], l[3]);
+        vh[c] = __builtin_bit_cast(h16x8, hv);
+        vl[c] = __builtin_bit_cast(h16x8, lv);
+    }
+}
+
 // k slot order of a B operand that is taken straight from a C/D result (and of every A operand contracted with it):
 // slot jj (0..7) of half hi of k chunk c  <->  k = 16*c + (jj&3) + 8*(jj>>2) + 4*hi.  With this order the 16 registers of
 // a 32-row D strip ARE two consecutive k chunks of the next contraction (regs 0-7 -> chunk 0, regs 8-15 -> chunk 1): no

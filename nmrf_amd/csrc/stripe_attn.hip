@@ -54,28 +54,6 @@ __device__ __forceinline__ int64_t stripe_row(const StripeGeom &g, int64_t base_
 // __launch_bounds__(256, 3): with a register budget <= 256 the compiler keeps the MFMA accumulators in VGPRs; without the
 // occupancy hint it parks them in AGPRs and every `acc *= alpha` / softmax pass pays v_accvgpr_read/write round trips
 // (112 of them per key tile in the first version of this kernel).
-// value c of a kv16 row's v third: hi | lo << 16 (include/nmrf_hip.h) -> the float it was split from (up to 2^-22 relative)
-__device__ __forceinline__ float kv16_value(float w) {
-    const unsigned u = __builtin_bit_cast(unsigned, w);
-    return (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu)) + (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16));
-}
-// 16 such words (MFMA k-slot order s = 8c + jj) -> the hi / lo operand chunks: two v_perm_b32 per pair of values, no arithmetic
-__device__ __forceinline__ void kv16_chunks(const float *w, h16x8 (&vh)[2], h16x8 (&vl)[2]) {
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        unsigned h[4], l[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned e0 = __builtin_bit_cast(unsigned, w[8 * c + 2 * k]), e1 = __builtin_bit_cast(unsigned, w[8 * c + 2 * k + 1]);
-            h[k] = __builtin_amdgcn_perm(e1, e0, 0x05040100u);
-            l[k] = __builtin_amdgcn_perm(e1, e0, 0x07060302u);
-        }
-        const uint4 hv = make_uint4(h[0], h[1], h[2], h[3]), lv = make_uint4(l[0], l[1], l[2], l[3]);
-        vh[c] = __builtin_bit_cast(h16x8, hv);
-        vl[c] = __builtin_bit_cast(h16x8, lv);
-    }
-}
-
 // KV16: the k and v thirds of a qkv row hold split fp16 operand pairs (the producing block kernel wrote them so: kv16 of
 // nmrf_nmp_block16_f32, include/nmrf_hip.h) -- the K fragment is four 16-byte loads that ARE the MFMA operands, the V fragment
 // 16 words and 16 v_perm_b32; without it each key tile pays 2 x 48 VALU instructions to split them (of ~250 in a tile).

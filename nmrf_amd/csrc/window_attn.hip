@@ -334,7 +334,10 @@ struct WinFastLds {
 // PK = 2 (refinement windows: 16 tokens): TWO windows share a wave's 32-token tile -- tokens 0..15 of window 2k, 16..31 of window
 // 2k+1; the off-diagonal quarters of S^T are masked.  Every per-lane phase (relative-position dots, softmax, value-embedding
 // term) then works on 32 real tokens instead of 16, and one MFMA pair serves two windows.
-template <int NKT, int WIN, int NL, int WPB, int OCC, bool TIMED = false, int PK = 1>
+// KV16: k | v arrive as split fp16 pairs (written so by the producing block kernel, include/nmrf_hip.h): the K fragment loads ARE the
+// MFMA operands, V takes 16 v_perm_b32, and the scaled Q fragment is parked in LDS already split -- 104 VALU instructions less per
+// key tile; the phase-0 operand of the key lanes is rebuilt as hi + lo once (2^-22 relative, the precision of the products).
+template <int NKT, int WIN, int NL, int WPB, int OCC, bool TIMED = false, int PK = 1, bool KV16 = false>
 __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(const float *__restrict__ qkv,
         const float *__restrict__ table, WinGeom g, float scale, float *__restrict__ out,
         unsigned long long *__restrict__ stamps = nullptr) {
@@ -416,6 +419,26 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
             float4 v = ldg4(src + 4 * c);
             vec[4 * c + 0] = v.x; vec[4 * c + 1] = v.y; vec[4 * c + 2] = v.z; vec[4 * c + 3] = v.w;
         }
+        if constexpr (KV16) {
+            // key lanes hold the head's [32 hi halves | 32 lo halves]: channel c = half c % 2 of word c / 2 (hi), of word 16 + c / 2 (lo)
+            auto dec = [&](int c) {                 // (float) hi + (float) lo of channel c
+                const unsigned wh = __builtin_bit_cast(unsigned, vec[c >> 1]), wl = __builtin_bit_cast(unsigned, vec[16 + (c >> 1)]);
+                const unsigned short hh = (unsigned short)((c & 1) ? (wh >> 16) : (wh & 0xffffu)), ll = (unsigned short)((c & 1) ? (wl >> 16) : (wl & 0xffffu));
+                return (float)__builtin_bit_cast(_Float16, hh) + (float)__builtin_bit_cast(_Float16, ll);
+            };
+            // in place with 16 temporaries: channels 16 .. 31 first (words 8 .. 15 and 24 .. 31), then 15 .. 0 downwards -- channel c
+            // lands in slot c, whose word (c < 16: hi word c, needed by channels 2c, 2c + 1 > c) has been consumed by then
+            float up[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) up[c] = dec(16 + c);
+#pragma unroll
+            for (int c = 15; c >= 0; --c) {
+                const float v = dec(c);
+                vec[c] = hi ? v : vec[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) vec[16 + c] = hi ? up[c] : vec[16 + c];
+        }
     }
     // ---- stage ek / eq (all loads first, then the LDS stores), build the row map ----------------------
     {
@@ -459,7 +482,16 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
         for (int c = 0; c < 4; ++c) {
             float4 v = ldg4(p + 4 * c);
             qf[4 * c + 0] = v.x * sc2; qf[4 * c + 1] = v.y * sc2; qf[4 * c + 2] = v.z * sc2; qf[4 * c + 3] = v.w * sc2;
-            if (QLDS) stg4(qsc + ((qt * 4 + c) * 64 + lane) * 4, make_float4(qf[4 * c], qf[4 * c + 1], qf[4 * c + 2], qf[4 * c + 3]));
+            if (QLDS && !KV16) stg4(qsc + ((qt * 4 + c) * 64 + lane) * 4, make_float4(qf[4 * c], qf[4 * c + 1], qf[4 * c + 2], qf[4 * c + 3]));
+        }
+        if constexpr (QLDS && KV16) {                                  // parked as operand chunks: hi 0, hi 1, lo 0, lo 1
+            h16x8 sh[2], sl[2];
+            split8u(qf, sh[0], sl[0]);
+            split8u(qf + 8, sh[1], sl[1]);
+            *reinterpret_cast<h16x8 *>(qsc + ((qt * 4 + 0) * 64 + lane) * 4) = sh[0];
+            *reinterpret_cast<h16x8 *>(qsc + ((qt * 4 + 1) * 64 + lane) * 4) = sh[1];
+            *reinterpret_cast<h16x8 *>(qsc + ((qt * 4 + 2) * 64 + lane) * 4) = sl[0];
+            *reinterpret_cast<h16x8 *>(qsc + ((qt * 4 + 3) * 64 + lane) * 4) = sl[1];
         }
     }
 
@@ -493,14 +525,14 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
     }
     WA_STAMP(3);
     // first K fragment: its latency overlaps the barrier and the ev stores
-    const float *kbase = qkv + g.C + head * 32 + 16 * hi;
+    const float *kbase = qkv + g.C + head * 32 + (KV16 ? 8 : 16) * hi;       // KV16: hi halves at 8 hi floats, lo halves 16 floats on
     const float *vbase = qkv + 2 * g.C + head * 32 + qi;
     float kf[16], vf[16];
     auto load_k = [&](int kt, float *kd) {
         const float *p = kbase + rowoff[32 * kt + qi];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            float4 v = ldg4(p + 4 * c);
+            float4 v = ldg4(p + (KV16 ? (c < 2 ? 4 * c : 8 + 4 * c) : 4 * c));
             kd[4 * c + 0] = v.x; kd[4 * c + 1] = v.y; kd[4 * c + 2] = v.z; kd[4 * c + 3] = v.w;
         }
     };
@@ -552,7 +584,7 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
         load_v(kt, vf);                             // needed only after S^T + softmax (~1.5k cycles from here); the K
         //                                             fragment of the NEXT tile is fetched right after this tile's S^T, so
         //                                             only one of the two 16-register fragments is live during the ev term
-        if (QLDS) {
+        if (QLDS && !KV16) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 float4 v = *reinterpret_cast<const float4 *>(qsc + ((qt * 4 + c) * 64 + lane) * 4);
@@ -562,6 +594,22 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
         f32x16 st;
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[r] = 0.f;
+        if constexpr (KV16) {                               // every operand chunk arrives split: no arithmetic before the MFMAs
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {                   // (one Q chunk in registers at a time: the kernel sits at its register cap)
+                const h16x8 kh = __builtin_bit_cast(h16x8, f32x4{kf[4 * c], kf[4 * c + 1], kf[4 * c + 2], kf[4 * c + 3]});
+                const h16x8 kl = __builtin_bit_cast(h16x8, f32x4{kf[8 + 4 * c], kf[9 + 4 * c], kf[10 + 4 * c], kf[11 + 4 * c]});
+                h16x8 qh2, ql2;
+                if constexpr (QLDS) {
+                    qh2 = *reinterpret_cast<const h16x8 *>(qsc + ((qt * 4 + c) * 64 + lane) * 4);
+                    ql2 = *reinterpret_cast<const h16x8 *>(qsc + ((qt * 4 + 2 + c) * 64 + lane) * 4);
+                } else {
+                    split8u(qf + 8 * c, qh2, ql2);
+                }
+                split_mma1(kh, kl, qh2, ql2, st);
+                if (c == 0) __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
         split_dot16(kf, qf, st);                            // S^T = K . Q^T on split-fp16 MFMA (split_mfma.h)
         if (kt + 1 < NKT) load_k(kt + 1, kf);
         // relative-position terms: one b128 of KR^T per key quad, QR^T per key pixel
@@ -628,6 +676,17 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
         for (int r = 0; r < 16; ++r) acc_o[r] *= alpha;
 #pragma unroll
         for (int r = 0; r < 8; ++r) oe[r] *= alpha;
+        if constexpr (KV16) {
+            float pv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pv[r] = st[r];
+            h16x8 ph[2], pl[2], vh[2], vl[2];
+            split8u(pv, ph[0], pl[0]);
+            split8u(pv + 8, ph[1], pl[1]);
+            kv16_chunks(vf, vh, vl);
+            split_mma1(vh[0], vl[0], ph[0], pl[0], acc_o);
+            split_mma1(vh[1], vl[1], ph[1], pl[1], acc_o);
+        } else
         split_dot16(vf, st, acc_o);                         // O^T += V^T . P^T on split-fp16 MFMA
         // value-embedding term: sum over key PIXELS of (sum_n p) * ev[rel(pq,pk)].  The two half-lanes of a query
         // swap the probabilities of their pixels, then each accumulates BOTH pixels for its own 16 channels.
@@ -677,7 +736,7 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
     WA_CENSUS(2, wall_clock64());
 }
 
-template <int NKT, int WIN, int NL, int WPB, int OCC, int PK = 1>
+template <int NKT, int WIN, int NL, int WPB, int OCC, int PK = 1, bool KV16 = false>
 static int launch_window_fast(const float *qkv, const float *table, const WinGeom &g, int B, float *out, hipStream_t st) {
     using L = WinFastLds<NKT, WIN, NL, WPB, PK>;
     static_assert(L::BYTES <= 160 * 1024, "LDS budget of one CU");
@@ -685,14 +744,14 @@ static int launch_window_fast(const float *qkv, const float *table, const WinGeo
     const int dev = nmrf_cur_device();
     if (dev < 0) return NMRF_ELAUNCH;
     if (L::BYTES > 64 * 1024 && !attr_set_dev[dev]) {
-        if (hipFuncSetAttribute((const void *)window_attn_fast_kernel<NKT, WIN, NL, WPB, OCC, false, PK>,
+        if (hipFuncSetAttribute((const void *)window_attn_fast_kernel<NKT, WIN, NL, WPB, OCC, false, PK, KV16>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES) != hipSuccess)
             return NMRF_ELAUNCH;
         attr_set_dev[dev] = true;
     }
     const int nwin = (g.Hp / WIN) * (g.Wp / WIN);
     dim3 grid((nwin + WPB * PK - 1) / (WPB * PK), g.heads, B);
-    hipLaunchKernelGGL((window_attn_fast_kernel<NKT, WIN, NL, WPB, OCC, false, PK>), grid, dim3(64 * NKT * WPB), L::BYTES, st, qkv,
+    hipLaunchKernelGGL((window_attn_fast_kernel<NKT, WIN, NL, WPB, OCC, false, PK, KV16>), grid, dim3(64 * NKT * WPB), L::BYTES, st, qkv,
                        table, g, 1.0f / sqrtf(32.0f), out, (unsigned long long *)nullptr);
     return nmrf_launch_status();
 }
@@ -775,8 +834,9 @@ extern "C" int nmrf_range_scan_f32(const float *x, int64_t n, int *range_flag, v
 }
 
 extern "C" int nmrf_window_attn_f32(const float *qkv, const float *table, int B, int Hp, int Wp, int N, int C, int heads,
-                                    int win, int shift, int sibling_mask, float *out, int *range_flag, void *stream) {
+                                    int win, int shift, int sibling_mask, int kv16, float *out, int *range_flag, void *stream) {
     if (!qkv || !table || !out) return NMRF_ENULL;
+    if (kv16 && (win != 6 || N != 4 || range_flag)) return NMRF_EINVAL;     // the pre-split form: 6 x 6 x 4 inference windows, range checked by the producer
     if (B < 1 || N < 1 || win < 1 || Hp % win || Wp % win || shift < 0 || shift >= win || heads * 32 != C || (C & 3))
         return NMRF_EINVAL;
     if ((int64_t)B * Hp * Wp * N >= (int64_t)1 << 31) return NMRF_EINVAL;
@@ -788,6 +848,7 @@ extern "C" int nmrf_window_attn_f32(const float *qkv, const float *table, int B,
         if (rc != NMRF_OK) return rc;
     }
     if ((int64_t)B * Hp * Wp * N * 3 * C < ((int64_t)1 << 32)) {                            // 32-bit element offsets
+        if (win == 6 && N == 4 && kv16) return launch_window_fast<5, 6, 4, 2, 3, 1, true>(qkv, table, g, B, out, st);
         if (win == 6 && N == 4) return launch_window_fast<5, 6, 4, 2, 3>(qkv, table, g, B, out, st);   // inference windows
 #ifdef NMRF_DEBUG_PROBES
         if (win == 4 && N == 1 && g_window_pack1 == 1) return launch_window_fast<1, 4, 1, 8, 2, 1>(qkv, table, g, B, out, st);

@@ -311,14 +311,16 @@ def self_attn(qkv, n, heads):
 
 
 @_on_device
-def window_attn(qkv, table, b, hp, wp, n, heads, win, shift, sibling_mask, checked=False):
+def window_attn(qkv, table, b, hp, wp, n, heads, win, shift, sibling_mask, checked=False, kv16=False):
+    """checked: the producer of qkv range-checked it (no scan pass).  kv16: the k | v thirds of qkv are split fp16 operand pairs
+    (nmp_block(q=dict(kv16=True)) / to_kv16; 6 x 6 windows of four labels; implies checked)."""
     _chk(qkv, table)
     t, c3 = qkv.shape
     c = c3 // 3
     assert t == b * hp * wp * n
     out = torch.empty(t, c, device=qkv.device, dtype=torch.float32)
     tw = win * win * n                                 # reference form: 5 contractions of tw^2 x 32 MACs per (window, head)
-    fast = {(6, 4): "window_attn_fast_kernel<5, 6, 4, 2, 3,", (4, 1): "window_attn_fast_kernel<1, 4, 1, 4, 3,"}
+    fast = {(6, 4): "window_attn_fast_kernel<5, 6, 4, 2, 3, false, 1, %s>" % ("true" if kv16 else "false"), (4, 1): "window_attn_fast_kernel<1, 4, 1, 4, 3,"}
     _hb("window_attn_w%d_n%d" % (win, n), row="A10" if n > 1 else "A13", bound="mfma", split=True,
         flops=b * (hp // win) * (wp // win) * heads * 5 * 2.0 * tw * tw * 32, bytes=4.0 * (qkv.numel() + t * c),
         label="%s (%s windows, %s)" % (fast.get((win, n), "window_attn_kernel<%d>" % ((tw + 31) // 32)).split("<")[0] +
@@ -327,7 +329,8 @@ def window_attn(qkv, table, b, hp, wp, n, heads, win, shift, sibling_mask, check
         pmc=[fast.get((win, n), "window_attn_kernel<%d>" % ((tw + 31) // 32))] + (["window_attn_fast_kernel<1, 4, 1, 8, 2, false, 2>"]
                                                                                     if (win, n) == (4, 1) else []))
     _lib.check(_lib.load().nmrf_window_attn_f32(_p(qkv), _p(table), b, hp, wp, n, c, heads, win, shift,
-                                                int(bool(sibling_mask)), _p(out), None if checked else _rf(qkv), _stream()),
+                                                int(bool(sibling_mask)), int(kv16), _p(out), None if (checked or kv16) else _rf(qkv),
+                                                _stream()),
                "window_attn")
     _he("window_attn_w%d_n%d" % (win, n))
     return out

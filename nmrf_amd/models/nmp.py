@@ -277,12 +277,17 @@ class WindowAttention(nn.Module):
         idx = (rel[0] + wh - 1) * (2 * ww - 1) + (rel[1] + ww - 1)
         self.register_buffer("relative_position_index", idx)      # state-dict parity; the kernel derives it itself
 
-    def forward(self, qkv, dims, sibling_mask, checked=False):
+    def kv16_ok(self, n):
+        """this window geometry has a kernel that takes k | v as split fp16 pairs (include/nmrf_hip.h): 6 x 6 windows of 4 labels"""
+        return tuple(self.window_size) == (6, 6) and n == 4 and self.num_heads == 4
+
+    def forward(self, qkv, dims, sibling_mask, checked=False, kv16=False):
         """qkv [T,3C] token-major on the padded grid dims=(B,Hp,Wp,N) -> [T,C].  checked: qkv comes from nmp_block16, which has
-        range-checked it (include/nmrf_hip.h, "fp16 range"); otherwise the entry point scans it first."""
+        range-checked it (include/nmrf_hip.h, "fp16 range"); otherwise the entry point scans it first.  kv16: ... and wrote its
+        k | v thirds as split fp16 operand pairs."""
         b, hp, wp, n = dims
         return K.window_attn(qkv, self.relative_position_enc_table, b, hp, wp, n, self.num_heads,
-                             self.window_size[0], self.shift_size, sibling_mask, checked=checked)
+                             self.window_size[0], self.shift_size, sibling_mask, checked=checked, kv16=kv16)
 
 
 class SwinNMP(nn.Module):
@@ -577,12 +582,15 @@ class Inference(nn.Module):
                 sites.append(("win", l.nmp))
             self._sites = sites
             first = sites[0][1]
-            self._launch = [_BlockLauncher(nxt_norm=first.norm1, nxt_linears=_qkv_of(first), kq=160)]
+            # a launch site that feeds a window attention with a pre-split form writes k | v as split fp16 pairs (kv16)
+            kv = lambda kind_m: kind_m[0] == "win" and kind_m[1].attn.kv16_ok(n)
+            self._site_kv16 = [kv(sm) for sm in sites]
+            self._launch = [_BlockLauncher(nxt_norm=first.norm1, nxt_linears=_qkv_of(first), kq=160, kv16=self._site_kv16[0])]
             for i, (kind, m) in enumerate(sites):
                 mlp = (m.norm2, m.mlp) if kind == "win" else None
                 if i + 1 < len(sites):
                     nx = sites[i + 1][1]
-                    self._launch.append(_BlockLauncher(m.proj, mlp, nx.norm1, _qkv_of(nx), 160))
+                    self._launch.append(_BlockLauncher(m.proj, mlp, nx.norm1, _qkv_of(nx), 160, kv16=self._site_kv16[i + 1]))
                 elif self.norm is not None:
                     self._launch.append(_BlockLauncher(m.proj, mlp, self.norm, (), 128, ln_out=True))
                 else:
@@ -596,7 +604,7 @@ class Inference(nn.Module):
             elif kind == "self":
                 msg = K.self_attn(qkv, n, m.num_heads)
             else:
-                msg = m.attn(qkv, pdims, n > 1, checked=True)           # sibling mask for N > 1 (inference), none for refinement
+                msg = m.attn(qkv, pdims, n > 1, checked=True, kv16=self._site_kv16[i])   # sibling mask for N > 1 (inference), none for refinement
             last = i + 1 == len(self._sites)
             if last and self.norm is not None and to_dense is not None:       # final norm, cropped to the dense grid on the way out
                 ln = torch.empty(t_dense, self.dim, device=x.device)

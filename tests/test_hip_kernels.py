@@ -539,6 +539,20 @@ def test_kv16_format_producer_and_stripe_consumer_bit_exact():
     assert torch.equal(kk.stripe_attn(r32, d(z), d(z), 1, 130, 3, 4), kk.stripe_attn(r16, d(z), d(z), 1, 130, 3, 4, kv16=True))
 
 
+@pytest.mark.parametrize("shift", [0, 3])
+def test_window_attention_on_kv16_rows(shift):
+    """The 6 x 6 x 4 inference-window kernel on rows whose k | v thirds are split fp16 pairs against the same kernel on the fp32
+    rows they were split from: same MFMA operands bit for bit; the relative-position terms of the keys are formed from hi + lo
+    (2^-22 relative), so the comparison carries the tolerance of one such rounding through the softmax."""
+    kk = K()
+    b, hp, wp, n = 2, 12, 18, 4
+    qkv = rnd(b * hp * wp * n, 384, seed=41, scale=1.2).to(DEV)
+    table = (rnd(121, 384, seed=42, scale=0.3)).to(DEV)
+    a = kk.window_attn(qkv, table, b, hp, wp, n, 4, 6, shift, True)
+    c = kk.window_attn(kk.to_kv16(qkv), table, b, hp, wp, n, 4, 6, shift, True, kv16=True)
+    report("window attention on kv16 rows", c.cpu(), a.cpu().double(), 3e-6, 1e-6)
+
+
 @pytest.mark.parametrize("t_", [64, 516, 29952, 40004])
 def test_nmp_block_with_self_edge_attention_on_the_way_in(t_):
     """The self-edge block (BasicAttention, NMP.py:90-108) with the 4 x 4 sibling attention evaluated inside the block kernel

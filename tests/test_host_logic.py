@@ -68,7 +68,7 @@ def test_entry_points_validate_arguments_without_touching_the_gpu():
     one = ctypes.c_void_p(16)
     assert lib.nmrf_cost_volume_f32(one, one, 1, 255, 4, 4, 40, 4, one, None) == -1           # C % G != 0
     assert lib.nmrf_nms_topk_f32(one, 10, 300, 4, 1e-3, 1, one, None) == -1                   # D > 64
-    assert lib.nmrf_window_attn_f32(one, one, 1, 13, 12, 4, 128, 4, 6, 0, 1, one, None, None) == -1 # Hp % win
+    assert lib.nmrf_window_attn_f32(one, one, 1, 13, 12, 4, 128, 4, 6, 0, 1, 0, one, None, None) == -1 # Hp % win
     assert lib.nmrf_stripe_attn_f32(one, one, one, 1, 4, 4, 4, 128, 0, 0, one, None, None) == -1    # axes == 0
 
 

@@ -186,8 +186,11 @@ if "block" in which:
 if "window" in which:
     hp, wp = 48, 156
     qkv, table = mk("q", b * hp * wp * n, 384), mk("t", 121, 384)
-    for shift in (0, 3):
-        timeit("window_attn 6x6x4 shift=%d" % shift, lambda: K.window_attn(qkv, table, b, hp, wp, n, 4, 6, shift, True))
+    q16 = K.to_kv16(qkv)
+    for rep in range(2):
+        for shift in (0, 3):
+            timeit("window_attn 6x6x4 shift=%d" % shift, lambda: K.window_attn(qkv, table, b, hp, wp, n, 4, 6, shift, True, checked=True))
+            timeit("window_attn 6x6x4 shift=%d, k | v pre-split (kv16)" % shift, lambda: K.window_attn(q16, table, b, hp, wp, n, 4, 6, shift, True, kv16=True))
 if "stripe" in which:
     qkv = mk("q2", b * h * w * n, 384)
     lv, lh = mk("lv", 64, 1, 3, 3), mk("lh", 64, 1, 3, 3)
