@@ -200,56 +200,66 @@ __global__ __launch_bounds__(256, 5) void warp_corr_concat_kernel(const float *_
     const WarpTaps tp = make_taps(labels[t], x, y, H, W);
     float *o = out + t * ld;
     const float *pf1 = f1 + (size_t)b * Cf * plane, *pf2 = f2 + (size_t)b * Cf * plane;
-    const int fc = Cf / WC_CHUNKS;                          // feature channels per chunk (multiple of 4, host-checked)
-    // Loads first, arithmetic after, in batches of 4 channels = 4 + 16 independent loads in flight per batch and thread; a
-    // channel row is `plane` floats from the next, the lane part of every address is one of five 32-bit offsets.
-    for (int c = chunk * fc; c < (chunk + 1) * fc; c += 4) {
-        float a[4], v[4][4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float *p1 = pf1 + (size_t)(c + k) * plane, *p2 = pf2 + (size_t)(c + k) * plane;      // uniform
-            a[k] = p1[pix];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[k][q] = p2[tp.off[q]];
-        }
-        float w[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) w[k] = warp_combine(v[k], tp);
-        stg4(o + c, make_float4(a[0], a[1], a[2], a[3]));
-        stg4(o + Cf + c, make_float4(w[0], w[1], w[2], w[3]));
-    }
     const float *pg1 = g1 + (size_t)b * Cg * plane, *pg2 = g2 + (size_t)b * Cg * plane;
-    const float inv = 1.0f / (float)cpg;
+    const int fc = Cf / WC_CHUNKS;                          // feature channels per chunk (multiple of 4, host-checked)
     const int gc = groups / WC_CHUNKS;                      // correlation groups per chunk (multiple of 4)
-    for (int g = chunk * gc; g < (chunk + 1) * gc; g += 4) {
-        float r[4];
+    const float inv = 1.0f / (float)cpg;
+    // The sampling row is the pixel's own row: gy -> iy reproduces y EXACTLY for ~4 of 5 rows (35 of 47 at KITTI 1/8 resolution),
+    // and then the two taps of row y0 + 1 carry the weight wy1 * wx = 0 * wx = exactly 0 -- for every lane of the wave, which
+    // shares y.  Such waves load two taps instead of four (0 * finite = 0 and r + 0 = r: bit-identical); the other rows, where
+    // the float round trip lands an ulp beside y, keep all four (H6).  A wave-uniform choice, so both bodies stay straight-line.
+    const bool two_taps = __builtin_amdgcn_ballot_w64(tp.w[2] != 0.f || tp.w[3] != 0.f) == 0;
+    auto body = [&](auto two_c) {
+        constexpr int NT = decltype(two_c)::value ? 2 : 4;
+        // Loads first, arithmetic after, in batches of 4 channels = 4 + 4 NT independent loads in flight per batch and thread; a
+        // channel row is `plane` floats from the next, the lane part of every address is one of five 32-bit offsets.
+        for (int c = chunk * fc; c < (chunk + 1) * fc; c += 4) {
+            float a[4], v[4][4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float s = 0.f;
-            if (cpg == 8) {                                 // every shipped config: 256 channels in 32 groups -- 8 + 32 loads per group
-                float a[8], v[8][4];
+            for (int k = 0; k < 4; ++k) {
+                const float *p1 = pf1 + (size_t)(c + k) * plane, *p2 = pf2 + (size_t)(c + k) * plane;      // uniform
+                a[k] = p1[pix];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const size_t ch = (size_t)((g + k) * 8 + c) * plane;
-                    a[c] = pg1[ch + pix];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[c][q] = (pg2 + ch)[tp.off[q]];
-                }
-#pragma unroll
-                for (int c = 0; c < 8; ++c) s = fmaf(a[c], warp_combine(v[c], tp), s);
-            } else {
-                for (int c = 0; c < cpg; ++c) {
-                    const size_t ch = (size_t)((g + k) * cpg + c) * plane;
-                    float v[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = (pg2 + ch)[tp.off[q]];
-                    s = fmaf(pg1[ch + pix], warp_combine(v, tp), s);
-                }
+                for (int q = 0; q < 4; ++q) v[k][q] = q < NT ? p2[tp.off[q]] : 0.f;
             }
-            r[k] = s * inv;
+            float w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] = warp_combine(v[k], tp);
+            stg4(o + c, make_float4(a[0], a[1], a[2], a[3]));
+            stg4(o + Cf + c, make_float4(w[0], w[1], w[2], w[3]));
         }
-        stg4(o + 2 * Cf + g, make_float4(r[0], r[1], r[2], r[3]));
-    }
+        for (int g = chunk * gc; g < (chunk + 1) * gc; g += 4) {
+            float r[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float s = 0.f;
+                if (cpg == 8) {                             // every shipped config: 256 channels in 32 groups -- 8 + 8 NT loads per group
+                    float a[8], v[8][4];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const size_t ch = (size_t)((g + k) * 8 + c) * plane;
+                        a[c] = pg1[ch + pix];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[c][q] = q < NT ? (pg2 + ch)[tp.off[q]] : 0.f;
+                    }
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) s = fmaf(a[c], warp_combine(v[c], tp), s);
+                } else {
+                    for (int c = 0; c < cpg; ++c) {
+                        const size_t ch = (size_t)((g + k) * cpg + c) * plane;
+                        float v[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = q < NT ? (pg2 + ch)[tp.off[q]] : 0.f;
+                        s = fmaf(pg1[ch + pix], warp_combine(v, tp), s);
+                    }
+                }
+                r[k] = s * inv;
+            }
+            stg4(o + 2 * Cf + g, make_float4(r[0], r[1], r[2], r[3]));
+        }
+    };
+    if (two_taps) body(std::true_type{});
+    else body(std::false_type{});
 }
 
 extern "C" int nmrf_warp_corr_concat_f32(const float *labels, const float *f1, const float *f2, const float *g1,
