@@ -121,10 +121,9 @@ __global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__rest
     const int64_t qrow = stripe_row<NSHIFT>(g, base_pix, wave_on ? qsc : 0);
     const int q_pix = div_n<NSHIFT>(g, qsc);
 
-    constexpr bool DUAL = false;                // (two MFMA chains per contraction, accumulators summed afterwards: measured 37.4 vs 37.1 us -- nothing)
-    f32x16 acc_o, acc_o2;
+    f32x16 acc_o;                               // (two accumulator chains per contraction, summed afterwards: measured 37.4 vs 37.1 us -- not kept)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc_o[r] = acc_o2[r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc_o[r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
     if constexpr (SHARED) {
@@ -333,21 +332,8 @@ __global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__rest
                     split8u_g(kf, kh[0], kl[0], guard);
                     split8u_g(kf + 8, kh[1], kl[1], guard);
                 }
-                if constexpr (DUAL) {
-                    // the two k chunks into two accumulators, their MFMAs interleaved: a dependent MFMA then issues behind an
-                    // independent one instead of waiting out its predecessor (six chained on one accumulator stall on each other)
-                    f32x16 st2;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) st2[r] = 0.f;
-                    st = mfma16h(kl[0], qh[0], st);   st2 = mfma16h(kl[1], qh[1], st2);
-                    st = mfma16h(kh[0], ql[0], st);   st2 = mfma16h(kh[1], ql[1], st2);
-                    st = mfma16h(kh[0], qh[0], st);   st2 = mfma16h(kh[1], qh[1], st2);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) st[r] += st2[r];
-                } else {
-                    split_mma1(kh[0], kl[0], qh[0], ql[0], st);
-                    split_mma1(kh[1], kl[1], qh[1], ql[1], st);
-                }
+                split_mma1(kh[0], kl[0], qh[0], ql[0], st);
+                split_mma1(kh[1], kl[1], qh[1], ql[1], st);
             }
             if (STEADY) load_k_fast(kt + 2, kf);                // K fragment is dead: refill now
             else if (kt + 2 < kt_end) load_k(kt + 2, kf);
@@ -381,10 +367,6 @@ __global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__rest
             m_run = m_new;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc_o[r] *= alpha;
-            if constexpr (DUAL) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc_o2[r] *= alpha;
-            }
             {
                 float pv[16];
 #pragma unroll
@@ -398,14 +380,8 @@ __global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__rest
                     split8u_g(vf, vh[0], vl[0], guard);
                     split8u_g(vf + 8, vh[1], vl[1], guard);
                 }
-                if constexpr (DUAL) {
-                    acc_o = mfma16h(vl[0], ph[0], acc_o);   acc_o2 = mfma16h(vl[1], ph[1], acc_o2);
-                    acc_o = mfma16h(vh[0], pl[0], acc_o);   acc_o2 = mfma16h(vh[1], pl[1], acc_o2);
-                    acc_o = mfma16h(vh[0], ph[0], acc_o);   acc_o2 = mfma16h(vh[1], ph[1], acc_o2);
-                } else {
-                    split_mma1(vh[0], vl[0], ph[0], pl[0], acc_o);
-                    split_mma1(vh[1], vl[1], ph[1], pl[1], acc_o);
-                }
+                split_mma1(vh[0], vl[0], ph[0], pl[0], acc_o);
+                split_mma1(vh[1], vl[1], ph[1], pl[1], acc_o);
             }
             if (STEADY) load_v_fast(kt + 2, vf);                // V fragment likewise
             else if (kt + 2 < kt_end) load_v(kt + 2, vf);
@@ -428,10 +404,6 @@ __global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__rest
         }
         SA_STAMP(7);
         l_run = half_sum(l_run);                        // both halves now hold the range's full (m, l)
-        if constexpr (DUAL) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc_o[r] += acc_o2[r];
-        }
     }
 
     // ---- LePE for width-1 stripes (NMP.py:433-449 / SURVEY H3), independent of the attention itself:
