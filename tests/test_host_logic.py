@@ -224,3 +224,31 @@ def test_conv_plan_covers_the_backbone_channel_counts():
             assert strips in (2, 3, 4) and strips * groups * 32 == co
     assert _conv3_plan(256, 240) == (4, 2) and _conv3_plan(256, 60) == (2, 4) and _conv3_plan(128, 240) == (2, 2)
     assert _conv3_plan(32, 100) is None and _conv3_plan(160, 100) is None
+
+
+def test_kv16_format_restatement_against_a_scalar_reading_of_the_header():
+    """kernels.to_kv16 (the torch statement of the kv16 row format that the GPU tests hold the block kernel to) against a
+    value-by-value reading of include/nmrf_hip.h: k per 32-channel head as [32 hi halves | 32 lo halves], v as hi | lo << 16,
+    q untouched; hi = rn_f16(x), lo = rn_f16(x - hi)."""
+    import numpy as np
+    import torch
+    from nmrf_amd import kernels as K
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn(7, 384, generator=g) * torch.tensor([1e-3, 1.0, 300.0, 1.0, 1.0, 1.0, 1.0]).view(7, 1)
+    out = K.to_kv16(qkv)
+    assert torch.equal(out[:, :128], qkv[:, :128])
+    raw = out.numpy().view(np.uint8).reshape(7, 384 * 4)
+    x = qkv.numpy()
+    for t in range(7):
+        for c in (0, 1, 31, 32, 77, 127):
+            hi = np.float16(x[t, 128 + c])
+            lo = np.float16(x[t, 128 + c] - np.float32(hi))
+            h, cc = divmod(c, 32)
+            base = 128 * 4 + h * 128
+            assert raw[t, base + 2 * cc: base + 2 * cc + 2].view(np.float16)[0] == hi
+            assert raw[t, base + 64 + 2 * cc: base + 64 + 2 * cc + 2].view(np.float16)[0] == lo
+            hv = np.float16(x[t, 256 + c])
+            lv = np.float16(x[t, 256 + c] - np.float32(hv))
+            word = raw[t, (256 + c) * 4: (256 + c) * 4 + 4]
+            assert word[:2].view(np.float16)[0] == hv and word[2:].view(np.float16)[0] == lv
+            assert abs(float(np.float32(hv) + np.float32(lv)) - float(x[t, 256 + c])) <= 2.0 ** -21 * abs(float(x[t, 256 + c])) + 1e-30
