@@ -248,7 +248,10 @@ int nmrf_selftest_mfma16x16_f16split(const float *A, const float *Bm, int K, flo
  * b1/b2/b3 may be NULL.  inv_scales: HOST array of 3 floats. */
 int nmrf_mlp_chain_f32(int kind, const float *in, int in_ld, int K1, const void *stream_w, int total_stages,
                        const float *b1, const float *b2, const float *b3, const float *extra, int extra_ld,
-                       const float *inv_scales, int64_t T, float *out, int out_ld, int n_out, const int *out_map, int *range_flag, void *stream);
+                       const float *inv_scales, int64_t T, float *out, int out_ld, int n_out, const int *out_map,
+                       const float *row_add, int row_add_ld, int relu_out, int *range_flag, void *stream);
+/* (row_add [T, row_add_ld >= n_out], optional: added to the stored columns; relu_out != 0: ReLU after that -- the label update
+ *  labels = relu(prop_head(memory) + seeds) of nmrf/models/DPN.py:131-132 leaves with the head's rows.) */
 
 /* Weight packing of the 32-row split-fp16 fragment streams (mlp_chain, conv kernels): w [N,K] row-major fp32 (an nn.Linear weight) -> N/32 x Kp/16 pairs of 2 KB in
  * [strip][chunk] order; a pair = [64 lanes][8 fp16] hi parts then the same for the lo parts (lo = fp16(w - hi), csrc/split_mfma.h);

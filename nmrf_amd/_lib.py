@@ -24,7 +24,7 @@ PROTOTYPES = {
     "nmrf_seed_features_f32": [_P, _P, _L, _I, _I, _I, _F, _P, _P, _I, _P],
     "nmrf_seed_select_f32": [_P, _P, _L, _I, _I, _I, _F, _I, _F, _P, _P, _P, _P, _I, _P],
     "nmrf_fourier_embed_f32": [_P, _L, _F, _P, _I, _P, _P],
-    "nmrf_mlp_chain_f32": [_I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _L, _P, _I, _I, _P, _P, _P],
+    "nmrf_mlp_chain_f32": [_I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _L, _P, _I, _I, _P, _P, _I, _I, _P, _P],
     "nmrf_ln_concat_f32": [_P, _P, _P, _F, _P, _I, _I, _L, _I, _P, _I, _P],
     "nmrf_add_ln_concat_f32": [_P, _P, _P, _P, _P, _F, _P, _I, _I, _L, _I, _P, _I, _P],
     "nmrf_stripe_attn_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],

@@ -35,6 +35,8 @@ struct ChainArgs {
     int n_tiles;
     float inv1, inv2, inv3;
     int *range_flag;             // sticky fp16-range flag of the split operands (split_mfma.h), may be NULL
+    const float *row_add;        // [T, row_add_ld] added to the stored columns (NULL: nothing) ...
+    int row_add_ld, relu_out;    // ... followed by a ReLU if relu_out: labels = relu(prop_head(x) + seeds), DPN.py:131-132
 };
 
 template <int ACT>
@@ -177,7 +179,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (t >= a.T) continue;
             int64_t orow = t;
             if (a.out_map) { orow = a.out_map[t]; if (orow < 0) continue; }
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(Ot + row * MC_OLD + 4 * c4);
+            f32x4 v = *reinterpret_cast<const f32x4 *>(Ot + row * MC_OLD + 4 * c4);
+            if (a.row_add) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * c4 + e < a.n_out) v[e] += a.row_add[(size_t)t * a.row_add_ld + 4 * c4 + e];
+            }
+            if (a.relu_out) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
             float *dst = a.out + (size_t)orow * a.out_ld + 4 * c4;
             if (4 * c4 + 4 <= a.n_out && !(a.out_ld & 3)) *reinterpret_cast<f32x4 *>(dst) = v;
             else
@@ -219,12 +230,13 @@ static int launch_chain(const ChainArgs &a, hipStream_t st) {
 extern "C" int nmrf_mlp_chain_f32(int kind, const float *in, int in_ld, int K1, const void *stream_w, int total_stages,
                                   const float *b1, const float *b2, const float *b3, const float *extra, int extra_ld,
                                   const float *inv_scales, int64_t T, float *out, int out_ld, int n_out, const int *out_map,
-                                  int *range_flag, void *stream) {
+                                  const float *row_add, int row_add_ld, int relu_out, int *range_flag, void *stream) {
     if (!in || !stream_w || !out || !inv_scales) return NMRF_ENULL;
+    if (row_add && row_add_ld < n_out) return NMRF_EINVAL;
     if (T < 1 || ceil_div64(T, MC_TOK) > 0x7fffffff || in_ld < K1 || (in_ld & 3) || (K1 & 3) || n_out < 1 || out_ld < n_out)
         return NMRF_EINVAL;
     ChainArgs a{in, in_ld, K1, stream_w, total_stages, b1, b2, b3, extra, extra_ld, out, out_ld, n_out, out_map, T,
-                (int)ceil_div64(T, MC_TOK), inv_scales[0], inv_scales[1], inv_scales[2], range_flag};
+                (int)ceil_div64(T, MC_TOK), inv_scales[0], inv_scales[1], inv_scales[2], range_flag, row_add, row_add_ld, relu_out};
     hipStream_t st = (hipStream_t)stream;
     switch (kind) {
         case 0:

@@ -500,9 +500,10 @@ def chain_stream(weights, kps):
 
 
 @_on_device
-def mlp_chain(kind, x, k1, stream, stages, inv_scales, biases, n_out, extra=None, out=None, out_map=None):
-    """nmrf_mlp_chain_f32: kind 0 ffn | 1 seed embed | 2 three-layer ReLU head | 3 single Linear.  x [T, ld] (k1 live columns)."""
-    _chk(x, extra, out, *[b for b in biases if b is not None])
+def mlp_chain(kind, x, k1, stream, stages, inv_scales, biases, n_out, extra=None, out=None, out_map=None, row_add=None, relu_out=False):
+    """nmrf_mlp_chain_f32: kind 0 ffn | 1 seed embed | 2 three-layer ReLU head | 3 single Linear.  x [T, ld] (k1 live columns).
+    row_add [T, >= n_out] / relu_out: out = [relu](chain(x) + row_add) in the kernel's store pass."""
+    _chk(x, extra, out, row_add, *[b for b in biases if b is not None])
     _chk(stream, out_map, dtype=torch.int32)
     t, ld = x.shape
     if out is None:
@@ -517,7 +518,8 @@ def mlp_chain(kind, x, k1, stream, stages, inv_scales, biases, n_out, extra=None
             pmc=["mlp_chain_kernel"])
     _lib.check(_lib.load().nmrf_mlp_chain_f32(kind, _p(x), ld, k1, _p(stream), stages, _p(b[0]), _p(b[1]), _p(b[2]), _p(extra),
                                               0 if extra is None else extra.shape[-1], inv_scales, t, _p(out), out.shape[-1], n_out,
-                                              _p(out_map), _rf(x), _stream()), "mlp_chain")
+                                              _p(out_map), _p(row_add), 0 if row_add is None else row_add.shape[-1], int(bool(relu_out)),
+                                              _rf(x), _stream()), "mlp_chain")
     if kernel_hook is not None:
         _he(name + "_n%d" % n_out)
     return out

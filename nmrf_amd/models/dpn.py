@@ -89,6 +89,6 @@ class DPN(nn.Module):
             torch.cuda.current_stream().wait_event(context_ready)
         context = context.permute(0, 2, 3, 1).contiguous()
         memory, seeds_f = self.propagation(cost_volume, seeds, context, feats=feats)
-        outputs = self.prop_head(memory).view(-1, *seeds_f.shape)
-        labels = F.relu(outputs + seeds_f[None])
+        # labels = relu(prop_head(memory) + seeds) (DPN.py:131-132): the add and the ReLU leave with the head's rows
+        labels = self.prop_head(memory, row_add=seeds_f.reshape(-1, 1), relu_out=True).view(-1, *seeds_f.shape)
         return cost_volume, prob, seeds_f, labels

@@ -35,13 +35,19 @@ class MLP(nn.Module):
         self.num_layers = num_layers
         self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
 
-    def forward(self, x):
+    def forward(self, x, row_add=None, relu_out=False):
+        """row_add [T, n_out] / relu_out (HIP chain only): [relu](MLP(x) + row_add) in the chain kernel's store pass."""
         if (_split() and x.is_cuda and self.num_layers == 3 and self.layers[0].in_features == 128
                 and self.layers[0].out_features == 128 and self.layers[1].out_features == 128 and self.layers[2].out_features <= 64):
             if not hasattr(self, "_chain"):
                 self._chain = _ChainLauncher(2, self.layers, (128, 128, 128), self.layers[2].out_features)
             shp = x.shape
-            return self._chain(x.reshape(-1, 128).contiguous(), 128).view(*shp[:-1], self.layers[2].out_features)
+            return self._chain(x.reshape(-1, 128).contiguous(), 128, row_add=row_add, relu_out=relu_out).view(
+                *shp[:-1], self.layers[2].out_features)
+        if row_add is not None or relu_out:
+            y = self.forward(x)
+            y = y if row_add is None else y + row_add.view_as(y)
+            return F.relu(y) if relu_out else y
         for i, layer in enumerate(self.layers):
             last = i == self.num_layers - 1
             if (x.is_cuda and layer.out_features % 32 == 0 and layer.out_features > 64
@@ -183,10 +189,11 @@ class _ChainLauncher:
         self.kind, self.linears, self.kps, self.n_out = kind, tuple(linears), tuple(kps), n_out
         self.cache = _FusedCache()
 
-    def __call__(self, x, k1, extra=None, out=None, out_map=None):
+    def __call__(self, x, k1, extra=None, out=None, out_map=None, row_add=None, relu_out=False):
         ps = tuple(l.weight for l in self.linears) + tuple(l.bias for l in self.linears if l.bias is not None)
         stream, stages, inv = self.cache.get(ps, lambda: K.chain_stream([l.weight for l in self.linears], self.kps))
-        return K.mlp_chain(self.kind, x, k1, stream, stages, inv, [l.bias for l in self.linears], self.n_out, extra, out, out_map)
+        return K.mlp_chain(self.kind, x, k1, stream, stages, inv, [l.bias for l in self.linears], self.n_out, extra, out, out_map,
+                           row_add=row_add, relu_out=relu_out)
 
 
 def _pad_maps(dims, win, device, cache):

@@ -616,6 +616,11 @@ def test_mlp_chain_fused(kind, t_, n_out):
     stream, stages, inv = kk.chain_stream([d(w) for w in ws], kps)
     got = kk.mlp_chain(kind, d(x), k1, stream, stages, inv, [d(b) for b in bs], n_out, d(extra))
     report("mlp_chain kind %d" % kind, got.cpu(), ref, 2e-5, 1e-5)
+    if kind == 2:                                     # [relu](chain(x) + row_add) in the store pass (the label update of DPN.py:131-132)
+        ra = rnd(t_, n_out, seed=9, scale=0.5)
+        got2 = kk.mlp_chain(kind, d(x), k1, stream, stages, inv, [d(b) for b in bs], n_out, d(extra), row_add=d(ra), relu_out=True)
+        report("mlp_chain kind 2 + row_add + relu", got2.cpu(), F.relu(ref + ra.double()), 2e-5, 1e-5)
+        assert torch.equal(got2, torch.relu(got + d(ra)))
     if kind == 0 and t_ < 1000:                       # row map: every other row of a twice as long zeroed buffer, the last 5 tokens dropped
         omap = torch.arange(t_, dtype=torch.int32) * 2
         omap[-5:] = -1
