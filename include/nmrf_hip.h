@@ -331,7 +331,8 @@ int nmrf_prep_images_f32(const float *img1, const float *img2, int B, int C, int
                          void *stream);
 
 /* Encoder tail (N2): y [planes = 2B*C, H, W] = the last 1x1 convolution WITHOUT its bias -> x = y + bias[c] and the 2x2 average
- * of x (backbone.py:96-98) in one pass.  H, W even. */
+ * of x (backbone.py:96-98) in one pass.  H, W even.  bias may be NULL; x may be NULL: only the average is written (for a producer
+ * that added its bias itself: y is then the finished 1/4-resolution map). */
 int nmrf_bias_avgpool2_f32(const float *y, const float *bias, int64_t planes, int C, int H, int W, float *x, float *pooled,
                            void *stream);
 

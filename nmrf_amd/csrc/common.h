@@ -63,6 +63,36 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// The same two reductions without the LDS crossbar (six dependent ds_bpermute round trips each): v_permlane32_swap / v_permlane16_swap
+// for the strides 32 and 16, row rotations (DPP) for 8, 4, 2, 1.  A rotation by o inside a row of 16 pairs lane l with lane l^o once
+// the values have period 2o inside the row, which is what the previous level leaves behind; so the additions form the SAME tree as
+// wave_sum's butterfly (fp add is commutative): identical bits, every lane holds the result.
+#define NMRF_ROW_ROR(v, n) __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x120 + (n), 0xf, 0xf, false))
+__device__ __forceinline__ float wave_sum_nolds(float v) {
+    v = half_sum(v);
+    {
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    v += NMRF_ROW_ROR(v, 8);
+    v += NMRF_ROW_ROR(v, 4);
+    v += NMRF_ROW_ROR(v, 2);
+    v += NMRF_ROW_ROR(v, 1);
+    return v;
+}
+__device__ __forceinline__ float wave_max_nolds(float v) {
+    v = half_max(v);
+    {
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    v = fmaxf(v, NMRF_ROW_ROR(v, 8));
+    v = fmaxf(v, NMRF_ROW_ROR(v, 4));
+    v = fmaxf(v, NMRF_ROW_ROR(v, 2));
+    v = fmaxf(v, NMRF_ROW_ROR(v, 1));
+    return v;
+}
+
 __device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void stg4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 

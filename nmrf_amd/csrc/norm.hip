@@ -231,32 +231,39 @@ extern "C" int nmrf_prep_images_u8(const uint8_t *img1, const uint8_t *img2, int
 template <typename PX>
 __global__ __launch_bounds__(256) void prep_images_s2d_kernel(const PX *__restrict__ img1, const PX *__restrict__ img2, int B,
                                                              int H, int W, int H2, int W2, float *__restrict__ out) {
-    const int64_t total = (int64_t)2 * B * 16 * H2 * W2;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int X = (int)(i % W2);
-        const int Y = (int)((i / W2) % H2);
-        const int64_t pc = i / ((int64_t)W2 * H2);                 // (view * B + b) * 16 + ch
-        const int ch = (int)(pc & 15);
-        const int64_t vb = pc >> 4, v = vb / B, bb = vb - v * B;
-        float r = 0.f;
-        if (ch < 12) {
-            const int c = ch >> 2, y = 2 * Y + ((ch >> 1) & 1), x = 2 * X + (ch & 1);
-            const PX *src = (v == 0 ? img1 : img2) + (bb * 3 + c) * (int64_t)H * W;
-            const float px = (float)src[(int64_t)(y < H ? y : H - 1) * W + (x < W ? x : W - 1)];
-            r = 2.0f * (px / 255.0f) - 1.0f;
-        }
-        out[i] = r;
+    // thread = one output cell (Y, X) of image blockIdx.y = view * B + b: its 12 source pixels are requested together (clamped
+    // addresses = the replicate padding) and go out as 16 coalesced plane stores.  (As a flat grid-stride loop over output
+    // elements -- three 64-bit divisions and one exposed load per element -- this pass took 15 us at KITTI.)
+    const int cell = blockIdx.x * 256 + threadIdx.x;
+    if (cell >= H2 * W2) return;
+    const int Y = cell / W2, X = cell - Y * W2;
+    const int vb = blockIdx.y, v = vb / B, bb = vb - v * B;
+    const PX *src = (v == 0 ? img1 : img2) + (size_t)bb * 3 * H * W;
+    const int y0 = min(2 * Y, H - 1), y1 = min(2 * Y + 1, H - 1), xa = min(2 * X, W - 1), xb = min(2 * X + 1, W - 1);
+    PX px[12];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const PX *pl = src + (size_t)c * H * W;
+        px[4 * c + 0] = pl[(size_t)y0 * W + xa];
+        px[4 * c + 1] = pl[(size_t)y0 * W + xb];
+        px[4 * c + 2] = pl[(size_t)y1 * W + xa];
+        px[4 * c + 3] = pl[(size_t)y1 * W + xb];
     }
+    float *dst = out + (size_t)vb * 16 * H2 * W2 + cell;
+#pragma unroll
+    for (int ch = 0; ch < 12; ++ch) dst[(size_t)ch * H2 * W2] = 2.0f * ((float)px[ch] / 255.0f) - 1.0f;
+#pragma unroll
+    for (int ch = 12; ch < 16; ++ch) dst[(size_t)ch * H2 * W2] = 0.f;
 }
 
 template <typename PX>
 static int launch_prep_images_s2d(const PX *img1, const PX *img2, int B, int H, int W, int Hp, int Wp, float *out, void *stream) {
     if (!img1 || !img2 || !out) return NMRF_ENULL;
-    if (B < 1 || H < 1 || W < 1 || Hp < H || Wp < W || (Hp & 1) || (Wp & 1)) return NMRF_EINVAL;
-    int64_t blocks = ceil_div64((int64_t)2 * B * 16 * (Hp / 2) * (Wp / 2), 256 * 4);
-    if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(prep_images_s2d_kernel<PX>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, img1, img2, B, H, W,
-                       Hp / 2, Wp / 2, out);
+    if (B < 1 || H < 1 || W < 1 || Hp < H || Wp < W || (Hp & 1) || (Wp & 1) || 2 * B > 65535) return NMRF_EINVAL;
+    const int64_t cells = (int64_t)(Hp / 2) * (Wp / 2);
+    if (cells > (int64_t)1 << 30) return NMRF_EINVAL;
+    hipLaunchKernelGGL(prep_images_s2d_kernel<PX>, dim3((unsigned)ceil_div64(cells, 256), 2 * B), dim3(256), 0, (hipStream_t)stream,
+                       img1, img2, B, H, W, Hp / 2, Wp / 2, out);
     return nmrf_launch_status();
 }
 
@@ -273,6 +280,7 @@ extern "C" int nmrf_prep_images_s2d_u8(const uint8_t *img1, const uint8_t *img2,
 // ------------------------------------------------------------------------------------------------------------------
 // Tail of the CNN encoder: y = conv1x1 output without its bias [BC planes of H x W]; x = y + bias[c] (the 1/4-resolution map)
 // and its 2x2 average (the 1/8 map, nmrf/models/backbone.py:96-98) in one pass over y.  H, W even; thread = one 2x2 cell.
+// x == NULL: only the average is written (the producer already added its bias: 75 MB instead of 135 MB at KITTI).
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bias_avgpool2_kernel(const float *__restrict__ y, const float *__restrict__ bias, int Cc,
                                                            int H, int W, int64_t cells, float *__restrict__ x,
@@ -285,15 +293,17 @@ __global__ __launch_bounds__(256) void bias_avgpool2_kernel(const float *__restr
         const int64_t o = plane * (int64_t)H * W + (int64_t)(2 * cy) * W + 2 * cx;
         const float2 t = *reinterpret_cast<const float2 *>(y + o), u = *reinterpret_cast<const float2 *>(y + o + W);
         const float a = t.x + bv, b = t.y + bv, c = u.x + bv, d = u.y + bv;
-        *reinterpret_cast<float2 *>(x + o) = make_float2(a, b);
-        *reinterpret_cast<float2 *>(x + o + W) = make_float2(c, d);
+        if (x) {
+            *reinterpret_cast<float2 *>(x + o) = make_float2(a, b);
+            *reinterpret_cast<float2 *>(x + o + W) = make_float2(c, d);
+        }
         pooled[i] = (((a + b) + c) + d) * 0.25f;          // ATen's avg_pool2d sums the window row by row, then divides
     }
 }
 
 extern "C" int nmrf_bias_avgpool2_f32(const float *y, const float *bias, int64_t planes, int C, int H, int W, float *x, float *pooled,
                                       void *stream) {
-    if (!y || !x || !pooled) return NMRF_ENULL;
+    if (!y || !pooled) return NMRF_ENULL;                          // x NULL: only the pooled map is written
     if (planes < 1 || C < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) return NMRF_EINVAL;
     const int64_t cells = planes * (int64_t)(H / 2) * (W / 2);
     int64_t blocks = ceil_div64(cells, 256 * 2);

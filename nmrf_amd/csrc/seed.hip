@@ -38,17 +38,27 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(const float *__restric
     for (int j = 0; j < NJ; ++j) acc[j] = 0.f;
 
     for (int c0 = 0; c0 < cpg; c0 += CV_CK) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < CV_CK * CV_TX; i += 256) {
-            int c = i / CV_TX, xx = i % CV_TX;
-            int x = x0 + xx;
-            s1[c][xx] = (c0 + c < cpg && x < W) ? p1[(size_t)(c0 + c) * plane + x] : 0.f;
+        // Staging: wave w takes channels w, w + 4, ...; lane = x.  All 48 loads of a thread are issued before the first LDS store
+        // (clamped addresses, values selected afterwards): as a loop of "load, wait, store" the block paid 42 serial memory round
+        // trips -- most of the kernel's 29 us.
+        float v1[CV_CK / 4], va[CV_CK / 4], vb[CV_CK / 4];
+        const int xa = x0 - halo + lane, xb = xa + CV_TX;
+#pragma unroll
+        for (int i = 0; i < CV_CK / 4; ++i) {
+            const int c = c0 + wv + 4 * i;
+            const size_t row = (size_t)(c < cpg ? c : cpg - 1) * plane;
+            v1[i] = p1[row + min(x0 + lane, W - 1)];
+            va[i] = p2[row + min(max(xa, 0), W - 1)];
+            vb[i] = p2[row + min(max(xb, 0), W - 1)];
         }
-        const int w2 = CV_TX + halo;
-        for (int i = threadIdx.x; i < CV_CK * w2; i += 256) {
-            int c = i / w2, xx = i % w2;
-            int x = x0 - halo + xx;
-            s2[c][xx] = (c0 + c < cpg && x >= 0 && x < W) ? p2[(size_t)(c0 + c) * plane + x] : 0.f;
+        __syncthreads();                                                    // the previous pass is done with the tiles
+#pragma unroll
+        for (int i = 0; i < CV_CK / 4; ++i) {
+            const int c = wv + 4 * i;
+            const bool okc = c0 + c < cpg;
+            s1[c][lane] = (okc && x0 + lane < W) ? v1[i] : 0.f;
+            s2[c][lane] = (okc && xa >= 0 && xa < W) ? va[i] : 0.f;
+            if (lane < halo) s2[c][CV_TX + lane] = (okc && xb >= 0 && xb < W) ? vb[i] : 0.f;
         }
         __syncthreads();
         const float *r2 = &s2[0][0] + lane + halo - wv;                     // disparity d = wv + 4 j sits 4 j floats below
@@ -101,76 +111,110 @@ extern "C" int nmrf_cost_volume_f32(const float *f1, const float *f2, int B, int
 
 // ------------------------------------------------------------------------------------------------
 // A3: Conv1d(G->8)-ReLU-Conv1d(8->16)-ReLU-Conv1d(16->1) along D (k=5, zero pad 2) + softmax.
-// One wave = one pixel, lane = disparity bin.  Activations go through a wave-private LDS strip
-// [ch][2+64+2] (zero guard cells realise the padding); softmax max/sum are wave shuffles.
-// Weights are wave-uniform -> scalar loads.
+// One wave = TWO pixels, lane = disparity bin: the two pixels are the two halves of a packed fp32 FMA
+// (v_pk_fma_f32: each half an IEEE fma, same (channel, tap) order as the scalar form -> same bits), the
+// weight is a wave-uniform SGPR broadcast to both halves, so the weights are read in their reference
+// layout and in memory order (s_load_dwordx16), once per two pixels.  Activations go through a
+// wave-private LDS strip [ch][2+64+2] of pixel pairs (zero guard cells realise the padding; one 8-byte
+// read per tap); softmax max/sum are wave shuffles.  Nothing is shared between waves: every ordering
+// point is a wave-level one.
+// (One pixel per wave with scalar v_fmac and SGPR weights: 5 400 cycles per pixel -- a wave64 v_fma_f32 with an SGPR operand
+// issues every 5.3 cycles on this chip, against 2.9 with VGPR operands and 4.9 for v_pk_fma_f32 with either; measured,
+// profiles/r03s_filter_ab.txt.  This form: 7 400 cycles per PAIR of pixels, unroll / block shape / reduction style make no
+// difference.)
 // ------------------------------------------------------------------------------------------------
-#define FS_PPB 4   // pixels (waves) per block
+#define FS_WPB 4   // waves per block
 #define FS_LD 68
+typedef float fs_f2 __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(256) void dpn_filter_softmax_kernel(const float *__restrict__ vol,
+__device__ __forceinline__ fs_f2 fs_fma(float w, fs_f2 v, fs_f2 acc) { return __builtin_elementwise_fma(fs_f2{w, w}, v, acc); }
+
+template <int GT>   // cost groups held in registers (4), or 0: any G <= 16, taps re-read from LDS
+__global__ __launch_bounds__(64 * FS_WPB) void dpn_filter_softmax_kernel(const float *__restrict__ vol,
         const float *__restrict__ w0, const float *__restrict__ b0, const float *__restrict__ w1,
         const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ b2,
         int64_t P, int G, int D, float *__restrict__ prob) {
-    __shared__ float sa[FS_PPB][16][FS_LD];   // input (G ch) then layer-2 output (16 ch)
-    __shared__ float sb[FS_PPB][8][FS_LD];    // layer-1 output
+    __shared__ fs_f2 sa[FS_WPB][16][FS_LD];   // input (G ch), then layer-1 output (8 ch), then layer-2 output (16 ch): each layer's taps
+                                              // are in registers before its outputs overwrite them (34 KB: four blocks per CU)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t p = (int64_t)blockIdx.x * FS_PPB + wv;
-    const bool live = p < P;                    // whole wave uniform
+    const int64_t p = ((int64_t)blockIdx.x * FS_WPB + wv) * 2;
+    if (p >= P) return;                         // wave uniform; no block barrier below
+    const bool two = p + 1 < P;
     const bool in = lane < D;
-    // guard cells
-    for (int i = threadIdx.x; i < FS_PPB * 16 * 4; i += 256) {
-        int q = i / 64, ch = (i / 4) % 16, k = i % 4;
-        sa[q][ch][k < 2 ? k : 64 + k] = 0.f;
-        if (ch < 8) sb[q][ch][k < 2 ? k : 64 + k] = 0.f;
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    const fs_f2 zero{0.f, 0.f};
+    {   // guard cells of this wave's strip (never written again)
+        const int ch = lane >> 2, k = lane & 3;
+        sa[wv][ch][k < 2 ? k : 64 + k] = zero;
     }
-    if (live) {
-        for (int g = 0; g < G; ++g) sa[wv][g][2 + lane] = in ? vol[((size_t)p * G + g) * D + lane] : 0.f;
+    if (GT) G = GT;
+    for (int g = 0; g < G; ++g) {
+        const float *src = vol + ((size_t)p * G + g) * D + lane;
+        sa[wv][g][2 + lane] = fs_f2{in ? src[0] : 0.f, (in && two) ? src[(size_t)G * D] : 0.f};
     }
-    __syncthreads();
-    float h1[8];
-    if (live) {
+    wave_sync();
+    // ---- layer 1
+    fs_f2 h1[8];
+    if (GT) {
+        fs_f2 x[GT ? GT * 5 : 1];
+#pragma unroll
+        for (int t = 0; t < GT * 5; ++t) x[t] = sa[wv][t / 5][lane + t % 5];
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
-            float s = b0[o];
+            const float bo = b0[o];
+            fs_f2 s{bo, bo};
+#pragma unroll
+            for (int t = 0; t < GT * 5; ++t) s = fs_fma(w0[o * GT * 5 + t], x[t], s);
+            h1[o] = in ? __builtin_elementwise_max(s, zero) : zero;
+        }
+    } else {
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            const float bo = b0[o];
+            fs_f2 s{bo, bo};
             for (int g = 0; g < G; ++g)
 #pragma unroll
-                for (int k = 0; k < 5; ++k) s = fmaf(w0[(o * G + g) * 5 + k], sa[wv][g][lane + k], s);
-            h1[o] = in ? fmaxf(s, 0.f) : 0.f;
+                for (int k = 0; k < 5; ++k) s = fs_fma(w0[(o * G + g) * 5 + k], sa[wv][g][lane + k], s);
+            h1[o] = in ? __builtin_elementwise_max(s, zero) : zero;
         }
-#pragma unroll
-        for (int o = 0; o < 8; ++o) sb[wv][o][2 + lane] = h1[o];
     }
-    __syncthreads();
-    float h2[16];
-    if (live) {
+    wave_sync();                                // every lane has read its input taps
 #pragma unroll
+    for (int o = 0; o < 8; ++o) sa[wv][o][2 + lane] = h1[o];
+    wave_sync();
+    // ---- layer 2: the 40 taps of the pair in registers
+    {
+        fs_f2 x[40];
+#pragma unroll
+        for (int t = 0; t < 40; ++t) x[t] = sa[wv][t / 5][lane + t % 5];
+        wave_sync();                            // ... before the outputs overwrite the strip
+#pragma unroll 2
         for (int o = 0; o < 16; ++o) {
-            float s = b1[o];
+            const float bo = b1[o];
+            fs_f2 s{bo, bo};
 #pragma unroll
-            for (int c = 0; c < 8; ++c)
-#pragma unroll
-                for (int k = 0; k < 5; ++k) s = fmaf(w1[(o * 8 + c) * 5 + k], sb[wv][c][lane + k], s);
-            h2[o] = in ? fmaxf(s, 0.f) : 0.f;
+            for (int t = 0; t < 40; ++t) s = fs_fma(w1[o * 40 + t], x[t], s);
+            sa[wv][o][2 + lane] = in ? __builtin_elementwise_max(s, zero) : zero;
         }
     }
-    __syncthreads();   // everyone finished reading sa (input) before it is overwritten
-    if (live) {
+    wave_sync();
+    // ---- layer 3 + softmax of both pixels
+    const float b2s = b2[0];
+    fs_f2 s{b2s, b2s};
 #pragma unroll
-        for (int o = 0; o < 16; ++o) sa[wv][o][2 + lane] = h2[o];
-    }
-    __syncthreads();
-    if (live) {
-        float s = b2[0];
+    for (int c = 0; c < 16; ++c)
 #pragma unroll
-        for (int c = 0; c < 16; ++c)
+        for (int k = 0; k < 5; ++k) s = fs_fma(w2[c * 5 + k], sa[wv][c][lane + k], s);
 #pragma unroll
-            for (int k = 0; k < 5; ++k) s = fmaf(w2[c * 5 + k], sa[wv][c][lane + k], s);
-        float logit = in ? s : -INFINITY;
-        float m = wave_max(logit);
-        float e = in ? expf(logit - m) : 0.f;
-        float z = wave_sum(e);
-        if (in) prob[(size_t)p * D + lane] = e / z;
+    for (int h = 0; h < 2; ++h) {
+        const float logit = in ? s[h] : -INFINITY;
+        const float m = wave_max_nolds(logit);
+        const float e = in ? expf(logit - m) : 0.f;
+        const float z = wave_sum_nolds(e);                    // (same addition tree as the butterfly: common.h)
+        if (in && (h == 0 || two)) prob[(size_t)(p + h) * D + lane] = e / z;
     }
 }
 
@@ -179,9 +223,13 @@ extern "C" int nmrf_dpn_filter_softmax_f32(const float *vol, const float *w0, co
                                            float *prob, void *stream) {
     if (!vol || !w0 || !b0 || !w1 || !b1 || !w2 || !b2 || !prob) return NMRF_ENULL;
     if (P < 1 || G < 1 || G > 16 || D < 1 || D > 64) return NMRF_EINVAL;
-    dim3 grid((unsigned)ceil_div64(P, FS_PPB));
-    hipLaunchKernelGGL(dpn_filter_softmax_kernel, grid, dim3(256), 0, (hipStream_t)stream, vol, w0, b0, w1, b1, w2, b2,
-                       P, G, D, prob);
+    dim3 grid((unsigned)ceil_div64(P, 2 * FS_WPB));
+    if (G == 4)
+        hipLaunchKernelGGL(dpn_filter_softmax_kernel<4>, grid, dim3(64 * FS_WPB), 0, (hipStream_t)stream, vol, w0, b0, w1, b1, w2, b2,
+                           P, G, D, prob);
+    else
+        hipLaunchKernelGGL(dpn_filter_softmax_kernel<0>, grid, dim3(64 * FS_WPB), 0, (hipStream_t)stream, vol, w0, b0, w1, b1, w2, b2,
+                           P, G, D, prob);
     return nmrf_launch_status();
 }
 

@@ -905,6 +905,16 @@ def bias_avgpool2(y, bias):
 
 
 @_on_device
+def avgpool2(x):
+    """x [B,C,H,W] (H, W even) -> its 2x2 average, summed row by row like ATen's avg_pool2d."""
+    _chk(x)
+    b, c, h, w = x.shape
+    pooled = torch.empty(b, c, h // 2, w // 2, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_bias_avgpool2_f32(_p(x), None, b * c, c, h, w, None, _p(pooled), _stream()), "avgpool2")
+    return pooled
+
+
+@_on_device
 def msda_forward(value, shapes, lvl_start, loc, w):
     dt = value.dtype
     if dt not in (torch.float32, torch.float64):

@@ -164,9 +164,10 @@ class Backbone(nn.Module):
                     key = (w2.data_ptr(), w2._version)
                     if self._c2.get("key") != key:
                         self._c2 = {"key": key, "packed": K.pack_conv1x1(w2)}
-                    y = K.conv1x1_in_relu(x.contiguous(), 0, w2.shape[1], None, self._c2["packed"])      # plain 1x1 conv (no norm)
-                else:
-                    y = F.conv2d(x, w2, None)
+                    # plain 1x1 conv (no norm), bias in its epilogue; the 1/8 map is one read of the result
+                    x = K.conv1x1_in_relu(x.contiguous(), 0, w2.shape[1], None, self._c2["packed"], bias=self.conv2.bias)
+                    return [x, K.avgpool2(x)]
+                y = F.conv2d(x, w2, None)
                 return list(K.bias_avgpool2(y.contiguous(), self.conv2.bias))     # bias add + 2x2 average in one pass
             x = self.conv2(x)
             return [x, F.avg_pool2d(x, 2, 2)]

@@ -124,6 +124,17 @@ def test_dpn_filter_softmax_and_golden_prob():
         got = K().dpn_filter_softmax(cvr.to(DEV), *args).cpu()
         report(f"prob D={d}", got, O.dpn_filter_softmax(cvr, w), 3e-6)
         assert torch.allclose(got.sum(-1), torch.ones(700), atol=1e-5)
+    # an odd pixel count (the last wave holds one pixel, not two) and a group count without a register form (G != 4):
+    # against the stock conv1d stack in fp32
+    import torch.nn.functional as F
+    for (pp, gg, d) in ((701, 4, 40), (333, 6, 37), (1, 16, 64)):
+        ws = [rnd(8, gg, 5, seed=1, scale=0.3), rnd(8, seed=2, scale=0.1), rnd(16, 8, 5, seed=3, scale=0.2), rnd(16, seed=4, scale=0.1),
+              rnd(1, 16, 5, seed=5, scale=0.3), rnd(1, seed=6, scale=0.1)]
+        cvr = rnd(pp, gg, d, seed=pp, scale=0.5)
+        want = torch.softmax(F.conv1d(F.relu(F.conv1d(F.relu(F.conv1d(cvr, ws[0], ws[1], padding=2)), ws[2], ws[3], padding=2)),
+                                      ws[4], ws[5], padding=2).squeeze(1), -1)
+        got = K().dpn_filter_softmax(cvr.to(DEV), *[w_.to(DEV) for w_ in ws]).cpu()
+        report(f"prob P={pp} G={gg} D={d}", got, want, 3e-6)
 
 
 @pytest.mark.parametrize("d", [16, 24, 32, 40, 48])
@@ -659,6 +670,7 @@ def test_prep_images_and_bias_avgpool():
     ref = y + bias[None, :, None, None]
     assert torch.equal(x.cpu(), ref)
     report("avgpool", pooled.cpu(), F.avg_pool2d(ref, 2, 2), 1e-6)
+    assert torch.equal(K().avgpool2(x), pooled)                     # the average alone (bias added by the producer)
 
 
 def test_fourier_embed_row_map_and_padding_columns():

@@ -16,7 +16,11 @@ ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--which", default="window,stripe,refine,warp")
 ap.add_argument("--xscale", type=float, default=1.0, help="conv section: scale of the input (fp16 subnormal probe)")
+ap.add_argument("--lib", default=None, help="A/B runs: load this build of the library instead of nmrf_amd/lib/libnmrf_hip.so")
 args = ap.parse_args()
+if args.lib:
+    import nmrf_amd._lib as _L
+    _L.LIB_PATH = os.path.abspath(args.lib)
 dev = "cuda"
 b, h, w, n = args.batch, 47, 156, 4
 
@@ -388,6 +392,16 @@ if "seed" in which:
     for pp in (7332, 8160, 58656, 261120):
         prob = torch.softmax(mk("sp%d" % pp, pp, 40) * 4.0, -1)
         vol = mk("sv%d" % pp, pp, 4, 40)
+        fw = [mk("fw%d" % i, *sh) * 0.3 for i, sh in enumerate(((8, 4, 5), (8,), (16, 8, 5), (16,), (1, 16, 5), (1,)))]
+        timeit("dpn_filter_softmax P=%d" % pp, lambda: K.dpn_filter_softmax(vol, *fw))
+        if os.environ.get("KB_PROB"):                     # A/B of two builds (--lib): bit-compare the probabilities across processes
+            pth = "gpurun_out/kb_prob_%d.pt" % pp
+            got = K.dpn_filter_softmax(vol, *fw).cpu()
+            if os.environ["KB_PROB"] == "save":
+                os.makedirs("gpurun_out", exist_ok=True)
+                torch.save(got, pth)
+            else:
+                print("  prob bit-identical to the saved build:", bool(torch.equal(got, torch.load(pth))))
         timeit("nms_topk (LDS rows) P=%d" % pp, lambda: K.nms_topk(prob, 4, 1e-3))
         sd = K.nms_topk(prob, 4, 1e-3)
         timeit("  + seed_features + seeds.float() P=%d" % pp, lambda: (K.seed_features(vol, sd, 3.14 / 64, 32), sd.float()))
