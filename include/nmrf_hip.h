@@ -40,7 +40,7 @@ const char *nmrf_strerror(int code);
  * in a separate pass when range_flag != NULL; pass NULL when qkv was produced by nmrf_nmp_block16_f32, which range-checks its q_out. */
 int nmrf_range_scan_f32(const float *x, int64_t n, int *range_flag, void *stream);   /* n % 4 == 0, x 16-byte aligned */
 /* ABI version of this header; bumps on any signature change. */
-int nmrf_abi_version(void);   /* currently 18 */
+int nmrf_abi_version(void);   /* currently 19 */
 
 /* A2  group-wise correlation volume.
  * replaces build_correlation_volume + the permute of DPN.forward
@@ -118,10 +118,12 @@ int nmrf_stripe_attn_f32(const float *qkv, const float *lepe_v, const float *lep
  * replaces Inference.sample_fmap x2 + corr + cat (nmrf/models/NMP.py:683-741, 839-844).
  * labels [B*H*W*N]; f1,f2 [B,Cf,H,W]; g1,g2 [B,Cg,H,W] (NCHW);
  * -> out[t, 0:Cf]=f1, [Cf:2Cf]=warp(f2), [2Cf:2Cf+groups]=mean over Cg/groups channels of g1*warp(g2); row stride ld.
- * Sampling reproduces F.grid_sample(bilinear, zeros, align_corners=True) incl. its normalise/unnormalise round trip. */
+ * Sampling reproduces F.grid_sample(bilinear, zeros, align_corners=True) incl. its normalise/unnormalise round trip.
+ * token_major != 0: the four maps are [B,HW,C] (nmrf_conv1x1_in_relu_f32 with token_major = 1; Cf = 64, Cg = 256, groups = 32
+ * only): every tap is then one contiguous row read with 16-byte loads.  Same results, bit for bit. */
 int nmrf_warp_corr_concat_f32(const float *labels, const float *f1, const float *f2, const float *g1,
                               const float *g2, int B, int H, int W, int N, int Cf, int Cg, int groups,
-                              float *out, int ld, void *stream);
+                              float *out, int ld, int token_major, void *stream);
 
 /* A10(i)  per-pixel self-edge attention over the N sibling labels.
  * replaces the attention core of BasicAttention.forward_pre (nmrf/models/NMP.py:97-103).
@@ -275,10 +277,12 @@ int nmrf_instance_apply_f32(const float *x, const float *ws, const float *residu
  *   out[b,co,p] = sum_ci W[co,ci] * relu((x[b,c0+ci,p] - mean[b,c0+ci]) * rstd[b,c0+ci]) (+ bias[co])      (stats == NULL: plain x)
  * x [B,Cx,HW] NCHW (the 3x3 conv output; several heads may share it through c0), stats = nmrf_instance_stats_f32 workspace of x,
  * K in {64, 128} input channels, N % 64 == 0 output channels, out [B,N,HW].  stream_w = nmrf_pack_split_weight_f32(W[N,K], Kp = K)
- * pairs (strip-major), total_stages = N/32 * K/16 / 8, inv_scale = 1 / its scale.  Split-operand fp16 MFMA. */
+ * pairs (strip-major), total_stages = N/32 * K/16 / 8, inv_scale = 1 / its scale.  Split-operand fp16 MFMA.
+ * token_major != 0: out is written [B,HW,N] (a pixel's N channels contiguous) -- the layout nmrf_warp_corr_concat_f32 reads with
+ * 16-byte loads and the layout of the DPN context rows (DPN.py:120: `context.permute(0, 2, 3, 1)`). */
 int nmrf_conv1x1_in_relu_f32(const float *x, int B, int Cx, int64_t HW, int c0, int K, const float *stats, int chunks, float eps,
                              const void *stream_w, int total_stages, float inv_scale, const float *bias, int N, float *out,
-                             int *range_flag, void *stream);
+                             int token_major, int *range_flag, void *stream);
 /* The same kernel as a plain strided 1x1 convolution over [B,Cx,H,W] (the down-sampling shortcuts of the encoder,
  * nmrf/models/backbone.py:33-35: Conv2d(64, 96, 1, stride 2), Conv2d(96, 128, 1)): out[b,co,y,x] = sum_ci W[co,ci] x[b,c0+ci,y*s,x*s]
  * (+ bias) -> [B,N,Ho,Wo], Ho = (H-1)/s + 1.  K in {16..128} (multiple of 16), any N: stream_w = nmrf_pack_split_weight_f32 of W
@@ -286,7 +290,7 @@ int nmrf_conv1x1_in_relu_f32(const float *x, int B, int Cx, int64_t HW, int c0, 
  * as in nmrf_conv1x1_in_relu_f32, which is this entry point with H*W = HW, stride 1. */
 int nmrf_conv1x1_f32(const float *x, int B, int Cx, int H, int W, int stride, int c0, int K, const float *stats, int chunks,
                      float eps, const void *stream_w, int total_stages, float inv_scale, const float *bias, int N, float *out,
-                     int *range_flag, void *stream);
+                     int token_major, int *range_flag, void *stream);
 
 /* N2: 3x3 / stride 1 / pad 1 / no-bias convolution as a direct implicit GEMM on the split-operand fp16 MFMA, optionally with the
  * InstanceNorm + ReLU of its INPUT folded into the operand load (conv1 / conv2 of ResidualBlock, nmrf/models/backbone.py:38-46;

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnmrf_hip.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -28,7 +28,7 @@ PROTOTYPES = {
     "nmrf_ln_concat_f32": [_P, _P, _P, _F, _P, _I, _I, _L, _I, _P, _I, _P],
     "nmrf_add_ln_concat_f32": [_P, _P, _P, _P, _P, _F, _P, _I, _I, _L, _I, _P, _I, _P],
     "nmrf_stripe_attn_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
-    "nmrf_warp_corr_concat_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P],
+    "nmrf_warp_corr_concat_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     "nmrf_self_attn_f32": [_P, _L, _I, _I, _I, _P, _P],
     "nmrf_window_attn_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "nmrf_linear_smalln_f32": [_P, _P, _P, _L, _I, _I, _I, _P, _P],
@@ -54,8 +54,8 @@ PROTOTYPES = {
     "nmrf_host_copy_nt": [_P, _P, ctypes.c_size_t],
     "nmrf_host_read_evict": [_P, _P, ctypes.c_size_t],
     "nmrf_conv3x3_split_f32": [_P, _I, _I, _I, _I, _P, _I, _F, _P, _I, _I, _F, _I, _P, _P, _P],
-    "nmrf_conv1x1_in_relu_f32": [_P, _I, _I, _L, _I, _I, _P, _I, _F, _P, _I, _F, _P, _I, _P, _P, _P],
-    "nmrf_conv1x1_f32": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _F, _P, _I, _F, _P, _I, _P, _P, _P],
+    "nmrf_conv1x1_in_relu_f32": [_P, _I, _I, _L, _I, _I, _P, _I, _F, _P, _I, _F, _P, _I, _P, _I, _P, _P],
+    "nmrf_conv1x1_f32": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _F, _P, _I, _F, _P, _I, _P, _I, _P, _P],
     "nmrf_prep_images_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "nmrf_bias_avgpool2_f32": [_P, _P, _L, _I, _I, _I, _P, _P, _P],
     "nmrf_selftest_mfma_f32": [_P, _P, _I, _P, _P],

@@ -33,6 +33,7 @@ struct Conv1x1Args {
     int *range_flag;             // sticky fp16-range flag of the split operands (split_mfma.h), may be NULL
     int stride, Wo, Win;         // stride > 1: output pixel (y, x) of a Wo-wide map reads input pixel (y * stride, x * stride) of a Win-wide one
     int64_t HWin;                // pixels of an input plane (== HW when stride == 1)
+    int tok;                     // out is token-major [B, HW, N] (a pixel's channels contiguous: the layout the per-token kernels read)
 };
 
 template <int KC>                // 16-deep k chunks: 4 (K = 64) or 8 (K = 128)
@@ -125,6 +126,25 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1x1Args a) {
                 }
                 __syncthreads();
                 // 32 rows (channels) of 128 pixels: thread = (row = tid / 32 + 8 * pass, 4 pixels)
+                if (a.tok) {
+                    // token-major: thread = (pixel tid / 8 + 32 pass, 4 channels): 8 threads write the strip's 128 bytes of a pixel
+                    float *tbase = a.out + (size_t)b * a.HW * a.N;
+#pragma unroll
+                    for (int pass = 0; pass < 4; ++pass) {
+                        const int px = (tid >> 3) + 32 * pass, cc = (tid & 7) * 4;
+                        const int co = co0 + cc;
+                        const int64_t pp = pb + px;
+                        if (co < a.N && pp < a.HW) {
+                            f32x4 v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = Ot[(cc + e) * C1_OLD + px];
+                            float *dst = tbase + (size_t)pp * a.N + co;
+                            if (co + 3 < a.N && (a.N & 3) == 0) *reinterpret_cast<f32x4 *>(dst) = v;
+                            else
+                                for (int e = 0; e < 4 && co + e < a.N; ++e) dst[e] = v[e];
+                        }
+                    }
+                } else
 #pragma unroll
                 for (int pass = 0; pass < 4; ++pass) {
                     const int row = (tid >> 5) + 8 * pass, px = (tid & 31) * 4;
@@ -177,14 +197,14 @@ static int launch_conv1x1(const Conv1x1Args &a, hipStream_t st) {
 
 extern "C" int nmrf_conv1x1_in_relu_f32(const float *x, int B, int Cx, int64_t HW, int c0, int K, const float *stats, int chunks,
                                         float eps, const void *stream_w, int total_stages, float inv_scale, const float *bias, int N,
-                                        float *out, int *range_flag, void *stream) {
+                                        float *out, int token_major, int *range_flag, void *stream) {
     return nmrf_conv1x1_f32(x, B, Cx, (int)HW, 1, 1, c0, K, stats, chunks, eps, stream_w, total_stages, inv_scale, bias, N, out,
-                            range_flag, stream);
+                            token_major, range_flag, stream);
 }
 
 extern "C" int nmrf_conv1x1_f32(const float *x, int B, int Cx, int H, int W, int stride, int c0, int K, const float *stats, int chunks,
                                 float eps, const void *stream_w, int total_stages, float inv_scale, const float *bias, int N,
-                                float *out, int *range_flag, void *stream) {
+                                float *out, int token_major, int *range_flag, void *stream) {
     if (!x || !stream_w || !out) return NMRF_ENULL;
     if (B < 1 || H < 1 || W < 1 || stride < 1 || stride > 4 || K < 16 || K > 128 || (K & 15) || c0 < 0 || c0 + K > Cx || N < 1 ||
         (stats && (chunks < 1 || stride != 1)))
@@ -198,7 +218,7 @@ extern "C" int nmrf_conv1x1_f32(const float *x, int B, int Cx, int H, int W, int
     const int tpi = (int)ceil_div64(HW, C1_PIX);
     if ((int64_t)tpi * B > 0x7fffffff) return NMRF_EINVAL;
     Conv1x1Args a{x, Cx, c0, K, stats, chunks, eps, stream_w, total_stages, bias, out, N, HW, tpi, tpi * B, inv_scale, range_flag,
-                  stride, Wo, W, HWin};
+                  stride, Wo, W, HWin, token_major != 0};
     hipStream_t st = (hipStream_t)stream;
     switch (kc) {
         case 4: return launch_conv1x1<4>(a, st);

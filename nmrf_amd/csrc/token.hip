@@ -126,12 +126,17 @@ extern "C" int nmrf_self_attn_f32(const float *qkv, int64_t T, int N, int C, int
 // per-channel NCHW read is coalesced for f1/g1 and near-coalesced for the warped f2/g2 taps.
 // The sampling position reproduces grid_sample(align_corners=True)'s float round trip (H6).
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float f4_get(const float4 &v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+
 struct WarpTaps {
     int off[4];     // y*W + x of the four taps (clamped in range)
     float w[4];     // weight, already zeroed for out-of-range taps
 };
 
 __device__ __forceinline__ WarpTaps make_taps(float label, int x, int y, int H, int W) {
+    // every operation below is rounded on its own, as in ATen (left to -ffp-contract=fast the compiler fused `ix - floor(ix)` with
+    // the product that makes ix, and (1 - wx1) * wy with its subtraction, differently from one kernel to the next)
+#pragma clang fp contract(off)
     // reference grid (NMP.py:696-704): gx = 2*(x + (-d))/(W-1) - 1 ; gy = 2*(y + 0)/(H-1) - 1
     float gx = 2.0f * ((float)x + (-label)) / (float)(W - 1) - 1.0f;
     float gy = 2.0f * ((float)y + 0.0f) / (float)(H - 1) - 1.0f;
@@ -164,10 +169,13 @@ __device__ __forceinline__ WarpTaps make_taps(float label, int x, int y, int H, 
 // nw*v + ne*v + sw*v + se*v in ATen's order.  All four taps are ALWAYS loaded (their offsets are clamped into the map; a
 // zero-weight tap contributes 0 * finite = exactly 0): unconditional loads let the compiler issue a whole channel batch as one
 // clause -- with the former `if (w != 0) load` every tap was its own branch + wait and the kernel sat at 88 % SQ_WAIT_ANY.
+// Products and sums are rounded separately, like ATen's vectorised CPU kernel (no FMA contraction: left to the compiler, each
+// instantiation got its own mix of fused and unfused terms, and the NCHW and token-major kernels differed in the last bit).
 __device__ __forceinline__ float warp_combine(const float (&v)[4], const WarpTaps &t) {
-    float r = 0.f;
+#pragma clang fp contract(off)
+    float r = v[0] * t.w[0];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) r += v[k] * t.w[k];
+    for (int k = 1; k < 4; ++k) r = r + v[k] * t.w[k];
     return r;
 }
 
@@ -262,10 +270,86 @@ __global__ __launch_bounds__(256, 5) void warp_corr_concat_kernel(const float *_
     else body(std::false_type{});
 }
 
+// The same operation on TOKEN-MAJOR maps ([B, HW, C]: what nmrf_conv1x1_in_relu_f32 writes with token_major = 1), for the shipped
+// 64 feature channels / 256 correlation channels in 32 groups.  32 lanes = one token: lane l owns correlation group l (its 8
+// channels are two 16-byte pieces of a pixel's row) and, for l < 16, feature channels 4l .. 4l+3; every tap is one contiguous row,
+// so a token costs 9 (two taps) or 15 16-byte loads per lane, all in flight at once, instead of 120-216 dword gathers from 320
+// channel planes.  Same taps, same products, same order of additions as the NCHW kernel: identical bits.
+__global__ __launch_bounds__(256) void warp_corr_concat_tok_kernel(const float *__restrict__ labels,
+        const float *__restrict__ f1, const float *__restrict__ f2, const float *__restrict__ g1,
+        const float *__restrict__ g2, int H, int W, int N, unsigned T, float *__restrict__ out, int ld) {
+    constexpr int Cf = 64, Cg = 256;
+    const int sub = threadIdx.x & 31;
+    const unsigned t_raw = blockIdx.x * 8u + (threadIdx.x >> 5);
+    const bool live = t_raw < T;
+    const unsigned t = live ? t_raw : T - 1;
+    const unsigned hw = (unsigned)(H * W);
+    const unsigned pixn = t / (unsigned)N;                                 // b * HW + pix
+    const unsigned b = pixn / hw, pix = pixn - b * hw;
+    const int y = (int)(pix / (unsigned)W), x = (int)(pix - (unsigned)y * W);
+    const WarpTaps tp = make_taps(labels[t], x, y, H, W);
+    const float *pf1 = f1 + (size_t)pixn * Cf + 4 * sub, *pf2 = f2 + (size_t)b * hw * Cf + 4 * sub;
+    const float *pg1 = g1 + (size_t)pixn * Cg + 8 * sub, *pg2 = g2 + (size_t)b * hw * Cg + 8 * sub;
+    const bool feat = sub < 16;
+    const bool two_taps = __builtin_amdgcn_ballot_w64(tp.w[2] != 0.f || tp.w[3] != 0.f) == 0;   // (see the NCHW kernel)
+    auto body = [&](auto two_c) {
+        constexpr int NT = decltype(two_c)::value ? 2 : 4;
+        float4 ga[2], gv[NT][2], fa = make_float4(0.f, 0.f, 0.f, 0.f), fv[NT];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ga[i] = ldg4(pg1 + 4 * i);
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) gv[q][i] = ldg4(pg2 + (size_t)tp.off[q] * Cg + 4 * i);
+            fv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (feat) {
+            fa = ldg4(pf1);
+#pragma unroll
+            for (int q = 0; q < NT; ++q) fv[q] = ldg4(pf2 + (size_t)tp.off[q] * Cf);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = q < NT ? f4_get(gv[q < NT ? q : 0][c >> 2], c & 3) : 0.f;
+            s = fmaf(f4_get(ga[c >> 2], c & 3), warp_combine(v, tp), s);
+        }
+        float w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = q < NT ? f4_get(fv[q < NT ? q : 0], k) : 0.f;
+            w[k] = warp_combine(v, tp);
+        }
+        if (live) {
+            float *o = out + (size_t)t * ld;
+            if (feat) {
+                stg4(o + 4 * sub, fa);
+                stg4(o + Cf + 4 * sub, make_float4(w[0], w[1], w[2], w[3]));
+            }
+            o[2 * Cf + sub] = s * (1.0f / 8.0f);
+        }
+    };
+    if (two_taps) body(std::true_type{});
+    else body(std::false_type{});
+}
+
 extern "C" int nmrf_warp_corr_concat_f32(const float *labels, const float *f1, const float *f2, const float *g1,
                                          const float *g2, int B, int H, int W, int N, int Cf, int Cg, int groups,
-                                         float *out, int ld, void *stream) {
+                                         float *out, int ld, int token_major, void *stream) {
     if (!labels || !f1 || !f2 || !g1 || !g2 || !out) return NMRF_ENULL;
+    if (token_major) {
+        const int64_t T = (int64_t)B * H * W * N;
+        if (B < 1 || H < 2 || W < 2 || N < 1 || Cf != 64 || Cg != 256 || groups != 32 || ld < 2 * Cf + groups || (ld & 3) ||
+            T >= ((int64_t)1 << 31))
+            return NMRF_EINVAL;
+        hipLaunchKernelGGL(warp_corr_concat_tok_kernel, dim3((unsigned)ceil_div64(T, 8)), dim3(256), 0, (hipStream_t)stream, labels,
+                           f1, f2, g1, g2, H, W, N, (unsigned)T, out, ld);
+        return nmrf_launch_status();
+    }
     if (B < 1 || H < 2 || W < 2 || N < 1 || Cf < 4 * WC_CHUNKS || Cf % (4 * WC_CHUNKS) || groups < 4 * WC_CHUNKS ||
         groups % (4 * WC_CHUNKS) || Cg % groups || ld < 2 * Cf + groups || (ld & 3) || B > 65535)
         return NMRF_EINVAL;

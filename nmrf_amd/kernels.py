@@ -262,10 +262,15 @@ def stripe_attn(qkv, lepe_v, lepe_h, b, h, w, n, kv16=False):
 
 
 @_on_device
-def warp_corr_concat(labels, f1, f2, g1, g2, n, groups=32, ld=None):
+def warp_corr_concat(labels, f1, f2, g1, g2, n, groups=32, ld=None, token_major=False):
+    """f1, f2 [B,Cf,H,W], g1, g2 [B,Cg,H,W] (token_major: [B,H,W,C], Cf 64 / Cg 256 / 32 groups) -> [T, ld]."""
     _chk(labels, f1, f2, g1, g2)
-    b, cf, h, w = f1.shape
-    cg = g1.shape[1]
+    if token_major:
+        b, h, w, cf = f1.shape
+        cg = g1.shape[3]
+    else:
+        b, cf, h, w = f1.shape
+        cg = g1.shape[1]
     if ld is None:
         ld = 2 * cf + groups
     t = b * h * w * n
@@ -274,9 +279,9 @@ def warp_corr_concat(labels, f1, f2, g1, g2, n, groups=32, ld=None):
     _hb("warp_corr_concat_n%d" % n, row="A9" if n > 1 else "A13", bound="hbm",
         bytes=4.0 * (2 * f1.numel() + 2 * g1.numel() + t + out.numel()), flops=2.0 * t * (cg + 2 * cf),
         label="warp_corr_concat_kernel (warp + 32-group correlation + concat, %s)" % ("A9, 1/8" if n > 1 else "A13, 1/4"),
-        pmc=["warp_corr_concat_kernel"])
+        pmc=["warp_corr_concat_tok_kernel" if token_major else "warp_corr_concat_kernel"])
     _lib.check(_lib.load().nmrf_warp_corr_concat_f32(_p(labels), _p(f1), _p(f2), _p(g1), _p(g2), b, h, w, n, cf, cg,
-                                                     groups, _p(out), ld, _stream()), "warp_corr_concat")
+                                                     groups, _p(out), ld, int(token_major), _stream()), "warp_corr_concat")
     _he("warp_corr_concat_n%d" % n)
     return out
 
@@ -816,18 +821,19 @@ def instance_stats(x):
 
 
 @_on_device
-def conv1x1_in_relu(x, c0, k, stats, packed, bias=None, eps=1e-5):
-    """out = Conv1x1(relu(InstanceNorm(x[:, c0:c0+k])))  (stats None: Conv1x1(x[:, c0:c0+k])).  packed = (stream, stages, 1/scale, N)."""
+def conv1x1_in_relu(x, c0, k, stats, packed, bias=None, eps=1e-5, token_major=False):
+    """out = Conv1x1(relu(InstanceNorm(x[:, c0:c0+k])))  (stats None: Conv1x1(x[:, c0:c0+k])).  packed = (stream, stages, 1/scale, N).
+    token_major: the result is [B,H,W,N] (a pixel's channels contiguous) instead of [B,N,H,W]."""
     _chk(x, stats, bias)
     stream, stages, inv, n = packed
     _chk(stream, dtype=torch.int32)
     b, cx, h, w = x.shape
-    out = torch.empty(b, n, h, w, device=x.device, dtype=torch.float32)
+    out = torch.empty((b, h, w, n) if token_major else (b, n, h, w), device=x.device, dtype=torch.float32)
     _hb("conv1x1_k%d_n%d" % (k, n), row="N2", bound="hbm", bytes=4.0 * b * h * w * (k + n), flops=2.0 * b * h * w * k * n, split=True,
         label="conv1x1_kernel (InstanceNorm + ReLU + 1x1 conv %d->%d of the conv heads, N2)" % (k, n), pmc=["conv1x1_kernel<%d>" % (k // 16)])
     _lib.check(_lib.load().nmrf_conv1x1_in_relu_f32(_p(x), b, cx, h * w, c0, k, _p(stats), 0 if stats is None else stats.shape[1],
-                                                    float(eps), _p(stream), stages, float(inv), _p(bias), n, _p(out), _rf(x), _stream()),
-               "conv1x1_in_relu")
+                                                    float(eps), _p(stream), stages, float(inv), _p(bias), n, _p(out), int(token_major), _rf(x),
+                                                    _stream()), "conv1x1_in_relu")
     _he("conv1x1_k%d_n%d" % (k, n))
     return out
 
@@ -857,7 +863,7 @@ def conv1x1(x, packed, k, stride=1, bias=None):
         split=True, label="conv1x1_kernel (1x1 stride-%d shortcut %d->%d of the encoder, N2)" % (stride, k, n),
         pmc=["conv1x1_kernel<%d>" % (4 if k <= 64 else 8)])
     _lib.check(_lib.load().nmrf_conv1x1_f32(_p(x), b, cx, h, w, stride, 0, k, None, 0, 1e-5, _p(stream), stages, float(inv), _p(bias), n,
-                                            _p(out), _rf(x), _stream()), "conv1x1")
+                                            _p(out), 0, _rf(x), _stream()), "conv1x1")
     _he("conv1x1_s%d_k%d_n%d" % (stride, k, n))
     return out
 

@@ -60,8 +60,9 @@ class DPN(nn.Module):
         seeds = K.nms_topk(prob, self.num_proposals, self.eps)
         return (prob, seeds) if features is None else (prob, seeds, None)
 
-    def context(self, fmap):
-        """proj (Conv3x3 - IN - ReLU - Conv1x1, DPN.py:45-49) of the 1/8-resolution left feature map -> [B,Cctx,H,W]."""
+    def context(self, fmap, token_major=False):
+        """proj (Conv3x3 - IN - ReLU - Conv1x1, DPN.py:45-49) of the 1/8-resolution left feature map -> [B,Cctx,H,W];
+        token_major: [B,H,W,Cctx], the rows the propagation consumes (DPN.py:120), written as such by the 1x1 kernel."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.proj.parameters()):
             raise NotImplementedError("nmrf_amd implements the inference path only: call under torch.no_grad()")
         if not hasattr(self, "_c3"):
@@ -72,11 +73,14 @@ class DPN(nn.Module):
             from .nmp import _FusedCache                    # IN + ReLU folded into the 1x1 conv's operand load (csrc/conv1x1.hip)
             if not hasattr(self, "_c1"):
                 self._c1 = _FusedCache()
-            return K.conv1x1_in_relu(raw, 0, w1.shape[1], K.instance_stats(raw), self._c1.get((w1,), lambda: K.pack_conv1x1(w1)))
-        return self.proj[3](K.instance_norm(raw, relu=True))     # conv3x3 - IN - ReLU fused
+            return K.conv1x1_in_relu(raw, 0, w1.shape[1], K.instance_stats(raw), self._c1.get((w1,), lambda: K.pack_conv1x1(w1)),
+                                     token_major=token_major)
+        out = self.proj[3](K.instance_norm(raw, relu=True))     # conv3x3 - IN - ReLU fused
+        return out.permute(0, 2, 3, 1).contiguous() if token_major else out
 
     def forward(self, cost_volume, fmap1_list, context=None, context_ready=None):
-        """cost_volume: [B,G,D,H,W] (reference layout) or token-major [B*H*W,G,D].  context: [B,Cctx,H,W] precomputed by the
+        """cost_volume: [B,G,D,H,W] (reference layout) or token-major [B*H*W,G,D].  context: [B,H,W,Cctx] rows
+        (self.context(fmap, token_major=True)) precomputed by the
         caller (possibly on another stream: context_ready = the event recorded behind it, waited for where it is first used).
         Returns (cost_volume [P,G,D], prob [P,D], label_seeds [P,N] float, labels [1,P,N])."""
         if cost_volume.dim() == 5:
@@ -84,10 +88,9 @@ class DPN(nn.Module):
             cost_volume = cost_volume.permute(0, 3, 4, 1, 2).reshape(b * h * w, g, d).contiguous()
         prob, seeds, feats = self.seeds(cost_volume, features=self.propagation.seed_feature_args(context))
         if context is None:
-            context = self.context(fmap1_list[0])
+            context = self.context(fmap1_list[0], token_major=True)
         elif context_ready is not None:
             torch.cuda.current_stream().wait_event(context_ready)
-        context = context.permute(0, 2, 3, 1).contiguous()
         memory, seeds_f = self.propagation(cost_volume, seeds, context, feats=feats)
         # labels = relu(prop_head(memory) + seeds) (DPN.py:131-132): the add and the ReLU leave with the head's rows
         labels = self.prop_head(memory, row_add=seeds_f.reshape(-1, 1), relu_out=True).view(-1, *seeds_f.shape)

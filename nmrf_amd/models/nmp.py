@@ -454,7 +454,7 @@ class Propagation(nn.Module):
     def seed_feature_args(self, context):
         """(Fourier normalizer, encoding row stride) of the seed features this module consumes (NMP.py:646-647), for the producer of
         the seeds to gather them in its own launch (DPN.seeds / K.seed_select)."""
-        cc = context.shape[1] if context is not None else self.layers[0].nmp.q.in_features - self.embed_dim
+        cc = context.shape[-1] if context is not None else self.layers[0].nmp.q.in_features - self.embed_dim   # rows [B,H,W,Cctx]
         return (3.14 / 64, 32 if self._split_ok(cc) else 31)
 
     def forward(self, cost_volume, label_seed, context, feats=None):
@@ -526,13 +526,16 @@ class Inference(nn.Module):
         self.ffn = Mlp(dim + cost_group, dim, dim)
         self.dim, self.layers, self.norm, self.cost_group = dim, layers, norm, cost_group
 
-    def _run(self, labels_flat, n, fmap1, fmap2, fmap1_gw, fmap2_gw):
-        b, _, h, wd = fmap1.shape
+    def _run(self, labels_flat, n, fmap1, fmap2, fmap1_gw, fmap2_gw, token_major=False):
+        if token_major:                                   # maps [B,H,W,C] (written so by the heads' 1x1 kernels)
+            b, h, wd, _ = fmap1.shape
+        else:
+            b, _, h, wd = fmap1.shape
         dims = (b, h, wd, n)
         split = _split() and self.dim == 128 and all(
             _block_ok(l.nmp.proj, l.nmp.mlp, *((l.self_nmp.proj,) if hasattr(l, "self_nmp") else ())) for l in self.layers)
         win = self.layers[0].window_size
-        wcc = K.warp_corr_concat(labels_flat, fmap1, fmap2, fmap1_gw, fmap2_gw, n, self.cost_group)
+        wcc = K.warp_corr_concat(labels_flat, fmap1, fmap2, fmap1_gw, fmap2_gw, n, self.cost_group, token_major=token_major)
         if split and wcc.shape[1] == 160 and self.ffn.fc1.out_features == 128 and self.ffn.fc2.out_features == 128:
             # ffn and Fourier rows are written straight into the zero-padded token grid; the final norm is cropped on the way out
             if not hasattr(self, "_maps"):
@@ -623,10 +626,10 @@ class Inference(nn.Module):
             return (ln if self.norm is not None else x).index_select(0, keep)
         return ln if self.norm is not None else x
 
-    def forward(self, labels, fmap1, fmap2, fmap1_gw, fmap2_gw):
-        """labels [B*H*W, N] -> [1, B*H*W, N, C]"""
+    def forward(self, labels, fmap1, fmap2, fmap1_gw, fmap2_gw, token_major=False):
+        """labels [B*H*W, N] -> [1, B*H*W, N, C]   (token_major: the four maps are [B,H,W,C] instead of [B,C,H,W])"""
         n = labels.shape[-1]
-        out = self._run(labels.reshape(-1).contiguous(), n, fmap1, fmap2, fmap1_gw, fmap2_gw)
+        out = self._run(labels.reshape(-1).contiguous(), n, fmap1, fmap2, fmap1_gw, fmap2_gw, token_major)
         return out.view(1, -1, n, self.dim)
 
 
@@ -635,7 +638,7 @@ class Refinement(Inference):
 
     normalizer = 3.14 / 128
 
-    def forward(self, labels, fmap1, fmap2, fmap1_gw, fmap2_gw):
+    def forward(self, labels, fmap1, fmap2, fmap1_gw, fmap2_gw, token_major=False):
         """labels [B,H,W] -> [1, B*H*W, C]"""
-        out = self._run(labels.reshape(-1).contiguous(), 1, fmap1, fmap2, fmap1_gw, fmap2_gw)
+        out = self._run(labels.reshape(-1).contiguous(), 1, fmap1, fmap2, fmap1_gw, fmap2_gw, token_major)
         return out.view(1, -1, self.dim)

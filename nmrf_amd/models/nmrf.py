@@ -152,7 +152,9 @@ class NMRF(nn.Module):
         """concatconv / gw on both views as ONE stock 3x3 convolution: the two heads share their input, so their
         first convs are stacked along the output channels and the two views along the batch (conv3x3 ->
         InstanceNorm -> ReLU are per-(sample, channel) independent: same arithmetic as NMRF.py:211-214,233-236),
-        then one 1x1 conv per head on its 128-channel slice.  Returns (fmap1, fmap2, fmap1_gw, fmap2_gw)."""
+        then one 1x1 conv per head on its 128-channel slice.  Returns ((fmap1, fmap2, fmap1_gw, fmap2_gw), token_major):
+        with the shipped head widths (64 / 256 channels) the maps are written token-major [B,H,W,C] -- their only consumer is the
+        warp + correlation kernel, which then reads every tap as one contiguous row."""
         heads = (self.concatconv, self.gw)
         w3 = cache.get(tuple(h[0].weight for h in heads), lambda: torch.cat([h[0].weight for h in heads], 0).contiguous())
         b = left.shape[0]
@@ -172,13 +174,15 @@ class NMRF(nn.Module):
             if not hasattr(cache, "c1"):
                 cache.c1 = (_FusedCache(), _FusedCache())
             stats = K.instance_stats(raw)
-            f = K.conv1x1_in_relu(raw, 0, 128, stats, cache.c1[0].get((wf,), lambda: K.pack_conv1x1(wf)))
-            g = K.conv1x1_in_relu(raw, 128, 128, stats, cache.c1[1].get((wg,), lambda: K.pack_conv1x1(wg)))
+            tok = wf.shape[0] == 64 and wg.shape[0] == 256 and self.inference.cost_group == 32
+            f = K.conv1x1_in_relu(raw, 0, 128, stats, cache.c1[0].get((wf,), lambda: K.pack_conv1x1(wf)), token_major=tok)
+            g = K.conv1x1_in_relu(raw, 128, 128, stats, cache.c1[1].get((wg,), lambda: K.pack_conv1x1(wg)), token_major=tok)
         else:
+            tok = False
             y = K.instance_norm(raw, relu=True)
             f = F.conv2d(y[:, 0:128], wf)
             g = F.conv2d(y[:, 128:256], wg)
-        return f[:b].contiguous(), f[b:].contiguous(), g[:b].contiguous(), g[b:].contiguous()
+        return (f[:b].contiguous(), f[b:].contiguous(), g[:b].contiguous(), g[b:].contiguous()), tok
 
     def hot_path(self, fmap1_list, fmap2_list, out_hw, stages=None):
         """Everything after the backbone (NMRF.py:207-262): fmap lists are [1/8-res, 1/4-res] NCHW maps of the
@@ -205,12 +209,12 @@ class NMRF(nn.Module):
         with torch.cuda.stream(side):
             if overlap:
                 # the DPN context convs first: the seed stage (cost volume, conv1d + softmax, NMS: latency-bound) runs beside them
-                context = self.dpn.context(fmap1_list[0])
+                context = self.dpn.context(fmap1_list[0], token_major=True)
                 ctx_ready = torch.cuda.Event()
                 ctx_ready.record(side)
                 context.record_stream(main)
-            heads8 = self._match_heads(fmap1_list[0], fmap2_list[0], self._head_cache8)
-            heads4 = self._match_heads(fmap1_list[1], fmap2_list[1], self._head_cache4)
+            heads8, tok8 = self._match_heads(fmap1_list[0], fmap2_list[0], self._head_cache8)
+            heads4, tok4 = self._match_heads(fmap1_list[1], fmap2_list[1], self._head_cache4)
             if overlap:
                 for t in heads8 + heads4:
                     t.record_stream(main)
@@ -223,8 +227,8 @@ class NMRF(nn.Module):
         fmap1, fmap2, fmap1_gw, fmap2_gw = heads8
 
         # ---- neural MRF inference at 1/8 -------------------------------------------------------------
-        tgt = self.inference(labels_curr, fmap1, fmap2, fmap1_gw, fmap2_gw).view(-1, self.inference.dim)
-        b, _, h8, w8 = fmap1.shape
+        tgt = self.inference(labels_curr, fmap1, fmap2, fmap1_gw, fmap2_gw, token_major=tok8).view(-1, self.inference.dim)
+        b, h8, w8 = fmap1_list[0].shape[0], fmap1_list[0].shape[2], fmap1_list[0].shape[3]
         disp_delta = self.infer_head(tgt)                                   # [T,64]
         from .nmp import _ChainLauncher, _split
         if _split() and self.infer_score_head.in_features == 128 and self.infer_score_head.out_features <= 64:
@@ -240,7 +244,7 @@ class NMRF(nn.Module):
 
         # ---- refinement at 1/4 ---------------------------------------------------------------------------
         fmap1, fmap2, fmap1_gw, fmap2_gw = heads4
-        tgt = self.refinement(disp_curr, fmap1, fmap2, fmap1_gw, fmap2_gw).view(-1, self.refinement.dim)
+        tgt = self.refinement(disp_curr, fmap1, fmap2, fmap1_gw, fmap2_gw, token_major=tok4).view(-1, self.refinement.dim)
         disp, disp_pred = K.refine_epilogue(self.refine_head(tgt), disp_curr, h0, w0)
         if stages is not None:
             stages["refine_tgt"] = tgt

@@ -325,6 +325,18 @@ def test_warp_corr_concat(b, h, w, n):
     # (gx in [-1,1], 1 ulp = 6e-8, times (W-1)/2): a last-bit difference in gx between the CPU and the GPU
     # division moves the tap by ~5e-6 px, i.e. ~1e-5 of a unit-gradient feature (measured 9e-6 at W=156)
     report("warp_corr_concat", got, O.warp_corr_concat(labels, f1, f2, g1, g2), 3e-5, 1e-5)
+    # token-major maps ([B,H,W,C], one contiguous row per tap): the same bits
+    nhwc = lambda m: m.permute(0, 2, 3, 1).contiguous().to(DEV)
+    tok = K().warp_corr_concat(labels.reshape(-1).to(DEV), nhwc(f1), nhwc(f2), nhwc(g1), nhwc(g2), n, token_major=True).cpu()
+    if not torch.equal(tok, got):
+        bad = (tok != got).nonzero()
+        rows = bad[:, 0].unique()
+        msg = [f"max|d|={float((tok - got).abs().max())} elements={len(bad)} rows={len(rows)} of {tok.shape[0]}",
+               f"cols: copy {int((bad[:, 1] < 64).sum())} warp {int(((bad[:, 1] >= 64) & (bad[:, 1] < 128)).sum())} corr {int((bad[:, 1] >= 128).sum())}"]
+        for r in rows[:6].tolist():
+            pix = r // n
+            msg.append(f"row {r} (y={pix // w % h} x={pix % w} n={r % n}) label={float(labels.reshape(-1)[r])!r} cols={bad[bad[:, 0] == r, 1][:8].tolist()}")
+        raise AssertionError("\n".join(msg))
 
 
 def test_wta_median_and_refine_epilogue():
@@ -655,6 +667,9 @@ def test_conv1x1_in_relu_fused(b, cx, c0, k, n, h, w, norm):
     stats = kk.instance_stats(x.to(DEV)) if norm else None
     got = kk.conv1x1_in_relu(x.to(DEV), c0, k, stats, kk.pack_conv1x1(wt.to(DEV)), bias.to(DEV))
     report("conv1x1", got.cpu(), ref, 2e-5, 1e-5)
+    # the token-major form writes the same values as [B,H,W,N]
+    tok = kk.conv1x1_in_relu(x.to(DEV), c0, k, stats, kk.pack_conv1x1(wt.to(DEV)), bias.to(DEV), token_major=True)
+    assert tok.shape == (b, h, w, n) and torch.equal(tok.permute(0, 3, 1, 2), got)
 
 
 def test_prep_images_and_bias_avgpool():

@@ -11,8 +11,10 @@ rm -f gpurun_out/e2e_stats.jsonl
 echo "pytest exit: ${PIPESTATUS[0]}" >> gpurun_out/pytest_gpu.log
 ( timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -20 ) > gpurun_out/smoke.log
 ( timeout 900 python bench.py --steps 20 --warmup 5 2>&1 | tail -5 ) > gpurun_out/bench.log
+if [ -z "$LEAN" ]; then      # LEAN=1: tests, smoke, bench and the kernel trace only
 ( NMRF_LINEAR=fp32 timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | tail -2 ) > gpurun_out/bench_fp32_linears.log
 ( timeout 600 python tools/kernel_bench.py --iters 20 --which window,stripe,refine,block 2>&1 | grep -v stamp | tail -60 ) > gpurun_out/kernel_bench_block.log
+fi
 if [ "$1" != "quick" ]; then
   # the other BASELINE configs: bench lines kept under profiles/
   ( timeout 600 python bench.py --steps 10 --warmup 3 --infer-layers 4 --no-cpu-baseline 2>&1 | tail -2 ) > gpurun_out/bench_infer4.log
@@ -32,5 +34,5 @@ for t in ${TAG} ${TAG}_swin; do
 done
 ls -la gpurun_out
 tail -60 gpurun_out/pytest_gpu.log; cat gpurun_out/smoke.log; for f in gpurun_out/bench*.log; do echo "== $f"; cut -c1-1500 $f; done
-cat gpurun_out/kernel_bench_block.log
+[ -z "$LEAN" ] && cat gpurun_out/kernel_bench_block.log
 head -40 gpurun_out/${TAG}_kernel_stats.txt
