@@ -84,4 +84,9 @@ def build_library(force=False, verbose=True, debug=False):
 
 
 if __name__ == "__main__":
-    build_library(force="--force" in sys.argv, debug="--debug" in sys.argv)
+    # both libraries by default: a product build next to a stale tools build fails every A/B test with an ABI mismatch
+    # (--debug / --main-only: one of them)
+    if "--debug" not in sys.argv:
+        build_library(force="--force" in sys.argv)
+    if "--main-only" not in sys.argv:
+        build_library(force="--force" in sys.argv, debug=True)

@@ -47,6 +47,8 @@ def test_every_declared_symbol_is_exported_and_bound():
         dbg = ctypes.CDLL(_lib.DEBUG_LIB_PATH)
         for name in dbg_declared | declared:
             assert hasattr(dbg, name), f"{name} missing from libnmrf_hip_debug.so"
+        # a tools build left behind by an older ABI fails every A/B test on the GPU box (it travels with the tree as built)
+        assert dbg.nmrf_abi_version() == _lib.ABI_VERSION, "libnmrf_hip_debug.so is stale: python -m nmrf_amd.build"
 
 
 def test_product_reads_two_environment_switches_only():
