@@ -82,24 +82,36 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(Conv1x1Args a) {
         const unsigned loff = (unsigned)(pin + (int64_t)(4 * hi) * a.HWin);   // pixel + the lane half's 4 channels
         const float *affl = Aff + 4 * hi;
         h16x8 bh[KC], bl[KC];
+        // The 8 loads of a 16-channel chunk used to be followed by a full wait before its split: KC serial memory round trips per
+        // tile (and a uniform branch per load for the zero-padded chunks).  Now the loads of four chunks are in flight together,
+        // unconditionally (a chunk beyond K reads chunk 0's rows and is zeroed afterwards): two round trips at K = 128, one at 64.
+        constexpr int GC = 4;
+        static_assert(KC % GC == 0, "chunks are loaded in groups of four");
 #pragma unroll
-        for (int c = 0; c < KC; ++c) {
-            float v[8];
+        for (int c0 = 0; c0 < KC; c0 += GC) {
+            float v[GC][8];
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const float *row = xu + (size_t)(16 * c + (jj & 3) + 8 * (jj >> 2)) * a.HWin;   // uniform
-                v[jj] = 16 * c < a.K ? row[loff] : 0.f;                       // (whole chunks of the zero-padded k range: nothing to load)
+            for (int c = 0; c < GC; ++c) {
+                const int cb = 16 * (c0 + c) < a.K ? 16 * (c0 + c) : 0;                                  // uniform
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) v[c][jj] = (xu + (size_t)(cb + (jj & 3) + 8 * (jj >> 2)) * a.HWin)[loff];
             }
-            if (a.stats) {
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(affl + 16 * c + 8 * g);
-                    const f32x4 sh = *reinterpret_cast<const f32x4 *>(affl + 128 + 16 * c + 8 * g);
+            for (int c = 0; c < GC; ++c) {
+                const bool live = 16 * (c0 + c) < a.K;                                                   // uniform
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[4 * g + e] = fmaxf(fmaf(v[4 * g + e], sc[e], sh[e]), 0.f);
+                for (int jj = 0; jj < 8; ++jj) v[c][jj] = live ? v[c][jj] : 0.f;
+                if (a.stats) {
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const f32x4 sc = *reinterpret_cast<const f32x4 *>(affl + 16 * (c0 + c) + 8 * g);
+                        const f32x4 sh = *reinterpret_cast<const f32x4 *>(affl + 128 + 16 * (c0 + c) + 8 * g);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[c][4 * g + e] = fmaxf(fmaf(v[c][4 * g + e], sc[e], sh[e]), 0.f);
+                    }
                 }
+                split8u_g(v[c], bh[c0 + c], bl[c0 + c], guard);
             }
-            split8u_g(v, bh[c], bl[c], guard);
         }
         // Output: a C/D register is 32 pixels of one channel = a 128-byte piece; written as such (8 strips x 16 pieces per wave,
         // 117 KB apart) the 1/4-resolution gw head ran at ~1 TB/s.  The four waves of the block stage each 32-channel strip in an
