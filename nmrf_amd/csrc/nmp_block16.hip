@@ -120,11 +120,20 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
         }
     }
     {
-        auto put = [&](int off, const float *src, int n) {
-            for (int i = tid; i < n; i += B16_THR) Par[off + i] = src ? src[i] : 0.f;
-        };
-        put(B16P_BP, a.bp, 128); put(B16P_G2, a.ln2_g, 128); put(B16P_B2N, a.ln2_b, 128); put(B16P_B1, a.b1, 512);
-        put(B16P_B2, a.b2, 128); put(B16P_GQ, a.lnq_g, 128); put(B16P_BQN, a.lnq_b, 128); put(B16P_BQ, a.bq, a.bq ? a.NQ : 512);
+        // The eight parameter vectors are requested TOGETHER: written as `Par[i] = src ? src[i] : 0` one vector after the other, every
+        // vector was its own uniform branch + load + full wait -- eight serial L2 round trips at the head of every launch
+        // (tools/isa_scan.py).  A NULL vector reads the head of the weight stream instead (always >= 2 KB) and is zeroed afterwards.
+        const float *dummy = reinterpret_cast<const float *>(a.stream);
+        const float *srcs[8] = {a.bp, a.ln2_g, a.ln2_b, a.b1, a.b2, a.lnq_g, a.lnq_b, a.bq};
+        const int offs[8] = {B16P_BP, B16P_G2, B16P_B2N, B16P_B1, B16P_B2, B16P_GQ, B16P_BQN, B16P_BQ};
+        const int ns[8] = {128, 128, 128, 512, 128, 128, 128, a.bq ? a.NQ : 512};
+        float pv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pv[k] = (srcs[k] ? srcs[k] : dummy)[tid < ns[k] ? tid : 0];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (tid < ns[k]) Par[offs[k] + tid] = srcs[k] ? pv[k] : 0.f;
+        for (int i = tid + B16_THR; i < ns[7]; i += B16_THR) Par[B16P_BQ + i] = a.bq ? a.bq[i] : 0.f;    // (NQ > 512: not a shipped shape)
     }
     auto par4 = [&](int off) { return *reinterpret_cast<const f32x4 *>(Par + off); };
 
