@@ -173,17 +173,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const int n4 = (a.n_out + 3) >> 2;                                     // float4 per output row
-        // the tile's 32 row-map entries in ONE request (lane = row), handed to the store loop by shuffle: looked up inside the loop,
-        // every trip was a dependent load + full wait -- 16 serial round trips per tile at 128 output columns
-        int my_map = -1;
-        if (a.out_map && (lane & 31) + t0 < a.T) my_map = a.out_map[t0 + (lane & 31)];
         for (int idx = lane; idx < 32 * n4; idx += 64) {
             const int row = idx / n4, c4 = idx - row * n4;
             const int64_t t = t0 + row;
-            const int mapped = __shfl(my_map, row & 31);                       // (every lane takes part: before any `continue`)
             if (t >= a.T) continue;
             int64_t orow = t;
-            if (a.out_map) { orow = mapped; if (orow < 0) continue; }
+            if (a.out_map) { orow = a.out_map[t]; if (orow < 0) continue; }
             f32x4 v = *reinterpret_cast<const f32x4 *>(Ot + row * MC_OLD + 4 * c4);
             if (a.row_add) {
 #pragma unroll
