@@ -53,7 +53,12 @@ def parse(argv=None):
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find mode)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the result gather even at N=1 (smoke)")
     ap.add_argument("--sync-gather", action="store_true", help="gather on the compute stream inside every step (round-2 behaviour)")
-    return ap.parse_args(argv)
+    ap.add_argument("--lib", default=None, help="same-box A/B runs (tools/gpu_ab.sh): another build of libnmrf_hip.so (same ABI, checked at load)")
+    args = ap.parse_args(argv)
+    if args.lib:
+        import nmrf_amd._lib as _L
+        _L.LIB_PATH = os.path.abspath(args.lib)
+    return args
 
 
 class KernelTimer:
@@ -97,40 +102,66 @@ def _set_infer_layers(cfg, n):
 
 
 def cpu_baseline(height, width, infer_layers, max_disp=320):
-    """The CPU oracle (a plain-PyTorch port of the reference path, pinned to the reference by tests/test_oracle_golden.py) on
-    the host cores, same synthetic pair, batch 1: 1 warm-up + median of 3 forwards on up to 16 threads, and one
-    forward on 1 thread.  A bounded sample: ~10 s + ~25 s of CPU work at KITTI size."""
+    """The CPU oracle (a plain-PyTorch port of the reference path, pinned to the reference by tests/test_oracle_golden.py) on the
+    host cores, same synthetic pairs, batch 1 (both 1242x375 and 960x540, all host cores, and a 1-thread figure).
+    The op-by-op CPU path stops scaling at ~16 threads, so each size is timed on 16 threads AND on every core of the host;
+    `value` / `cores` is the faster of the two at the bench's own size, the other numbers ride along.  A bounded sample:
+    per size 1 warm-up + median of 3 forwards (16 threads) and 1 warm-up + 2 forwards (all cores); one forward on 1 thread."""
     from oracle import nmrf_oracle as O
     from nmrf_amd.config import get_cfg
     from nmrf_amd.models import build_model
     from nmrf_amd.utils.hashinit import hash_state_dict, synthetic_pair
     cores = os.cpu_count() or 1
-    nthr = min(cores, 16)                     # the op-by-op CPU path stops scaling (and collapses) beyond ~16 threads
-    torch.set_num_threads(nthr)
     cfg = get_cfg()
     _set_infer_layers(cfg, infer_layers)
     cfg.DPN.MAX_DISP = max_disp
     w = hash_state_dict(build_model(cfg)[0].state_dict())
     ocfg = O.OracleCfg(num_infer_layers=infer_layers, max_disp=max_disp)
-    l, r, _ = synthetic_pair(height, width, seed=1000)
 
-    def once():
-        t0 = time.perf_counter()
-        O.forward(w, ocfg, l[None], r[None])
-        return time.perf_counter() - t0
-
-    with torch.no_grad():
-        once()                                                  # warm-up
-        ts = sorted(once() for _ in range(3))
-        dt = ts[1]
-        torch.set_num_threads(1)
-        dt1 = once()
+    def timed(l, r, nthr, reps):
         torch.set_num_threads(nthr)
-    return {"value": 1.0 / dt, "unit": "stereo pairs/s", "cores": nthr, "kind": "port",
-            "value_1thread": 1.0 / dt1,
-            "sample": "one %dx%d pair, batch 1 (oracle/nmrf_oracle.py, torch CPU fp32): 1 warm-up + median of 3 forwards on %d "
-                      "threads = %.2f s; one forward on 1 thread = %.2f s; host has %d cores"
-                      % (width, height, nthr, dt, dt1, cores)}
+        ts = []
+        with torch.no_grad():
+            for i in range(reps + 1):                               # first = warm-up
+                t0 = time.perf_counter()
+                O.forward(w, ocfg, l[None], r[None])
+                ts.append(time.perf_counter() - t0)
+        ts = sorted(ts[1:])
+        return ts[len(ts) // 2] if len(ts) % 2 else ts[0]           # median of 3 / the better of 2
+
+    def one_size(h, wd, with_1thread):
+        l, r, _ = synthetic_pair(h, wd, seed=1000)
+        n16 = min(cores, 16)
+        rec = {"threads_%d_s" % n16: round(timed(l, r, n16, 3), 3)}
+        if cores > n16:
+            rec["threads_%d_s" % cores] = round(timed(l, r, cores, 2), 3)
+        if with_1thread:
+            torch.set_num_threads(1)
+            with torch.no_grad():
+                t0 = time.perf_counter()
+                O.forward(w, ocfg, l[None], r[None])
+                rec["threads_1_s"] = round(time.perf_counter() - t0, 3)
+        return rec
+
+    prev = torch.get_num_threads()
+    try:
+        main_rec = one_size(height, width, True)
+        sizes = {"%dx%d" % (width, height): main_rec}
+        for (h2, w2) in ((375, 1242), (540, 960)):
+            if (h2, w2) != (height, width):
+                sizes["%dx%d" % (w2, h2)] = one_size(h2, w2, False)
+    finally:
+        torch.set_num_threads(prev)
+    best_key = min((k for k in main_rec if k != "threads_1_s"), key=lambda k: main_rec[k])
+    nthr, dt = int(best_key.split("_")[1]), main_rec[best_key]
+    return {"value": round(1.0 / dt, 4), "unit": "stereo pairs/s", "cores": nthr, "kind": "port",
+            "value_1thread": round(1.0 / main_rec["threads_1_s"], 4), "host_cores": cores,
+            "seconds_per_forward": sizes,
+            "pairs_per_s": {sz: {k[:-2]: round(1.0 / v, 4) for k, v in rec.items()} for sz, rec in sizes.items()},
+            "sample": "one synthetic pair per size, batch 1 (oracle/nmrf_oracle.py, torch CPU fp32): per size 1 warm-up + median of 3 "
+                      "forwards on 16 threads and 1 warm-up + the better of 2 on all %d host cores; one forward on 1 thread at "
+                      "%dx%d; `value` = the faster thread count at %dx%d (%d threads, %.2f s)"
+                      % (cores, width, height, width, height, nthr, dt)}
 
 
 def _free_port():

@@ -7,8 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# NMRF_HIP_LIB: another build of the SAME library (same ABI, checked below) -- same-box A/B runs of one kernel change (tools/gpu_ab.sh)
-LIB_PATH = os.environ.get("NMRF_HIP_LIB") or os.path.join(_HERE, "lib", "libnmrf_hip.so")
+LIB_PATH = os.path.join(_HERE, "lib", "libnmrf_hip.so")      # (tools may point this at another build BEFORE the first load(): bench.py --lib)
 ABI_VERSION = 19
 
 _P = ctypes.c_void_p

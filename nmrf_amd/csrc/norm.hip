@@ -319,10 +319,18 @@ extern "C" int nmrf_bias_avgpool2_f32(const float *y, const float *bias, int64_t
 // of them out: measured on the MI355X host, ~20 ms per batch regardless of its size (31 pairs/s instead of 270 at KITTI
 // batch 1, tools/driver_probe3.py).  Streaming stores go to memory through the write-combining buffers and leave nothing behind.
 // ------------------------------------------------------------------------------------------------------------------
-#include <immintrin.h>
+// (The MI355X hosts of this build are x86-64; on any other host architecture both helpers are plain memcpy -- correct, minus the
+// cache hygiene.)
 #include <string.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 extern "C" int nmrf_host_copy_nt(void *dst, const void *src, size_t bytes) {
     if (!dst || !src) return NMRF_ENULL;
+#if !defined(__x86_64__)
+    memcpy(dst, src, bytes);
+    return NMRF_OK;
+#else
     unsigned char *d = static_cast<unsigned char *>(dst);
     const unsigned char *s = static_cast<const unsigned char *>(src);
     size_t head = (16 - (reinterpret_cast<uintptr_t>(d) & 15)) & 15;
@@ -339,6 +347,7 @@ extern "C" int nmrf_host_copy_nt(void *dst, const void *src, size_t bytes) {
     }
     _mm_sfence();
     return NMRF_OK;
+#endif
 }
 
 // The other direction: copy a finished result OUT of a pinned buffer and evict the lines the read pulled into the CPU cache, so
@@ -346,9 +355,11 @@ extern "C" int nmrf_host_copy_nt(void *dst, const void *src, size_t bytes) {
 extern "C" int nmrf_host_read_evict(void *dst, const void *src, size_t bytes) {
     if (!dst || !src) return NMRF_ENULL;
     memcpy(dst, src, bytes);
+#if defined(__x86_64__)
     const unsigned char *s = static_cast<const unsigned char *>(src);
     const uintptr_t first = reinterpret_cast<uintptr_t>(s) & ~(uintptr_t)63, last = reinterpret_cast<uintptr_t>(s) + bytes;
     for (uintptr_t a = first; a < last; a += 64) _mm_clflush(reinterpret_cast<const void *>(a));
     _mm_sfence();
+#endif
     return NMRF_OK;
 }

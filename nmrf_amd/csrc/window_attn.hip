@@ -859,6 +859,8 @@ extern "C" int nmrf_window_attn_f32(const float *qkv, const float *table, int B,
         // refinement windows, two per tile, four tiles per block (three blocks per CU: 24.0 us; eight tiles per block: 26.6 us)
         if (win == 4 && N == 1) return launch_window_fast<1, 4, 1, 4, 3, 2>(qkv, table, g, B, out, st);
     }
+    if (kv16) return NMRF_EINVAL;     // pre-split k | v rows are only understood by the fast kernel above (32-bit offsets): the generic
+                                      // kernel would read the fp16 pairs as floats
     switch (nkt) {                                                                         // any other configuration
         case 1: return launch_window<1>(qkv, table, g, B, out, st);
         case 2: return launch_window<2>(qkv, table, g, B, out, st);

@@ -34,10 +34,13 @@ def load_rgb(path):
 
 
 def batches(items, size):
-    """Group consecutive items of equal image size into batches of at most `size` (order preserved)."""
+    """Group consecutive items of equal image size AND dtype (of both views) into batches of at most `size` (order preserved):
+    a batch shares one pinned staging buffer, so a uint8 pair never lands in a float32 group."""
     cur, shape = [], None
     for it in items:
-        s = tuple(it[1].shape)
+        s = (tuple(it[1].shape), it[1].dtype, tuple(it[2].shape), it[2].dtype)
+        if s[0] != s[2] or s[1] != s[3]:
+            raise ValueError("left and right view of %r differ in shape or dtype: %s %s vs %s %s" % (it[0], s[0], s[1], s[2], s[3]))
         if cur and (s != shape or len(cur) == size):
             yield cur
             cur = []
@@ -82,16 +85,19 @@ class StereoStream:
     * the forward is ONE hipGraph per (shape, batch), captured on first use and replayed on static device buffers (a short final
       batch is padded with copies of its last pair and the padding discarded): per batch the host issues two copies and a replay
       instead of ~150 kernel launches.  graph=False, a model that cannot be captured, or a CPU device -> eager calls.
-    Results are yielded in input order as CPU tensors (`copy_out=False`: views into the pinned ring, valid until `depth` more
-    batches have been yielded -- and every line of them the consumer reads stays in the CPU cache and slows the next D2H into that
-    slot down, see nmrf_host_read_evict; the default hands out pageable copies and evicts).
+    Results are yielded in input order as CPU tensors.  `copy_out=False` hands out VIEWS into the pinned result ring (and runs on
+    the caller's thread): batch i's slot is re-armed when batch i + depth is enqueued, which happens just before the first item of
+    batch i + depth - 1 is yielded -- so a view of batch i is valid until the consumer asks for the first item of batch
+    i + depth - 1 (the ring is at least three deep in this mode: a view survives the whole next batch).  Every line the consumer
+    reads of a view stays in the CPU cache and slows the next D2H into that slot down, see nmrf_host_read_evict; the default
+    hands out pageable copies and evicts.
     Host-side staging uses non-temporal stores (nmrf_host_copy_nt): a DMA that has to snoop freshly written lines out of a CPU
     cache costs ~20 ms per batch on this platform, whatever the batch size (tools/driver_probe3.py)."""
 
     def __init__(self, model, device="cuda", batch=8, graph=True, depth=2, copy_out=True, threaded=True):
         self.model, self.device, self.batch = model, torch.device(device), batch
         self.on_gpu = self.device.type == "cuda"
-        self.depth, self.copy_out, self.use_graph = max(2, depth), copy_out, graph and self.on_gpu
+        self.depth, self.copy_out, self.use_graph = max(2 if copy_out else 3, depth), copy_out, graph and self.on_gpu
         # threaded: staging + launches of batch i+1 / i+2 on a producer thread while the caller's thread drains batch i (the staging
         # copies and the evicting read-out run outside the GIL).  Needs a third slot (see _run_threaded) and handed-out COPIES.
         self.threaded = bool(threaded) and self.on_gpu and copy_out
@@ -99,10 +105,9 @@ class StereoStream:
             self.depth = max(3, self.depth)
             self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.plans = {}
-        # models of this package defer their fp16 range check to the driver (one flag read per drained batch)
+        # models of this package defer their fp16 range check to the driver (one flag read per drained batch) -- only while run()
+        # is active: the model's own check is switched back on when the stream ends (run()'s finally)
         self._range_model = model if (self.on_gpu and hasattr(model, "range_check")) else None
-        if self._range_model is not None:
-            self._range_model.range_check = False
         if self.on_gpu:
             self.h2d = torch.cuda.Stream(self.device)
             self.d2h = torch.cuda.Stream(self.device)
@@ -237,9 +242,16 @@ class StereoStream:
     def run(self, pairs):
         """pairs: iterable of (key, left [3,H,W], right [3,H,W]) (uint8 or float32, 0..255) -> yields (key, disparity [H,W] CPU
         tensor) in input order."""
-        if self.threaded:
-            yield from self._run_threaded(pairs)
-            return
+        prev_check = None if self._range_model is None else self._range_model.range_check
+        if self._range_model is not None:
+            self._range_model.range_check = False
+        try:
+            yield from (self._run_threaded(pairs) if self.threaded else self._run_inline(pairs))
+        finally:
+            if self._range_model is not None:
+                self._range_model.range_check = prev_check
+
+    def _run_inline(self, pairs):
         pending, i = None, 0
         for group in batches(pairs, self.batch):
             if self.on_gpu:

@@ -63,9 +63,10 @@ class MLP(nn.Module):
                 y = K.linear_smalln(x.reshape(-1, shp[-1]).contiguous(), layer.weight, layer.bias, relu=not last)
                 x = y.view(*shp[:-1], layer.out_features)
             else:
-                x = layer(x)
-                if not last:
-                    x = F.relu(x)
+                # no silent stock-torch tail: a shape no HIP kernel covers is an unsupported configuration, like every other one here
+                raise NotImplementedError("MLP layer %d (%d -> %d) on %s: no HIP kernel covers this shape (token_linear: in 32/64/128/160, "
+                                          "out a multiple of 32 above 64; linear_smalln: out <= 64, in <= 128 and a multiple of 4)"
+                                          % (i, layer.in_features, layer.out_features, x.device))
         return x
 
 
@@ -84,7 +85,9 @@ class Mlp(nn.Module):
             if not hasattr(self, "_lin1"):
                 self._lin1 = _Lin(self.fc1)
             return self.fc2(self._lin1(x.contiguous(), act="gelu"))
-        return self.fc2(F.gelu(self.fc1(x)))
+        raise NotImplementedError("Mlp (%d -> %d -> %d) on %s: the unfused form exists for the NMRF_LINEAR=fp32 A/B chain only (2-D CUDA rows, "
+                                  "fc1 in 64/128/160, hidden a multiple of 32); the product runs it inside nmp_block16 / mlp_chain"
+                                  % (self.fc1.in_features, self.fc1.out_features, self.fc2.out_features, x.device))
 
     def forward_ln(self, x, y, norm):
         """fc2(GELU(fc1(LayerNorm(x + y)))) with add, norm, fc1 and GELU in one kernel -> (x + y, out)."""

@@ -164,6 +164,8 @@ def check_chain(tag, cand, base, refine_from, tau_score=TAU_SCORE, tau_coarse=TA
     raw = disp_stats(cand["disp"].cpu(), base["disp"].cpu())
     st.update({"cond_" + k: v for k, v in cond.items()})
     st.update({"raw_" + k: v for k, v in raw.items()})
+    budget = wta_flip_budget().get(tag)
+    st["wta_flip_budget"] = None if budget is None else max(2 * budget["wta_flips"], budget["wta_flips"] + 3)
     record_disp_stats(tag + " | same decisions", cond)
     record_disp_stats(tag, raw)
     record_chain_stats(tag, st)
@@ -171,6 +173,10 @@ def check_chain(tag, cand, base, refine_from, tau_score=TAU_SCORE, tau_coarse=TA
     assert st["wta_flip_margin_max"] <= 2 * tau_score, \
         (tag, "a winner changed at a pixel the reference decides by more than the noise bound", st)
     assert st["wta_flips"] <= max(4, flip_rate * flip.numel()), (tag, st)
+    # regression bound per fixture: the count this arithmetic produced when the budget file was written
+    if st["wta_flip_budget"] is not None:
+        assert st["wta_flips"] <= st["wta_flip_budget"], \
+            (tag, "more winner-take-all flips than 2x the committed count (tests/golden/wta_flip_budget.json): arithmetic regression?", st)
     assert st["wta_self_consistency"] <= 1e-5, (tag, st)
     assert st["disp_curr_maxdiff_unflipped"] <= 2 * 2 * tau_coarse, (tag, st)       # x2: disp_curr is in 1/4-px units
     assert cond["epe"] <= cond_epe and cond["max"] <= max_cond, (tag, "refinement on identical decisions", cond)
@@ -178,6 +184,22 @@ def check_chain(tag, cand, base, refine_from, tau_score=TAU_SCORE, tau_coarse=TA
         assert raw["epe"] <= epe, (tag, "no decision differs, raw EPE must meet the contract", raw)
     assert raw["median"] <= median and raw["frac_gt_0p5"] <= frac, (tag, raw)
     return st
+
+
+_WTA_BUDGET = None
+
+
+def wta_flip_budget():
+    """tests/golden/wta_flip_budget.json: measured flip counts per fixture tag (see the file's _what)."""
+    global _WTA_BUDGET
+    if _WTA_BUDGET is None:
+        import json
+        try:
+            with open(os.path.join(GOLDEN, "wta_flip_budget.json")) as f:
+                _WTA_BUDGET = json.load(f)["fixtures"]
+        except OSError:
+            _WTA_BUDGET = {}
+    return _WTA_BUDGET
 
 
 def seeds_explained_by_prob_noise(tag, got, want, eps, prob_tol, budget=1e-4):
@@ -211,9 +233,9 @@ def seeds_explained_by_prob_noise(tag, got, want, eps, prob_tol, budget=1e-4):
 
 def record_chain_stats(tag, st):
     from tests.conftest import record_note
-    record_note("%s: WTA decisions differing %d (%.1e of px, reference margin <= %.1e), score/coarse maxdiff %.1e / %.1e, "
-                "same-decision EPE %.2e max %.2e, raw EPE %.2e max %.2f" % (
-                    tag, st["wta_flips"], st["wta_flip_rate"], st["wta_flip_margin_max"], st["score_maxdiff"],
+    record_note("%s: WTA decisions differing %d (budget %s; %.1e of px, reference margin <= %.1e), score/coarse maxdiff %.1e / %.1e, "
+                "same-decision EPE %.2e max %.2e, RAW EPE %.2e max %.2f" % (
+                    tag, st["wta_flips"], st.get("wta_flip_budget"), st["wta_flip_rate"], st["wta_flip_margin_max"], st["score_maxdiff"],
                     st["coarse_maxdiff"], st["cond_epe"], st["cond_max"], st["raw_epe"], st["raw_max"]))
     try:
         import json
