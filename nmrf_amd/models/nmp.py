@@ -524,12 +524,15 @@ class Inference(nn.Module):
 
     normalizer = 3.14 / 64
 
-    def __init__(self, cost_group, dim, layers, norm):
+    def __init__(self, cost_group, dim, layers, norm, return_intermediate=False):
         super().__init__()
         self.ffn = Mlp(dim + cost_group, dim, dim)
         self.dim, self.layers, self.norm, self.cost_group = dim, layers, norm, cost_group
+        self.return_intermediate = return_intermediate     # NMP.py:777,879: honoured in training mode only
 
-    def _run(self, labels_flat, n, fmap1, fmap2, fmap1_gw, fmap2_gw, token_major=False):
+    def _run(self, labels_flat, n, fmap1, fmap2, fmap1_gw, fmap2_gw, token_major=False, collect=None):
+        """collect: a list that receives norm(crop(x)) after every layer (return_intermediate, NMP.py:777-796 / 879-898); its last
+        entry is the returned tensor."""
         if token_major:                                   # maps [B,H,W,C] (written so by the heads' 1x1 kernels)
             b, h, wd, _ = fmap1.shape
         else:
@@ -564,7 +567,9 @@ class Inference(nn.Module):
                 x = self._ffn(wcc, 160, out=xbuf, out_map=to_p)
                 enc = K.fourier_embed(labels_flat, self.normalizer, 32, out=ebuf, out_map=to_p)
             t_dense = dims[0] * dims[1] * dims[2] * dims[3]
-            return self._run_blocks(x, enc, pdims, to_d, t_dense)
+            return self._run_blocks(x, enc, pdims, to_d, t_dense, collect)
+        if collect is not None:
+            raise NotImplementedError("return_intermediate is implemented on the fused block path (128-wide tokens, shipped head shapes)")
         x = self.ffn(wcc)
         enc = K.fourier_embed(labels_flat, self.normalizer, 32 if split else 31)
         x, pdims, off = _pad_grid(x, dims, win)
@@ -583,9 +588,16 @@ class Inference(nn.Module):
             return _add_ln(x, y, self.norm)[1]
         return x if y is None else x + y
 
-    def _run_blocks(self, x, enc, pdims, to_dense=None, t_dense=None):
+    def _run_blocks(self, x, enc, pdims, to_dense=None, t_dense=None, collect=None):
         """Per layer: [self-edge attention -> fused block (proj + residual -> window q|k|v)] (inference only), then
-        window attention -> fused block (proj + residual + MLP -> the next layer's first q|k|v, or the final norm)."""
+        window attention -> fused block (proj + residual + MLP -> the next layer's first q|k|v, or the final norm).
+        collect (training-mode forward): after every layer but the last, the stage's final LayerNorm of the layer's residual stream on
+        the dense token grid (one ln kernel per layer; the last layer's entry is the fused kernel's own ln output)."""
+        if collect is not None and self.norm is None:
+            raise NotImplementedError("return_intermediate without a final norm (never configured by the reference, NMRF.py:79,102)")
+        keep = None
+        if collect is not None and to_dense is not None:
+            keep = (to_dense >= 0).nonzero().squeeze(1)
         n = pdims[3]
         if not hasattr(self, "_launch"):
             sites = []                                                   # (kind, module) in execution order
@@ -622,17 +634,29 @@ class Inference(nn.Module):
             if last and self.norm is not None and to_dense is not None:       # final norm, cropped to the dense grid on the way out
                 ln = torch.empty(t_dense, self.dim, device=x.device)
                 self._launch[i + 1](x, msg, enc, 1, want_x=False, ln_out=ln, ln_out_map=to_dense)
+                if collect is not None:
+                    collect.append(ln)
                 return ln
             x, qkv, ln = self._launch[i + 1](x, msg, enc, 1, want_x=not last or self.norm is None, attn_qkv=attn_qkv)
+            if collect is not None and kind == "win":
+                if last:
+                    collect.append(ln)
+                else:
+                    xd = x if keep is None else x.index_select(0, keep)
+                    collect.append(K.ln_concat(xd.contiguous(), self.norm.weight, self.norm.bias, ld=self.dim, eps=self.norm.eps))
         if to_dense is not None:
             keep = (to_dense >= 0).nonzero().squeeze(1)
             return (ln if self.norm is not None else x).index_select(0, keep)
         return ln if self.norm is not None else x
 
     def forward(self, labels, fmap1, fmap2, fmap1_gw, fmap2_gw, token_major=False):
-        """labels [B*H*W, N] -> [1, B*H*W, N, C]   (token_major: the four maps are [B,H,W,C] instead of [B,C,H,W])"""
+        """labels [B*H*W, N] -> [1, B*H*W, N, C]   (token_major: the four maps are [B,H,W,C] instead of [B,C,H,W]);
+        [num_layers, B*H*W, N, C] in training mode with return_intermediate (NMP.py:777-798)."""
         n = labels.shape[-1]
-        out = self._run(labels.reshape(-1).contiguous(), n, fmap1, fmap2, fmap1_gw, fmap2_gw, token_major)
+        collect = [] if (self.return_intermediate and self.training) else None
+        out = self._run(labels.reshape(-1).contiguous(), n, fmap1, fmap2, fmap1_gw, fmap2_gw, token_major, collect)
+        if collect is not None:
+            return torch.stack(collect).view(len(collect), -1, n, self.dim)
         return out.view(1, -1, n, self.dim)
 
 
@@ -642,6 +666,9 @@ class Refinement(Inference):
     normalizer = 3.14 / 128
 
     def forward(self, labels, fmap1, fmap2, fmap1_gw, fmap2_gw, token_major=False):
-        """labels [B,H,W] -> [1, B*H*W, C]"""
-        out = self._run(labels.reshape(-1).contiguous(), 1, fmap1, fmap2, fmap1_gw, fmap2_gw, token_major)
+        """labels [B,H,W] -> [1, B*H*W, C]; [num_layers, B*H*W, C] in training mode with return_intermediate (NMP.py:879-900)"""
+        collect = [] if (self.return_intermediate and self.training) else None
+        out = self._run(labels.reshape(-1).contiguous(), 1, fmap1, fmap2, fmap1_gw, fmap2_gw, token_major, collect)
+        if collect is not None:
+            return torch.stack(collect).view(len(collect), -1, self.dim)
         return out.view(1, -1, self.dim)

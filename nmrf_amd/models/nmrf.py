@@ -1,6 +1,8 @@
 """NMRF top module: same constructor arguments, forward API and state-dict names as
-nmrf/models/NMRF.py:21-262, with the hot path on libnmrf_hip.so.  Inference only: the aux-loss outputs of the
-reference's training mode are not produced (forward-only kernels); the `Criterion` lives in models/criterion.py.
+nmrf/models/NMRF.py:21-262, with the hot path on libnmrf_hip.so.  The kernels are forward-only: model.eval() is the product path;
+model.train() runs the reference's TRAINING-mode forward (no input padding, per-layer intermediates, `aux_outputs`,
+NMRF.py:203-205, 216-223, 259-273) under no_grad, so that the `Criterion` (models/criterion.py) can be evaluated on it -- there is
+no autograd graph to back-propagate through (backward kernels are not built).
 """
 import os
 
@@ -43,7 +45,7 @@ class NMRF(nn.Module):
         infer_layers = nn.ModuleList(
             InferenceLayer(infer_embed_dim, mlp_ratio, window_size, 0 if i % 2 == 0 else window_size // 2,
                            infer_n_heads, normalize_before) for i in range(num_infer_layers))
-        self.inference = Inference(32, infer_embed_dim, infer_layers, nn.LayerNorm(infer_embed_dim))
+        self.inference = Inference(32, infer_embed_dim, infer_layers, nn.LayerNorm(infer_embed_dim), return_intermediate)
         self.infer_head = MLP(infer_embed_dim, infer_embed_dim, 8 * 8, 3)
         self.infer_score_head = nn.Linear(infer_embed_dim, 8 * 8)
         for m in self.modules():
@@ -57,7 +59,7 @@ class NMRF(nn.Module):
             RefinementLayer(infer_embed_dim, mlp_ratio, refine_window_size,
                             0 if i % 2 == 0 else refine_window_size // 2, infer_n_heads, normalize_before)
             for i in range(num_refine_layers))
-        self.refinement = Refinement(32, infer_embed_dim, refine_layers, nn.LayerNorm(infer_embed_dim))
+        self.refinement = Refinement(32, infer_embed_dim, refine_layers, nn.LayerNorm(infer_embed_dim), return_intermediate)
         self.refine_head = MLP(infer_embed_dim, infer_embed_dim, 4 * 4, 3)
         self.dpn = dpn
         self.compat = compat
@@ -104,18 +106,25 @@ class NMRF(nn.Module):
 
     @torch.no_grad()
     def forward(self, sample):
-        """model(sample) of NMRF.py:189-262.  Inference build: always runs under no_grad (the HIP kernels are forward-only),
-        so the returned tensors never carry a grad_fn -- fine-tuning needs the reference's training path."""
-        if self.training:
-            raise NotImplementedError("nmrf_amd implements the inference path only; call model.eval()")
+        """model(sample) of NMRF.py:189-262.  Always runs under no_grad (the HIP kernels are forward-only): the returned tensors
+        never carry a grad_fn.  In training mode (model.train()) the forward is the reference's training-mode forward -- no input
+        padding (NMRF.py:203-205: H and W must be multiples of divis_by), no un-padding, per-layer intermediates when
+        return_intermediate, `aux_outputs` when aux_loss (NMRF.py:259-273) -- so that losses can be EVALUATED on it; a
+        loss.backward() on them fails loudly (no grad_fn), fine-tuning needs the reference's training path."""
+        enc = self.backbone if self.compat else self.image_encoder
+        from .backbone import Backbone
+        if self.training and not isinstance(enc, Backbone):
+            raise NotImplementedError("training-mode forward: CNN backbone only (the Swin-T trunk has stochastic depth in training mode)")
+        if self.training and not getattr(self, "_warned_train", False):
+            import warnings
+            warnings.warn("nmrf_amd: model.train() runs the training-mode FORWARD only (forward-only HIP kernels, no autograd graph)")
+            self._warned_train = True
         if self.device.type != "cuda":
             raise RuntimeError("the NMRF hot path runs on an MI355X through libnmrf_hip.so; there is no CPU "
                                "fallback (move the model with .to('cuda'))")
         image1 = sample["img1"].to(self.device)
         image2 = sample["img2"].to(self.device)
         h0, w0 = image1.shape[-2:]
-        enc = self.backbone if self.compat else self.image_encoder
-        from .backbone import Backbone
         if image1.dtype != image2.dtype:
             image1, image2 = image1.float(), image2.float()
         if isinstance(enc, Backbone) and image1.dtype in (torch.float32, torch.uint8) and image1.shape == image2.shape:
@@ -123,6 +132,8 @@ class NMRF(nn.Module):
             # pad (A1) + stack + normalise in one HIP pass, straight into the encoder
             b = image1.shape[0]
             hp, wp = h0 + (-h0) % self.divis_by, w0 + (-w0) % self.divis_by
+            if self.training and (hp, wp) != (h0, w0):
+                raise ValueError("training mode does not pad its input (NMRF.py:203-205): %dx%d is not a multiple of %d" % (h0, w0, self.divis_by))
             stem = enc.conv1
             if (enc.fused and image1.shape[1] == 3 and hp % 2 == 0 and wp % 2 == 0 and stem.weight.shape[0] % 64 == 0
                     and tuple(stem.weight.shape[1:]) == (3, 7, 7) and stem.stride == (2, 2) and stem.padding == (3, 3)):
@@ -133,8 +144,10 @@ class NMRF(nn.Module):
             self._joint_feats = feats
             fmap1_list, fmap2_list = [f[:b] for f in feats], [f[b:] for f in feats]
         else:
-            padder = InputPadder(image1.shape, mode="proposal", divis_by=self.divis_by)
-            image1, image2 = padder.pad(image1.float(), image2.float())
+            image1, image2 = image1.float(), image2.float()
+            if not self.training:
+                padder = InputPadder(image1.shape, mode="proposal", divis_by=self.divis_by)
+                image1, image2 = padder.pad(image1, image2)
             fmap1_list, fmap2_list = self.extract_feature(image1, image2)
         try:
             out = self.hot_path(fmap1_list, fmap2_list, (h0, w0))
@@ -227,7 +240,8 @@ class NMRF(nn.Module):
         fmap1, fmap2, fmap1_gw, fmap2_gw = heads8
 
         # ---- neural MRF inference at 1/8 -------------------------------------------------------------
-        tgt = self.inference(labels_curr, fmap1, fmap2, fmap1_gw, fmap2_gw, token_major=tok8).view(-1, self.inference.dim)
+        tgt_all = self.inference(labels_curr, fmap1, fmap2, fmap1_gw, fmap2_gw, token_major=tok8)    # [1 | layers, P, N, C]
+        tgt = tgt_all[-1].reshape(-1, self.inference.dim)
         b, h8, w8 = fmap1_list[0].shape[0], fmap1_list[0].shape[2], fmap1_list[0].shape[3]
         disp_delta = self.infer_head(tgt)                                   # [T,64]
         from .nmp import _ChainLauncher, _split
@@ -244,13 +258,40 @@ class NMRF(nn.Module):
 
         # ---- refinement at 1/4 ---------------------------------------------------------------------------
         fmap1, fmap2, fmap1_gw, fmap2_gw = heads4
-        tgt = self.refinement(disp_curr, fmap1, fmap2, fmap1_gw, fmap2_gw, token_major=tok4).view(-1, self.refinement.dim)
+        tgt4_all = self.refinement(disp_curr, fmap1, fmap2, fmap1_gw, fmap2_gw, token_major=tok4)    # [1 | layers, P4, C]
+        tgt = tgt4_all[-1].reshape(-1, self.refinement.dim)
         disp, disp_pred = K.refine_epilogue(self.refine_head(tgt), disp_curr, h0, w0)
         if stages is not None:
             stages["refine_tgt"] = tgt
 
-        return {"proposal": labels_curr.reshape(b, -1, n), "prob": prob,
-                "initial_proposal": label_seeds.reshape(b, -1, n), "disp": disp, "disp_pred": disp_pred}
+        out = {"proposal": labels_curr.reshape(b, -1, n), "prob": prob,
+               "initial_proposal": label_seeds.reshape(b, -1, n), "disp": disp, "disp_pred": disp_pred}
+        if self.aux_loss and self.training:
+            out["aux_outputs"] = self._aux_outputs(tgt_all, tgt4_all, labels_curr, disp_curr, (b, h8, w8, n), (h0, w0),
+                                                   (disp_delta, score))
+        return out
+
+    def _aux_outputs(self, tgt_all, tgt4_all, labels, disp_curr, dims8, out_hw, last_heads):
+        """_set_aux_loss of the reference (NMRF.py:216-223, 240-244, 264-273): every inference layer's normalised tokens through the
+        SAME heads -> {disp_pred: relu(label + delta) [B,8H,8W,N], logits_pred: 0.25 x score}, then every refinement layer's but the
+        last -> {disp_pred [B,4H4,4W4]}.  The heads are this module's HIP chains; the 8x8 un-shuffle is a view + permute."""
+        b, h8, w8, n = dims8
+        un = lambda x: x.reshape(b, h8, w8, n, 8, 8).permute(0, 1, 4, 2, 5, 3).reshape(b, h8 * 8, w8 * 8, n)
+        lab = labels.reshape(-1, 1)
+        res = []
+        for i in range(tgt_all.shape[0]):
+            if i + 1 == tgt_all.shape[0]:
+                delta, score = last_heads                                   # the heads of the last layer ran on the hot path already
+            else:
+                t = tgt_all[i].reshape(-1, self.inference.dim).contiguous()
+                delta = self.infer_head(t)
+                score = self._score(t, 128) if hasattr(self, "_score") else K.linear_smalln(t, self.infer_score_head.weight,
+                                                                                             self.infer_score_head.bias)
+            res.append({"disp_pred": un(torch.relu(lab + delta)), "logits_pred": un(0.25 * score)})
+        for i in range(tgt4_all.shape[0] - 1):
+            t = tgt4_all[i].reshape(-1, self.refinement.dim).contiguous()
+            res.append({"disp_pred": K.refine_epilogue(self.refine_head(t), disp_curr, *out_hw)[1]})
+        return res
 
 
 def build(cfg):

@@ -538,8 +538,10 @@ def _crop_tokens(x, pdims, dims, off):
     return x.view(b, hp, wp, n, -1)[:, off[0]:off[0] + h, off[1]:off[1] + wd].reshape(-1, x.shape[-1])
 
 
-def inference(labels, f1, f2, g1, g2, w, cfg, stages=None):
-    """Inference.forward (NMP.py:722-798). labels [B*H*W,N] in 1/8-px units."""
+def inference(labels, f1, f2, g1, g2, w, cfg, stages=None, intermediate=None):
+    """Inference.forward (NMP.py:722-798). labels [B*H*W,N] in 1/8-px units.
+    intermediate: a list that receives norm(crop(x)) after EVERY layer (return_intermediate in training mode, NMP.py:777-796;
+    the last entry is the returned tensor itself)."""
     b, _, h, wd = f1.shape
     n = labels.shape[-1]
     dims = (b, h, wd, n)
@@ -556,11 +558,13 @@ def inference(labels, f1, f2, g1, g2, w, cfg, stages=None):
         x = swin_layer(x, enc, w, pre + ".nmp", pdims, cfg.window_size, shift, cfg.infer_heads, True)
         if stages is not None:
             stages[f"infer_layer{i}"] = x
+        if intermediate is not None:
+            intermediate.append(_ln(_crop_tokens(x, pdims, dims, off), w, "inference.norm"))
     return _ln(_crop_tokens(x, pdims, dims, off), w, "inference.norm")
 
 
-def refinement(disp_q, f1, f2, g1, g2, w, cfg, stages=None):
-    """Refinement.forward (NMP.py:828-900). disp_q [B,H4,W4] in 1/4-px units, N=1."""
+def refinement(disp_q, f1, f2, g1, g2, w, cfg, stages=None, intermediate=None):
+    """Refinement.forward (NMP.py:828-900). disp_q [B,H4,W4] in 1/4-px units, N=1.  intermediate: as in inference (NMP.py:879-898)."""
     b, _, h, wd = f1.shape
     dims = (b, h, wd, 1)
     labels = disp_q.reshape(-1, 1)
@@ -576,6 +580,8 @@ def refinement(disp_q, f1, f2, g1, g2, w, cfg, stages=None):
         x = swin_layer(x, enc, w, f"refinement.layers.{i}.nmp", pdims, win, shift, cfg.infer_heads, False)
         if stages is not None:
             stages[f"refine_layer{i}"] = x
+        if intermediate is not None:
+            intermediate.append(_ln(_crop_tokens(x, pdims, dims, off), w, "refinement.norm"))
     return _ln(_crop_tokens(x, pdims, dims, off), w, "refinement.norm")
 
 
@@ -646,8 +652,11 @@ def msda_core(value, shapes, loc, wgt):
 # --------------------------------------------------------------------------- #
 # full forward (NMRF.py:189-262), CNN backbone
 # --------------------------------------------------------------------------- #
-def hot_path(w, cfg, feats8, feats4, pad_hw, out_hw, stages=None, seeds=None):
+def hot_path(w, cfg, feats8, feats4, pad_hw, out_hw, stages=None, seeds=None, aux=False):
     """Everything after the backbone (NMRF.py:207-262).  feats8 / feats4: [2B,C,H,W] maps, left views first.
+    aux: also return `aux_outputs` as the reference does in training mode with SOLVER.AUX_LOSS and NMP.RETURN_INTERMEDIATE
+    (NMRF.py:216-223, 240-244, 259-273): one {disp_pred: coarse [B,8H,8W,N], logits_pred} per inference layer from that layer's
+    normalised tokens through the SAME heads, then one {disp_pred [B,4H4,4W4]} per refinement layer but the last.
     seeds: [P,N] int64 label seeds to continue from instead of the oracle's own NMS + top-k (test infrastructure: at a pixel
     whose candidates tie within the fp32 noise of `prob`, the checker continues from the candidate's choice -- tests/util.py
     seeds_explained_by_prob_noise -- so that everything downstream is compared on identical seeds)."""
@@ -668,14 +677,24 @@ def hot_path(w, cfg, feats8, feats4, pad_hw, out_hw, stages=None, seeds=None):
 
     f1, f2 = conv_head(l8, w, "concatconv"), conv_head(r8, w, "concatconv")
     g1, g2 = conv_head(l8, w, "gw"), conv_head(r8, w, "gw")
-    tgt = inference(labels, f1, f2, g1, g2, w, cfg, stages)
+    inter8 = [] if aux else None
+    tgt = inference(labels, f1, f2, g1, g2, w, cfg, stages, inter8)
     coarse, score = coarse_heads(tgt, labels, w, dims8)
     disp_q = wta_median(coarse, score)
 
     f1, f2 = conv_head(l4, w, "concatconv"), conv_head(r4, w, "concatconv")
     g1, g2 = conv_head(l4, w, "gw"), conv_head(r4, w, "gw")
-    tgt4 = refinement(disp_q, f1, f2, g1, g2, w, cfg, stages)
+    inter4 = [] if aux else None
+    tgt4 = refinement(disp_q, f1, f2, g1, g2, w, cfg, stages, inter4)
     disp, pred = refine_epilogue(tgt4, disp_q, w, pad_hw, out_hw)
+    aux_outputs = None
+    if aux:
+        aux_outputs = []
+        for t in inter8:                                                   # every inference layer, the last included
+            c_i, s_i = coarse_heads(t, labels, w, dims8)
+            aux_outputs.append({"disp_pred": c_i, "logits_pred": s_i})
+        for t in inter4[:-1]:                                              # refinement layers but the last (NMRF.py:271-272)
+            aux_outputs.append({"disp_pred": refine_epilogue(t, disp_q, w, pad_hw, out_hw)[1]})
 
     out = {
         "proposal": labels.view(b, -1, n),
@@ -684,6 +703,8 @@ def hot_path(w, cfg, feats8, feats4, pad_hw, out_hw, stages=None, seeds=None):
         "disp": disp,
         "disp_pred": pred,
     }
+    if aux_outputs is not None:
+        out["aux_outputs"] = aux_outputs
     if stages is not None:
         stages.update(cost_volume=cv, seeds=seeds, context=ctx, prop_memory=mem, infer_tgt=tgt,
                       coarse=coarse, score=score, disp_curr=disp_q, refine_tgt=tgt4,
@@ -702,9 +723,16 @@ def refine_from(w, cfg, disp_q, l4, r4, out_hw):
     return refine_epilogue(tgt4, disp_q, w, None, out_hw)
 
 
-def forward(w, cfg, img1, img2, return_stages=False):
+def forward(w, cfg, img1, img2, return_stages=False, training=False):
+    """training: the reference's model.train() forward (NMRF.py:203-205, 250-251, 259-260): no input padding (the crop size is
+    assumed adequate: H, W multiples of divis_by), no un-padding, aux_outputs returned.  No dropout / batch statistics exist in
+    the CNN configuration, so everything else is the eval arithmetic."""
     stages = {} if return_stages else None
     h0, w0 = img1.shape[-2:]
-    img1, img2, pad_hw = pad_images(img1, img2, cfg.divis_by)
+    if training:
+        assert h0 % cfg.divis_by == 0 and w0 % cfg.divis_by == 0, "training mode does not pad (NMRF.py:203-205)"
+        img1, img2, pad_hw = img1.float(), img2.float(), (0, 0)
+    else:
+        img1, img2, pad_hw = pad_images(img1, img2, cfg.divis_by)
     feats4, feats8 = cnn_backbone(torch.cat((img1, img2), 0), w, cfg.backbone_prefix)
-    return hot_path(w, cfg, feats8, feats4, pad_hw, (h0, w0), stages)
+    return hot_path(w, cfg, feats8, feats4, pad_hw, (h0, w0), stages, aux=training)

@@ -532,3 +532,64 @@ def test_model_raises_on_out_of_range_activations_instead_of_returning_garbage()
         with pytest.raises(NmrfHipError, match="fp16 range"):
             model.check_range()
         assert model.check_range()
+
+
+def test_training_mode_forward_outputs_and_criterion():
+    """N4 (first step): model.train() runs the reference's training-mode FORWARD on the HIP kernels -- no padding, per-layer
+    intermediates (NMP.py:777-796, 879-898) through the shared heads, `aux_outputs` of NMRF.py:259-273 -- under no_grad.  Fed with
+    the features the reference saw: seeds bit-exact, every inference layer's candidates / scores within 2e-4 of the reference's
+    training-mode golden, the refinement entries too when no winner-take-all decision differs, and the reference Criterion's
+    losses reproduced by nmrf_amd.models.criterion on the HIP dictionary.  Then the whole model(sample) in training mode."""
+    import warnings
+    from nmrf_amd.models.criterion import build_criterion
+    from tests.util import golden_images, make_cfg
+    g = golden("e2e_train")
+    md = int(g["max_disp"])
+    w, cfg = oracle_weights(md), oracle_cfg(md)
+    img1, img2 = golden_images(g)
+    with torch.no_grad():
+        oout = O.forward(w, cfg, img1, img2, return_stages=True, training=True)
+    st = oout["stages"]
+    fl, fr = [st["fmap8_l"].to(DEV), st["fmap4_l"].to(DEV)], [st["fmap8_r"].to(DEV), st["fmap4_r"].to(DEV)]
+    model = build_product(md, DEV).train()
+    assert model.aux_loss and model.inference.return_intermediate and model.refinement.return_intermediate   # the config defaults
+    with torch.no_grad():
+        out = model.hot_path(fl, fr, tuple(g["disp"].shape[-2:]))
+    assert torch.equal(out["initial_proposal"].cpu().long(), t(g["seeds"]).long())
+    report("proposal", out["proposal"].cpu(), t(g["proposal"]), 2e-4)
+    aux = out["aux_outputs"]
+    n_inf, n_ref = cfg.num_infer_layers, cfg.num_refine_layers
+    assert len(aux) == n_inf + n_ref - 1
+    for i in range(n_inf):
+        assert set(aux[i]) == {"disp_pred", "logits_pred"}
+        report("aux%d coarse" % i, aux[i]["disp_pred"].cpu(), t(g["aux%d_disp_pred" % i]), 2e-4)
+        report("aux%d logits" % i, aux[i]["logits_pred"].cpu(), t(g["aux%d_logits_pred" % i]), 2e-4)
+    same = torch.equal(aux[n_inf - 1]["logits_pred"].cpu().max(-1).indices, t(g["aux%d_logits_pred" % (n_inf - 1)]).max(-1).indices)
+    if same:
+        for i in range(n_inf, len(aux)):
+            assert set(aux[i]) == {"disp_pred"}
+            report("aux%d disp_pred" % i, aux[i]["disp_pred"].cpu(), t(g["aux%d_disp_pred" % i]), 4e-4)
+        report("disp_pred", out["disp_pred"].cpu(), t(g["disp_pred"]), 4e-4)
+    from tests.conftest import record_note
+    record_note("training-mode forward: %d + %d aux entries, winners of the last inference layer %s the reference's"
+                % (n_inf, n_ref - 1, "equal" if same else "differ from"))
+    crit = build_criterion(make_cfg(md))
+    cpu = lambda d: {k: (v.cpu() if torch.is_tensor(v) else [cpu(a) for a in v]) for k, v in d.items()}
+    got = crit(cpu(out), {"disp": t(g["gt"]).clone(), "valid": t(g["valid"])})
+    want = {k[5:]: float(g[k]) for k in g if k.startswith("loss/")}
+    assert set(got) == set(want)
+    for k, v in want.items():
+        tol = (2e-4 if same or not k.startswith(("loss_disp", "epe")) else 5e-2) * max(1.0, abs(v))
+        assert abs(float(got[k]) - v) <= tol, (k, float(got[k]), v)
+    assert not any(torch.is_tensor(v) and v.requires_grad for v in out.values())        # forward only: no autograd graph
+    # whole model in training mode: runs, same structure; eval mode afterwards is the product path again
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        full = model({"img1": img1, "img2": img2})
+    assert len(full["aux_outputs"]) == n_inf + n_ref - 1 and full["disp"].shape == g["disp"].shape
+    with pytest.raises(ValueError, match="does not pad"), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model({"img1": img1[..., :50, :], "img2": img2[..., :50, :]})
+    ev = model.eval()({"img1": img1, "img2": img2})
+    assert "aux_outputs" not in ev
+    assert float((ev["disp"] - full["disp"]).abs().median()) < 1e-3

@@ -236,3 +236,40 @@ def test_msda_oracle(tag):
     report("gvalue", gv, t(g[f"{tag}_gvalue"]), 1e-6, 1e-5)
     report("gloc", gl, t(g[f"{tag}_gloc"]), 1e-6, 1e-5)
     report("gw", gw, t(g[f"{tag}_gw"]), 1e-6, 1e-5)
+
+
+def test_training_mode_outputs_match_the_reference():
+    """N4: the reference in model.train() (forward only, tools/gen_golden.py:run_train): no input padding, `aux_outputs` of every
+    inference layer (coarse candidates + 0.25 x scores through the shared heads, NMRF.py:216-223) and of every refinement layer
+    but the last (NMRF.py:240-244, 264-273) -- and the Criterion's losses on the oracle's dictionary equal the reference's."""
+    from nmrf_amd.config import get_cfg
+    from nmrf_amd.models.criterion import build_criterion
+    g = golden("e2e_train")
+    w, cfg = oracle_weights(int(g["max_disp"])), oracle_cfg(int(g["max_disp"]))
+    with torch.no_grad():
+        out = O.forward(w, cfg, *_imgs(g), training=True)
+    assert torch.equal(out["initial_proposal"].long(), t(g["seeds"]).long())
+    report("proposal", out["proposal"], t(g["proposal"]), 5e-5)
+    aux = out["aux_outputs"]
+    assert len(aux) == cfg.num_infer_layers + cfg.num_refine_layers - 1
+    for i, a in enumerate(aux):
+        assert set(a) == ({"disp_pred", "logits_pred"} if i < cfg.num_infer_layers else {"disp_pred"})
+    # the last inference entry is the tensor pair the winner-take-all sees; earlier layers are held to the same bound
+    for i in range(cfg.num_infer_layers):
+        report("aux%d coarse" % i, aux[i]["disp_pred"], t(g["aux%d_disp_pred" % i]), 1e-4)
+        report("aux%d logits" % i, aux[i]["logits_pred"], t(g["aux%d_logits_pred" % i]), 1e-4)
+    io, ir = aux[cfg.num_infer_layers - 1]["logits_pred"].max(-1).indices, t(g["aux%d_logits_pred" % (cfg.num_infer_layers - 1)]).max(-1).indices
+    if torch.equal(io, ir):                       # same winners -> same disp_curr -> the refinement entries compare directly
+        for i in range(cfg.num_infer_layers, len(aux)):
+            report("aux%d disp_pred" % i, aux[i]["disp_pred"], t(g["aux%d_disp_pred" % i]), 2e-4)
+        report("disp_pred", out["disp_pred"], t(g["disp_pred"]), 2e-4)
+        st = disp_stats(out["disp"], t(g["disp"]))
+        assert st["epe"] < 1e-3, st
+    c = get_cfg()
+    c.DPN.MAX_DISP = int(g["max_disp"])
+    crit = build_criterion(c)
+    got = crit({k: v for k, v in out.items() if k != "stages"}, {"disp": t(g["gt"]).clone(), "valid": t(g["valid"])})
+    want = {k[5:]: float(g[k]) for k in g if k.startswith("loss/")}
+    assert set(got) == set(want), (sorted(got), sorted(want))
+    for k, v in want.items():
+        assert abs(float(got[k]) - v) <= 2e-4 * max(1.0, abs(v)), (k, float(got[k]), v)

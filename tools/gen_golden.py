@@ -18,6 +18,8 @@ Fixtures
   nms_cases.npz   crafted logits rows (ties, plateaus, NaN, ...) pushed through
               the reference's DPN.forward NMS+topk (DPN.py:119-125), D in {16,24,32,40,48}
   e2e_swin.npz / state_dict_keys.json   Swin-T + DeformNeck config: encoder features + outputs; key/shape listings
+  e2e_train.npz   the reference in TRAINING mode (forward only): aux_outputs of every inference / refinement layer + its Criterion's
+              losses on them (see run_train)
   msda.npz    ops/test.py known-answer case (seed 3) + model-shaped cases through
               ms_deform_attn_core_pytorch, fp32 outputs; gradients computed in fp64 autograd, stored fp32
 """
@@ -111,6 +113,41 @@ def run_e2e(name, shapes_seeds, opts, full, store_images=True):
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **d)
     print(name, {k: v.shape for k, v in d.items() if hasattr(v, "shape")}, os.path.getsize(path) // 1024, "KiB")
+
+
+def run_train():
+    """e2e_train.npz: the reference in TRAINING mode (model.train(), SOLVER.AUX_LOSS and NMP.RETURN_INTERMEDIATE at their defaults
+    = True), forward only, under no_grad: no input padding (56x104 is a multiple of 8), `aux_outputs` of NMRF.py:259-273 -- one
+    {disp_pred, logits_pred} per inference layer, one {disp_pred} per refinement layer but the last.  1/8 grid 7x13 (window
+    padding 2+3 / 2+3), 1/4 grid 14x26 (1+1 / 1+1); B=1, MAX_DISP 128.  Also the reference Criterion's losses on that output
+    against a seeded synthetic ground truth."""
+    model, cfg = refshim.build_reference_model(["DPN.MAX_DISP", 128])
+    apply_hash_weights(model)
+    model.train()
+    from nmrf.models import build_model
+    crit = build_model(cfg)[1]
+    shapes_seeds = [(56, 104, 1010)]
+    ls, rs, gts = zip(*[synthetic_pair(h, w, seed=sd) for (h, w, sd) in shapes_seeds])
+    img1, img2 = torch.stack(ls), torch.stack(rs)
+    with torch.no_grad():
+        out = model({"img1": img1.clone().float(), "img2": img2.clone().float()})
+    assert "aux_outputs" in out and len(out["aux_outputs"]) == 5 + 4
+    gt = torch.stack([torch.as_tensor(g) for g in gts]).float()
+    valid = (gt > 0) & (gt < cfg.SOLVER.MAX_DISP)
+    with torch.no_grad():
+        losses = crit(out, {"disp": gt, "valid": valid})
+    d = {"pair_hws": np.asarray(shapes_seeds, np.int64), "max_disp": np.int64(cfg.DPN.MAX_DISP),
+         "img1": _np(img1).astype(np.uint8), "img2": _np(img2).astype(np.uint8), "gt": _np(gt), "valid": _np(valid),
+         "prob": _np(out["prob"]), "seeds": _np(out["initial_proposal"]).astype(np.int16), "proposal": _np(out["proposal"]),
+         "disp": _np(out["disp"]), "disp_pred": _np(out["disp_pred"])}
+    for i, a in enumerate(out["aux_outputs"]):
+        for k, v in a.items():
+            d["aux%d_%s" % (i, k)] = _np(v)
+    for k, v in losses.items():
+        d["loss/" + k] = _np(torch.as_tensor(v))
+    path = os.path.join(OUT, "e2e_train.npz")
+    np.savez_compressed(path, **d)
+    print("e2e_train", {k: v.shape for k, v in d.items() if hasattr(v, "shape")}, os.path.getsize(path) // 1024, "KiB")
 
 
 def run_swin():
@@ -246,6 +283,9 @@ def run_msda():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if "--train-only" in sys.argv:
+        run_train()
+        sys.exit(0)
     run_e2e("e2e_a", [(52, 100, 1000)], ["DPN.MAX_DISP", 128], full=True)
     run_e2e("e2e_b", [(96, 328, 1001)], [], full="stages")
     run_e2e("e2e_c", [(40, 72, 1002), (40, 72, 1003)], ["DPN.MAX_DISP", 128], full=False)
@@ -255,3 +295,4 @@ if __name__ == "__main__":
     run_nms()
     run_msda()
     run_swin()
+    run_train()
