@@ -10,6 +10,7 @@
 // identical to grid_sample(align_corners=False).
 #include "common.h"
 #include "split_mfma.h"
+#include <type_traits>
 
 template <typename T, int CH>
 __global__ __launch_bounds__(256) void msda_fwd_kernel(const T *__restrict__ value, const int64_t *__restrict__ shapes,
@@ -61,6 +62,117 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const T *__restrict__ val
     }
 }
 
+
+// Fast path of the Swin-T neck's shape family (fp32, D = 8 channels per head, L * P = NPT = 4 sampling points): one thread =
+// one (b, query, head) = ALL 8 channels of the head, so
+//   * the sampling locations (NPT x 2 floats) and weights (NPT floats) of a thread are three 16-byte loads,
+//   * a bilinear tap is the head's whole 32-byte row = two 16-byte loads, and the taps of PB points (PB x 4 x 2 loads) are ALL in
+//     flight before the first is consumed (the generic kernel walks point by point, tap by tap behind range branches: a chain of
+//     dependent L2 round trips per thread; 0.19 of HBM at [2, 96 256, 8, 8]),
+//   * taps outside the map load a clamped (valid) address and get weight 0 -- no divergence,
+//   * consecutive lanes are consecutive heads: 8 lanes write one full 256-byte output row.
+// Same arithmetic as the generic kernel: s = sum_k tw[k] * v_k in tap order, acc += s * aw in point order.
+// PB: points whose taps are requested together.  Measured at [2, 96 256, 8, 8] over the four levels of the neck (r04d): PB = 2 with
+// four blocks per CU (126 VGPRs) 109 / 84 / 72 / 66 us, PB = 4 with three (168 VGPRs, 4 spilled) 101 / 83 / 77 / 73, one item per thread
+// without the prefetch 124 / 87 / 77 / 69, the generic kernel 155 / 101 / 89 / 73: PB = 2 is the product form.
+template <int NPT, int PB = 2, bool PRE = true>
+__global__ __launch_bounds__(256, PB == 2 ? 4 : 3) void msda_fwd_d8_kernel(const float *__restrict__ value, const int64_t *__restrict__ shapes,
+        const int64_t *__restrict__ lvl_start, const float *__restrict__ loc, const float *__restrict__ wgt, int B, int S, int M,
+        int L, int Lq, int P, float *__restrict__ out) {
+    static_assert(NPT == 4, "three 16-byte operand loads per thread");
+    // Persistent: a thread walks items gid, gid + stride, ... and requests the NEXT item's three operand vectors before it touches
+    // the current one (PRE; pinned by the sched_barrier), so their HBM round trip runs under the current item's 32 tap loads and
+    // FMAs instead of in front of the next item's -- with one item per thread a wave's life is two dependent memory round trips
+    // back to back and ~12 waves per CU do not cover them.
+    const int64_t total = (int64_t)B * Lq * M, stride = (int64_t)gridDim.x * 256;
+    int64_t bqm = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (bqm >= total) return;
+    float4 l0 = ldg4(loc + bqm * (NPT * 2)), l1 = ldg4(loc + bqm * (NPT * 2) + 4), w4 = ldg4(wgt + bqm * NPT);
+    for (;;) {
+        const int64_t nxt = bqm + stride;
+        const int64_t nc = PRE && nxt < total ? nxt : bqm;                  // (the last item re-reads itself: no divergent load)
+        float4 n0, n1, nw;
+        if constexpr (PRE) {
+            n0 = ldg4(loc + nc * (NPT * 2)); n1 = ldg4(loc + nc * (NPT * 2) + 4); nw = ldg4(wgt + nc * NPT);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int m = (int)(bqm % M);
+        const int b = (int)(bqm / ((int64_t)M * Lq));
+        const float lx[NPT] = {l0.x, l0.z, l1.x, l1.z}, ly[NPT] = {l0.y, l0.w, l1.y, l1.w}, aw[NPT] = {w4.x, w4.y, w4.z, w4.w};
+        // tap addresses as 32-bit element offsets from `value` (the launcher checks that the tensor is below 2^32 bytes): one integer
+        // multiply-add per tap; the bilinear weights as products of per-axis weights that are zeroed where the axis index leaves the
+        // map (the same products as the generic kernel's hh * hw ... for the taps it takes, 0 for those it skips)
+        unsigned tap[NPT][4];
+        // geometry of point pt: floor / validity / (with WEIGHTS) the four bilinear weights.  Evaluated twice -- for the addresses
+        // before the loads, for the weights behind them -- so that only the 8 location floats stay live across the 32 loads
+        // (16 weight registers less: 170 -> under the 168 of three waves per SIMD)
+        auto point = [&](int pt, unsigned *offs, float *tw4) {
+            const int l = pt / P;                                       // (uniform)
+            const int Hh = (int)shapes[2 * l], Ww = (int)shapes[2 * l + 1];
+            const float w_im = lx[pt] * Ww - 0.5f, h_im = ly[pt] * Hh - 0.5f;
+            const bool inside = h_im > -1 && w_im > -1 && h_im < Hh && w_im < Ww;
+            const float hf = floorf(h_im), wf = floorf(w_im);
+            const int h0 = inside ? (int)hf : 0, w0 = inside ? (int)wf : 0;
+            if (offs) {
+                const unsigned base = (unsigned)((((int64_t)b * S + lvl_start[l]) * M + m) * 8);
+                const int yc[2] = {h0 < 0 ? 0 : h0, h0 + 1 < Hh ? h0 + 1 : Hh - 1}, xc[2] = {w0 < 0 ? 0 : w0, w0 + 1 < Ww ? w0 + 1 : Ww - 1};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) offs[k] = base + (unsigned)(yc[k >> 1] * Ww + xc[k & 1]) * (unsigned)(M * 8);
+            }
+            if (tw4) {
+                const float lh = h_im - hf, lw = w_im - wf;
+                const float wy[2] = {inside && h0 >= 0 ? 1 - lh : 0.f, inside && h0 + 1 < Hh ? lh : 0.f};
+                const float wx[2] = {w0 >= 0 ? 1 - lw : 0.f, w0 + 1 < Ww ? lw : 0.f};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tw4[k] = wy[k >> 1] * wx[k & 1];
+            }
+        };
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) point(pt, tap[pt], nullptr);
+        // a batch of PB points: all its loads first, then one wait -- the empty asm "uses" the eight vectors of a point, so none of the
+        // FMAs below can be scheduled (by the DAG or the machine scheduler) between the loads; left alone they are fed five at a time
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int p0 = 0; p0 < NPT; p0 += PB) {
+            f32x4 va[PB][4], vb[PB][4];
+#pragma unroll
+            for (int pp = 0; pp < PB; ++pp)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    va[pp][k] = *reinterpret_cast<const f32x4 *>(value + tap[p0 + pp][k]);
+                    vb[pp][k] = *reinterpret_cast<const f32x4 *>(value + tap[p0 + pp][k] + 4);
+                }
+#pragma unroll
+            for (int pp = 0; pp < PB; ++pp)
+                asm volatile("" : "+v"(va[pp][0]), "+v"(va[pp][1]), "+v"(va[pp][2]), "+v"(va[pp][3]), "+v"(vb[pp][0]), "+v"(vb[pp][1]),
+                             "+v"(vb[pp][2]), "+v"(vb[pp][3]));
+#pragma unroll
+            for (int pp = 0; pp < PB; ++pp) {
+                float sx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                float tw4[4];
+                point(p0 + pp, nullptr, tw4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float t = tw4[k];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        sx[c] += t * va[pp][k][c];
+                        sx[4 + c] += t * vb[pp][k][c];
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[c] += sx[c] * aw[p0 + pp];
+            }
+        }
+        stg4(out + bqm * 8, make_float4(acc[0], acc[1], acc[2], acc[3]));
+        stg4(out + bqm * 8 + 4, make_float4(acc[4], acc[5], acc[6], acc[7]));
+        if (nxt >= total) break;
+        bqm = nxt;
+        if constexpr (PRE) { l0 = n0; l1 = n1; w4 = nw; }
+        else { l0 = ldg4(loc + bqm * (NPT * 2)); l1 = ldg4(loc + bqm * (NPT * 2) + 4); w4 = ldg4(wgt + bqm * NPT); }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void msda_bwd_kernel(const T *__restrict__ value, const int64_t *__restrict__ shapes,
         const int64_t *__restrict__ lvl_start, const T *__restrict__ loc, const T *__restrict__ wgt,
@@ -109,6 +221,11 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(const T *__restrict__ val
     }
 }
 
+#ifdef NMRF_DEBUG_PROBES
+static int g_msda_variant = 0;       // tools: 1 = generic kernel, 2 = four points per load batch, 3 = one item per thread without prefetch
+extern "C" int nmrf_debug_msda_variant(int v) { g_msda_variant = v; return NMRF_OK; }
+#endif
+
 static inline unsigned grid_for(int64_t total) {
     int64_t blocks = ceil_div64(total, 256);
     return (unsigned)(blocks > 65536 ? 65536 : (blocks < 1 ? 1 : blocks));
@@ -120,6 +237,40 @@ static int msda_forward(const T *value, const int64_t *shapes, const int64_t *lv
     if (!value || !shapes || !lvl_start || !loc || !w || !out) return NMRF_ENULL;
     if (B < 1 || S < 1 || M < 1 || D < 1 || L < 1 || Lq < 1 || P < 1) return NMRF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    if constexpr (std::is_same<T, float>::value) {
+        const auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+        if (D == 8 && L * P == 4 && (int64_t)B * S * M * 8 < ((int64_t)1 << 30) && al16(value) && al16(loc) && al16(w) && al16(out)) {   // the Swin-T neck's shapes
+            static int n_cu_dev[NMRF_MAX_DEV] = {};
+            const int dev = nmrf_cur_device();
+            if (dev < 0) return NMRF_ELAUNCH;
+            if (!n_cu_dev[dev]) {
+                hipDeviceProp_t prop;
+                if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return NMRF_ELAUNCH;
+                n_cu_dev[dev] = prop.multiProcessorCount;
+            }
+            const int64_t items = (int64_t)B * Lq * M;
+            const unsigned one_each = grid_for(items), resident = (unsigned)n_cu_dev[dev] * 4;      // four 256-thread blocks per CU (126 VGPRs)
+            const unsigned persistent = one_each < resident ? one_each : resident;
+#ifdef NMRF_DEBUG_PROBES
+            if (g_msda_variant == 2) {                                       // all 32 tap loads of an item together, three blocks per CU
+                hipLaunchKernelGGL((msda_fwd_d8_kernel<4, 4>), dim3(n_cu_dev[dev] * 3 < (int)one_each ? n_cu_dev[dev] * 3 : one_each), dim3(256), 0, st,
+                                   value, shapes, lvl_start, loc, w, B, S, M, L, Lq, P, out);
+                return nmrf_launch_status();
+            }
+            if (g_msda_variant == 3) {                                       // one item per thread, no prefetch (the first form of this kernel)
+                hipLaunchKernelGGL((msda_fwd_d8_kernel<4, 4, false>), dim3(one_each), dim3(256), 0, st, value, shapes, lvl_start, loc, w, B, S, M,
+                                   L, Lq, P, out);
+                return nmrf_launch_status();
+            }
+            if (g_msda_variant != 1)
+#endif
+            {
+                hipLaunchKernelGGL((msda_fwd_d8_kernel<4>), dim3(persistent), dim3(256), 0, st, value, shapes, lvl_start, loc, w, B, S, M, L, Lq,
+                                   P, out);
+                return nmrf_launch_status();
+            }
+        }
+    }
     if (D % 4 == 0) {
         hipLaunchKernelGGL((msda_fwd_kernel<T, 4>), dim3(grid_for((int64_t)B * Lq * M * (D / 4))), dim3(256), 0, st, value,
                            shapes, lvl_start, loc, w, B, S, M, D, L, Lq, P, out);

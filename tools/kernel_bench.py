@@ -187,6 +187,42 @@ if "block" in which:
         y2 = F.linear(h, w2, b2)
         return K.token_linear(x1, pwq, 384, 159, bq, ln=(g, be, 1e-5), y=y2, extra=enc31)
     timeit("round-1 sequence (4 launches, fp32)", old)
+if "msda" in which:
+    # A15 at the config-5 shapes of the Swin-T neck: [2, 96 256 queries, 8 heads, 8 channels], one level, 4 points (4 calls per forward,
+    # levels 256x376 ... 32x47).  A/B against the round-3 library if a copy is present (nmrf_amd/lib/ab_main: the generic kernel).
+    import numpy as np
+    lq = 256 * 376
+    # sampling locations as the neck produces them: the query's own reference point (pixel centres of the 256 x 376 query grid in
+    # normalised coordinates) plus an offset of a few pixels of the sampled level (adaptor_modules.py:78-90) -- NOT uniform noise over
+    # the map, which turns every tap into an L2 / HBM miss (3.4x slower, and not what the model does)
+    ys, xs = torch.meshgrid((torch.arange(256, device=dev) + 0.5) / 256, (torch.arange(376, device=dev) + 0.5) / 376, indexing="ij")
+    ref = torch.stack((xs, ys), -1).reshape(1, lq, 1, 1, 1, 2)
+    noise = mk("mloc", 2, lq, 8, 1, 4, 2)
+    wgt = torch.softmax(mk("mw", 2, lq, 8, 1, 4) * 2, -1).contiguous()
+    old = None
+    abp = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nmrf_amd", "lib", "ab_main", "libnmrf_hip.so")
+    if os.path.exists(abp):
+        old = ctypes.CDLL(abp)
+        old.nmrf_msda_forward_f32.argtypes = _lib.PROTOTYPES["nmrf_msda_forward_f32"]
+    for (hh, ww) in ((256, 376), (128, 188), (64, 94), (32, 47)):
+        value = mk("mv%d" % hh, 2, hh * ww, 8, 8)
+        loc = (ref + noise * 4.0 / torch.tensor([ww, hh], device=dev, dtype=torch.float32)).contiguous()      # +- ~4 px (noise is unit-range)
+        shapes = torch.tensor([[hh, ww]], device=dev)
+        start = torch.tensor([0], device=dev)
+        out_new = K.msda_forward(value, shapes, start, loc, wgt)
+        for var, tag in ((0, "product: persistent, operands prefetched, 2 points per load batch"), (3, "one item per thread, no prefetch"),
+                         (2, "persistent, 4 points per load batch"), (1, "generic kernel"), (0, "product again")):
+            _l.nmrf_debug_msda_variant(var)
+            timeit("msda_forward level %dx%d (%s)" % (hh, ww, tag), lambda: K.msda_forward(value, shapes, start, loc, wgt))
+        _l.nmrf_debug_msda_variant(0)
+        if old is not None:
+            out_old = torch.empty_like(out_new)
+            call_old = lambda: old.nmrf_msda_forward_f32(value.data_ptr(), shapes.data_ptr(), start.data_ptr(), loc.data_ptr(), wgt.data_ptr(),
+                                                        2, hh * ww, 8, 8, 1, lq, 4, out_old.data_ptr(), None)
+            call_old(); torch.cuda.synchronize()
+            timeit("msda_forward level %dx%d (round-3 library)" % (hh, ww), call_old)
+            print("   max |new - old| %.3e ; algorithmic bytes %.1f MB" % (float((out_new - out_old).abs().max()),
+                  (loc.numel() + wgt.numel() + out_new.numel() + value.numel()) * 4 / 1e6))
 if "window" in which:
     hp, wp = 48, 156
     qkv, table = mk("q", b * hp * wp * n, 384), mk("t", 121, 384)
