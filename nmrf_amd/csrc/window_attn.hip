@@ -302,7 +302,12 @@ __global__ __launch_bounds__(64 * NKT) void window_attn_kernel(const float *__re
 #define WA_TROW 32                         // floats per staged table row
 #define WA_LOG2E 1.4426950408889634f
 
-template <int NKT, int WIN, int NL, int WPB, int PK = 1>
+// QAL (tools-only instantiation: one window per five-wave block, kv16 + MFMA phase 0): the parked Q fragments (20 KB) take over the ek
+// table's region -- widened to their size -- once phase 0 is done with it, and ev goes where eq was: 77.6 KB per block instead of
+// 93.7, meant to let TWO independent blocks share a CU.  Measured (profiles/r04e): the runtime reports 2 resident blocks, the hardware
+// never runs two at once (a five-wave block has two waves on one SIMD; two blocks would need 4 x 160 VGPRs there), 67 vs 51 us --
+// the product stays at two windows per ten-wave block.
+template <int NKT, int WIN, int NL, int WPB, int PK = 1, bool QAL = false>
 struct WinFastLds {
     static constexpr int W2 = WIN * WIN;
     static constexpr int R = (2 * WIN - 1) * (2 * WIN - 1);
@@ -321,8 +326,11 @@ struct WinFastLds {
     static constexpr int POSN = WIN == 4 ? GB * GB * 16 + 1 : R;
     static constexpr int TP = NKT * 32;
     static constexpr bool QLDS = NKT > 1;
-    static constexpr int SLOT = 2 * W2 * TS + 32 + (QLDS ? NKT * 16 * 64 : 0) + TP;   // floats per window slot
-    static constexpr size_t BYTES = (size_t)(2 * POSN * WA_TROW + WPB * SLOT) * 4;
+    static constexpr int QSC = QLDS ? NKT * 16 * 64 : 0;                           // floats of the parked Q fragments of a window
+    static constexpr int SLOT = 2 * W2 * TS + 32 + (QAL ? 0 : QSC) + TP;           // floats per window slot
+    static constexpr int TABA = QAL && QSC > POSN * WA_TROW ? QSC : POSN * WA_TROW;   // floats of the first table region
+    static constexpr size_t BYTES = (size_t)(TABA + POSN * WA_TROW + WPB * SLOT) * 4;
+    static_assert(!QAL || WPB == 1, "aliased Q park: one window per block");
 };
 
 // TIMED: debug instantiation writing s_memtime stamps per wave and a per-block census (nmrf_debug_window_timing).
@@ -337,11 +345,20 @@ struct WinFastLds {
 // KV16: k | v arrive as split fp16 pairs (written so by the producing block kernel, include/nmrf_hip.h): the K fragment loads ARE the
 // MFMA operands, V takes 16 v_perm_b32, and the scaled Q fragment is parked in LDS already split -- 104 VALU instructions less per
 // key tile; the phase-0 operand of the key lanes is rebuilt as hi + lo once (2^-22 relative, the precision of the products).
-template <int NKT, int WIN, int NL, int WPB, int OCC, bool TIMED = false, int PK = 1, bool KV16 = false>
+// P0M (NL == 4): phase 0 -- the relative-position logit terms QR[i, pj] = s q_i . ek[rel(pi, pj)] and KR[j, pi] = s k_j . eq[rel(pi, pj)] -- on
+// v_mfma_f32_4x4x4_16b_f16: 16 independent 4x4x4 products per wave (layout pinned by tools/ab/mfma4x4.hip on the MI355X: block b =
+// lanes 4b..4b+3; A: lane 4b+i holds A_b[i][0..3]; B: lane 4b+j holds B_b[0..3][j]; D: lane 4b+j, register i = D_b[i][j]).  The four
+// lanes of a block are the four labels of ONE pixel -- they need the same 36 table rows -- so block b multiplies (4 key pixels x 4
+// channels of the table rows rel(P_b, .)) by (4 channels x the pixel's 4 tokens): lane j ends up with its own token's dot products
+// for 4 key pixels, accumulated over the 8 channel chunks.  Split fp16 operands (3 products, table scaled by 2^10 so that its low
+// parts are normal fp16 numbers).  Per lane and phase: 144 ds_read_b64 + 216 of these 8-cycle MFMAs instead of 288 ds_read_b128 + 576
+// v_pk_fma_f32 -- the VALU form was bound by the LDS (11.5k array cycles per block of ten waves for the table rows, of a 12.4k phase).
+template <int NKT, int WIN, int NL, int WPB, int OCC, bool TIMED = false, int PK = 1, bool KV16 = false, bool P0M = false, bool QAL = false>
 __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(const float *__restrict__ qkv,
         const float *__restrict__ table, WinGeom g, float scale, float *__restrict__ out,
         unsigned long long *__restrict__ stamps = nullptr) {
-    using L = WinFastLds<NKT, WIN, NL, WPB, PK>;
+    using L = WinFastLds<NKT, WIN, NL, WPB, PK, QAL>;
+    static_assert(!QAL || (KV16 && P0M && L::QLDS), "aliased Q park: the kv16 / MFMA-phase-0 form");
     constexpr int TP = L::TP, W2 = L::W2, R = L::R, Tw = L::Tw, TS = L::TS;
     constexpr int TwE = Tw * PK;                    // tokens of a wave's tile
     static_assert(PK == 1 || (PK == 2 && NKT == 1 && NL == 1 && 2 * Tw <= 32), "two windows per tile: one key tile, one label");
@@ -353,8 +370,9 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
     static_assert(NL == 1 || NL == 2 || NL == 4, "fast path: labels per pixel must divide 4");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *tab_a = smem;                            // ek (later: ev), chunk-major [8][POSN][4]
-    float *tab_b = tab_a + L::POSN * WA_TROW;       // eq*s*log2e, same layout
+    float *tab_a = smem;                            // ek (later: ev; QAL: later the parked Q fragments), chunk-major [8][POSN][4]
+    float *tab_b = tab_a + L::TABA;                 // eq*s*log2e, same layout (QAL: later ev)
+    float *tab_ev = QAL ? tab_b : tab_a;
     constexpr int POSN = L::POSN;
     auto tab_pos = [](int ra, int rb) -> int {      // row slot of table row (ra, rb), see WinFastLds
         return WIN == 4 ? ((ra >> 2) * L::GB + (rb >> 2)) * 16 + (ra & 3) * 4 + (rb & 3) : ra * SPAN + rb;
@@ -371,8 +389,8 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
     float *qrt = slot_mem;                          // [W2][TS]   QR^T : [key pixel][query token]
     float *krt = qrt + W2 * TS;                     // [W2][TS]+32 KR^T : [query pixel][key token]; the last tile's quad
     //                                                 reads may run past Tw (those keys are masked)
-    float *qsc = krt + W2 * TS + 32;                // [NKT][4][64] float4: scaled Q fragments (QLDS only)
-    unsigned *rowoff = reinterpret_cast<unsigned *>(qsc + (QLDS ? NKT * 16 * 64 : 0));   // [TP]
+    float *qsc = QAL ? tab_a : krt + W2 * TS + 32;  // [NKT][4][64] float4: scaled Q fragments (QLDS only)
+    unsigned *rowoff = reinterpret_cast<unsigned *>(krt + W2 * TS + 32 + (QAL ? 0 : L::QSC));   // [TP]
 
     const int nwx = g.Wp / WIN, nwin = nwx * (g.Hp / WIN);
     const int win_raw = (blockIdx.x * WPB + slot) * PK;      // first window of the wave; idle ones keep running (barriers) on window 0
@@ -441,6 +459,10 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
         }
     }
     // ---- stage ek / eq (all loads first, then the LDS stores), build the row map ----------------------
+    static_assert(!P0M || (NL == 4 && WIN == 6 && PK == 1), "MFMA phase 0: four labels per pixel = one 4-lane block");
+    constexpr float P0_SCALE = 1024.0f;            // tables are staged x 2^10 as split fp16 (entries up to 32 in magnitude; checked by the caller)
+    // P0M layout of a table in its 15.5 KB: [hi | lo][8 chunks][R rows][4 halves]
+    typedef _Float16 wa_h4 __attribute__((ext_vector_type(4)));
     {
         float4 te[TAB_IT], tq[TAB_IT];
 #pragma unroll
@@ -456,9 +478,22 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
         for (int it = 0; it < TAB_IT; ++it) {
             const int i = tid + it * NTHR;
             if (i < R * 8) {
-                const int sw = tab_off(i >> 3, i & 7);
-                stg4(tab_a + sw, te[it]);
-                stg4(tab_b + sw, make_float4(tq[it].x * sc2, tq[it].y * sc2, tq[it].z * sc2, tq[it].w * sc2));
+                if constexpr (P0M) {
+                    auto put = [&](float *tab, float4 v, float mul) {
+                        h16x2 h01, l01, h23, l23;
+                        split2u(f32x2{v.x * mul, v.y * mul}, h01, l01);
+                        split2u(f32x2{v.z * mul, v.w * mul}, h23, l23);
+                        wa_h4 *th = reinterpret_cast<wa_h4 *>(tab) + (i & 7) * R + (i >> 3);
+                        th[0] = wa_h4{h01[0], h01[1], h23[0], h23[1]};
+                        th[8 * R] = wa_h4{l01[0], l01[1], l23[0], l23[1]};
+                    };
+                    put(tab_a, te[it], P0_SCALE);
+                    put(tab_b, tq[it], P0_SCALE * sc2);
+                } else {
+                    const int sw = tab_off(i >> 3, i & 7);
+                    stg4(tab_a + sw, te[it]);
+                    stg4(tab_b + sw, make_float4(tq[it].x * sc2, tq[it].y * sc2, tq[it].z * sc2, tq[it].w * sc2));
+                }
             }
         }
     }
@@ -484,7 +519,7 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
             qf[4 * c + 0] = v.x * sc2; qf[4 * c + 1] = v.y * sc2; qf[4 * c + 2] = v.z * sc2; qf[4 * c + 3] = v.w * sc2;
             if (QLDS && !KV16) stg4(qsc + ((qt * 4 + c) * 64 + lane) * 4, make_float4(qf[4 * c], qf[4 * c + 1], qf[4 * c + 2], qf[4 * c + 3]));
         }
-        if constexpr (QLDS && KV16) {                                  // parked as operand chunks: hi 0, hi 1, lo 0, lo 1
+        if constexpr (QLDS && KV16 && !QAL) {                          // parked as operand chunks: hi 0, hi 1, lo 0, lo 1
             h16x8 sh[2], sl[2];
             split8u(qf, sh[0], sl[0]);
             split8u(qf + 8, sh[1], sl[1]);
@@ -496,6 +531,43 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
     }
 
     // ---- phase 0: relative-position logit terms (log2 domain) -------------------------------------------
+    if constexpr (P0M) {
+        // every lane takes part (the matrix instruction ignores EXEC): lanes of a padded token compute on the clamped token and store nothing
+        const float sc = hi ? 1.0f : sc2;
+        wa_h4 vh[8], vl[8];                            // this token's vector as the B operand of the 8 channel chunks
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            h16x2 h01, l01, h23, l23;
+            split2u(f32x2{vec[4 * c] * sc, vec[4 * c + 1] * sc}, h01, l01);
+            split2u(f32x2{vec[4 * c + 2] * sc, vec[4 * c + 3] * sc}, h23, l23);
+            vh[c] = wa_h4{h01[0], h01[1], h23[0], h23[1]};
+            vl[c] = wa_h4{l01[0], l01[1], l23[0], l23[1]};
+        }
+        const int pt = tokl / NL;
+        const int at = pt / WIN, bt = pt - at * WIN;
+        const wa_h4 *tab = reinterpret_cast<const wa_h4 *>(hi ? tab_b : tab_a);
+        float *dst = (hi ? krt : qrt) + tok;
+        const int i4 = lane & 3;
+#pragma unroll 3
+        for (int gk = 0; gk < W2 / 4; ++gk) {              // key (hi == 0) / query (hi == 1) pixels 4 gk .. 4 gk + 3; this lane's A row: 4 gk + i4
+            const int p = 4 * gk + i4;
+            const int aj = p / WIN, bj = p - aj * WIN;
+            const int da = hi ? (aj - at) : (at - aj), db = hi ? (bj - bt) : (bt - bj);
+            const wa_h4 *row = tab + (da + WIN - 1) * SPAN + (db + WIN - 1);
+            f32x4 ax = {0.f, 0.f, 0.f, 0.f}, ah = {0.f, 0.f, 0.f, 0.f};      // cross terms / hi x hi: two chains
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const wa_h4 th = row[c * R], tl = row[(8 + c) * R];
+                ax = __builtin_amdgcn_mfma_f32_4x4x4f16(tl, vh[c], ax, 0, 0, 0);
+                ah = __builtin_amdgcn_mfma_f32_4x4x4f16(th, vh[c], ah, 0, 0, 0);
+                ax = __builtin_amdgcn_mfma_f32_4x4x4f16(th, vl[c], ax, 0, 0, 0);
+            }
+            if (tok_ok) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[(4 * gk + r) * TS] = (ah[r] + ax[r]) * (1.0f / P0_SCALE);
+            }
+        }
+    } else
     if (tok_ok) {
         const float sc = hi ? 1.0f : sc2;
 #pragma unroll
@@ -546,7 +618,16 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
 #pragma unroll
     for (int it = 0; it < TAB_IT; ++it) {
         const int i = tid + it * NTHR;
-        if (i < R * 8) stg4(tab_a + tab_off(i >> 3, i & 7), tv[it]);
+        if (i < R * 8) stg4(tab_ev + tab_off(i >> 3, i & 7), tv[it]);
+    }
+    if constexpr (QAL) {                                               // ek is dead: its region takes the Q fragments (held in registers across phase 0)
+        h16x8 sh[2], sl[2];
+        split8u(qf, sh[0], sl[0]);
+        split8u(qf + 8, sh[1], sl[1]);
+        *reinterpret_cast<h16x8 *>(qsc + ((qt * 4 + 0) * 64 + lane) * 4) = sh[0];
+        *reinterpret_cast<h16x8 *>(qsc + ((qt * 4 + 1) * 64 + lane) * 4) = sh[1];
+        *reinterpret_cast<h16x8 *>(qsc + ((qt * 4 + 2) * 64 + lane) * 4) = sl[0];
+        *reinterpret_cast<h16x8 *>(qsc + ((qt * 4 + 3) * 64 + lane) * 4) = sl[1];
     }
     __syncthreads();
     WA_STAMP(5);
@@ -705,7 +786,7 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
                     int pk = local_key(k0 + 8 * rq + 4 * h2) / NL + pp;
                     pk = pk < W2 ? pk : W2 - 1;
                     const int ka = pk / WIN, kb = pk - ka * WIN;
-                    const float *e = tab_a + (WIN == 4 ? tab_pos(qa - ka + WIN - 1, qb - kb + WIN - 1) + hi * POSN : ev_r0 - (ka * SPAN + kb)) * 4;
+                    const float *e = tab_ev + (WIN == 4 ? tab_pos(qa - ka + WIN - 1, qb - kb + WIN - 1) + hi * POSN : ev_r0 - (ka * SPAN + kb)) * 4;
                     const float psv = h2 ? p1 : p0;
                     const f32x2 ps = {psv, psv};
 #pragma unroll
@@ -736,22 +817,22 @@ __global__ __launch_bounds__(64 * NKT * WPB, OCC) void window_attn_fast_kernel(c
     WA_CENSUS(2, wall_clock64());
 }
 
-template <int NKT, int WIN, int NL, int WPB, int OCC, int PK = 1, bool KV16 = false>
+template <int NKT, int WIN, int NL, int WPB, int OCC, int PK = 1, bool KV16 = false, bool P0M = false, bool QAL = false>
 static int launch_window_fast(const float *qkv, const float *table, const WinGeom &g, int B, float *out, hipStream_t st) {
-    using L = WinFastLds<NKT, WIN, NL, WPB, PK>;
+    using L = WinFastLds<NKT, WIN, NL, WPB, PK, QAL>;
     static_assert(L::BYTES <= 160 * 1024, "LDS budget of one CU");
     static bool attr_set_dev[NMRF_MAX_DEV] = {};      // set once per instantiation and device, outside any stream capture
     const int dev = nmrf_cur_device();
     if (dev < 0) return NMRF_ELAUNCH;
     if (L::BYTES > 64 * 1024 && !attr_set_dev[dev]) {
-        if (hipFuncSetAttribute((const void *)window_attn_fast_kernel<NKT, WIN, NL, WPB, OCC, false, PK, KV16>,
+        if (hipFuncSetAttribute((const void *)window_attn_fast_kernel<NKT, WIN, NL, WPB, OCC, false, PK, KV16, P0M, QAL>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES) != hipSuccess)
             return NMRF_ELAUNCH;
         attr_set_dev[dev] = true;
     }
     const int nwin = (g.Hp / WIN) * (g.Wp / WIN);
     dim3 grid((nwin + WPB * PK - 1) / (WPB * PK), g.heads, B);
-    hipLaunchKernelGGL((window_attn_fast_kernel<NKT, WIN, NL, WPB, OCC, false, PK, KV16>), grid, dim3(64 * NKT * WPB), L::BYTES, st, qkv,
+    hipLaunchKernelGGL((window_attn_fast_kernel<NKT, WIN, NL, WPB, OCC, false, PK, KV16, P0M, QAL>), grid, dim3(64 * NKT * WPB), L::BYTES, st, qkv,
                        table, g, 1.0f / sqrtf(32.0f), out, (unsigned long long *)nullptr);
     return nmrf_launch_status();
 }
@@ -792,13 +873,31 @@ extern "C" int nmrf_debug_window_occupancy(int *blocks_infer, int *blocks_refine
 // census [blocks][3] (device buffer).
 extern "C" int nmrf_debug_window_timing(const float *qkv, const float *table, int B, int Hp, int Wp, int shift, float *out,
                                         unsigned long long *stamps, void *stream) {
+    // (qkv: kv16 rows -- the product instantiation, phase 0 on the 4x4x4 MFMA; shift >= 100: phase 0 on the VALU, shift - 100)
     using L = WinFastLds<5, 6, 4, 2>;
-    WinGeom g{Hp, Wp, 4, 128, 4, 6, shift, 1, 144, 121};
-    hipFuncSetAttribute((const void *)window_attn_fast_kernel<5, 6, 4, 2, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES);
+    const bool valu = shift >= 100 && shift < 200, one = shift >= 200;
+    WinGeom g{Hp, Wp, 4, 128, 4, 6, shift % 100, 1, 144, 121};
     const int nwin = (Hp / 6) * (Wp / 6);
     dim3 grid((nwin + 1) / 2, 4, B);
-    hipLaunchKernelGGL((window_attn_fast_kernel<5, 6, 4, 2, 3, true>), grid, dim3(640), L::BYTES, (hipStream_t)stream, qkv, table, g,
-                       1.0f / sqrtf(32.0f), out, stamps);
+    if (one) {                                       // one window per five-wave block, Q park aliased (77.6 KB of LDS)
+        using L1 = WinFastLds<5, 6, 4, 1, 1, true>;
+        hipFuncSetAttribute((const void *)window_attn_fast_kernel<5, 6, 4, 1, 3, true, 1, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L1::BYTES);
+        int occ = -1;
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, window_attn_fast_kernel<5, 6, 4, 1, 3, true, 1, true, true, true>, 320, L1::BYTES);
+        printf("[window timing] one-window form: %zu bytes of LDS, runtime occupancy %d blocks per CU\n", (size_t)L1::BYTES, occ);
+        hipLaunchKernelGGL((window_attn_fast_kernel<5, 6, 4, 1, 3, true, 1, true, true, true>), dim3(nwin, 4, B), dim3(320), L1::BYTES, (hipStream_t)stream, qkv,
+                           table, g, 1.0f / sqrtf(32.0f), out, stamps);
+        return nmrf_launch_status();
+    }
+    if (valu) {
+        hipFuncSetAttribute((const void *)window_attn_fast_kernel<5, 6, 4, 2, 3, true, 1, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES);
+        hipLaunchKernelGGL((window_attn_fast_kernel<5, 6, 4, 2, 3, true, 1, true, false>), grid, dim3(640), L::BYTES, (hipStream_t)stream, qkv, table, g,
+                           1.0f / sqrtf(32.0f), out, stamps);
+    } else {
+        hipFuncSetAttribute((const void *)window_attn_fast_kernel<5, 6, 4, 2, 3, true, 1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES);
+        hipLaunchKernelGGL((window_attn_fast_kernel<5, 6, 4, 2, 3, true, 1, true, true>), grid, dim3(640), L::BYTES, (hipStream_t)stream, qkv, table, g,
+                           1.0f / sqrtf(32.0f), out, stamps);
+    }
     return nmrf_launch_status();
 }
 #endif  // NMRF_DEBUG_PROBES
@@ -848,7 +947,13 @@ extern "C" int nmrf_window_attn_f32(const float *qkv, const float *table, int B,
         if (rc != NMRF_OK) return rc;
     }
     if ((int64_t)B * Hp * Wp * N * 3 * C < ((int64_t)1 << 32)) {                            // 32-bit element offsets
-        if (win == 6 && N == 4 && kv16) return launch_window_fast<5, 6, 4, 2, 3, 1, true>(qkv, table, g, B, out, st);
+#ifdef NMRF_DEBUG_PROBES
+        if (win == 6 && N == 4 && kv16 && g_window_pack1 == 10) return launch_window_fast<5, 6, 4, 2, 3, 1, true>(qkv, table, g, B, out, st);   // A/B: phase 0 on the VALU
+#endif
+#ifdef NMRF_DEBUG_PROBES
+        if (win == 6 && N == 4 && kv16 && g_window_pack1 == 11) return launch_window_fast<5, 6, 4, 1, 3, 1, true, true, true>(qkv, table, g, B, out, st);   // A/B: ONE window per block
+#endif
+        if (win == 6 && N == 4 && kv16) return launch_window_fast<5, 6, 4, 2, 3, 1, true, true>(qkv, table, g, B, out, st);
         if (win == 6 && N == 4) return launch_window_fast<5, 6, 4, 2, 3>(qkv, table, g, B, out, st);   // inference windows
 #ifdef NMRF_DEBUG_PROBES
         if (win == 4 && N == 1 && g_window_pack1 == 1) return launch_window_fast<1, 4, 1, 8, 2, 1>(qkv, table, g, B, out, st);

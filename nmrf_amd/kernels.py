@@ -325,7 +325,9 @@ def window_attn(qkv, table, b, hp, wp, n, heads, win, shift, sibling_mask, check
     assert t == b * hp * wp * n
     out = torch.empty(t, c, device=qkv.device, dtype=torch.float32)
     tw = win * win * n                                 # reference form: 5 contractions of tw^2 x 32 MACs per (window, head)
-    fast = {(6, 4): "window_attn_fast_kernel<5, 6, 4, 2, 3, false, 1, %s>" % ("true" if kv16 else "false"), (4, 1): "window_attn_fast_kernel<1, 4, 1, 4, 3,"}
+    fast = {(6, 4): ("window_attn_fast_kernel<5, 6, 4, 2, 3, false, 1, true, true, false>" if kv16 else
+                     "window_attn_fast_kernel<5, 6, 4, 2, 3, false, 1, false, false, false>"),
+            (4, 1): "window_attn_fast_kernel<1, 4, 1, 4, 3,"}
     _hb("window_attn_w%d_n%d" % (win, n), row="A10" if n > 1 else "A13", bound="mfma", split=True,
         flops=b * (hp // win) * (wp // win) * heads * 5 * 2.0 * tw * tw * 32, bytes=4.0 * (qkv.numel() + t * c),
         label="%s (%s windows, %s)" % (fast.get((win, n), "window_attn_kernel<%d>" % ((tw + 31) // 32)).split("<")[0] +

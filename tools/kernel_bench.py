@@ -224,13 +224,26 @@ if "msda" in which:
             print("   max |new - old| %.3e ; algorithmic bytes %.1f MB" % (float((out_new - out_old).abs().max()),
                   (loc.numel() + wgt.numel() + out_new.numel() + value.numel()) * 4 / 1e6))
 if "window" in which:
+    _l.nmrf_debug_window_pack1.restype = ctypes.c_int
     hp, wp = 48, 156
     qkv, table = mk("q", b * hp * wp * n, 384), mk("t", 121, 384)
     q16 = K.to_kv16(qkv)
     for rep in range(2):
         for shift in (0, 3):
             timeit("window_attn 6x6x4 shift=%d" % shift, lambda: K.window_attn(qkv, table, b, hp, wp, n, 4, 6, shift, True, checked=True))
-            timeit("window_attn 6x6x4 shift=%d, k | v pre-split (kv16)" % shift, lambda: K.window_attn(q16, table, b, hp, wp, n, 4, 6, shift, True, kv16=True))
+            o_new = K.window_attn(q16, table, b, hp, wp, n, 4, 6, shift, True, kv16=True)
+            for rep in range(2):
+                timeit("window_attn 6x6x4 shift=%d, kv16, MFMA phase 0, two windows per 10-wave block (product)" % shift, lambda: K.window_attn(q16, table, b, hp, wp, n, 4, 6, shift, True, kv16=True))
+                _l.nmrf_debug_window_pack1(11)
+                o_two = K.window_attn(q16, table, b, hp, wp, n, 4, 6, shift, True, kv16=True)
+                timeit("window_attn 6x6x4 shift=%d, kv16, MFMA phase 0, ONE window per 5-wave block" % shift, lambda: K.window_attn(q16, table, b, hp, wp, n, 4, 6, shift, True, kv16=True))
+                _l.nmrf_debug_window_pack1(10)
+                o_old = K.window_attn(q16, table, b, hp, wp, n, 4, 6, shift, True, kv16=True)
+                timeit("window_attn 6x6x4 shift=%d, kv16, phase 0 on the VALU (round 3)" % shift, lambda: K.window_attn(q16, table, b, hp, wp, n, 4, 6, shift, True, kv16=True))
+                _l.nmrf_debug_window_pack1(0)
+                if not rep:
+                    print("   one vs two windows per block: max |diff| %.3e" % float((o_new - o_two).abs().max()))
+            print("   MFMA vs VALU phase 0: max |diff| %.3e (output scale %.3e)" % (float((o_new - o_old).abs().max()), float(o_old.abs().max())))
 if "stripe" in which:
     qkv = mk("q2", b * h * w * n, 384)
     lv, lh = mk("lv", 64, 1, 3, 3), mk("lh", 64, 1, 3, 3)
@@ -267,38 +280,43 @@ if "timing" in which:
     out = torch.empty(b * hp * wp * n, 128, device=dev)
     nblk = (hp // 6) * (wp // 6) * 4 * b
     nblk = ((hp // 6) * (wp // 6) + 1) // 2 * 4 * b          # two windows per block
-    stamps = torch.zeros(64 * 10 * 16 + nblk * 3, dtype=torch.int64, device=dev)
-    for _ in range(3):
-        _l.nmrf_debug_window_timing(ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(table.data_ptr()), b, hp, wp, 0,
-                                    ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(stamps.data_ptr()), None)
-    torch.cuda.synchronize()
-    allst = stamps.cpu().numpy().astype(np.int64)
-    st = allst[:64 * 10 * 16].reshape(64, 10, 16)[:, :5]
-    cen = allst[64 * 10 * 16:].reshape(nblk, 3)
-    names = ["vec+tables issued", "barrier1 wait", "ev issue+phase0", "q/k/v issue+barrier2", "ev store+barrier3",
-             "tile0", "tile1", "tile2", "tile3", "tile4", "normalise+exchange", "stores"]
-    d = np.diff(st[:, :, :13], axis=2)
-    print("window 6x6x4 per-wave phase durations in shader cycles (mean over 64 blocks), waves 0..4:")
-    for i, nm in enumerate(names):
-        print("  %-20s" % nm, " ".join("%7.0f" % v for v in d[:, :, i].mean(0)))
-    print("  %-20s" % "total", " ".join("%7.0f" % v for v in (st[:, :, 12] - st[:, :, 0]).mean(0)))
-    # census: per-CU concurrency from realtime (100 MHz) block start/end
-    t0 = cen[:, 1].min()
-    dur = (cen[:, 2] - cen[:, 1]) / 100.0
-    print("  blocks %d, distinct smid %d, block duration us: mean %.1f min %.1f max %.1f; kernel span %.1f us"
-          % (nblk, len(set(cen[:, 0].tolist())), dur.mean(), dur.min(), dur.max(), (cen[:, 2].max() - t0) / 100.0))
-    conc = []
-    for sm in set(cen[:, 0].tolist()):
-        rows = cen[cen[:, 0] == sm]
-        ev = sorted([(r[1], 1) for r in rows] + [(r[2], -1) for r in rows])
-        cur = mx = 0
-        for _, dlt in ev:
-            cur += dlt
-            mx = max(mx, cur)
-        conc.append((len(rows), mx))
-    import collections
-    print("  blocks per smid histogram:", dict(collections.Counter(c[0] for c in conc)))
-    print("  max concurrent blocks per smid histogram:", dict(collections.Counter(c[1] for c in conc)))
+    q16 = K.to_kv16(qkv)
+    for p0_shift, p0_tag in ((0, "phase 0 on the 4x4x4 MFMA (product)"), (100, "phase 0 on the VALU (round 3)"), (200, "ONE window per five-wave block")):
+        print("---- window 6x6x4, kv16 rows,", p0_tag)
+        wpb = 1 if p0_shift >= 200 else 2
+        nblk = ((hp // 6) * (wp // 6) + wpb - 1) // wpb * 4 * b
+        stamps = torch.zeros(64 * 10 * 16 + nblk * 3, dtype=torch.int64, device=dev)
+        for _ in range(3):
+            _l.nmrf_debug_window_timing(ctypes.c_void_p(q16.data_ptr()), ctypes.c_void_p(table.data_ptr()), b, hp, wp, p0_shift,
+                                        ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(stamps.data_ptr()), None)
+        torch.cuda.synchronize()
+        allst = stamps.cpu().numpy().astype(np.int64)
+        st = allst[:64 * 5 * wpb * 16].reshape(64, 5 * wpb, 16)[:, :5]
+        cen = allst[64 * 5 * wpb * 16:64 * 5 * wpb * 16 + nblk * 3].reshape(nblk, 3)
+        names = ["vec+tables issued", "barrier1 wait", "ev issue+phase0", "q/k/v issue+barrier2", "ev store+barrier3",
+                 "tile0", "tile1", "tile2", "tile3", "tile4", "normalise+exchange", "stores"]
+        d = np.diff(st[:, :, :13], axis=2)
+        print("window 6x6x4 per-wave phase durations in shader cycles (mean over 64 blocks), waves 0..4:")
+        for i, nm in enumerate(names):
+            print("  %-20s" % nm, " ".join("%7.0f" % v for v in d[:, :, i].mean(0)))
+        print("  %-20s" % "total", " ".join("%7.0f" % v for v in (st[:, :, 12] - st[:, :, 0]).mean(0)))
+        # census: per-CU concurrency from realtime (100 MHz) block start/end
+        t0 = cen[:, 1].min()
+        dur = (cen[:, 2] - cen[:, 1]) / 100.0
+        print("  blocks %d, distinct smid %d, block duration us: mean %.1f min %.1f max %.1f; kernel span %.1f us"
+              % (nblk, len(set(cen[:, 0].tolist())), dur.mean(), dur.min(), dur.max(), (cen[:, 2].max() - t0) / 100.0))
+        conc = []
+        for sm in set(cen[:, 0].tolist()):
+            rows = cen[cen[:, 0] == sm]
+            ev = sorted([(r[1], 1) for r in rows] + [(r[2], -1) for r in rows])
+            cur = mx = 0
+            for _, dlt in ev:
+                cur += dlt
+                mx = max(mx, cur)
+            conc.append((len(rows), mx))
+        import collections
+        print("  blocks per smid histogram:", dict(collections.Counter(c[0] for c in conc)))
+        print("  max concurrent blocks per smid histogram:", dict(collections.Counter(c[1] for c in conc)))
 
 if "stripe_census" in which:
     import numpy as np, collections
