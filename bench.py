@@ -401,10 +401,10 @@ def run(args):
         if world == 1 and not args.no_stream_figure:
             from nmrf_amd.driver import StereoStream
 
-            def stream_figure(bs, dtype):
+            def stream_figure(bs, dtype, inflight=None):
                 n_pairs = max(8 * bs, min(64, 4 * args.steps))
                 host_pairs = [(i,) + tuple(t.cpu().to(dtype) for t in pairs[i % len(pairs)]) for i in range(n_pairs)]
-                drv = StereoStream(model, dev, batch=bs, graph=not args.no_graph)
+                drv = StereoStream(model, dev, batch=bs, graph=not args.no_graph, inflight=inflight)
                 list(drv.run(iter(host_pairs[:2 * bs])))                       # warm-up: buffers, hipGraph capture
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
@@ -412,7 +412,8 @@ def run(args):
                 torch.cuda.synchronize()
                 dt_s = time.perf_counter() - t1
                 return {"value": round(n_done / dt_s, 2), "unit": "stereo pairs/s", "pairs": n_done, "batch": bs,
-                        "host_dtype": str(dtype).replace("torch.", ""), "launch": "hipGraph" if drv.use_graph else "eager"}
+                        "host_dtype": str(dtype).replace("torch.", ""), "launch": "hipGraph" if drv.use_graph else "eager",
+                        "forwards_in_flight": drv.inflight}
             try:
                 K.kernel_hook = None
                 stream_rec = stream_figure(b, torch.uint8)
@@ -420,6 +421,10 @@ def run(args):
                                       "pinned rings, H2D / D2H on their own streams overlapped with compute, one hipGraph replay per batch, "
                                       "results back in host memory; `value` above is compute-only (hipGraph replay on resident inputs)")
                 stream_rec["float32_host_images"] = stream_figure(b, torch.float32)["value"]
+                if b == 1 and not args.no_graph:
+                    stream_rec["two_forwards_in_flight"] = stream_figure(b, torch.uint8, inflight=2)["value"]
+                    stream_rec["note"] += ("; `two_forwards_in_flight`: batches dealt to two replicas of the model, each with its own hipGraph and "
+                                           "compute stream (StereoStream(inflight=2), off by default)")
                 if b == 1 and (args.height, args.width) == (375, 1242) and args.backbone == "resnet":
                     stream_b8 = stream_figure(8, torch.uint8)                  # the batch the driver defaults to (N1)
             except Exception as e:

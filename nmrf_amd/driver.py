@@ -50,6 +50,24 @@ def batches(items, size):
         yield cur
 
 
+def _replica(model):
+    """A private copy of the model for one more lane: own parameters, own lazily-built launch state (packed weights, persistent
+    activation grids, side stream).  Stream objects are not copied (the replica creates its own on first use)."""
+    import copy
+    memo = {}
+    for m in (model.modules() if hasattr(model, "modules") else ()):
+        for v in vars(m).values():
+            if isinstance(v, (torch.cuda.Stream, torch.cuda.Event)):
+                memo[id(v)] = None
+    with torch.no_grad():
+        rep = copy.deepcopy(model, memo)
+    if hasattr(rep, "eval"):
+        rep.eval()
+    if hasattr(rep, "range_check"):
+        rep.range_check = False           # the stream reads the (device-wide) range flag once per drained batch
+    return rep
+
+
 class _Plan:
     """Everything StereoStream keeps per (image shape, dtype): a ring of pinned host buffers and device staging buffers for the
     inputs, the static input / output tensors of ONE captured hipGraph of model.forward, and a ring of device + pinned host
@@ -94,44 +112,62 @@ class StereoStream:
     Host-side staging uses non-temporal stores (nmrf_host_copy_nt): a DMA that has to snoop freshly written lines out of a CPU
     cache costs ~20 ms per batch on this platform, whatever the batch size (tools/driver_probe3.py)."""
 
-    def __init__(self, model, device="cuda", batch=8, graph=True, depth=2, copy_out=True, threaded=True):
+    def __init__(self, model, device="cuda", batch=8, graph=True, depth=2, copy_out=True, threaded=True, inflight=None):
+        """inflight: forwards that may run on the GPU AT THE SAME TIME (default 1).  With inflight = 2 the stream deals batches to two
+        LANES -- each a replica of the model (weights copied once: 24 MB) with its own activations, its own captured hipGraph and its
+        own compute stream -- so that the encoder of pair i + 1 runs beside the message-passing stages of pair i (inference.py:61-100 /
+        evaluation.py:203-267 process one pair at a time); results are still yielded in input order and are bit-equal to one lane's.
+        Measured at KITTI batch 1 on the MI355X (profiles/r04f_driver_lanes.txt): 249.8 pairs/s with two lanes against 285.6 with one
+        (compute-only 309.3 on that box) -- the two forwards' one-workgroup-per-CU kernels (156 KB of LDS each) cannot share a CU and
+        everything that does overlap runs slower than in turn -- so one lane stays the default; the option is kept for small images."""
         self.model, self.device, self.batch = model, torch.device(device), batch
         self.on_gpu = self.device.type == "cuda"
         self.depth, self.copy_out, self.use_graph = max(2 if copy_out else 3, depth), copy_out, graph and self.on_gpu
+        self._inflight_req = inflight
         # threaded: staging + launches of batch i+1 / i+2 on a producer thread while the caller's thread drains batch i (the staging
         # copies and the evicting read-out run outside the GIL).  Needs a third slot (see _run_threaded) and handed-out COPIES.
         self.threaded = bool(threaded) and self.on_gpu and copy_out
+        inflight = self._inflight_req
+        if inflight is None:
+            inflight = 1
+        self.inflight = max(1, int(inflight)) if self.threaded else 1    # (lanes are fed by the producer thread)
         if self.threaded:
             self.depth = max(3, self.depth)
             self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.plans = {}
+        self._lane_models, self._lane_streams = [model], [None]          # lane 0: the caller's model on the current stream
         # models of this package defer their fp16 range check to the driver (one flag read per drained batch) -- only while run()
         # is active: the model's own check is switched back on when the stream ends (run()'s finally)
         self._range_model = model if (self.on_gpu and hasattr(model, "range_check")) else None
         if self.on_gpu:
             self.h2d = torch.cuda.Stream(self.device)
             self.d2h = torch.cuda.Stream(self.device)
+            for _ in range(1, self.inflight):
+                self._lane_models.append(_replica(model))
+                self._lane_streams.append(torch.cuda.Stream(self.device))
 
     # ---- GPU path ------------------------------------------------------------------------------------------------------
-    def _plan(self, group):
+    def _plan(self, group, lane=0):
         t = group[0][1]
-        key = (tuple(t.shape), t.dtype)
+        key = (lane, tuple(t.shape), t.dtype)
         plan = self.plans.get(key)
         if plan is None:
             plan = self.plans[key] = _Plan(self, tuple(t.shape), t.dtype)
+            plan.lane = lane
         return plan
 
     def _capture(self, plan):
         """Two eager forwards (weight packing, function attributes, allocator warm-up), then the capture."""
         sample = plan.sample()
+        model = self._lane_models[plan.lane]
         try:
             with torch.no_grad():
                 for _ in range(2):
-                    self.model(sample)
+                    model(sample)
                 torch.cuda.synchronize(self.device)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    out = self.model(sample)["disp"]
+                    out = model(sample)["disp"]
             plan.graph, plan.static_out = g, out
         except Exception as e:                                  # not capturable (e.g. a model with host syncs): eager from now on
             print("[nmrf_amd.driver] hipGraph capture failed (%s); eager launches" % str(e).splitlines()[0], file=sys.stderr)
@@ -139,6 +175,13 @@ class StereoStream:
             self.use_graph = False
 
     def _enqueue(self, plan, group, slot):
+        lane_stream = self._lane_streams[plan.lane]
+        if lane_stream is None:
+            return self._enqueue_on_current(plan, group, slot)
+        with torch.cuda.stream(lane_stream):
+            return self._enqueue_on_current(plan, group, slot)
+
+    def _enqueue_on_current(self, plan, group, slot):
         n = len(group)
         pin = plan.pin_in[slot]
         plan.ev_in[slot].synchronize()                          # the slot's previous H2D has left the pinned buffer (long ago)
@@ -167,7 +210,7 @@ class StereoStream:
                 disp = plan.static_out
             else:
                 x = plan.dev_in[slot]
-                disp = self.model({"img1": x[0, :n], "img2": x[1, :n]})["disp"]
+                disp = self._lane_models[plan.lane]({"img1": x[0, :n], "img2": x[1, :n]})["disp"]
                 used = torch.cuda.Event()
                 used.record(main)
         plan.ev_used[slot] = used
@@ -203,7 +246,8 @@ class StereoStream:
         shares batch j's slot in the three-slot ring, before batch j+1 has been taken, i.e. before batch j is fully read out."""
         import queue
         import threading
-        q, stop = queue.Queue(maxsize=1), threading.Event()
+        # `inflight` batches may be queued behind the one being drained; the rings are deep enough for it (see _slot)
+        q, stop = queue.Queue(maxsize=self.inflight), threading.Event()
 
         def put(item):
             while not stop.is_set():
@@ -218,7 +262,8 @@ class StereoStream:
             try:
                 torch.cuda.set_device(self._dev_index)
                 for i, group in enumerate(batches(pairs, self.batch)):
-                    if stop.is_set() or not put(self._enqueue(self._plan(group), group, i % self.depth)):
+                    lane, slot = self._slot(i)
+                    if stop.is_set() or not put(self._enqueue(self._plan(group, lane), group, slot)):
                         return
                 put(None)
             except BaseException as e:                          # surfaces in the caller's thread
@@ -251,11 +296,16 @@ class StereoStream:
             if self._range_model is not None:
                 self._range_model.range_check = prev_check
 
+    def _slot(self, i):
+        """batch i -> (lane, ring slot of that lane's plan).  The producer is at most `inflight` + 1 batches ahead of the batch being
+        drained, and batch i shares its (lane, slot) with batch i - inflight * depth: depth >= 3 keeps them apart."""
+        return i % self.inflight, (i // self.inflight) % self.depth
+
     def _run_inline(self, pairs):
         pending, i = None, 0
         for group in batches(pairs, self.batch):
             if self.on_gpu:
-                cur = self._enqueue(self._plan(group), group, i % self.depth)
+                cur = self._enqueue(self._plan(group, 0), group, i % self.depth)
             else:
                 with torch.no_grad():
                     disp = self.model({"img1": torch.stack([g[1] for g in group]), "img2": torch.stack([g[2] for g in group])})["disp"]

@@ -593,3 +593,35 @@ def test_training_mode_forward_outputs_and_criterion():
     ev = model.eval()({"img1": img1, "img2": img2})
     assert "aux_outputs" not in ev
     assert float((ev["disp"] - full["disp"]).abs().median()) < 1e-3
+
+
+def test_driver_two_forwards_in_flight():
+    """N1, two lanes (an option, off by default -- measured slower at KITTI size): with `inflight=2` the stream deals
+    batches to two replicas of the model, each with its own captured hipGraph and compute stream, so that two forwards overlap on the GPU.  Same values as one lane and as direct calls
+    (bit-equal: same kernels on the same inputs), input order kept over a long run, mixed shapes and early exit still fine, and
+    the caller's model keeps its range check."""
+    from nmrf_amd.driver import StereoStream
+    from nmrf_amd.utils.hashinit import synthetic_pair
+    model = build_product(128, DEV)
+    pairs = [(i,) + tuple(t.to(torch.uint8) for t in synthetic_pair(64, 104, seed=50 + i)[:2]) for i in range(5)]
+    one = dict(StereoStream(model, DEV, batch=1, inflight=1).run(iter(pairs)))
+    assert StereoStream(model, DEV, batch=1).inflight == 1             # the default (two lanes measured slower at KITTI size)
+    s2 = StereoStream(model, DEV, batch=1, inflight=2)
+    assert s2.inflight == 2 and len(s2._lane_models) == 2 and s2._lane_models[1] is not model
+    two = dict(s2.run(iter(pairs)))
+    assert list(two) == [0, 1, 2, 3, 4] and all(torch.equal(one[i], two[i]) for i in one)
+    with torch.no_grad():
+        want = model({"img1": pairs[3][1][None], "img2": pairs[3][2][None]})["disp"][0].cpu()
+    assert torch.equal(two[3], want)
+    many = [(k, pairs[k % 5][1], pairs[k % 5][2]) for k in range(31)]
+    longrun = list(s2.run(iter(many)))                       # the same stream object again: graphs of both lanes replayed
+    assert [k for k, _ in longrun] == list(range(31)) and all(torch.equal(d, one[k % 5]) for k, d in longrun)
+    three = list(StereoStream(model, DEV, batch=1, inflight=3).run(iter(many)))
+    assert [k for k, _ in three] == list(range(31)) and all(torch.equal(d, one[k % 5]) for k, d in three)
+    more = [(10 + i,) + tuple(t.to(torch.uint8) for t in synthetic_pair(48, 88, seed=70 + i)[:2]) for i in range(3)]
+    mixed = dict(StereoStream(model, DEV, batch=1, inflight=2).run(iter(pairs[:2] + more + pairs[2:4])))
+    assert list(mixed) == [0, 1, 10, 11, 12, 2, 3] and mixed[11].shape == (48, 88) and torch.equal(mixed[2], one[2])
+    gen = StereoStream(model, DEV, batch=1, inflight=2).run(iter(many))
+    k0, d0 = next(gen)
+    gen.close()
+    assert k0 == 0 and torch.equal(d0, one[0]) and model.range_check is True
