@@ -223,6 +223,16 @@ if "msda" in which:
             timeit("msda_forward level %dx%d (round-3 library)" % (hh, ww), call_old)
             print("   max |new - old| %.3e ; algorithmic bytes %.1f MB" % (float((out_new - out_old).abs().max()),
                   (loc.numel() + wgt.numel() + out_new.numel() + value.numel()) * 4 / 1e6))
+if "block16" in which:
+    # the product block kernel only (PMC passes at KITTI batch-1 and batch-32 token counts)
+    T = b * 48 * 156 * 4
+    x, msg, enc = mk("bx", T, 128), mk("bm", T, 128), mk("be", T, 32)
+    wp, w1, w2, wq = mk("wp", 128, 128) * 0.1, mk("w1", 512, 128) * 0.1, mk("w2", 128, 512) * 0.05, mk("wq", 384, 159) * 0.1
+    bp, b1, b2, bq = mk("bp", 128), mk("b1", 512), mk("b2", 128), mk("bq", 384)
+    g, be = mk("g", 128) * 0.1 + 1, mk("bb", 128) * 0.1
+    qd = dict(g=g, b=be, eps=1e-5, extra=enc, extra_div=1, bias=bq, kq=160, nq=384)
+    s16, st16, i16 = K.block_stream16(wp, w1, w2, wq, 160)
+    timeit("nmp_block16 proj+mlp+qkv T=%d" % T, lambda: K.nmp_block(x, s16, st16, i16, msg, bp, (g, be, 1e-5, b1, b2), qd, tokens_per_wave=16))
 if "window" in which:
     _l.nmrf_debug_window_pack1.restype = ctypes.c_int
     hp, wp = 48, 156
