@@ -255,7 +255,7 @@ def stripe_attn(qkv, lepe_v, lepe_h, b, h, w, n, kv16=False):
     # per (row, head): QK^T and PV, 2*T^2*32 FLOPs each, T = W*N, 2 heads of 32 channels
     _hb("stripe_attn_horizontal", row="A7", bound="mfma", split=True, flops=b * h * 2 * 4.0 * 32 * (w * n) ** 2, bytes=4.0 * (qkv.numel() / 2 + t * c / 2),
         label="stripe_attn_kernel<1> (horizontal stripes, A7)",
-        pmc=["stripe_attn_kernel<1, 2, 1, false", "stripe_attn_kernel<1, 2, 2, false"])
+        pmc=["stripe_attn_kernel<1, 2, 1, false, %s>" % ("true" if kv16 else "false"), "stripe_attn_kernel<1, 2, 2, false,"])
     _lib.check(fn(_p(qkv), _p(lepe_v), _p(lepe_h), b, h, w, n, c, 2, int(kv16), _p(out), rf, _stream()), "stripe_attn(horizontal)")
     _he("stripe_attn_horizontal")
     return out

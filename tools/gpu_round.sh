@@ -3,7 +3,7 @@
 # Outputs under gpurun_out/.   TAG=r02a tools/gpu_round.sh [quick]
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
 REPO=$(pwd)
-TAG=${TAG:-r03}
+TAG=${TAG:-r04}
 mkdir -p gpurun_out
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 rm -f gpurun_out/e2e_stats.jsonl
