@@ -24,7 +24,7 @@
 
 #define C3_TC 32                          // tile columns = the MFMA's 32 columns
 #define C3_PSTRIDE 80                     // bytes per pixel record
-#define C3_AFF 256                        // channels of the affine table
+#define C3_AFF 256                        // most channels the affine table takes (its LDS is sized by the call: 2 * Ci floats)
 #define C3_OLD 36                         // row pitch (floats) of the output staging tile
 #define C3_OUTSIDE 0xffffffffu
 // s_waitcnt immediate of gfx9: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14; here vmcnt = n, the others unconstrained
@@ -66,7 +66,8 @@ struct Conv3Args {
     int Co;
     float inv;
     int tiles_x, tiles_per_image, n_tiles, per_xcd;
-    unsigned long long *stamps;  // debug build: s_memtime stamps of the first 128 tiles (DBG & 64)
+    unsigned long long *stamps;  // debug build: s_memtime stamps of the first stamp_tiles tiles (DBG & 64)
+    int stamp_tiles;
     int *range_flag;             // sticky fp16-range flag of the split operands (split_mfma.h), may be NULL
 };
 
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256, STRIDE == 2 ? 1 : (STRIPS == 2 && KT == 3 ? 3 
     constexpr int STAGE_U4 = STRIPS * KT * 128;             // 16-byte words per weight stage
     ss_u32x4 *ring = reinterpret_cast<ss_u32x4 *>(smem);                       // 2 slots
     unsigned char *tile = smem + 2 * STAGE_U4 * 16;
-    float *Aff = reinterpret_cast<float *>(tile + C3_NPIX * C3_PSTRIDE);        // [2][C3_AFF]: scale, shift
+    float *Aff = reinterpret_cast<float *>(tile + C3_NPIX * C3_PSTRIDE);        // [2][Ci]: scale, shift
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256, STRIDE == 2 ? 1 : (STRIPS == 2 && KT == 3 ? 3 
     const int t = (blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);
     if (t >= a.n_tiles) return;
     unsigned long long acc_wait = 0, acc_comp = 0, t_prev = 0;
-#define C3_STAMP(k) do { if constexpr ((DBG & 64) != 0) { if (lane == 0 && t < 128 && blockIdx.y == 0) a.stamps[(t * 4 + wv) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#define C3_STAMP(k) do { if constexpr ((DBG & 64) != 0) { if (lane == 0 && t < a.stamp_tiles && blockIdx.y == 0) a.stamps[(t * 4 + wv) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
 #define C3_NOW() (((DBG & 64) != 0) ? __builtin_amdgcn_s_memtime() : 0ull)
     C3_STAMP(0);
     const int b = t / a.tiles_per_image;
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256, STRIDE == 2 ? 1 : (STRIPS == 2 && KT == 3 ? 3 
         if (a.stats) {
             const int hh = (tid + 256 * k) >= C3_NPIX ? 1 : 0;
             const float *af = Aff + 16 * slab + 4 * hh + ((2 * i) & 3) + 8 * ((2 * i) >> 2);
-            const f32x2 sc = *reinterpret_cast<const f32x2 *>(af), sh = *reinterpret_cast<const f32x2 *>(af + C3_AFF);
+            const f32x2 sc = *reinterpret_cast<const f32x2 *>(af), sh = *reinterpret_cast<const f32x2 *>(af + a.Ci);
             v[0] = fmaxf(fmaf(v[0], sc[0], sh[0]), 0.f);
             v[1] = fmaxf(fmaf(v[1], sc[1], sh[1]), 0.f);
         }
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256, STRIDE == 2 ? 1 : (STRIPS == 2 && KT == 3 ? 3 
             float sc, sh;
             in_affine_of(a.stats + ((size_t)b * a.Ci + c) * a.chunks * 2, a.chunks, HW, a.eps, sc, sh);
             Aff[c] = sc;
-            Aff[C3_AFF + c] = sh;
+            Aff[a.Ci + c] = sh;
         }
     __builtin_amdgcn_s_waitcnt(C3_VMCNT(0));
     C3_STAMP(1);
@@ -396,7 +397,8 @@ __global__ __launch_bounds__(256, STRIDE == 2 ? 1 : (STRIPS == 2 && KT == 3 ? 3 
     }
     C3_STAMP(7);
     if constexpr ((DBG & 64) != 0) {
-        if (lane == 0 && t < 128 && blockIdx.y == 0) {
+        if (lane == 0 && t < a.stamp_tiles && blockIdx.y == 0) {
+            a.stamps[(t * 4 + wv) * 16 + 15] = ((unsigned long long)(blockIdx.x & 7) << 32) | __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
             a.stamps[(t * 4 + wv) * 16 + 8] = acc_wait;
             a.stamps[(t * 4 + wv) * 16 + 9] = acc_comp;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -408,9 +410,16 @@ __global__ __launch_bounds__(256, STRIDE == 2 ? 1 : (STRIPS == 2 && KT == 3 ? 3 
 #ifdef NMRF_DEBUG_PROBES
 static int g_conv3_variant = 0;
 static unsigned long long *g_conv3_stamps = nullptr;
+static int g_conv3_stamp_tiles = 128;
 extern "C" int nmrf_debug_conv3_variant(int v) { g_conv3_variant = v; return NMRF_OK; }
 // stamps: device buffer of 128 tiles x 4 waves x 16 words, or NULL to switch the timing build off
-extern "C" int nmrf_debug_conv3_timing(void *stamps) { g_conv3_stamps = (unsigned long long *)stamps; return NMRF_OK; }
+extern "C" int nmrf_debug_conv3_timing(void *stamps) { g_conv3_stamps = (unsigned long long *)stamps; g_conv3_stamp_tiles = 128; return NMRF_OK; }
+// the same for the first `tiles` tiles (word 15 of a wave's record: XCD of the block << 32 | HW_ID)
+extern "C" int nmrf_debug_conv3_timing_n(void *stamps, int tiles) {
+    g_conv3_stamps = (unsigned long long *)stamps;
+    g_conv3_stamp_tiles = tiles;
+    return NMRF_OK;
+}
 #endif
 
 template <int STRIPS, int KT, int STRIDE, int DBG = 0, int ROWS = (STRIDE == 1 ? 2 : 1)>
@@ -420,6 +429,7 @@ static int launch_conv3(const Conv3Args &a, int groups, hipStream_t st) {
         if (g_conv3_stamps) {
             Conv3Args b = a;
             b.stamps = g_conv3_stamps;
+            b.stamp_tiles = g_conv3_stamp_tiles;
             return launch_conv3<STRIPS, KT, STRIDE, 64>(b, groups, st);
         }
         switch (g_conv3_variant) {
@@ -441,7 +451,12 @@ static int launch_conv3(const Conv3Args &a, int groups, hipStream_t st) {
     static bool attr_set_dev[NMRF_MAX_DEV] = {};
     const int dev = nmrf_cur_device();
     if (dev < 0) return NMRF_ELAUNCH;
-    const size_t lds = (size_t)2 * STRIPS * KT * 2048 + C3Geom<KT, STRIDE, ROWS>::NPIX * C3_PSTRIDE + 2 * C3_AFF * sizeof(float);
+    // The CU hands out its 160 KB of LDS in 1 280-byte granules (tools/ab/occupancy_probe.hip: at 53 824 B -- this kernel with a fixed
+    // 256-channel table -- a CU holds TWO blocks, at 53 760 B three, whatever the occupancy API computes): the table is sized by Ci.
+    size_t lds = (size_t)2 * STRIPS * KT * 2048 + C3Geom<KT, STRIDE, ROWS>::NPIX * C3_PSTRIDE + 2 * (size_t)a.Ci * sizeof(float);
+#ifdef NMRF_DEBUG_PROBES
+    if (g_conv3_variant == 300) lds += 2 * (size_t)(C3_AFF - a.Ci) * sizeof(float);       // A/B: the fixed 256-channel table of rounds 2-4
+#endif
     if (!attr_set_dev[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_split_kernel<STRIPS, KT, STRIDE, DBG, ROWS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
@@ -474,7 +489,7 @@ extern "C" int nmrf_conv_split_f32(const float *x, int B, int Ci, int H, int W, 
     const int64_t n = (int64_t)tx * ty * B;
     if (n > 0x7ffffff) return NMRF_EINVAL;
     Conv3Args a{x, Ci, H, W, Ho, Wo, pad, stats, chunks, eps, reinterpret_cast<const ss_u32x4 *>(stream_w),
-                (int64_t)(Ci / 16) * kt * strips * kt * 128, out, Co, inv_scale, tx, tx * ty, (int)n, (int)((n + 7) / 8), nullptr, range_flag};
+                (int64_t)(Ci / 16) * kt * strips * kt * 128, out, Co, inv_scale, tx, tx * ty, (int)n, (int)((n + 7) / 8), nullptr, 0, range_flag};
     hipStream_t st = (hipStream_t)stream;
     const int key = kt * 100 + stride * 10 + strips;
     switch (key) {

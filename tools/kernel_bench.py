@@ -562,6 +562,93 @@ if "conv_stamps" in which:
                   "DMA + prefetch issue %.0f" % (med(s2[:, :, 12]), med(s2[:, :, 13]), med(s2[:, :, 14]), med(s2[:, :, 10] - s2[:, :, 14])))
         # (s_memtime counters of different CUs are not synchronised: only differences inside one wave are meaningful)
 
+if "conv_lds" in which:
+    # A/B of the LDS request of the 3x3 kernels (debug build): variant 300 = the fixed 256-channel affine table of rounds 2-4 (one
+    # 1 280-byte granule too many for a third resident block of the two-strip form), 0 = table sized by Ci.  Interleaved, min of 3.
+    _l.nmrf_debug_conv3_variant.restype = ctypes.c_int
+    def t_us(fn, n):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / n
+    for (bb, ci, co, hh, ww, strips) in ((2, 64, 64, 192, 624, 2), (2, 32, 64, 192, 624, 2), (8, 64, 64, 192, 624, 2), (16, 64, 64, 192, 624, 2),
+                                         (64, 64, 64, 272, 480, 2), (2, 128, 128, 96, 312, 2), (16, 128, 128, 96, 312, 2), (2, 96, 96, 96, 312, 3),
+                                         (16, 96, 96, 96, 312, 3), (2, 256, 256, 96, 312, 4), (16, 256, 256, 96, 312, 4), (2, 128, 128, 48, 156, 2)):
+        xx = mk("clx%d_%d_%d" % (ci, bb, hh), bb, ci, hh, ww)
+        wt = mk("clw%d%d" % (ci, co), co, ci, 3, 3) * 0.05
+        pk = K.pack_conv3x3(wt, strips, co // 32 // strips)
+        packed = (pk[0], strips, co // 32 // strips, pk[1])
+        st = K.instance_stats(xx)
+        _l.nmrf_debug_conv3_variant(300)
+        ref = K.conv3x3_split(xx, packed, co, st).clone()
+        best, same = {}, {}
+        for rnd in range(3):
+            for var in (300, 0):
+                _l.nmrf_debug_conv3_variant(var)
+                same[var] = bool(torch.equal(K.conv3x3_split(xx, packed, co, st), ref))
+                best[var] = min(best.get(var, 1e9), t_us(lambda: K.conv3x3_split(xx, packed, co, st), args.iters))
+        _l.nmrf_debug_conv3_variant(0)
+        print("conv3x3 %3d->%3d @%dx%dx%d strips %d +IN: fixed table %.1f us, sized by Ci %.1f us (%+.1f %%)%s" % (
+            ci, co, bb, hh, ww, strips, best[300], best[0], 100.0 * (best[0] / best[300] - 1.0), "" if same[0] else "  MISMATCH"), flush=True)
+
+if "conv_timeline" in which:
+    # where the workgroups of one launch run and when: start / end of EVERY tile with the CU it ran on (debug build), per XCD clock
+    import numpy as np
+    _l.nmrf_debug_conv3_timing_n.restype = ctypes.c_int
+    for (bb, ci, co, hh, ww, strips) in ((2, 64, 64, 192, 624, 2), (8, 64, 64, 192, 624, 2), (2, 128, 128, 96, 312, 2)):
+        xx = mk("ctx%d_%d" % (ci, bb), bb, ci, hh, ww)
+        wt = mk("cw%d%d" % (ci, co), co, ci, 3, 3) * 0.05
+        pk = K.pack_conv3x3(wt, strips, co // 32 // strips)
+        packed = (pk[0], strips, co // 32 // strips, pk[1])
+        st_in = K.instance_stats(xx)
+        for _ in range(3):
+            K.conv3x3_split(xx, packed, co, st_in)
+        torch.cuda.synchronize()
+        nt = bb * ((hh + 7) // 8) * ((ww + 31) // 32)
+        per_xcd = (nt + 7) // 8
+        stamps = torch.zeros(nt * 4 * 16, dtype=torch.int64, device=dev)
+        _l.nmrf_debug_conv3_timing_n(ctypes.c_void_p(stamps.data_ptr()), nt)
+        K.conv3x3_split(xx, packed, co, st_in)
+        torch.cuda.synchronize()
+        _l.nmrf_debug_conv3_timing_n(None, 0)
+        st = stamps.cpu().numpy().reshape(nt, 4, 16)
+        ok = st[:, 0, 0] > 0
+        start = st[:, :, 0].min(axis=1); end = st[:, :, 11].max(axis=1)
+        xcd = np.arange(nt) // per_xcd
+        hw = st[:, 0, 15] & 0xffffffff
+        cu = (xcd << 16) | (hw & 0xff00)                      # se_id | sh_id | cu_id
+        print("conv3x3 %d->%d @%dx%dx%d: %d tiles (%d stamped), %d distinct CUs" % (ci, co, bb, hh, ww, nt, int(ok.sum()), len(np.unique(cu[ok]))))
+        span = []
+        for x in range(8):
+            m = ok & (xcd == x)
+            if not m.any():
+                continue
+            t0 = start[m].min()
+            span.append((end[m].max() - t0))
+            if x == 0:
+                rel_s = (start[m] - t0); rel_e = (end[m] - t0)
+                order = np.argsort(rel_s)
+                edges = np.arange(0, rel_e.max() + 10000, 10000)
+                print("  XCD 0: span %d cycles; per 10k-cycle bucket: blocks started / blocks running at the bucket's start / median life of those started"
+                      % span[-1])
+                for e in edges:
+                    sel = (rel_s >= e) & (rel_s < e + 10000)
+                    running = int(((rel_s <= e) & (rel_e > e)).sum())
+                    life = float(np.median((rel_e - rel_s)[sel])) if sel.any() else 0.0
+                    print("    %7d: %4d started  %4d running  life %7.0f" % (e, int(sel.sum()), running, life))
+                cus = cu[m]
+                per = {}
+                for c, a_, b_ in zip(cus, rel_s, rel_e):
+                    per.setdefault(int(c), []).append((int(a_), int(b_)))
+                cnt = np.array([len(v) for v in per.values()])
+                print("  XCD 0: %d CUs, blocks per CU min / median / max %d / %.1f / %d" % (len(per), cnt.min(), np.median(cnt), cnt.max()))
+                for c in list(per)[:4]:
+                    print("    CU %06x: " % c + "  ".join("%d-%d" % ab for ab in sorted(per[c])))
+        print("  spans of the 8 XCDs (cycles): " + " ".join("%d" % v for v in span), flush=True)
+
 if "conv_timing" in which:
     import numpy as np
     for (bb, ci, co, hh, ww) in ((2, 64, 64, 188, 624), (2, 128, 128, 94, 312)):
