@@ -99,6 +99,11 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
     float *Par = reinterpret_cast<float *>(smem + B16_PAR_OFF);
 #define B16_STAMP(k) do { if constexpr ((DBG & 32) != 0) { if (lane == 0 && blockIdx.x < 64) a.stamps[(blockIdx.x * 8 + wv) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
     B16_STAMP(0);
+    // DBG & 32: every block also leaves (realtime at entry, realtime at exit, XCC << 32 | HW_ID) behind the 64 stamped blocks' records
+    // (s_memrealtime: the 100 MHz counter that all CUs share -- s_memtime is per CU)
+    if constexpr ((DBG & 32) != 0) {
+        if (tid == 0) a.stamps[64 * 8 * 16 + (size_t)blockIdx.x * 4] = __builtin_amdgcn_s_memrealtime();
+    }
     float guard = 0.f;                                                  // fp16 range guard of the activation splits (split_mfma.h)
     float qmax = 0.f;                       // ... and of q_out: the attention kernels split it without a guard of their own (window_attn.hip)
     // The x / msg rows of the block's FIRST tile are requested before the prologue (parameter table, first weight stages, barrier):
@@ -559,6 +564,14 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
     }
 #pragma unroll 1
     for (; tile < a.n_tiles; tile += gridDim.x) tile_body(tile, std::false_type{});
+    if constexpr ((DBG & 32) != 0) {
+        __syncthreads();
+        if (tid == 0) {
+            a.stamps[64 * 8 * 16 + (size_t)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+            a.stamps[64 * 8 * 16 + (size_t)blockIdx.x * 4 + 2] =
+                ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (3 << 11)) << 32) | __builtin_amdgcn_s_getreg(4 | (31 << 11));
+        }
+    }
     split_guard_commit(guard, a.range_flag);
     if (a.range_flag && !(qmax < 65520.0f)) atomicOr(a.range_flag, 1);   // (a NaN in q_out has a NaN operand upstream: caught by `guard`)
 }
@@ -600,8 +613,14 @@ extern "C" int nmrf_pack_split_weight16_f32(const float *w, int N, int K, int Kp
 static int g_b16_variant = 0;
 static unsigned long long *g_b16_stamps = nullptr;
 extern "C" int nmrf_debug_nmp_block16_variant(int v) { g_b16_variant = v; return NMRF_OK; }
-// stamps: device buffer of 64 blocks x 8 waves x 16 words, or NULL to switch the timing build off
+// stamps: device buffer of 64 blocks x 8 waves x 16 words + 4 words per block of the grid, or NULL to switch the timing build off
 extern "C" int nmrf_debug_nmp_block16_timing(void *stamps) { g_b16_stamps = (unsigned long long *)stamps; return NMRF_OK; }
+// one thread that writes s_memrealtime: a mark on the stream between two launches
+__global__ void b16_realtime_mark_kernel(unsigned long long *dst) { *dst = __builtin_amdgcn_s_memrealtime(); }
+extern "C" int nmrf_debug_realtime_mark(void *dst, void *stream) {
+    hipLaunchKernelGGL(b16_realtime_mark_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long *)dst);
+    return nmrf_launch_status();
+}
 #endif
 
 template <bool MLP, int KQC, int DBG = 0>

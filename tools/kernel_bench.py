@@ -131,13 +131,13 @@ if "block" in which:
     _l.nmrf_debug_nmp_block16_variant(0)
     _l.nmrf_debug_nmp_block16_timing.restype = ctypes.c_int
     def stamp16(tag, call):
-        st16s = torch.zeros(64 * 8 * 16, dtype=torch.int64, device=dev)
+        st16s = torch.zeros(64 * 8 * 16 + 4 * 16384, dtype=torch.int64, device=dev)
         call(); call()
         _l.nmrf_debug_nmp_block16_timing(ctypes.c_void_p(st16s.data_ptr()))
         call()
         torch.cuda.synchronize()
         _l.nmrf_debug_nmp_block16_timing(None)
-        s_ = st16s.cpu().numpy().reshape(64, 8, 16).astype(np.int64)
+        s_ = st16s.cpu().numpy()[:64 * 8 * 16].reshape(64, 8, 16).astype(np.int64)
         nm = {1: "prologue: params + 2 stages to LDS + barrier", 2: "x / msg row loads + split", 3: "proj (4 stages, 96 MFMAs) + residual",
               4: "LN2 + split + park x1", 5: "MLP (32 stages, 768 MFMAs, GELU)", 6: "x_out staging + row stores", 7: "LNq + extra + split",
               8: "q group 0", 9: "q group 1", 10: "q group 2", 11: "drain (vmcnt 0)"}
@@ -187,6 +187,60 @@ if "block" in which:
         y2 = F.linear(h, w2, b2)
         return K.token_linear(x1, pwq, 384, 159, bq, ln=(g, be, 1e-5), y=y2, extra=enc31)
     timeit("round-1 sequence (4 launches, fp32)", old)
+if "block_timeline" in which:
+    # when and where the workgroups of ONE block-kernel launch run (debug build, s_memrealtime = the chip-wide 100 MHz counter):
+    # marks on the stream before and after, entry / exit of every block, its CU
+    import numpy as np
+    for bmul in (1, 8):
+        T = bmul * 48 * 156 * 4
+        x, msg, enc = mk("btx%d" % bmul, T, 128), mk("btm%d" % bmul, T, 128), mk("bte%d" % bmul, T, 32)
+        wp, w1, w2, wq = mk("wp", 128, 128) * 0.1, mk("w1", 512, 128) * 0.1, mk("w2", 128, 512) * 0.05, mk("wq", 384, 159) * 0.1
+        bp, b1, b2, bq = mk("bp", 128), mk("b1", 512), mk("b2", 128), mk("bq", 384)
+        g, be = mk("g", 128) * 0.1 + 1, mk("bb", 128) * 0.1
+        s16, st16, i16 = K.block_stream16(wp, w1, w2, wq, 160)
+        qd = dict(g=g, b=be, eps=1e-5, extra=enc, extra_div=1, bias=bq, kq=160, nq=384)
+        call = lambda: K.nmp_block(x, s16, st16, i16, msg, bp, (g, be, 1e-5, b1, b2), qd, tokens_per_wave=16)
+        timeit("nmp_block16 proj+mlp+qkv, %d tokens (product build)" % T, call)
+        buf = torch.zeros(64 * 8 * 16 + 4 * 16384, dtype=torch.int64, device=dev)
+        marks = torch.zeros(4, dtype=torch.int64, device=dev)
+        _l.nmrf_debug_nmp_block16_timing.restype = ctypes.c_int
+        _l.nmrf_debug_realtime_mark.restype = ctypes.c_int
+        cs = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        call(); call()
+        _l.nmrf_debug_nmp_block16_timing(ctypes.c_void_p(buf.data_ptr()))
+        call(); torch.cuda.synchronize()
+        buf.zero_()
+        _l.nmrf_debug_realtime_mark(ctypes.c_void_p(marks.data_ptr()), cs)
+        call()
+        _l.nmrf_debug_realtime_mark(ctypes.c_void_p(marks.data_ptr() + 8), cs)
+        torch.cuda.synchronize()
+        _l.nmrf_debug_nmp_block16_timing(None)
+        rec = buf.cpu().numpy()[64 * 8 * 16:].reshape(-1, 4)
+        rec = rec[rec[:, 0] > 0]
+        mk_ = marks.cpu().numpy()
+        t0 = mk_[0]
+        s_, e_ = rec[:, 0] - t0, rec[:, 1] - t0
+        cu = ((rec[:, 2] >> 32) << 16) | (rec[:, 2] & 0xff00)
+        print("  %d blocks on %d CUs; times in 10 ns ticks after the mark kernel in front: first entry %d, last entry %d, first exit %d, "
+              "last exit %d, mark behind %d" % (len(rec), len(np.unique(cu)), s_.min(), s_.max(), e_.min(), e_.max(), mk_[1] - t0))
+        life = e_ - s_
+        print("  block life: min %d  median %.0f  max %d ticks; entry-time deciles %s" % (
+            life.min(), np.median(life), life.max(), " ".join("%d" % v for v in np.percentile(s_, [10, 30, 50, 70, 90]))))
+        print("  exit-time deciles %s" % " ".join("%d" % v for v in np.percentile(e_, [10, 30, 50, 70, 90, 99])))
+        per = {}
+        for c in cu:
+            per[int(c)] = per.get(int(c), 0) + 1
+        cnt = np.array(list(per.values()))
+        print("  blocks per CU: min %d max %d; CUs with 2+: %d" % (cnt.min(), cnt.max(), int((cnt > 1).sum())), flush=True)
+        # s_memtime ticks per 10 ns realtime tick over the life of the first 64 blocks: what s_memtime counts
+        w = buf.cpu().numpy()[:64 * 8 * 16].reshape(64, 8, 16)
+        allrec = buf.cpu().numpy()[64 * 8 * 16:].reshape(-1, 4)[:64]
+        mt = (w[:, 0, 11] - w[:, 0, 0]).astype(np.float64)
+        rt = (allrec[:, 1] - allrec[:, 0]).astype(np.float64)
+        okk = (rt > 0) & (mt > 0)
+        print("  s_memtime ticks per microsecond of s_memrealtime over a block's life: median %.1f (min %.1f max %.1f)" % (
+            np.median(mt[okk] / rt[okk] * 100), (mt[okk] / rt[okk] * 100).min(), (mt[okk] / rt[okk] * 100).max()), flush=True)
+
 if "msda" in which:
     # A15 at the config-5 shapes of the Swin-T neck: [2, 96 256 queries, 8 heads, 8 channels], one level, 4 points (4 calls per forward,
     # levels 256x376 ... 32x47).  A/B against the round-3 library if a copy is present (nmrf_amd/lib/ab_main: the generic kernel).
