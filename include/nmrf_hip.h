@@ -40,7 +40,7 @@ const char *nmrf_strerror(int code);
  * in a separate pass when range_flag != NULL; pass NULL when qkv was produced by nmrf_nmp_block16_f32, which range-checks its q_out. */
 int nmrf_range_scan_f32(const float *x, int64_t n, int *range_flag, void *stream);   /* n % 4 == 0, x 16-byte aligned */
 /* ABI version of this header; bumps on any signature change. */
-int nmrf_abi_version(void);   /* currently 19 */
+int nmrf_abi_version(void);   /* currently 20 */
 
 /* A2  group-wise correlation volume.
  * replaces build_correlation_volume + the permute of DPN.forward
@@ -124,6 +124,14 @@ int nmrf_stripe_attn_f32(const float *qkv, const float *lepe_v, const float *lep
 int nmrf_warp_corr_concat_f32(const float *labels, const float *f1, const float *f2, const float *g1,
                               const float *g2, int B, int H, int W, int N, int Cf, int Cg, int groups,
                               float *out, int ld, int token_major, void *stream);
+/* The same with the Fourier embedding of the labels (nmrf_fourier_embed_f32: FourierEmbedding of the stage's label_seed,
+ * nmrf/models/NMP.py:675, 683-741) written in the same launch: enc[row(t), 0:31] (+ zero pad columns up to enc_ld), row(t) =
+ * enc_map ? enc_map[t] : t, rows with a negative map entry are skipped.  token_major maps only (NMRF_EINVAL otherwise); enc == NULL:
+ * exactly nmrf_warp_corr_concat_f32.  Same bits as the two separate calls. */
+int nmrf_warp_corr_concat_fourier_f32(const float *labels, const float *f1, const float *f2, const float *g1,
+                                      const float *g2, int B, int H, int W, int N, int Cf, int Cg, int groups,
+                                      float *out, int ld, int token_major, float normalizer, float *enc, int enc_ld,
+                                      const int *enc_map, void *stream);
 
 /* A10(i)  per-pixel self-edge attention over the N sibling labels.
  * replaces the attention core of BasicAttention.forward_pre (nmrf/models/NMP.py:97-103).

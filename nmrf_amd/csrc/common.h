@@ -108,3 +108,23 @@ __device__ __forceinline__ float gelu_fast(float v) {
     return 0.5f * v * (1.0f + er);
 }
 
+// Fourier(31) of a disparity label (NMP.py: the label embedding of every stage): c = coord * normalizer; bands c * 2^f (exact), full-range
+// sincosf.  16 work items per token (f = 0..15).
+__device__ __forceinline__ void fourier_write(float coord, float normalizer, int f, float *row) {
+    // f in [0,16): f<15 -> sin/cos of band f ; f==15 -> the scaled coordinate itself
+    float c = coord * normalizer;
+    if (f < 15) {
+        float arg = c * (float)(1 << f);
+        float s, co;
+        sincosf(arg, &s, &co);
+        row[f] = s;
+        row[15 + f] = co;
+    } else {
+        row[30] = c;
+    }
+}
+
+// rows wider than 31 floats (ld = 32: 16-byte aligned rows for the fused block kernel's side input): the pad columns are zero
+__device__ __forceinline__ void fourier_pad(int f, float *row, int ld) {
+    if (f == 15) for (int k = 31; k < ld; ++k) row[k] = 0.f;
+}

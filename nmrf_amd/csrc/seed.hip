@@ -397,24 +397,7 @@ extern "C" int nmrf_nms_topk_f32(const float *prob, int64_t P, int D, int K, flo
 // A6: 9-tap x G-group cost gather and Fourier(31) of the integer seed.
 // Fourier op order (H2): c = coord*normalizer ; f = c * 2^i (exact) ; full-range sinf/cosf.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void fourier_write(float coord, float normalizer, int f, float *row) {
-    // f in [0,16): f<15 -> sin/cos of band f ; f==15 -> the scaled coordinate itself
-    float c = coord * normalizer;
-    if (f < 15) {
-        float arg = c * (float)(1 << f);
-        float s, co;
-        sincosf(arg, &s, &co);
-        row[f] = s;
-        row[15 + f] = co;
-    } else {
-        row[30] = c;
-    }
-}
-
-// rows wider than 31 floats (ld = 32: 16-byte aligned rows for the fused block kernel's side input): the pad columns are zero
-__device__ __forceinline__ void fourier_pad(int f, float *row, int ld) {
-    if (f == 15) for (int k = 31; k < ld; ++k) row[k] = 0.f;
-}
+// (fourier_write / fourier_pad: common.h -- shared with the warp kernel of token.hip)
 
 // ------------------------------------------------------------------------------------------------
 // A4 + A6 in one launch, one WAVE per pixel, the row in REGISTERS: lane j holds bin j as an order-preserving integer key and its

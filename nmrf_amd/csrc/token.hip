@@ -277,7 +277,8 @@ __global__ __launch_bounds__(256, 5) void warp_corr_concat_kernel(const float *_
 // channel planes.  Same taps, same products, same order of additions as the NCHW kernel: identical bits.
 __global__ __launch_bounds__(256) void warp_corr_concat_tok_kernel(const float *__restrict__ labels,
         const float *__restrict__ f1, const float *__restrict__ f2, const float *__restrict__ g1,
-        const float *__restrict__ g2, int H, int W, int N, unsigned T, float *__restrict__ out, int ld) {
+        const float *__restrict__ g2, int H, int W, int N, unsigned T, float *__restrict__ out, int ld, float normalizer,
+        float *__restrict__ enc, int enc_ld, const int *__restrict__ enc_map) {
     constexpr int Cf = 64, Cg = 256;
     const int sub = threadIdx.x & 31;
     const unsigned t_raw = blockIdx.x * 8u + (threadIdx.x >> 5);
@@ -287,7 +288,17 @@ __global__ __launch_bounds__(256) void warp_corr_concat_tok_kernel(const float *
     const unsigned pixn = t / (unsigned)N;                                 // b * HW + pix
     const unsigned b = pixn / hw, pix = pixn - b * hw;
     const int y = (int)(pix / (unsigned)W), x = (int)(pix - (unsigned)y * W);
-    const WarpTaps tp = make_taps(labels[t], x, y, H, W);
+    const float label = labels[t];
+    const WarpTaps tp = make_taps(label, x, y, H, W);
+    // enc != NULL: the Fourier embedding of the label (the side input of the stage's blocks) leaves with the token -- lanes 0..15 are
+    // the 16 work items of fourier_embed_kernel (seed.hip), same arithmetic, same row map; one launch less per stage
+    if (enc && live && sub < 16) {
+        const int64_t row = enc_map ? (int64_t)enc_map[t] : (int64_t)t;
+        if (row >= 0) {
+            fourier_write(label, normalizer, sub, enc + row * enc_ld);
+            fourier_pad(sub, enc + row * enc_ld, enc_ld);
+        }
+    }
     const float *pf1 = f1 + (size_t)pixn * Cf + 4 * sub, *pf2 = f2 + (size_t)b * hw * Cf + 4 * sub;
     const float *pg1 = g1 + (size_t)pixn * Cg + 8 * sub, *pg2 = g2 + (size_t)b * hw * Cg + 8 * sub;
     const bool feat = sub < 16;
@@ -337,17 +348,19 @@ __global__ __launch_bounds__(256) void warp_corr_concat_tok_kernel(const float *
     else body(std::false_type{});
 }
 
-extern "C" int nmrf_warp_corr_concat_f32(const float *labels, const float *f1, const float *f2, const float *g1,
-                                         const float *g2, int B, int H, int W, int N, int Cf, int Cg, int groups,
-                                         float *out, int ld, int token_major, void *stream) {
+extern "C" int nmrf_warp_corr_concat_fourier_f32(const float *labels, const float *f1, const float *f2, const float *g1,
+                                                 const float *g2, int B, int H, int W, int N, int Cf, int Cg, int groups,
+                                                 float *out, int ld, int token_major, float normalizer, float *enc, int enc_ld,
+                                                 const int *enc_map, void *stream) {
     if (!labels || !f1 || !f2 || !g1 || !g2 || !out) return NMRF_ENULL;
+    if (enc && (!token_major || enc_ld < 31)) return NMRF_EINVAL;          // the embedding rides with the token-major kernel only
     if (token_major) {
         const int64_t T = (int64_t)B * H * W * N;
         if (B < 1 || H < 2 || W < 2 || N < 1 || Cf != 64 || Cg != 256 || groups != 32 || ld < 2 * Cf + groups || (ld & 3) ||
             T >= ((int64_t)1 << 31))
             return NMRF_EINVAL;
         hipLaunchKernelGGL(warp_corr_concat_tok_kernel, dim3((unsigned)ceil_div64(T, 8)), dim3(256), 0, (hipStream_t)stream, labels,
-                           f1, f2, g1, g2, H, W, N, (unsigned)T, out, ld);
+                           f1, f2, g1, g2, H, W, N, (unsigned)T, out, ld, normalizer, enc, enc_ld, enc_map);
         return nmrf_launch_status();
     }
     if (B < 1 || H < 2 || W < 2 || N < 1 || Cf < 4 * WC_CHUNKS || Cf % (4 * WC_CHUNKS) || groups < 4 * WC_CHUNKS ||
@@ -361,12 +374,22 @@ extern "C" int nmrf_warp_corr_concat_f32(const float *labels, const float *f1, c
     return nmrf_launch_status();
 }
 
+extern "C" int nmrf_warp_corr_concat_f32(const float *labels, const float *f1, const float *f2, const float *g1,
+                                         const float *g2, int B, int H, int W, int N, int Cf, int Cg, int groups,
+                                         float *out, int ld, int token_major, void *stream) {
+    return nmrf_warp_corr_concat_fourier_f32(labels, f1, f2, g1, g2, B, H, W, N, Cf, Cg, groups, out, ld, token_major, 0.f, nullptr, 0,
+                                             nullptr, stream);
+}
+
 // ------------------------------------------------------------------------------------------------
 // A11/A12: relu(label+delta) -> WTA over N by score (first max wins) -> x2 -> 4x4 lower median.
 // One thread = one 1/4-res output pixel = one 4x4 block of full-res sub-pixels, all inside a single
 // 1/8 cell, so it reads 4 float4 rows of delta and of score per label.
 // ------------------------------------------------------------------------------------------------
 #define WTA_MAXN 8
+// NS > 0: N == NS known at compile time -- all 9 NS loads of the thread are requested before the first comparison (the runtime loop
+// waited for every label's rows in turn: 4 dependent round trips on a launch of 115 blocks that is pure latency)
+template <int NS>
 __global__ __launch_bounds__(256) void wta_median_kernel(const float *__restrict__ delta, const float *__restrict__ score,
         const float *__restrict__ labels, int B, int H, int W, int N, float *__restrict__ disp_curr) {
     const int H4 = 2 * H, W4 = 2 * W;
@@ -379,13 +402,10 @@ __global__ __launch_bounds__(256) void wta_median_kernel(const float *__restrict
     float best_s[16], val[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) { best_s[k] = -INFINITY; val[k] = 0.f; }
-    for (int n = 0; n < N; ++n) {
-        const float lab = labels[t0 + n];
-        const float *dp = delta + (t0 + n) * 64 + j0, *sp = score + (t0 + n) * 64 + j0;
+    auto take_label = [&](int n, float lab, const float4 (&d4)[4], const float4 (&s4)[4]) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float4 d4 = ldg4(dp + r * 8), s4 = ldg4(sp + r * 8);
-            const float dd[4] = {d4.x, d4.y, d4.z, d4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w};
+            const float dd[4] = {d4[r].x, d4[r].y, d4[r].z, d4[r].w}, ss[4] = {s4[r].x, s4[r].y, s4[r].z, s4[r].w};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int k = r * 4 + c;
@@ -393,6 +413,28 @@ __global__ __launch_bounds__(256) void wta_median_kernel(const float *__restrict
                 bool take = (n == 0) || (ss[c] > best_s[k]) || (isnan(ss[c]) && !isnan(best_s[k]));
                 if (take) { best_s[k] = ss[c]; val[k] = fmaxf(lab + dd[c], 0.f) * 2.0f; }
             }
+        }
+    };
+    if constexpr (NS > 0) {
+        float lab[NS];
+        float4 d4[NS][4], s4[NS][4];
+#pragma unroll
+        for (int n = 0; n < NS; ++n) {
+            lab[n] = labels[t0 + n];
+            const float *dp = delta + (t0 + n) * 64 + j0, *sp = score + (t0 + n) * 64 + j0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { d4[n][r] = ldg4(dp + r * 8); s4[n][r] = ldg4(sp + r * 8); }
+        }
+#pragma unroll
+        for (int n = 0; n < NS; ++n) take_label(n, lab[n], d4[n], s4[n]);
+    } else {
+        for (int n = 0; n < N; ++n) {
+            const float lab = labels[t0 + n];
+            const float *dp = delta + (t0 + n) * 64 + j0, *sp = score + (t0 + n) * 64 + j0;
+            float4 d4[4], s4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { d4[r] = ldg4(dp + r * 8); s4[r] = ldg4(sp + r * 8); }
+            take_label(n, lab, d4, s4);
         }
     }
     // lower median of 16 = element of rank 7 (0-based) under a stable order
@@ -412,8 +454,10 @@ extern "C" int nmrf_wta_median_f32(const float *delta, const float *score, const
     if (!delta || !score || !labels || !disp_curr) return NMRF_ENULL;
     if (B < 1 || H < 1 || W < 1 || N < 1 || N > WTA_MAXN) return NMRF_EINVAL;
     dim3 grid((unsigned)ceil_div64((int64_t)B * 4 * H * W, 256));
-    hipLaunchKernelGGL(wta_median_kernel, grid, dim3(256), 0, (hipStream_t)stream, delta, score, labels, B, H, W, N,
-                       disp_curr);
+    if (N == 4)
+        hipLaunchKernelGGL(wta_median_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, delta, score, labels, B, H, W, N, disp_curr);
+    else
+        hipLaunchKernelGGL(wta_median_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, delta, score, labels, B, H, W, N, disp_curr);
     return nmrf_launch_status();
 }
 

@@ -262,8 +262,11 @@ def stripe_attn(qkv, lepe_v, lepe_h, b, h, w, n, kv16=False):
 
 
 @_on_device
-def warp_corr_concat(labels, f1, f2, g1, g2, n, groups=32, ld=None, token_major=False):
-    """f1, f2 [B,Cf,H,W], g1, g2 [B,Cg,H,W] (token_major: [B,H,W,C], Cf 64 / Cg 256 / 32 groups) -> [T, ld]."""
+def warp_corr_concat(labels, f1, f2, g1, g2, n, groups=32, ld=None, token_major=False, fourier=None):
+    """f1, f2 [B,Cf,H,W], g1, g2 [B,Cg,H,W] (token_major: [B,H,W,C], Cf 64 / Cg 256 / 32 groups) -> [T, ld].
+    fourier = (normalizer, enc [rows, enc_ld] or None, out_map int32 [T] or None): the Fourier embedding of the labels is written by
+    the same launch (token_major only; what fourier_embed(labels, normalizer, enc_ld, out=enc, out_map=out_map) writes) and the
+    result is (rows, enc)."""
     _chk(labels, f1, f2, g1, g2)
     if token_major:
         b, h, w, cf = f1.shape
@@ -276,14 +279,30 @@ def warp_corr_concat(labels, f1, f2, g1, g2, n, groups=32, ld=None, token_major=
     t = b * h * w * n
     assert labels.numel() == t
     out = torch.empty(t, ld, device=f1.device, dtype=torch.float32)
+    enc = None
+    if fourier is not None:
+        if not token_major:
+            raise NmrfHipError("warp_corr_concat: the Fourier rows ride with the token-major kernel only")
+        normalizer, enc, out_map = fourier
+        if enc is None:
+            enc = torch.empty(t, 32, device=f1.device, dtype=torch.float32)
+        _chk(enc)
+        if out_map is not None:
+            _chk(out_map, dtype=torch.int32)
+            assert out_map.numel() == t
     _hb("warp_corr_concat_n%d" % n, row="A9" if n > 1 else "A13", bound="hbm",
         bytes=4.0 * (2 * f1.numel() + 2 * g1.numel() + t + out.numel()), flops=2.0 * t * (cg + 2 * cf),
         label="warp_corr_concat_kernel (warp + 32-group correlation + concat, %s)" % ("A9, 1/8" if n > 1 else "A13, 1/4"),
         pmc=["warp_corr_concat_tok_kernel" if token_major else "warp_corr_concat_kernel"])
-    _lib.check(_lib.load().nmrf_warp_corr_concat_f32(_p(labels), _p(f1), _p(f2), _p(g1), _p(g2), b, h, w, n, cf, cg,
-                                                     groups, _p(out), ld, int(token_major), _stream()), "warp_corr_concat")
+    if fourier is None:
+        _lib.check(_lib.load().nmrf_warp_corr_concat_f32(_p(labels), _p(f1), _p(f2), _p(g1), _p(g2), b, h, w, n, cf, cg,
+                                                         groups, _p(out), ld, int(token_major), _stream()), "warp_corr_concat")
+    else:
+        _lib.check(_lib.load().nmrf_warp_corr_concat_fourier_f32(
+            _p(labels), _p(f1), _p(f2), _p(g1), _p(g2), b, h, w, n, cf, cg, groups, _p(out), ld, int(token_major), float(normalizer),
+            _p(enc), enc.shape[-1], _p(out_map), _stream()), "warp_corr_concat_fourier")
     _he("warp_corr_concat_n%d" % n)
-    return out
+    return out if fourier is None else (out, enc)
 
 
 def to_kv16(qkv):

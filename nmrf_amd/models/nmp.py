@@ -552,35 +552,41 @@ class Inference(nn.Module):
         split = _split() and self.dim == 128 and all(
             _block_ok(l.nmp.proj, l.nmp.mlp, *((l.self_nmp.proj,) if hasattr(l, "self_nmp") else ())) for l in self.layers)
         win = self.layers[0].window_size
-        wcc = K.warp_corr_concat(labels_flat, fmap1, fmap2, fmap1_gw, fmap2_gw, n, self.cost_group, token_major=token_major)
-        if split and wcc.shape[1] == 160 and self.ffn.fc1.out_features == 128 and self.ffn.fc2.out_features == 128:
+        fused = (split and self.ffn.fc1.in_features == 160 and self.ffn.fc1.out_features == 128 and self.ffn.fc2.out_features == 128)
+        if fused:
             # ffn and Fourier rows are written straight into the zero-padded token grid; the final norm is cropped on the way out
             if not hasattr(self, "_maps"):
                 self._maps = {}
                 self._ffn = _ChainLauncher(0, (self.ffn.fc1, self.ffn.fc2), (160, 128), 128)
-            pdims, to_p, to_d = _pad_maps(dims, win, wcc.device, self._maps)
+            dev = fmap1.device
+            pdims, to_p, to_d = _pad_maps(dims, win, dev, self._maps)
             tp = pdims[0] * pdims[1] * pdims[2] * pdims[3]
-            if to_p is None:
-                x = self._ffn(wcc, 160)
-                enc = K.fourier_embed(labels_flat, self.normalizer, 32)
-            else:
+            ebuf = None
+            if to_p is not None:
                 # the padded grids are persistent: their padding rows are zeroed once and never written (the row maps only address
                 # real tokens), the interior is overwritten by every forward -- no fill kernels on the hot path
                 # keyed like the row maps (geometry, not size): two inputs with the same padded size but different padding
                 # (KITTI 1242x375 vs 1224x370 -> both 48x156 cells) must not share a buffer, or the rows that were real tokens of
                 # the first become non-zero "padding" of the second
-                gkey = (dims, win, str(wcc.device))
+                gkey = (dims, win, str(dev))
                 if not hasattr(self, "_grids"):
                     self._grids = {}
                 if gkey not in self._grids:
-                    self._grids[gkey] = (torch.zeros(tp, self.dim, device=wcc.device), torch.zeros(tp, 32, device=wcc.device))
+                    self._grids[gkey] = (torch.zeros(tp, self.dim, device=dev), torch.zeros(tp, 32, device=dev))
                 xbuf, ebuf = self._grids[gkey]
-                x = self._ffn(wcc, 160, out=xbuf, out_map=to_p)
+            if token_major:
+                # token-major maps: the Fourier rows of the labels leave with the warp kernel's tokens (one launch less per stage)
+                wcc, enc = K.warp_corr_concat(labels_flat, fmap1, fmap2, fmap1_gw, fmap2_gw, n, self.cost_group, token_major=True,
+                                              fourier=(self.normalizer, ebuf, to_p))
+            else:
+                wcc = K.warp_corr_concat(labels_flat, fmap1, fmap2, fmap1_gw, fmap2_gw, n, self.cost_group)
                 enc = K.fourier_embed(labels_flat, self.normalizer, 32, out=ebuf, out_map=to_p)
+            x = self._ffn(wcc, 160) if to_p is None else self._ffn(wcc, 160, out=xbuf, out_map=to_p)
             t_dense = dims[0] * dims[1] * dims[2] * dims[3]
             return self._run_blocks(x, enc, pdims, to_d, t_dense, collect)
         if collect is not None:
             raise NotImplementedError("return_intermediate is implemented on the fused block path (128-wide tokens, shipped head shapes)")
+        wcc = K.warp_corr_concat(labels_flat, fmap1, fmap2, fmap1_gw, fmap2_gw, n, self.cost_group, token_major=token_major)
         x = self.ffn(wcc)
         enc = K.fourier_embed(labels_flat, self.normalizer, 32 if split else 31)
         x, pdims, off = _pad_grid(x, dims, win)

@@ -337,6 +337,25 @@ def test_warp_corr_concat(b, h, w, n):
             pix = r // n
             msg.append(f"row {r} (y={pix // w % h} x={pix % w} n={r % n}) label={float(labels.reshape(-1)[r])!r} cols={bad[bad[:, 0] == r, 1][:8].tolist()}")
         raise AssertionError("\n".join(msg))
+    # the Fourier rows of the labels written by the same launch (nmrf_warp_corr_concat_fourier_f32): rows and embedding are the bits
+    # of the two separate calls, dense and through a row map with skipped (negative) entries into a wider, pre-filled buffer
+    lab_d = labels.reshape(-1).to(DEV)
+    t = lab_d.numel()
+    norm = 1.0 / 128.0
+    rows2, enc2 = K().warp_corr_concat(lab_d, nhwc(f1), nhwc(f2), nhwc(g1), nhwc(g2), n, token_major=True, fourier=(norm, None, None))
+    assert torch.equal(rows2.cpu(), tok)
+    assert torch.equal(enc2.cpu(), K().fourier_embed(lab_d, norm, 32).cpu())
+    perm = torch.randperm(t + 5, generator=torch.Generator().manual_seed(7))[:t].to(torch.int32)
+    perm[::11] = -1
+    buf_a = torch.full((t + 5, 32), 7.0, device=DEV)
+    buf_b = buf_a.clone()
+    rows3, enc3 = K().warp_corr_concat(lab_d, nhwc(f1), nhwc(f2), nhwc(g1), nhwc(g2), n, token_major=True,
+                                       fourier=(norm, buf_a, perm.to(DEV)))
+    K().fourier_embed(lab_d, norm, 32, out=buf_b, out_map=perm.to(DEV))
+    assert enc3 is buf_a and torch.equal(rows3.cpu(), tok) and torch.equal(buf_a.cpu(), buf_b.cpu())
+    assert bool((buf_a.cpu()[~torch.isin(torch.arange(t + 5), perm[perm >= 0].long())] == 7.0).all())     # unmapped rows untouched
+    with pytest.raises(Exception):
+        K().warp_corr_concat(lab_d, f1.to(DEV), f2.to(DEV), g1.to(DEV), g2.to(DEV), n, fourier=(norm, None, None))
 
 
 def test_wta_median_and_refine_epilogue():
@@ -349,6 +368,17 @@ def test_wta_median_and_refine_epilogue():
     un = lambda x: x.view(b, h, w, n, 8, 8).permute(0, 1, 4, 2, 5, 3).reshape(b, h * 8, w * 8, n)
     want = O.wta_median(un(F.relu(labels[:, None] + delta)), un(0.25 * score))
     assert torch.equal(got, want), f"max|d|={float((got - want).abs().max())}"
+    # NaN scores win like in ATen's max; label counts other than 4 take the kernel's runtime loop
+    for n2 in (4, 3, 1):
+        tk2 = b * h * w * n2
+        d2, s2 = rnd(tk2, 64, seed=11 + n2, scale=3.0), rnd(tk2, 64, seed=12 + n2)
+        s2[::7] = s2[::7].round()
+        s2[3::13, ::5] = float("nan")
+        l2 = rnd(tk2, seed=13 + n2).abs() * 30
+        got2 = K().wta_median(d2.to(DEV), s2.to(DEV), l2.to(DEV), b, h, w, n2).cpu()
+        un2 = lambda x: x.view(b, h, w, n2, 8, 8).permute(0, 1, 4, 2, 5, 3).reshape(b, h * 8, w * 8, n2)
+        want2 = O.wta_median(un2(F.relu(l2[:, None] + d2)), un2(0.25 * s2))
+        assert torch.equal(got2, want2), f"N={n2}: max|d|={float((got2 - want2).abs().max())}"
 
     h4, w4 = 6, 9
     d16 = rnd(b * h4 * w4, 16, seed=4, scale=2.0)
