@@ -57,20 +57,14 @@ __device__ __forceinline__ int64_t stripe_row(const StripeGeom &g, int64_t base_
 // KV16: the k and v thirds of a qkv row hold split fp16 operand pairs (the producing block kernel wrote them so: kv16 of
 // nmrf_nmp_block16_f32, include/nmrf_hip.h) -- the K fragment is four 16-byte loads that ARE the MFMA operands, the V fragment
 // 16 words and 16 v_perm_b32; without it each key tile pays 2 x 48 VALU instructions to split them (of ~250 in a tile).
+// The body of one block: work item `item` of the logical grid g.gx x g.gy x g.gz (the kernels below map blockIdx to items).
 template <int AXIS, int NSHIFT, int KSPLIT, bool CENSUS = false, bool KV16 = false>
-__global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__restrict__ qkv, const float *__restrict__ lepe,
-                                                         StripeGeom g, float scale, float *__restrict__ out,
-                                                         unsigned long long *__restrict__ census = nullptr) {
+__device__ __forceinline__ void stripe_attn_body(const float *__restrict__ qkv, const float *__restrict__ lepe, const StripeGeom &g,
+                                                 float scale, float *__restrict__ out, unsigned long long *__restrict__ census,
+                                                 const int item) {
     constexpr int QPB = 4 / KSPLIT;                           // query tiles per block
     float guard = 0.f;                                        // fp16 range guard of the q / k / v splits (split_mfma.h)
-    // XCD-aware block order.  Workgroups go round-robin over the 8 XCDs (linear id % 8), each with a private 4 MB L2.
-    // All query tiles of one (stripe, head) read the same K/V rows, so the logical work items are handed out in
-    // contiguous runs per XCD: with the natural order every XCD streamed the whole K/V set (15 MB at KITTI) through
-    // its L2 and the kernel re-fetched it from MALL/HBM (137 MB of traffic for 60 MB of tensors).
     const int total = g.gx * g.gy * g.gz;
-    const int chunk = gridDim.x >> 3;                          // the launch pads the grid to a multiple of 8
-    const int item = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
-    if (item >= total) return;
     const int bx = item % g.gx, by = (item / g.gx) % g.gy, bz = item / (g.gx * g.gy);
     struct Scope {
         unsigned long long *p;
@@ -502,6 +496,39 @@ __global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__rest
     SA_STAMP(11);
 }
 
+template <int AXIS, int NSHIFT, int KSPLIT, bool CENSUS = false, bool KV16 = false>
+__global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__restrict__ qkv, const float *__restrict__ lepe,
+                                                         StripeGeom g, float scale, float *__restrict__ out,
+                                                         unsigned long long *__restrict__ census = nullptr) {
+    // XCD-aware block order.  Workgroups go round-robin over the 8 XCDs (linear id % 8), each with a private 4 MB L2.
+    // All query tiles of one (stripe, head) read the same K/V rows, so the logical work items are handed out in
+    // contiguous runs per XCD: with the natural order every XCD streamed the whole K/V set (15 MB at KITTI) through
+    // its L2 and the kernel re-fetched it from MALL/HBM (137 MB of traffic for 60 MB of tensors).
+    const int total = g.gx * g.gy * g.gz;
+    const int chunk = gridDim.x >> 3;                          // the launch pads the grid to a multiple of 8
+    const int item = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if (item >= total) return;
+    stripe_attn_body<AXIS, NSHIFT, KSPLIT, CENSUS, KV16>(qkv, lepe, g, scale, out, census, item);
+}
+
+// Both axes of a propagation layer in ONE launch (four labels per pixel, pre-split k | v rows): the two kernels are independent --
+// vertical stripes attend on channel half 0, horizontal ones on half 1 (NMP.py:429-600) -- and each alone leaves the chip partly
+// idle at batch 1 (470 and 624 blocks of 4 waves for 768 resident slots).  The horizontal items (20 key tiles each) are handed out
+// first, the vertical ones (6 key tiles) fill in behind them; per axis the same per-XCD runs as above.
+template <int NSHIFT, bool KV16>
+__global__ __launch_bounds__(256, 2) void stripe_attn_both_kernel(const float *__restrict__ qkv, const float *__restrict__ lepe_v,
+                                                              const float *__restrict__ lepe_h, StripeGeom gv, StripeGeom gh,
+                                                              float scale, float *__restrict__ out, int chunk_h, int chunk_v) {
+    const int xcd = (int)(blockIdx.x & 7), k = (int)(blockIdx.x >> 3);
+    if (k < chunk_h) {
+        const int item = xcd * chunk_h + k;
+        if (item < gh.gx * gh.gy * gh.gz) stripe_attn_body<1, NSHIFT, 1, false, KV16>(qkv, lepe_h, gh, scale, out, nullptr, item);
+    } else {
+        const int item = xcd * chunk_v + (k - chunk_h);
+        if (item < gv.gx * gv.gy * gv.gz) stripe_attn_body<0, NSHIFT, 1, false, KV16>(qkv, lepe_v, gv, scale, out, nullptr, item);
+    }
+}
+
 template <int AXIS, int NSHIFT, bool KV16 = false>
 static void launch_stripe(const float *qkv, const float *lepe, const StripeGeom &g_in, int stripes, int B, float scale,
                           float *out, hipStream_t st) {
@@ -555,6 +582,23 @@ extern "C" int nmrf_stripe_attn_f32(const float *qkv, const float *lepe_v, const
     if (W * 2 > 65535 || H * 2 > 65535 || B > 65535) return NMRF_EINVAL;
     const float scale = 1.0f / sqrtf(32.0f);
     hipStream_t st = (hipStream_t)stream;
+    bool both = axes == 3 && N == 4 && kv16;
+#ifdef NMRF_DEBUG_PROBES
+    static const char *two = getenv("NMRF_STRIPE_TWO_LAUNCHES");   // A/B (tools/kernel_bench.py), debug library only
+    if (two && two[0] == '1') both = false;
+#endif
+    if (both) {
+        StripeGeom gv{H, W, N, C, H, H * N, (int64_t)W, 0, 0, 0, range_flag};
+        StripeGeom gh{H, W, N, C, W, W * N, (int64_t)1, 0, 0, 0, range_flag};
+        gv.gx = ((gv.Ts + SA_TILE - 1) / SA_TILE + 3) / 4; gv.gy = W * 2; gv.gz = B;
+        gh.gx = ((gh.Ts + SA_TILE - 1) / SA_TILE + 3) / 4; gh.gy = H * 2; gh.gz = B;
+        const int64_t tv = (int64_t)gv.gx * gv.gy * gv.gz, th = (int64_t)gh.gx * gh.gy * gh.gz;
+        if (tv + th > 0x7ffffff0) return NMRF_EINVAL;
+        const int chunk_v = (int)((tv + 7) / 8), chunk_h = (int)((th + 7) / 8);
+        hipLaunchKernelGGL((stripe_attn_both_kernel<2, true>), dim3((unsigned)(8 * (chunk_v + chunk_h))), dim3(256), 0, st, qkv, lepe_v,
+                           lepe_h, gv, gh, scale, out, chunk_h, chunk_v);
+        return nmrf_launch_status();
+    }
     if (axes & 1) {   // vertical stripes: one per column, H*N tokens each, channel half 0
         StripeGeom g{H, W, N, C, H, H * N, (int64_t)W, 0, 0, 0, range_flag};
         if (N == 4 && kv16) launch_stripe<0, 2, true>(qkv, lepe_v, g, W, B, scale, out, st);

@@ -242,8 +242,9 @@ def _he(name):
 
 
 @_on_device
-def stripe_attn(qkv, lepe_v, lepe_h, b, h, w, n, kv16=False):
-    """kv16: the k | v thirds of qkv are split fp16 operand pairs (nmp_block(q=dict(kv16=True)) / to_kv16)."""
+def stripe_attn(qkv, lepe_v, lepe_h, b, h, w, n, kv16=False, two_launches=False):
+    """kv16: the k | v thirds of qkv are split fp16 operand pairs (nmp_block(q=dict(kv16=True)) / to_kv16); with four labels both axes
+    then run in ONE launch (two_launches=True: the vertical and the horizontal kernel one after the other -- tests, A/B)."""
     _chk(qkv, lepe_v, lepe_h)
     t, c3 = qkv.shape
     c = c3 // 3
@@ -251,9 +252,18 @@ def stripe_attn(qkv, lepe_v, lepe_h, b, h, w, n, kv16=False):
     out = torch.empty(t, c, device=qkv.device, dtype=torch.float32)
     fn = _lib.load().nmrf_stripe_attn_f32
     rf = None if kv16 else _rf(qkv)                      # (pre-split operands were range-checked by their producer)
+    # per (row, head): QK^T and PV, 2*T^2*32 FLOPs each, T = W*N, 2 heads of 32 channels (columns: T = H*N)
+    fl_h, fl_v = b * h * 2 * 4.0 * 32 * (w * n) ** 2, b * w * 2 * 4.0 * 32 * (h * n) ** 2
+    if kv16 and n == 4 and not two_launches:
+        # pre-split rows, four labels: both axes in one launch (stripe_attn_both_kernel: the horizontal items first, the vertical ones
+        # fill in behind them)
+        _hb("stripe_attn_both", row="A7", bound="mfma", split=True, flops=fl_h + fl_v, bytes=4.0 * (qkv.numel() + t * c),
+            label="stripe_attn_both_kernel (vertical + horizontal stripes in one launch, A7)", pmc=["stripe_attn_both_kernel<2, true>"])
+        _lib.check(fn(_p(qkv), _p(lepe_v), _p(lepe_h), b, h, w, n, c, 3, 1, _p(out), rf, _stream()), "stripe_attn(both axes)")
+        _he("stripe_attn_both")
+        return out
     _lib.check(fn(_p(qkv), _p(lepe_v), _p(lepe_h), b, h, w, n, c, 1, int(kv16), _p(out), rf, _stream()), "stripe_attn(vertical)")
-    # per (row, head): QK^T and PV, 2*T^2*32 FLOPs each, T = W*N, 2 heads of 32 channels
-    _hb("stripe_attn_horizontal", row="A7", bound="mfma", split=True, flops=b * h * 2 * 4.0 * 32 * (w * n) ** 2, bytes=4.0 * (qkv.numel() / 2 + t * c / 2),
+    _hb("stripe_attn_horizontal", row="A7", bound="mfma", split=True, flops=fl_h, bytes=4.0 * (qkv.numel() / 2 + t * c / 2),
         label="stripe_attn_kernel<1> (horizontal stripes, A7)",
         pmc=["stripe_attn_kernel<1, 2, 1, false, %s>" % ("true" if kv16 else "false"), "stripe_attn_kernel<1, 2, 2, false,"])
     _lib.check(fn(_p(qkv), _p(lepe_v), _p(lepe_h), b, h, w, n, c, 2, int(kv16), _p(out), rf, _stream()), "stripe_attn(horizontal)")

@@ -581,6 +581,8 @@ def test_kv16_format_producer_and_stripe_consumer_bit_exact():
     for (b, h, w) in ((1, 47, 12), (2, 6, 47)):
         a = kk.stripe_attn(q32, d(lv), d(lh), b, h, w, 4)
         c = kk.stripe_attn(q16, d(lv), d(lh), b, h, w, 4, kv16=True)
+        # (one launch for both axes; the two single-axis kernels one after the other write the same bits)
+        assert torch.equal(c, kk.stripe_attn(q16, d(lv), d(lh), b, h, w, 4, kv16=True, two_launches=True))
         # attention: identical operands -> identical bits; LePE reads v back as hi + lo (2^-22 relative)
         report("stripe attention on kv16 rows", c.cpu(), a.cpu().double(), 2e-6, 1e-6)
     # the attention itself bit for bit (zero LePE weights), on a grid where both forms walk their keys as ONE range (the kv16 form

@@ -320,6 +320,27 @@ if "stripe" in which:
                 timeit("stripe_attn %s only, %s" % (nm, "k | v pre-split (kv16)" if fmt else "fp32 rows"), lambda: _l.nmrf_stripe_attn_f32(
                     ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(lv.data_ptr()), ctypes.c_void_p(lh.data_ptr()), b, h, w, n, 128, ax,
                     fmt, ctypes.c_void_p(so.data_ptr()), None, None))
+if "stripe_both" in which:
+    # both axes of a propagation layer in one launch against the two single-axis launches (kv16 rows), interleaved, min of 3 rounds
+    qkv = mk("q2", b * h * w * n, 384)
+    lv, lh = mk("lv", 64, 1, 3, 3), mk("lh", 64, 1, 3, 3)
+    q16 = K.to_kv16(qkv)
+    one = K.stripe_attn(q16, lv, lh, b, h, w, n, kv16=True)
+    two = K.stripe_attn(q16, lv, lh, b, h, w, n, kv16=True, two_launches=True)
+    print("stripe_attn kv16, batch %d: one launch == two launches bit for bit: %s" % (b, bool(torch.equal(one, two))))
+    def t_us(fn, nrep):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(nrep):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / nrep
+    best = {}
+    for rnd_ in range(3):
+        for tag, kw in (("two launches", dict(two_launches=True)), ("one launch", dict())):
+            best[tag] = min(best.get(tag, 1e9), t_us(lambda: K.stripe_attn(q16, lv, lh, b, h, w, n, kv16=True, **kw), args.iters))
+    print("stripe_attn kv16, batch %d: two launches %.1f us, one launch %.1f us" % (b, best["two launches"], best["one launch"]), flush=True)
 if "refine" in which:
     hp, wp = 96, 312
     qkv, table = mk("q3", b * hp * wp, 384), mk("t3", 49, 384)
