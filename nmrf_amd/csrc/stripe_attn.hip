@@ -582,11 +582,7 @@ extern "C" int nmrf_stripe_attn_f32(const float *qkv, const float *lepe_v, const
     if (W * 2 > 65535 || H * 2 > 65535 || B > 65535) return NMRF_EINVAL;
     const float scale = 1.0f / sqrtf(32.0f);
     hipStream_t st = (hipStream_t)stream;
-    bool both = axes == 3 && N == 4 && kv16;
-#ifdef NMRF_DEBUG_PROBES
-    static const char *two = getenv("NMRF_STRIPE_TWO_LAUNCHES");   // A/B (tools/kernel_bench.py), debug library only
-    if (two && two[0] == '1') both = false;
-#endif
+    const bool both = axes == 3 && N == 4 && kv16;          // (a caller that wants the two kernels one after the other passes 1, then 2)
     if (both) {
         StripeGeom gv{H, W, N, C, H, H * N, (int64_t)W, 0, 0, 0, range_flag};
         StripeGeom gh{H, W, N, C, W, W * N, (int64_t)1, 0, 0, 0, range_flag};
