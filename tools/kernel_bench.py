@@ -637,6 +637,15 @@ if "conv_stamps" in which:
                   "DMA + prefetch issue %.0f" % (med(s2[:, :, 12]), med(s2[:, :, 13]), med(s2[:, :, 14]), med(s2[:, :, 10] - s2[:, :, 14])))
         # (s_memtime counters of different CUs are not synchronised: only differences inside one wave are meaningful)
 
+if "conv_one" in which:
+    # the 64 -> 64 convolution of layer 1 alone (for counter passes): --batch images of 192 x 624
+    xx = mk("c1x%d" % args.batch, args.batch, 64, 192, 624)
+    wt = mk("c1w", 64, 64, 3, 3) * 0.05
+    pk = K.pack_conv3x3(wt, 2, 1)
+    packed = (pk[0], 2, 1, pk[1])
+    st = K.instance_stats(xx)
+    timeit("conv3x3 64->64 @%dx192x624 +IN" % args.batch, lambda: K.conv3x3_split(xx, packed, 64, st))
+
 if "conv_lds" in which:
     # A/B of the LDS request of the 3x3 kernels (debug build): variant 300 = the fixed 256-channel affine table of rounds 2-4 (one
     # 1 280-byte granule too many for a third resident block of the two-strip form), 0 = table sized by Ci.  Interleaved, min of 3.
