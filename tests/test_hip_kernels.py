@@ -766,7 +766,9 @@ def test_conv3x3_winograd(b, ci, co, h, w):
 @pytest.mark.parametrize("b,ci,co,h,w,strips,norm", [
     (1, 16, 64, 4, 64, 2, False), (2, 32, 64, 7, 9, 2, True), (1, 64, 64, 47, 156, 2, True), (2, 96, 96, 23, 70, 3, True),
     (1, 128, 128, 12, 33, 2, False), (1, 128, 128, 12, 33, 4, True), (2, 128, 256, 24, 78, 2, False), (1, 128, 256, 9, 40, 4, True),
-    (1, 16, 64, 1, 1, 2, False), (2, 64, 64, 192, 624, 2, True)])
+    (1, 16, 64, 1, 1, 2, False), (2, 64, 64, 192, 624, 2, True),
+    # the affine table of the folded InstanceNorm is sized by Ci (its LDS decides how many blocks a CU holds): the largest Ci it takes
+    (1, 256, 64, 9, 40, 2, True), (1, 256, 256, 10, 33, 4, True), (1, 48, 64, 10, 33, 2, True)])
 def test_conv3x3_split(b, ci, co, h, w, strips, norm):
     """csrc/conv3x3.hip: direct split-fp16 MFMA conv [of relu(InstanceNorm(x))] against torch fp64; tolerance of the split
     linears scaled by sqrt(taps) (2^-22-relative products, fp32 accumulation over 9*Ci terms).  The last case is layer1 of the
