@@ -637,6 +637,25 @@ if "conv_stamps" in which:
                   "DMA + prefetch issue %.0f" % (med(s2[:, :, 12]), med(s2[:, :, 13]), med(s2[:, :, 14]), med(s2[:, :, 10] - s2[:, :, 14])))
         # (s_memtime counters of different CUs are not synchronised: only differences inside one wave are meaningful)
 
+if "in_stats" in which:
+    # the InstanceNorm statistics pass alone, on maps that fit / do not fit the 256 MB memory-side cache, repeated on ONE map (its lines
+    # can stay cached between calls) and rotating over several maps (they cannot)
+    for (bb, ch, hh, ww) in ((2, 64, 192, 624), (2, 128, 96, 312), (16, 64, 192, 624)):
+        maps = [mk("is%d_%d_%d" % (bb, ch, k), bb, ch, hh, ww) for k in range(6 if bb <= 2 else 2)]
+        mb = maps[0].numel() * 4 / 1e6
+        def t_us(fn, nrep):
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(nrep):
+                fn(i)
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / nrep
+        same = t_us(lambda i=0: K.instance_stats(maps[0]), 60)
+        rot = t_us(lambda i=0: K.instance_stats(maps[i % len(maps)]), 60)
+        print("in_stats %dx%dx%dx%d (%.0f MB): same map %.1f us (%.2f TB/s), rotating over %d maps %.1f us (%.2f TB/s)" % (
+            bb, ch, hh, ww, mb, same, mb / same, len(maps), rot, mb / rot), flush=True)
+
 if "conv_one" in which:
     # the 64 -> 64 convolution of layer 1 alone (for counter passes): --batch images of 192 x 624
     xx = mk("c1x%d" % args.batch, args.batch, 64, 192, 624)
