@@ -582,18 +582,18 @@ extern "C" int nmrf_stripe_attn_f32(const float *qkv, const float *lepe_v, const
     if (W * 2 > 65535 || H * 2 > 65535 || B > 65535) return NMRF_EINVAL;
     const float scale = 1.0f / sqrtf(32.0f);
     hipStream_t st = (hipStream_t)stream;
-    const bool both = axes == 3 && N == 4 && kv16;          // (a caller that wants the two kernels one after the other passes 1, then 2)
-    if (both) {
+    if (axes == 3 && N == 4 && kv16) {                      // (a caller that wants the two kernels one after the other passes 1, then 2)
         StripeGeom gv{H, W, N, C, H, H * N, (int64_t)W, 0, 0, 0, range_flag};
         StripeGeom gh{H, W, N, C, W, W * N, (int64_t)1, 0, 0, 0, range_flag};
         gv.gx = ((gv.Ts + SA_TILE - 1) / SA_TILE + 3) / 4; gv.gy = W * 2; gv.gz = B;
         gh.gx = ((gh.Ts + SA_TILE - 1) / SA_TILE + 3) / 4; gh.gy = H * 2; gh.gz = B;
         const int64_t tv = (int64_t)gv.gx * gv.gy * gv.gz, th = (int64_t)gh.gx * gh.gy * gh.gz;
-        if (tv + th > 0x7ffffff0) return NMRF_EINVAL;
-        const int chunk_v = (int)((tv + 7) / 8), chunk_h = (int)((th + 7) / 8);
-        hipLaunchKernelGGL((stripe_attn_both_kernel<2, true>), dim3((unsigned)(8 * (chunk_v + chunk_h))), dim3(256), 0, st, qkv, lepe_v,
-                           lepe_h, gv, gh, scale, out, chunk_h, chunk_v);
-        return nmrf_launch_status();
+        if (tv + th <= 0x7ffffff0) {                        // (larger grids: the two launches below)
+            const int chunk_v = (int)((tv + 7) / 8), chunk_h = (int)((th + 7) / 8);
+            hipLaunchKernelGGL((stripe_attn_both_kernel<2, true>), dim3((unsigned)(8 * (chunk_v + chunk_h))), dim3(256), 0, st, qkv,
+                               lepe_v, lepe_h, gv, gh, scale, out, chunk_h, chunk_v);
+            return nmrf_launch_status();
+        }
     }
     if (axes & 1) {   // vertical stripes: one per column, H*N tokens each, channel half 0
         StripeGeom g{H, W, N, C, H, H * N, (int64_t)W, 0, 0, 0, range_flag};
