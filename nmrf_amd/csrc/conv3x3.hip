@@ -103,6 +103,9 @@ __global__ __launch_bounds__(256, STRIDE == 2 ? 1 : (STRIPS == 2 && KT == 3 ? 3 
 #define C3_STAMP(k) do { if constexpr ((DBG & 64) != 0) { if (lane == 0 && t < a.stamp_tiles && blockIdx.y == 0) a.stamps[(t * 4 + wv) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
 #define C3_NOW() (((DBG & 64) != 0) ? __builtin_amdgcn_s_memtime() : 0ull)
     C3_STAMP(0);
+    if constexpr ((DBG & 64) != 0) {             // word 12 / 13: the chip-wide 100 MHz counter at entry / exit (the shader clock = the ratio)
+        if (lane == 0 && t < a.stamp_tiles && blockIdx.y == 0) a.stamps[(t * 4 + wv) * 16 + 12] = __builtin_amdgcn_s_memrealtime();
+    }
     const int b = t / a.tiles_per_image;
     const int rem = t - b * a.tiles_per_image;
     const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
@@ -403,6 +406,7 @@ __global__ __launch_bounds__(256, STRIDE == 2 ? 1 : (STRIPS == 2 && KT == 3 ? 3 
             a.stamps[(t * 4 + wv) * 16 + 9] = acc_comp;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             a.stamps[(t * 4 + wv) * 16 + 11] = __builtin_amdgcn_s_memtime();
+            a.stamps[(t * 4 + wv) * 16 + 13] = __builtin_amdgcn_s_memrealtime();
         }
     }
 }

@@ -750,7 +750,13 @@ if "conv_timeline" in which:
                 print("  XCD 0: %d CUs, blocks per CU min / median / max %d / %.1f / %d" % (len(per), cnt.min(), np.median(cnt), cnt.max()))
                 for c in list(per)[:4]:
                     print("    CU %06x: " % c + "  ".join("%d-%d" % ab for ab in sorted(per[c])))
-        print("  spans of the 8 XCDs (cycles): " + " ".join("%d" % v for v in span), flush=True)
+        mt = (st[:, 0, 11] - st[:, 0, 0]).astype(np.float64); rt = (st[:, 0, 13] - st[:, 0, 12]).astype(np.float64)
+        okk = ok & (rt > 0)
+        rate = mt[okk] / rt[okk] * 100
+        rs, re = st[okk, 0, 12], st[okk, 0, 13]
+        print("  shader clock over a block's life (s_memtime per us of s_memrealtime): median %.0f MHz (min %.0f, max %.0f); launch on the chip-wide "
+              "counter: first entry to last exit %.1f us, entries within %.1f us" % (np.median(rate), rate.min(), rate.max(),
+                                                                                   (re.max() - rs.min()) / 100.0, (rs.max() - rs.min()) / 100.0), flush=True)
 
 if "conv_timing" in which:
     import numpy as np
