@@ -15,6 +15,7 @@ template <int VGPR> __global__ void k(unsigned long long *rec, int spin_ticks) {
     else if (VGPR >= 160) asm volatile("v_mov_b32 v159, 0" ::: "v159");
     else if (VGPR >= 128) asm volatile("v_mov_b32 v127, 0" ::: "v127");
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
     if (spin_ticks < 0) lds[threadIdx.x] = 1.f;
     while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < spin_ticks) __builtin_amdgcn_s_sleep(8);
     if (threadIdx.x == 0) {
@@ -23,6 +24,7 @@ template <int VGPR> __global__ void k(unsigned long long *rec, int spin_ticks) {
         rec[blockIdx.x * 3 + 0] = t0;
         rec[blockIdx.x * 3 + 1] = __builtin_amdgcn_s_memrealtime();
         rec[blockIdx.x * 3 + 2] = ((unsigned long long)xcc << 32) | (hw & 0xff00);      // se_id | sh_id | cu_id
+        if (blockIdx.x == 0) rec[4096 * 3] = __builtin_amdgcn_s_memtime() - c0;          // shader cycles of block 0's spin
     }
 }
 template <int VGPR> void run(const char *name, int grid, int block, size_t lds, unsigned long long *rec) {
@@ -46,11 +48,13 @@ template <int VGPR> void run(const char *name, int grid, int block, size_t lds, 
         for (auto &e : kv.second) { cur += e.second; mx = std::max(mx, cur); }
         worst = std::max(worst, mx); best = std::min(best, mx);
     }
-    printf("%-44s %4d thr %6zu B LDS %3d VGPRs: API says %d / CU; observed max concurrent per CU %d (min over %zu CUs %d)\n", name, block, lds,
-           VGPR, api, worst, ev.size(), best);
+    unsigned long long cyc = 0;
+    hipMemcpy(&cyc, rec + 4096 * 3, 8, hipMemcpyDeviceToHost);
+    printf("%-44s %4d thr %6zu B LDS %3d VGPRs: API says %d / CU; observed max concurrent per CU %d (min over %zu CUs %d); shader clock while "
+           "spinning %.0f MHz\n", name, block, lds, VGPR, api, worst, ev.size(), best, (double)cyc / ((double)(h[1] - h[0]) / 100.0));
 }
 int main() {
-    unsigned long long *rec; hipMalloc(&rec, 4096 * 24);
+    unsigned long long *rec; hipMalloc(&rec, 4096 * 24 + 8);
     run<168>("conv3x3<2,3,1> shape", 2048, 256, 53824, rec);
     run<168>("same, 53760 B", 2048, 256, 53760, rec);
     run<168>("same, 53248 B (52 KB)", 2048, 256, 53248, rec);
