@@ -40,7 +40,7 @@ const char *nmrf_strerror(int code);
  * in a separate pass when range_flag != NULL; pass NULL when qkv was produced by nmrf_nmp_block16_f32, which range-checks its q_out. */
 int nmrf_range_scan_f32(const float *x, int64_t n, int *range_flag, void *stream);   /* n % 4 == 0, x 16-byte aligned */
 /* ABI version of this header; bumps on any signature change. */
-int nmrf_abi_version(void);   /* currently 20 */
+int nmrf_abi_version(void);   /* currently 21 */
 
 /* A2  group-wise correlation volume.
  * replaces build_correlation_volume + the permute of DPN.forward
@@ -170,6 +170,16 @@ int nmrf_superpixel_downsample_f32(const float *disp, const int *labels, int B, 
  * delta, score [T,64] (token-major, 64 = 8x8 sub-pixels hs-major); labels [T] -> disp_curr [B, 2H, 2W] (1/4-px units). */
 int nmrf_wta_median_f32(const float *delta, const float *score, const float *labels, int B, int H, int W, int N,
                         float *disp_curr, void *stream);
+
+/* A11 + A12 in one launch: infer_head (MLP 128-128-128-64, ReLU) and infer_score_head (Linear 128-64) on tgt [T = B*H*W*4, 128], then
+ * what nmrf_wta_median_f32 does with their rows -- which never leave the CU.  replaces NMRF.forward (nmrf/models/NMRF.py:218-232); the
+ * 0.25 factor of the score (NMRF.py:221) does not change the arg-max and is not applied.  N must be 4.
+ * stream_w: nmrf_pack_split_weight_f32 pairs (Kp = 128) of infer_head.layers[0].weight, infer_score_head.weight, layers[1].weight,
+ * layers[2].weight, in this order (96 pairs: total_stages = 12); b1 / b2 / b3: the head's biases, bs: the score head's (may be NULL);
+ * inv_scales: HOST array of 4 floats (1 / pack scale of W1, W2, W3, Ws).  Same bits as the three separate launches. */
+int nmrf_heads_wta_f32(const float *tgt, int B, int H, int W, int N, const void *stream_w, int total_stages, const float *b1,
+                       const float *b2, const float *b3, const float *bs, const float *inv_scales, const float *labels,
+                       float *disp_curr, int *range_flag, void *stream);
 
 /* A14  refinement epilogue: relu(disp_curr+delta), 4x4 pixel shuffle, x4, crop.
  * replaces NMRF.forward (nmrf/models/NMRF.py:240-251) + InputPadder.unpad (nmrf/utils/frame_utils.py:277-281).

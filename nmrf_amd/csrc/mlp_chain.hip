@@ -9,6 +9,12 @@
 //   prop_head / infer_head / refine_head   MLP(128 -> 128 -> 128 -> 1 | 64 | 16, ReLU)               DPN.py:65, NMRF.py:82, 105; NMP.py:54-66
 //   infer_score_head                 Linear(128, 64)                                                 NMRF.py:83
 //
+//   WTA (kind 4): infer_head + infer_score_head + the winner-take-all over a pixel's four labels + x2 + the 4 x 4 lower medians
+//   (NMRF.py:218-232) in ONE launch: the score layer runs on the layer-1 operand right behind layer 1, and the 16 C/D registers of
+//   (output strip s, lane half hi) of the disparity head ARE the 4 x 4 block (row half s, column half hi) of the token's 8 x 8
+//   sub-pixel cell, so a lane selects per register across its quad (the four labels of its pixel) and takes the median of its own
+//   registers -- no row of delta or score ever leaves the CU.
+//
 // replacing chains of token_linear (fp32 MFMA) / hipBLASLt / linear_smalln launches with their intermediates in HBM.  Same
 // formulation as nmp_block.hip: transposed GEMMs (weights = A operand from the shared LDS stream, activations = B operand with
 // the token on the lane), a layer's C/D registers are the next layer's B operand.  Rows leave through a wave-private LDS tile;
@@ -37,6 +43,12 @@ struct ChainArgs {
     int *range_flag;             // sticky fp16-range flag of the split operands (split_mfma.h), may be NULL
     const float *row_add;        // [T, row_add_ld] added to the stored columns (NULL: nothing) ...
     int row_add_ld, relu_out;    // ... followed by a ReLU if relu_out: labels = relu(prop_head(x) + seeds), DPN.py:131-132
+    // WTA form only:
+    const float *bs;             // bias of the score layer (64) or NULL
+    float invs;                  // 1 / scale of its packed weights
+    const float *labels;         // [T] disparity label of every token (tokens = pixels x 4 labels, pixel-major)
+    int H, W;                    // the 1/8 grid: T = B * H * W * 4
+    float *disp_curr;            // [B, 2H, 2W]
 };
 
 template <int ACT>
@@ -48,28 +60,37 @@ __device__ __forceinline__ float mc_act(float v) {
 
 // K1C: k chunks of layer 1; N1S: its output strips; L2: 128 -> 128 layer present; K3C: k chunks of layer 3 (0 = absent, 8 =
 // h2 only, 10 = h2 | 32 side columns); N3S: its output strips.
-template <int K1C, int N1S, int ACT1, bool L2, int ACT2, int K3C, int N3S>
+// value of quad lane N (lanes 4p .. 4p+3 = the four labels of one pixel) in every lane of the quad
+template <int N>
+__device__ __forceinline__ float mc_quad(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), N * 0x55, 0xf, 0xf, false));
+}
+
+template <int K1C, int N1S, int ACT1, bool L2, int ACT2, int K3C, int N3S, bool WTA = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void mlp_chain_kernel(ChainArgs a) {
     static_assert(!L2 || N1S == 4, "layer 2 consumes a 128-wide layer 1");
+    static_assert(!WTA || (K1C == 8 && L2 && K3C == 8 && N3S == 2), "WTA form: 128 -> 128 -> 128 -> 64 head beside a 128 -> 64 score layer");
     static_assert(K3C == 0 || (L2 ? true : N1S == 4), "layer 3 consumes a 128-wide activation");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, hi = lane >> 5;
     float *Ot = reinterpret_cast<float *>(smem + SS_RING_BYTES) + wv * 32 * MC_OLD;          // wave-private [32][132]
-    float *Par = reinterpret_cast<float *>(smem + SS_RING_BYTES + 4 * 32 * MC_OLD * 4);      // b1 | b2 | b3, 128 floats each
+    float *Par = reinterpret_cast<float *>(smem + SS_RING_BYTES + 4 * 32 * MC_OLD * 4);      // b1 | b2 | b3 (| bs), 128 floats each
     constexpr bool LAST_IS_L1 = !L2 && K3C == 0;                       // then b1 has n_out entries, not 32 * N1S
     for (int i = tid; i < 128; i += 256) {
         Par[i] = (a.b1 && i < (LAST_IS_L1 ? a.n_out : 32 * N1S)) ? a.b1[i] : 0.f;
         Par[128 + i] = (L2 && a.b2) ? a.b2[i] : 0.f;
         Par[256 + i] = (K3C > 0 && a.b3 && i < a.n_out) ? a.b3[i] : 0.f;
+        if constexpr (WTA) Par[384 + i] = (a.bs && i < 64) ? a.bs[i] : 0.f;
     }
     auto par4 = [&](int off) { return *reinterpret_cast<const f32x4 *>(Par + off); };
     SplitStream<MC_PF> ss;
     ss.init(a.stream, smem, a.total_stages, tid);
     float guard = 0.f;                                                 // fp16 range guard of the activation splits
 
-    constexpr int P1 = K1C * N1S, P2 = L2 ? 32 : 0, P3 = K3C * N3S;
+    constexpr int PS = WTA ? 16 : 0;                                   // the score layer's pairs, right behind layer 1's
+    constexpr int P1 = K1C * N1S + PS, P2 = L2 ? 32 : 0, P3 = K3C * N3S;
     constexpr int PAIRS = P1 + P2 + P3, PADDED = (PAIRS + 7) / 8 * 8;
     constexpr int NLAST = K3C > 0 ? N3S : (L2 ? 4 : N1S);
 
@@ -105,6 +126,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int e = 0; e < 4; ++e) h[st][4 * q + e] = mc_act<ACT1>(fmaf(acc[4 * q + e], a.inv1, b4[e]));
             }
         });
+        // ---- score layer (WTA form): the same operand, 128 -> 64 -----------------------------------------------------------------------
+        float sc[WTA ? 2 : 1][16];
+        if constexpr (WTA) {
+            ss_static_for<2>([&](auto ss_) {
+                constexpr int st = decltype(ss_)::value;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                ss_static_for<8>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    ss_pair<K1C * N1S + st * 8 + c>(ss, bh[c], bl[c], acc);
+                });
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 b4 = par4(384 + st * 32 + 8 * q + 4 * hi);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sc[st][4 * q + e] = fmaf(acc[4 * q + e], a.invs, b4[e]);
+                }
+            });
+        }
         // ---- layer 2 ---------------------------------------------------------------------------------------------------------------
         if constexpr (L2) {
 #pragma unroll
@@ -163,6 +204,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int r = 0; r < 16; ++r) dump[r] = 0.f;
             ss_static_for<PADDED - PAIRS>([&](auto pp) { ss_pair<PAIRS + decltype(pp)::value>(ss, bh[0], bl[0], dump); });
         }
+        if constexpr (WTA) {
+            // ---- winner-take-all over the pixel's four labels, x2, 4 x 4 lower medians (wta_median_kernel of token.hip, same steps) ---------
+            // register r of strip st, half hi  <->  sub-pixel (row 4 st + (r >> 2), column 4 hi + (r & 3)) of the token's 8 x 8 cell
+            const float lab = a.labels[tc];
+            float med[2];
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                float val[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float mine = fmaxf(lab + h[st][r], 0.f) * 2.0f;
+                    float best_s = mc_quad<0>(sc[st][r]), v = mc_quad<0>(mine);
+                    // torch.max returns the first maximal index; a NaN score also wins (ATen max semantics)
+                    { const float s1 = mc_quad<1>(sc[st][r]), v1 = mc_quad<1>(mine);
+                      const bool take = (s1 > best_s) || (isnan(s1) && !isnan(best_s)); best_s = take ? s1 : best_s; v = take ? v1 : v; }
+                    { const float s2 = mc_quad<2>(sc[st][r]), v2 = mc_quad<2>(mine);
+                      const bool take = (s2 > best_s) || (isnan(s2) && !isnan(best_s)); best_s = take ? s2 : best_s; v = take ? v2 : v; }
+                    { const float s3 = mc_quad<3>(sc[st][r]), v3 = mc_quad<3>(mine);
+                      const bool take = (s3 > best_s) || (isnan(s3) && !isnan(best_s)); best_s = take ? s3 : best_s; v = take ? v3 : v; }
+                    val[r] = v;
+                }
+                // lower median of 16 = element of rank 7 (0-based) under a stable order; the block's sub-pixels in row-major order
+                // are exactly r = 0 .. 15
+                float m = val[0];
+#pragma unroll
+                for (int x = 0; x < 16; ++x) {
+                    int rank = 0;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) rank += (val[c] < val[x]) || (val[c] == val[x] && c < x);
+                    if (rank == 7) m = val[x];
+                }
+                med[st] = m;
+            }
+            if ((j & 3) == 0 && tq < a.T) {
+                const int64_t pix = tq >> 2;                                   // (b * H + y) * W + x
+                const int x = (int)(pix % a.W);
+                const int64_t by = pix / a.W;                                  // b * H + y
+                float *o = a.disp_curr + (by * 2) * (int64_t)(2 * a.W) + 2 * x + hi;
+                o[0] = med[0];
+                o[2 * a.W] = med[1];
+            }
+        } else {
         // ---- rows out ------------------------------------------------------------------------------------------------------------------
 #pragma unroll
         for (int st = 0; st < NLAST; ++st)
@@ -196,18 +279,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        }
     }
     split_guard_commit(guard, a.range_flag);
 }
 
-template <int K1C, int N1S, int ACT1, bool L2, int ACT2, int K3C, int N3S>
+template <int K1C, int N1S, int ACT1, bool L2, int ACT2, int K3C, int N3S, bool WTA = false>
 static int launch_chain(const ChainArgs &a, hipStream_t st) {
     static bool attr_set_dev[NMRF_MAX_DEV] = {};
     static int n_cu_dev[NMRF_MAX_DEV] = {};
     const int dev = nmrf_cur_device();
     if (dev < 0) return NMRF_ELAUNCH;
-    const size_t lds = (size_t)SS_RING_BYTES + 4 * 32 * MC_OLD * 4 + 384 * 4;
-    auto kern = mlp_chain_kernel<K1C, N1S, ACT1, L2, ACT2, K3C, N3S>;
+    const size_t lds = (size_t)SS_RING_BYTES + 4 * 32 * MC_OLD * 4 + 512 * 4;
+    auto kern = mlp_chain_kernel<K1C, N1S, ACT1, L2, ACT2, K3C, N3S, WTA>;
     if (!attr_set_dev[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return NMRF_ELAUNCH;
@@ -218,7 +302,7 @@ static int launch_chain(const ChainArgs &a, hipStream_t st) {
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return NMRF_ELAUNCH;
         n_cu_dev[dev] = prop.multiProcessorCount;
     }
-    constexpr int PAIRS = K1C * N1S + (L2 ? 32 : 0) + K3C * N3S;
+    constexpr int PAIRS = K1C * N1S + (WTA ? 16 : 0) + (L2 ? 32 : 0) + K3C * N3S;
     if (a.total_stages != (PAIRS + 7) / 8) return NMRF_EINVAL;
     const int grid = a.n_tiles < n_cu_dev[dev] ? a.n_tiles : n_cu_dev[dev];
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
@@ -236,7 +320,8 @@ extern "C" int nmrf_mlp_chain_f32(int kind, const float *in, int in_ld, int K1, 
     if (T < 1 || ceil_div64(T, MC_TOK) > 0x7fffffff || in_ld < K1 || (in_ld & 3) || (K1 & 3) || n_out < 1 || out_ld < n_out)
         return NMRF_EINVAL;
     ChainArgs a{in, in_ld, K1, stream_w, total_stages, b1, b2, b3, extra, extra_ld, out, out_ld, n_out, out_map, T,
-                (int)ceil_div64(T, MC_TOK), inv_scales[0], inv_scales[1], inv_scales[2], range_flag, row_add, row_add_ld, relu_out};
+                (int)ceil_div64(T, MC_TOK), inv_scales[0], inv_scales[1], inv_scales[2], range_flag, row_add, row_add_ld, relu_out,
+                nullptr, 0.f, nullptr, 0, 0, nullptr};
     hipStream_t st = (hipStream_t)stream;
     switch (kind) {
         case 0:
@@ -253,6 +338,20 @@ extern "C" int nmrf_mlp_chain_f32(int kind, const float *in, int in_ld, int K1, 
             return n_out > 32 ? launch_chain<8, 2, 0, false, 0, 0, 0>(a, st) : launch_chain<8, 1, 0, false, 0, 0, 0>(a, st);
         default: return NMRF_EINVAL;
     }
+}
+
+// A11 + A12 in one launch (the WTA form above): tgt [T,128] -> disp_curr [B, 2H, 2W].  stream_w: the pairs of W1 [128,128],
+// Ws [64,128], W2 [128,128], W3 [64,128] in this order (12 stages); inv_scales: 1 / scale of W1, W2, W3, Ws.
+extern "C" int nmrf_heads_wta_f32(const float *tgt, int B, int H, int W, int N, const void *stream_w, int total_stages, const float *b1,
+                                  const float *b2, const float *b3, const float *bs, const float *inv_scales, const float *labels,
+                                  float *disp_curr, int *range_flag, void *stream) {
+    if (!tgt || !stream_w || !inv_scales || !labels || !disp_curr) return NMRF_ENULL;
+    if (B < 1 || H < 1 || W < 1 || N != 4) return NMRF_EINVAL;           // (four labels per pixel: the quad of a wave)
+    const int64_t T = (int64_t)B * H * W * N;
+    if (ceil_div64(T, MC_TOK) > 0x7fffffff) return NMRF_EINVAL;
+    ChainArgs a{tgt, 128, 128, stream_w, total_stages, b1, b2, b3, nullptr, 0, nullptr, 0, 64, nullptr, T, (int)ceil_div64(T, MC_TOK),
+                inv_scales[0], inv_scales[1], inv_scales[2], range_flag, nullptr, 0, 0, bs, inv_scales[3], labels, H, W, disp_curr};
+    return launch_chain<8, 4, 1, true, 1, 8, 2, true>(a, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------

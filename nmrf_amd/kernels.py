@@ -561,6 +561,38 @@ def mlp_chain(kind, x, k1, stream, stages, inv_scales, biases, n_out, extra=None
     return out
 
 
+def heads_wta_stream(w1, w2, w3, ws):
+    """Weight stream of heads_wta: the pairs of W1, Ws, W2, W3 (the score layer runs on layer 1's operand, right behind it).
+    -> (int32 [96, 512], 12, 1/scales of W1, W2, W3, Ws)"""
+    import ctypes
+    parts, inv = [], {}
+    for name, w in (("1", w1), ("s", ws), ("2", w2), ("3", w3)):
+        pk, inv[name] = pack_split_weight(w.contiguous(), 128)
+        parts.append(pk.view(-1, 512))
+    stream = torch.cat(parts).contiguous()
+    assert stream.shape[0] == 96
+    return stream, 12, (ctypes.c_float * 4)(inv["1"], inv["2"], inv["3"], inv["s"])
+
+
+@_on_device
+def heads_wta(tgt, stream, stages, inv_scales, biases, labels, b, h, w, n=4):
+    """nmrf_heads_wta_f32: infer_head + infer_score_head + winner-take-all + x2 + 4x4 lower medians in one launch.
+    tgt [T,128], labels [T], biases = (b1, b2, b3, bs) -> disp_curr [B, 2H, 2W]."""
+    _chk(tgt, labels, *[x for x in biases if x is not None])
+    _chk(stream, dtype=torch.int32)
+    t = tgt.shape[0]
+    assert t == b * h * w * n and tgt.shape[1] == 128 and labels.numel() == t
+    out = torch.empty(b, 2 * h, 2 * w, device=tgt.device, dtype=torch.float32)
+    _hb("heads_wta", row="A11/A12 (N3)", bound="mfma", flops=2.0 * t * (2 * 128 * 128 + 2 * 128 * 64), bytes=4.0 * t * 129 + 4.0 * out.numel(), split=True,
+        label="mlp_chain_kernel WTA form (head 128->128->128->64 + score 128->64 + winner-take-all + medians, split-fp16 MFMA)",
+        pmc=["mlp_chain_kernel<8, 4, 1, true, 1, 8, 2, true>"])
+    b1, b2, b3, bs = biases
+    _lib.check(_lib.load().nmrf_heads_wta_f32(_p(tgt), b, h, w, n, _p(stream), stages, _p(b1), _p(b2), _p(b3), _p(bs), inv_scales,
+                                              _p(labels), _p(out), _rf(tgt), _stream()), "heads_wta")
+    _he("heads_wta")
+    return out
+
+
 @_on_device
 def nmp_block(x, stream, stages, inv_scales, msg=None, bp=None, mlp=None, q=None, want_x=True, ln_out=None, ln_out_map=None,
               tokens_per_wave=16, attn_qkv=None):

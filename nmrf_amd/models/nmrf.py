@@ -243,16 +243,30 @@ class NMRF(nn.Module):
         tgt_all = self.inference(labels_curr, fmap1, fmap2, fmap1_gw, fmap2_gw, token_major=tok8)    # [1 | layers, P, N, C]
         tgt = tgt_all[-1].reshape(-1, self.inference.dim)
         b, h8, w8 = fmap1_list[0].shape[0], fmap1_list[0].shape[2], fmap1_list[0].shape[3]
-        disp_delta = self.infer_head(tgt)                                   # [T,64]
-        from .nmp import _ChainLauncher, _split
-        if _split() and self.infer_score_head.in_features == 128 and self.infer_score_head.out_features <= 64:
-            if not hasattr(self, "_score"):
-                self._score = _ChainLauncher(3, (self.infer_score_head,), (128,), self.infer_score_head.out_features)
-            score = self._score(tgt, 128)
+        from .nmp import _ChainLauncher, _FusedCache, _split
+        hl = self.infer_head.layers
+        if (stages is None and not self.training and _split() and n == 4 and len(hl) == 3
+                and all(l.in_features == 128 for l in hl) and hl[0].out_features == 128 and hl[1].out_features == 128
+                and hl[2].out_features == 64 and self.infer_score_head.in_features == 128 and self.infer_score_head.out_features == 64):
+            # disparity head + score head + winner-take-all + medians in one launch (nmrf_heads_wta_f32): their [T,64] rows stay on
+            # the CU.  (The parity chain of the tests asks for those rows through `stages` and takes the three launches below.)
+            if not hasattr(self, "_heads_wta"):
+                self._heads_wta = _FusedCache()
+            ws = (hl[0].weight, hl[1].weight, hl[2].weight, self.infer_score_head.weight)
+            bs = (hl[0].bias, hl[1].bias, hl[2].bias, self.infer_score_head.bias)
+            stream, st, inv = self._heads_wta.get(ws + tuple(x for x in bs if x is not None), lambda: K.heads_wta_stream(*ws))
+            disp_curr = K.heads_wta(tgt.contiguous(), stream, st, inv, bs, labels_curr.reshape(-1).contiguous(), b, h8, w8, n)
+            disp_delta = score = None                                       # (only the training-mode outputs and `stages` use them)
         else:
-            score = K.linear_smalln(tgt, self.infer_score_head.weight, self.infer_score_head.bias)   # [T,64]; the 0.25 factor
-        #                                                                     does not change the arg-max
-        disp_curr = K.wta_median(disp_delta, score, labels_curr.reshape(-1).contiguous(), b, h8, w8, n)
+            disp_delta = self.infer_head(tgt)                               # [T,64]
+            if _split() and self.infer_score_head.in_features == 128 and self.infer_score_head.out_features <= 64:
+                if not hasattr(self, "_score"):
+                    self._score = _ChainLauncher(3, (self.infer_score_head,), (128,), self.infer_score_head.out_features)
+                score = self._score(tgt, 128)
+            else:
+                score = K.linear_smalln(tgt, self.infer_score_head.weight, self.infer_score_head.bias)   # [T,64]; the 0.25 factor
+            #                                                                 does not change the arg-max
+            disp_curr = K.wta_median(disp_delta, score, labels_curr.reshape(-1).contiguous(), b, h8, w8, n)
         if stages is not None:
             stages.update(infer_tgt=tgt, infer_delta=disp_delta, infer_score=score, disp_curr=disp_curr)
 

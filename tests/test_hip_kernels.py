@@ -358,6 +358,41 @@ def test_warp_corr_concat(b, h, w, n):
         K().warp_corr_concat(lab_d, f1.to(DEV), f2.to(DEV), g1.to(DEV), g2.to(DEV), n, fourier=(norm, None, None))
 
 
+@pytest.mark.parametrize("b,h,w", [(1, 5, 7), (2, 6, 47), (1, 47, 156)])
+def test_heads_wta_equals_the_three_launches(b, h, w):
+    """nmrf_heads_wta_f32 (disparity head + score head + winner-take-all + medians in one launch) against mlp_chain kind 2, kind 3
+    and wta_median: the same bits, also with tied and NaN scores (weights that make whole score columns equal / NaN)."""
+    kk = K()
+    d = lambda x: x.to(DEV)
+    n = 4
+    tkn = b * h * w * n
+    tgt = rnd(tkn, 128, seed=1, scale=1.5)
+    w1, w2, w3 = rnd(128, 128, seed=2, scale=0.15), rnd(128, 128, seed=3, scale=0.15), rnd(64, 128, seed=4, scale=0.2)
+    ws = rnd(64, 128, seed=5, scale=0.2)
+    ws[5] = 0.0                                  # score column 5: the bias alone -> four-way ties, the first label must win
+    ws[9] = ws[8]                                # (two equal columns: nothing special, same winners)
+    b1, b2, b3, bs = rnd(128, seed=6), rnd(128, seed=7), rnd(64, seed=8), rnd(64, seed=9)
+    bs[17] = float("nan")                        # score column 17 is NaN everywhere: ATen's max takes the first label
+    labels = rnd(tkn, seed=10).abs() * 30
+    labels[::9] = 0.0
+    for tag, tg in (("plain", tgt), ("rows with NaN", None)):
+        if tg is None:
+            tg = tgt.clone()
+            tg[7::23, 3] = float("nan")          # whole rows of delta / score become NaN for some tokens
+        chain2 = kk.chain_stream([d(w1), d(w2), d(w3)], (128, 128, 128))
+        delta = kk.mlp_chain(2, d(tg), 128, chain2[0], chain2[1], chain2[2], [d(b1), d(b2), d(b3)], 64)
+        chain3 = kk.chain_stream([d(ws)], (128,))
+        score = kk.mlp_chain(3, d(tg), 128, chain3[0], chain3[1], chain3[2], [d(bs)], 64)
+        want = kk.wta_median(delta, score, d(labels), b, h, w, n)
+        stream, st, inv = kk.heads_wta_stream(d(w1), d(w2), d(w3), d(ws))
+        got = kk.heads_wta(d(tg), stream, st, inv, (d(b1), d(b2), d(b3), d(bs)), d(labels), b, h, w)
+        same = torch.equal(got.cpu().view(torch.int32), want.cpu().view(torch.int32))
+        assert same, f"{tag}: {int((got.cpu().view(torch.int32) != want.cpu().view(torch.int32)).sum())} of {got.numel()} values differ"
+    with pytest.raises(Exception):               # the NaN rows above were seen by the range guard of both forms: read (and clear) the flag
+        kk.check_range()
+    kk.check_range()
+
+
 def test_wta_median_and_refine_epilogue():
     b, h, w, n = 2, 5, 7, 4
     tkn = b * h * w * n

@@ -166,6 +166,23 @@ def test_full_forward_vs_oracle_mid_size():
     assert float(d.median()) < 1e-3, "model(sample) and encoder + hot_path disagree"
 
 
+def test_hot_path_with_and_without_the_fused_heads_launch():
+    """hot_path() runs the disparity head, the score head and the winner-take-all as ONE launch unless the caller asks for their rows
+    through `stages` (the parity chains of this file do): both forms must return the same bits."""
+    from nmrf_amd.utils.hashinit import synthetic_pair
+    l, r, _ = synthetic_pair(120, 264, seed=4321)
+    model = build_product(320, DEV)
+    f4, f8 = _features(model, l[None], r[None])
+    fl, fr = [f8[:1].contiguous(), f4[:1].contiguous()], [f8[1:].contiguous(), f4[1:].contiguous()]
+    with torch.no_grad():
+        fused = model.hot_path(fl, fr, (120, 264))
+        st = {}
+        plain = model.hot_path(fl, fr, (120, 264), stages=st)
+    assert "infer_delta" in st and st["infer_delta"] is not None
+    for k in ("disp", "disp_pred", "proposal"):
+        assert torch.equal(fused[k], plain[k]), k
+
+
 def test_driver_pipeline_matches_direct_calls():
     """The pipelined batched driver (N1) returns, per pair and in order, what model(sample) returns: uint8 host images through
     one captured hipGraph per shape (short final batch padded), float images, and eager launches all agree with direct calls."""
