@@ -40,7 +40,7 @@ const char *nmrf_strerror(int code);
  * in a separate pass when range_flag != NULL; pass NULL when qkv was produced by nmrf_nmp_block16_f32, which range-checks its q_out. */
 int nmrf_range_scan_f32(const float *x, int64_t n, int *range_flag, void *stream);   /* n % 4 == 0, x 16-byte aligned */
 /* ABI version of this header; bumps on any signature change. */
-int nmrf_abi_version(void);   /* currently 21 */
+int nmrf_abi_version(void);   /* currently 22 */
 
 /* A2  group-wise correlation volume.
  * replaces build_correlation_volume + the permute of DPN.forward
@@ -186,6 +186,13 @@ int nmrf_heads_wta_f32(const float *tgt, int B, int H, int W, int N, const void 
  * delta [B*H4*W4,16], disp_curr [B,H4,W4] -> disp_pred [B,4H4,4W4] (1/4-px units), disp [B,outH,outW] = 4*pred cropped. */
 int nmrf_refine_epilogue_f32(const float *delta, const float *disp_curr, int B, int H4, int W4, int outH, int outW,
                              float *disp_pred, float *disp, void *stream);
+/* The same with its head in one launch: tgt [T = B*H4*W4, 128] -> refine_head (MLP 128-128-128-16, ReLU; nmrf/models/NMRF.py:105, 238)
+ * -> the epilogue above, the head's [T,16] rows staying in registers.  stream_w / total_stages / b1..b3 / inv_scales (HOST, 3 floats):
+ * exactly those of nmrf_mlp_chain_f32 kind 2 with n_out = 16.  Same bits as the two launches. */
+int nmrf_refine_head_epilogue_f32(const float *tgt, int B, int H4, int W4, const void *stream_w, int total_stages,
+                                  const float *b1, const float *b2, const float *b3, const float *inv_scales,
+                                  const float *disp_curr, int outH, int outW, float *disp_pred, float *disp, int *range_flag,
+                                  void *stream);
 
 /* N2 (stock conv band)  InstanceNorm2d without affine, fused with what follows it:
  *   y = [relu_mid] IN(x) ; y = [relu_out] (y + residual)        residual may be NULL

@@ -49,6 +49,9 @@ struct ChainArgs {
     const float *labels;         // [T] disparity label of every token (tokens = pixels x 4 labels, pixel-major)
     int H, W;                    // the 1/8 grid: T = B * H * W * 4
     float *disp_curr;            // [B, 2H, 2W]
+    // EPI form only (labels = disp_curr [T], H / W = the 1/4 grid, disp_curr = disp_pred [B, 4H, 4W]):
+    int outH, outW;              // un-padded image size
+    float *disp;                 // [B, outH, outW]
 };
 
 template <int ACT>
@@ -66,8 +69,12 @@ __device__ __forceinline__ float mc_quad(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), N * 0x55, 0xf, 0xf, false));
 }
 
-template <int K1C, int N1S, int ACT1, bool L2, int ACT2, int K3C, int N3S, bool WTA = false>
+// EPI (refine_head): the 16 outputs of a token are the 4 x 4 patch of its 1/4-resolution pixel -- relu(disp_curr + delta), pixel
+// shuffle, x4 and crop (refine_epilogue_kernel of token.hip, NMRF.py:238-251) leave straight from the C/D registers: lane half hi
+// holds patch rows hi and 2 + hi as registers 0-3 and 4-7.
+template <int K1C, int N1S, int ACT1, bool L2, int ACT2, int K3C, int N3S, bool WTA = false, bool EPI = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void mlp_chain_kernel(ChainArgs a) {
+    static_assert(!EPI || (!WTA && K3C == 8 && N3S == 1), "EPI form: a head with one output strip");
     static_assert(!L2 || N1S == 4, "layer 2 consumes a 128-wide layer 1");
     static_assert(!WTA || (K1C == 8 && L2 && K3C == 8 && N3S == 2), "WTA form: 128 -> 128 -> 128 -> 64 head beside a 128 -> 64 score layer");
     static_assert(K3C == 0 || (L2 ? true : N1S == 4), "layer 3 consumes a 128-wide activation");
@@ -245,6 +252,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 o[0] = med[0];
                 o[2 * a.W] = med[1];
             }
+        } else if constexpr (EPI) {
+            if (tq < a.T) {
+                const float base = a.labels[tq];
+                const int xq = (int)(tq % a.W);
+                const int64_t byq = tq / a.W;                                  // b * H4 + yq
+                const int bimg = (int)(byq / a.H), yq = (int)(byq - (int64_t)bimg * a.H);
+                const int Wf = 4 * a.W;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {                         // registers 4 half .. 4 half + 3 = patch row hi + 2 half
+                    const int Y = 4 * yq + hi + 2 * half, X = 4 * xq;
+                    const f32x4 p = {fmaxf(base + h[0][4 * half], 0.f), fmaxf(base + h[0][4 * half + 1], 0.f),
+                                     fmaxf(base + h[0][4 * half + 2], 0.f), fmaxf(base + h[0][4 * half + 3], 0.f)};
+                    *reinterpret_cast<f32x4 *>(a.disp_curr + ((size_t)bimg * 4 * a.H + Y) * Wf + X) = p;
+                    if (Y < a.outH) {
+                        float *o = a.disp + ((size_t)bimg * a.outH + Y) * a.outW;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (X + c < a.outW) o[X + c] = p[c] * 4.0f;
+                    }
+                }
+            }
         } else {
         // ---- rows out ------------------------------------------------------------------------------------------------------------------
 #pragma unroll
@@ -284,14 +312,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     split_guard_commit(guard, a.range_flag);
 }
 
-template <int K1C, int N1S, int ACT1, bool L2, int ACT2, int K3C, int N3S, bool WTA = false>
+template <int K1C, int N1S, int ACT1, bool L2, int ACT2, int K3C, int N3S, bool WTA = false, bool EPI = false>
 static int launch_chain(const ChainArgs &a, hipStream_t st) {
     static bool attr_set_dev[NMRF_MAX_DEV] = {};
     static int n_cu_dev[NMRF_MAX_DEV] = {};
     const int dev = nmrf_cur_device();
     if (dev < 0) return NMRF_ELAUNCH;
     const size_t lds = (size_t)SS_RING_BYTES + 4 * 32 * MC_OLD * 4 + 512 * 4;
-    auto kern = mlp_chain_kernel<K1C, N1S, ACT1, L2, ACT2, K3C, N3S, WTA>;
+    auto kern = mlp_chain_kernel<K1C, N1S, ACT1, L2, ACT2, K3C, N3S, WTA, EPI>;
     if (!attr_set_dev[dev]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return NMRF_ELAUNCH;
@@ -321,7 +349,7 @@ extern "C" int nmrf_mlp_chain_f32(int kind, const float *in, int in_ld, int K1, 
         return NMRF_EINVAL;
     ChainArgs a{in, in_ld, K1, stream_w, total_stages, b1, b2, b3, extra, extra_ld, out, out_ld, n_out, out_map, T,
                 (int)ceil_div64(T, MC_TOK), inv_scales[0], inv_scales[1], inv_scales[2], range_flag, row_add, row_add_ld, relu_out,
-                nullptr, 0.f, nullptr, 0, 0, nullptr};
+                nullptr, 0.f, nullptr, 0, 0, nullptr, 0, 0, nullptr};
     hipStream_t st = (hipStream_t)stream;
     switch (kind) {
         case 0:
@@ -350,8 +378,25 @@ extern "C" int nmrf_heads_wta_f32(const float *tgt, int B, int H, int W, int N, 
     const int64_t T = (int64_t)B * H * W * N;
     if (ceil_div64(T, MC_TOK) > 0x7fffffff) return NMRF_EINVAL;
     ChainArgs a{tgt, 128, 128, stream_w, total_stages, b1, b2, b3, nullptr, 0, nullptr, 0, 64, nullptr, T, (int)ceil_div64(T, MC_TOK),
-                inv_scales[0], inv_scales[1], inv_scales[2], range_flag, nullptr, 0, 0, bs, inv_scales[3], labels, H, W, disp_curr};
+                inv_scales[0], inv_scales[1], inv_scales[2], range_flag, nullptr, 0, 0, bs, inv_scales[3], labels, H, W, disp_curr,
+                0, 0, nullptr};
     return launch_chain<8, 4, 1, true, 1, 8, 2, true>(a, (hipStream_t)stream);
+}
+
+// A14 with its head (the EPI form above): tgt [T = B*H4*W4, 128] -> refine_head (MLP 128-128-128-16, ReLU) -> what
+// nmrf_refine_epilogue_f32 does with its rows.  stream_w / biases / inv_scales: those of nmrf_mlp_chain_f32 kind 2 with n_out = 16.
+extern "C" int nmrf_refine_head_epilogue_f32(const float *tgt, int B, int H4, int W4, const void *stream_w, int total_stages,
+                                             const float *b1, const float *b2, const float *b3, const float *inv_scales,
+                                             const float *disp_curr, int outH, int outW, float *disp_pred, float *disp, int *range_flag,
+                                             void *stream) {
+    if (!tgt || !stream_w || !inv_scales || !disp_curr || !disp_pred || !disp) return NMRF_ENULL;
+    if (B < 1 || H4 < 1 || W4 < 1 || outH < 1 || outW < 1 || outH > 4 * H4 || outW > 4 * W4) return NMRF_EINVAL;
+    const int64_t T = (int64_t)B * H4 * W4;
+    if (ceil_div64(T, MC_TOK) > 0x7fffffff) return NMRF_EINVAL;
+    ChainArgs a{tgt, 128, 128, stream_w, total_stages, b1, b2, b3, nullptr, 0, nullptr, 0, 16, nullptr, T, (int)ceil_div64(T, MC_TOK),
+                inv_scales[0], inv_scales[1], inv_scales[2], range_flag, nullptr, 0, 0, nullptr, 0.f, disp_curr, H4, W4, disp_pred,
+                outH, outW, disp};
+    return launch_chain<8, 4, 1, true, 1, 8, 1, false, true>(a, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------

@@ -561,6 +561,28 @@ def mlp_chain(kind, x, k1, stream, stages, inv_scales, biases, n_out, extra=None
     return out
 
 
+@_on_device
+def refine_head_epilogue(tgt, stream, stages, inv_scales, biases, disp_curr, out_h, out_w):
+    """nmrf_refine_head_epilogue_f32: refine_head (chain_stream of its three layers, n_out 16) + refine_epilogue in one launch.
+    tgt [B*H4*W4, 128], disp_curr [B,H4,W4] -> (disp [B,out_h,out_w], disp_pred [B,4H4,4W4])."""
+    _chk(tgt, disp_curr, *[x for x in biases if x is not None])
+    _chk(stream, dtype=torch.int32)
+    b, h4, w4 = disp_curr.shape
+    assert tgt.shape == (b * h4 * w4, 128)
+    pred = torch.empty(b, 4 * h4, 4 * w4, device=tgt.device, dtype=torch.float32)
+    disp = torch.empty(b, out_h, out_w, device=tgt.device, dtype=torch.float32)
+    b1, b2, b3 = biases
+    _hb("refine_head_epilogue", row="A14 (N3)", bound="mfma", flops=2.0 * tgt.shape[0] * (2 * 128 * 128 + 128 * 16),
+        bytes=4.0 * tgt.shape[0] * 129 + 4.0 * (pred.numel() + disp.numel()), split=True,
+        label="mlp_chain_kernel EPI form (refine head 128->128->128->16 + pixel shuffle + crop, split-fp16 MFMA)",
+        pmc=["mlp_chain_kernel<8, 4, 1, true, 1, 8, 1, false, true>"])
+    _lib.check(_lib.load().nmrf_refine_head_epilogue_f32(_p(tgt), b, h4, w4, _p(stream), stages, _p(b1), _p(b2), _p(b3), inv_scales,
+                                                         _p(disp_curr), out_h, out_w, _p(pred), _p(disp), _rf(tgt), _stream()),
+               "refine_head_epilogue")
+    _he("refine_head_epilogue")
+    return disp, pred
+
+
 def heads_wta_stream(w1, w2, w3, ws):
     """Weight stream of heads_wta: the pairs of W1, Ws, W2, W3 (the score layer runs on layer 1's operand, right behind it).
     -> (int32 [96, 512], 12, 1/scales of W1, W2, W3, Ws)"""

@@ -393,6 +393,25 @@ def test_heads_wta_equals_the_three_launches(b, h, w):
     kk.check_range()
 
 
+@pytest.mark.parametrize("b,h4,w4,oh,ow", [(1, 6, 9, 21, 34), (2, 30, 66, 120, 264), (1, 94, 312, 375, 1242)])
+def test_refine_head_epilogue_equals_the_two_launches(b, h4, w4, oh, ow):
+    """nmrf_refine_head_epilogue_f32 (refine head + pixel shuffle + x4 + crop in one launch) against mlp_chain kind 2 (n_out 16) +
+    refine_epilogue: the same bits."""
+    kk = K()
+    d = lambda x: x.to(DEV)
+    tkn = b * h4 * w4
+    tgt = rnd(tkn, 128, seed=1, scale=1.5)
+    w1, w2, w3 = rnd(128, 128, seed=2, scale=0.15), rnd(128, 128, seed=3, scale=0.15), rnd(16, 128, seed=4, scale=0.2)
+    b1, b2, b3 = rnd(128, seed=6), rnd(128, seed=7), rnd(16, seed=8)
+    dq = rnd(b, h4, w4, seed=9).abs() * 20
+    dq[0, ::3, ::2] = 0.0
+    stream, st, inv = kk.chain_stream([d(w1), d(w2), d(w3)], (128, 128, 128))
+    delta = kk.mlp_chain(2, d(tgt), 128, stream, st, inv, [d(b1), d(b2), d(b3)], 16)
+    want_disp, want_pred = kk.refine_epilogue(delta, d(dq), oh, ow)
+    got_disp, got_pred = kk.refine_head_epilogue(d(tgt), stream, st, inv, (d(b1), d(b2), d(b3)), d(dq), oh, ow)
+    assert torch.equal(got_pred.cpu(), want_pred.cpu()) and torch.equal(got_disp.cpu(), want_disp.cpu())
+
+
 def test_wta_median_and_refine_epilogue():
     b, h, w, n = 2, 5, 7, 4
     tkn = b * h * w * n
