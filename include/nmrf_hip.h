@@ -40,7 +40,7 @@ const char *nmrf_strerror(int code);
  * in a separate pass when range_flag != NULL; pass NULL when qkv was produced by nmrf_nmp_block16_f32, which range-checks its q_out. */
 int nmrf_range_scan_f32(const float *x, int64_t n, int *range_flag, void *stream);   /* n % 4 == 0, x 16-byte aligned */
 /* ABI version of this header; bumps on any signature change. */
-int nmrf_abi_version(void);   /* currently 22 */
+int nmrf_abi_version(void);   /* currently 23 */
 
 /* A2  group-wise correlation volume.
  * replaces build_correlation_volume + the permute of DPN.forward
@@ -249,6 +249,20 @@ int nmrf_nmp_block16_f32(const float *x, const float *msg, const float *attn_qkv
                          const float *lnq_g, const float *lnq_b, float epsq, const float *extra, int extra_ld,
                          int extra_div, const float *bq, int has_mlp, int KQ, int NQ, int64_t T, const float *inv_scales,
                          float *x_out, float *q_out, float *ln_out, const int *ln_out_map, int kv16, int *range_flag, void *stream);
+
+/* N3: a full block and the self-edge block that follows it in the layer sequence, in ONE launch (the pair of launches
+ * nmrf_nmp_block16_f32(has_mlp, KQ 160, NQ 384) -> nmrf_nmp_block16_f32(attn_qkv = its q_out, KQ 160, NQ2); NMP.py:90-108, 337-364):
+ * the first block's q | k | v never leave the registers, the 4 x 4 sibling attention runs on them, then the second parameter set
+ * (bp2, lnq2_*, extra2, bq2) with the stages that follow in the same weight stream.  stream_w = the two launches' streams back to
+ * back (51 + 4 + 5 NQ2 / 128 stages); inv_scales: HOST array of 6 floats (proj, fc1, fc2, q of the first block; proj, q of the second).
+ * T a multiple of 4.  Outputs as the second launch's (x_out2, q_out2 [kv16_2], ln_out2 through ln_out2_map).  Same bits. */
+int nmrf_nmp_block16_pair_f32(const float *x, const float *msg, const void *stream_w, int total_stages, const float *bp,
+                              const float *ln2_g, const float *ln2_b, float eps2, const float *b1, const float *b2,
+                              const float *lnq_g, const float *lnq_b, float epsq, const float *extra, int extra_ld, int extra_div,
+                              const float *bq, const float *bp2, const float *lnq2_g, const float *lnq2_b, float epsq2,
+                              const float *extra2, int extra2_ld, int extra2_div, const float *bq2, int NQ2, int64_t T,
+                              const float *inv_scales, float *x_out2, float *q_out2, float *ln_out2, const int *ln_out2_map,
+                              int kv16_2, int *range_flag, void *stream);
 /* kv16 != 0 (NQ == 384, q_out = q | k | v for nmrf_stripe_attn_f32 / nmrf_window_attn_f32 called with kv16 != 0): the k and v
  * thirds of a q_out row carry the split fp16 operand pairs the attention kernels contract (csrc/split_mfma.h: hi = rn_f16(x),
  * lo = rn_f16(x - hi)) instead of the floats -- the same 4 bytes per value, split once by the producer instead of by every query

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnmrf_hip.so")      # (tools may point this at another build BEFORE the first load(): bench.py --lib)
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -25,6 +25,8 @@ PROTOTYPES = {
     "nmrf_seed_select_f32": [_P, _P, _L, _I, _I, _I, _F, _I, _F, _P, _P, _P, _P, _I, _P],
     "nmrf_fourier_embed_f32": [_P, _L, _F, _P, _I, _P, _P],
     "nmrf_mlp_chain_f32": [_I, _P, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _L, _P, _I, _I, _P, _P, _I, _I, _P, _P],
+    "nmrf_nmp_block16_pair_f32": [_P, _P, _P, _I, _P, _P, _P, _F, _P, _P, _P, _P, _F, _P, _I, _I, _P, _P, _P, _P, _F, _P, _I, _I, _P, _I, _L,
+                                  _P, _P, _P, _P, _P, _I, _P, _P],
     "nmrf_heads_wta_f32": [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "nmrf_refine_head_epilogue_f32": [_P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "nmrf_ln_concat_f32": [_P, _P, _P, _F, _P, _I, _I, _L, _I, _P, _I, _P],

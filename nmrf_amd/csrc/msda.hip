@@ -528,4 +528,4 @@ extern "C" const char *nmrf_strerror(int code) {
     }
 }
 
-extern "C" int nmrf_abi_version(void) { return 22; }
+extern "C" int nmrf_abi_version(void) { return 23; }

@@ -37,6 +37,12 @@ typedef unsigned int b16_u32x4 __attribute__((ext_vector_type(4)));
 #define B16P_BQN 1152
 #define B16P_BQ 1280
 #define B16P_FLOATS (1280 + 512)
+// FUSE: the parameters of the second block of the launch (bp | lnq gamma | lnq beta | bq) behind the first set
+#define B16P2_BP 1792
+#define B16P2_GQ 1920
+#define B16P2_BQN 2048
+#define B16P2_BQ 2176
+#define B16P2_FLOATS (2176 + 512)
 
 __host__ __device__ __forceinline__ int split_kslot16(int jj, int g) { return (jj & 3) + 16 * (jj >> 2) + 4 * g; }
 
@@ -84,12 +90,24 @@ struct NmpBlock16Args {
     int *range_flag;             // sticky fp16-range flag of the split operands (split_mfma.h), may be NULL
     int kv16;                    // q_out is q | k | v for an attention kernel (NQ == 384): write k and v as the split fp16 operand
                                  // pairs those kernels would otherwise make of them on every key tile (format: include/nmrf_hip.h)
+    // FUSE: the self-edge block that consumes this block's q | k | v (which then stay in registers) runs in the same launch:
+    const float *bp2, *lnq2_g, *lnq2_b, *extra2, *bq2;
+    int extra2_ld, extra2_div;
+    float *x_out2, *q_out2, *ln_out2;
+    const int *ln_out2_map;
+    float epsq2, inv_p2, inv_q2;
+    int NQ2, kv16_2;
 };
 
 // MLP: run fc1-GELU-fc2.  KQC: 32-deep k chunks of the q stage's operand [LNq(x2) | extra]: 0 none, 4 = LayerNorm only,
 // 5 = + 32 side columns (Fourier31 + 0), 6 = + 64 context columns.
-template <bool MLP, int KQC, int DBG = 0>          // DBG: timing experiments of the debug build (wrong results)
+// FUSE (MLP, KQC == 5, NQ == 384, four sibling labels): the launch continues with the self-edge block that follows in the layer
+// sequence (NMP.py:90-108, 337-364) -- this block's q | k | v never leave the registers, the 4 x 4 sibling attention runs on them,
+// then proj + residual -> LayerNorm | enc -> the window attention's q | k | v with the second parameter set and the stages that
+// follow in the same weight stream.  One launch, one x round trip and one [T,384] round trip less per layer.
+template <bool MLP, int KQC, int DBG = 0, bool FUSE = false>          // DBG: timing experiments of the debug build (wrong results)
 __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args a) {
+    static_assert(!FUSE || (MLP && KQC == 5), "FUSE: a full block whose q stage feeds a self-edge block");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     b16_u32x4 *ring = reinterpret_cast<b16_u32x4 *>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -139,6 +157,18 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
         for (int k = 0; k < 8; ++k)
             if (tid < ns[k]) Par[offs[k] + tid] = srcs[k] ? pv[k] : 0.f;
         for (int i = tid + B16_THR; i < ns[7]; i += B16_THR) Par[B16P_BQ + i] = a.bq ? a.bq[i] : 0.f;    // (NQ > 512: not a shipped shape)
+    }
+    if constexpr (FUSE) {
+        const float *dummy = reinterpret_cast<const float *>(a.stream);
+        const float *srcs[4] = {a.bp2, a.lnq2_g, a.lnq2_b, a.bq2};
+        const int offs[4] = {B16P2_BP, B16P2_GQ, B16P2_BQN, B16P2_BQ};
+        const int ns[4] = {128, 128, 128, a.bq2 ? a.NQ2 : 512};
+        float pv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pv[k] = (srcs[k] ? srcs[k] : dummy)[tid < ns[k] ? tid : 0];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (tid < ns[k]) Par[offs[k] + tid] = srcs[k] ? pv[k] : 0.f;
     }
     auto par4 = [&](int off) { return *reinterpret_cast<const f32x4 *>(Par + off); };
 
@@ -296,6 +326,48 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
         }
     };
 
+    // one head of the 4 x 4 sibling attention: this lane's 8 channels of q, k, v of its token -> its 8 channels of the message
+    auto sib_weights = [&](const float (&q)[8], const float (&k)[8], float (&w)[4]) {       // softmax_n(q . k_n / sqrt(32))
+        const float sc = 0.17677669529663687f;                               // 32^-0.5
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s[0] = fmaf(q[e], b16_quad<0>(k[e]), s[0]);
+            s[1] = fmaf(q[e], b16_quad<1>(k[e]), s[1]);
+            s[2] = fmaf(q[e], b16_quad<2>(k[e]), s[2]);
+            s[3] = fmaf(q[e], b16_quad<3>(k[e]), s[3]);
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            s[n] += __shfl_xor(s[n], 16);
+            s[n] += __shfl_xor(s[n], 32);
+            s[n] *= sc;
+            m = fmaxf(m, s[n]);
+        }
+        float z = 0.f;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) { s[n] = expf(s[n] - m); z += s[n]; }
+        const float rz = 1.0f / z;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) w[n] = s[n] * rz;
+    };
+    auto sib_apply = [&](const float (&w)[4], const float (&vv)[8], float (&o)[8]) {         // sum_n w_n v_n
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float acc_o = w[0] * b16_quad<0>(vv[e]);
+            acc_o = fmaf(w[1], b16_quad<1>(vv[e]), acc_o);
+            acc_o = fmaf(w[2], b16_quad<2>(vv[e]), acc_o);
+            acc_o = fmaf(w[3], b16_quad<3>(vv[e]), acc_o);
+            o[e] = acc_o;
+        }
+    };
+    auto sib_attn = [&](const float (&q)[8], const float (&k)[8], const float (&vv)[8], float (&o)[8]) {
+        float w[4];
+        sib_weights(q, k, w);
+        sib_apply(w, vv, o);
+    };
+
     // the body of one tile; PRE: its x / msg rows are the ones requested before the prologue (first tile of the block)
     auto tile_body = [&](const int tile, auto pre_c) {
         constexpr bool first = decltype(pre_c)::value;
@@ -312,6 +384,26 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
         }
         h16x8 bmh[4], bml[4];
         f32x4 acc[8];
+        // x1 += proj(message operand) + bias: four stages, strips 2k, 2k+1 = one stage
+        auto proj_stage = [&](const h16x8 (&mh)[4], const h16x8 (&ml)[4], int bp_off, float inv_p) {
+            b16_static_for<4>([&](auto kk) {
+                constexpr int k = decltype(kk)::value;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[2 * k][r] = acc[2 * k + 1][r] = 0.f;
+                stage_top();
+                b16_static_for<4>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    consume2(std::integral_constant<int, 2 * c>{}, mh[c], ml[c], acc[2 * k], acc[2 * k + 1]);
+                });
+                stage_end();
+            });
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                const f32x4 b4 = par4(bp_off + 16 * st + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x1[4 * st + e] += fmaf(acc[st][e], inv_p, b4[e]);
+            }
+        };
         // ---- stage P -----------------------------------------------------------------------------------------------------------
         bool have_msg = a.msg != nullptr;
         if constexpr (!MLP) have_msg = have_msg || a.attn_qkv != nullptr;
@@ -324,7 +416,6 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
                 // which this lane holds 8 channels (the other 24 in lanes j + 16, j + 32, j + 48).  softmax_j(q_i . k_j / sqrt(32)) v_j
                 // with the arithmetic of self_attn_kernel (token.hip); replaces that launch and the [T,128] round trip of its output.
                 const float *qp = a.attn_qkv + tc * 384;
-                const float sc = 0.17677669529663687f;                       // 32^-0.5
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float q[8], k[8], vv[8];
@@ -336,35 +427,8 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
                         k[0] = k0.x; k[1] = k0.y; k[2] = k0.z; k[3] = k0.w; k[4] = k1.x; k[5] = k1.y; k[6] = k1.z; k[7] = k1.w;
                         vv[0] = v0.x; vv[1] = v0.y; vv[2] = v0.z; vv[3] = v0.w; vv[4] = v1.x; vv[5] = v1.y; vv[6] = v1.z; vv[7] = v1.w;
                     }
-                    float s[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        s[0] = fmaf(q[e], b16_quad<0>(k[e]), s[0]);
-                        s[1] = fmaf(q[e], b16_quad<1>(k[e]), s[1]);
-                        s[2] = fmaf(q[e], b16_quad<2>(k[e]), s[2]);
-                        s[3] = fmaf(q[e], b16_quad<3>(k[e]), s[3]);
-                    }
-                    float m = -INFINITY;
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) {
-                        s[n] += __shfl_xor(s[n], 16);
-                        s[n] += __shfl_xor(s[n], 32);
-                        s[n] *= sc;
-                        m = fmaxf(m, s[n]);
-                    }
-                    float z = 0.f;
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) { s[n] = expf(s[n] - m); z += s[n]; }
-                    const float rz = 1.0f / z;
                     float o[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float acc_o = (s[0] * rz) * b16_quad<0>(vv[e]);
-                        acc_o = fmaf(s[1] * rz, b16_quad<1>(vv[e]), acc_o);
-                        acc_o = fmaf(s[2] * rz, b16_quad<2>(vv[e]), acc_o);
-                        acc_o = fmaf(s[3] * rz, b16_quad<3>(vv[e]), acc_o);
-                        o[e] = acc_o;
-                    }
+                    sib_attn(q, k, vv, o);
                     split8u_g(o, bmh[c], bml[c], guard);
                 }
             } else {
@@ -378,23 +442,7 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
                 }
             }
             B16_STAMP(2);
-            b16_static_for<4>([&](auto kk) {                                  // strips 2k, 2k+1 = one stage
-                constexpr int k = decltype(kk)::value;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[2 * k][r] = acc[2 * k + 1][r] = 0.f;
-                stage_top();
-                b16_static_for<4>([&](auto cc) {
-                    constexpr int c = decltype(cc)::value;
-                    consume2(std::integral_constant<int, 2 * c>{}, bmh[c], bml[c], acc[2 * k], acc[2 * k + 1]);
-                });
-                stage_end();
-            });
-#pragma unroll
-            for (int st = 0; st < 8; ++st) {
-                const f32x4 b4 = par4(B16P_BP + 16 * st + 4 * g);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) x1[4 * st + e] += fmaf(acc[st][e], a.inv_p, b4[e]);
-            }
+            proj_stage(bmh, bml, B16P_BP, a.inv_p);
         }
         B16_STAMP(3);
         // ---- stage M -----------------------------------------------------------------------------------------------------------
@@ -494,8 +542,10 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
                 }
             }
             B16_STAMP(7);
-            if (a.q_out) {
-                const int n_groups = a.NQ >> 7;
+            // the q stage proper: NQ / 128 groups of 128 outputs (5 stages each at KQC = 5), every group flushed as rows of q_out
+            auto emit_q = [&](const h16x8 (&bh)[KQC], const h16x8 (&bl)[KQC], int bq_off, float inv_q, int kv16, float *q_out, int NQ,
+                              bool stamps) {
+                const int n_groups = NQ >> 7;
 #pragma unroll 1
                 for (int gq = 0; gq < n_groups; ++gq) {
                     b16_static_for<4>([&](auto ss) {                          // strips 2sp, 2sp+1 of the group, chunk-interleaved
@@ -507,14 +557,14 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
                             constexpr int c = decltype(cc)::value;
                             constexpr int pg = sp * 2 * KQC + 2 * c;
                             if constexpr (pg % 8 == 0) stage_top();
-                            consume2(std::integral_constant<int, pg % 8>{}, bqh[c], bql[c], qh0, qh1);
+                            consume2(std::integral_constant<int, pg % 8>{}, bh[c], bl[c], qh0, qh1);
                             if constexpr (pg % 8 == 6) stage_end();
                         });
-                        const f32x4 ba = par4(B16P_BQ + gq * 128 + 32 * sp + 4 * g), bb = par4(B16P_BQ + gq * 128 + 32 * sp + 16 + 4 * g);
+                        const f32x4 ba = par4(bq_off + gq * 128 + 32 * sp + 4 * g), bb = par4(bq_off + gq * 128 + 32 * sp + 16 + 4 * g);
                         // kv16: the k group leaves as [hi fp16 x 32 | lo fp16 x 32] per 32-channel head, the v group as (hi, lo)
                         // half pairs in place of the floats -- the same 4 bytes per value, split ONCE here (split2u, bit for bit what
                         // the attention kernels' split8u would produce) instead of by every query tile that reads the row
-                        const int kvmode = (a.kv16 && n_groups == 3) ? gq : 0;        // 0: floats, 1: k, 2: v
+                        const int kvmode = (kv16 && n_groups == 3) ? gq : 0;          // 0: floats, 1: k, 2: v
                         auto put_strip = [&](const float (&v)[4], int col0) {
                             if (kvmode == 0) { stage_strip(v, col0); return; }
                             h16x2 h01, l01, h23, l23;
@@ -535,17 +585,109 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
                         };
                         float ov[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) ov[e] = fmaf(qh0[e], a.inv_q, ba[e]);
+                        for (int e = 0; e < 4; ++e) ov[e] = fmaf(qh0[e], inv_q, ba[e]);
                         qmax = fmaxf(fmaxf(qmax, fmaxf(fabsf(ov[0]), fabsf(ov[1]))), fmaxf(fabsf(ov[2]), fabsf(ov[3])));
                         put_strip(ov, 32 * sp);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) ov[e] = fmaf(qh1[e], a.inv_q, bb[e]);
+                        for (int e = 0; e < 4; ++e) ov[e] = fmaf(qh1[e], inv_q, bb[e]);
                         qmax = fmaxf(fmaxf(qmax, fmaxf(fabsf(ov[0]), fabsf(ov[1]))), fmaxf(fabsf(ov[2]), fabsf(ov[3])));
                         put_strip(ov, 32 * sp + 16);
                     });
-                    flush_rows(a.q_out, a.NQ, gq * 128, t0);
-                    if (gq < 3) B16_STAMP(8 + gq);
+                    flush_rows(q_out, NQ, gq * 128, t0);
+                    if (stamps && gq < 3) B16_STAMP(8 + gq);
                 }
+            };
+            if constexpr (FUSE) {
+                // ---- this block's q | k | v (three groups of 128) stay in registers: a group = [8 * head + 0..7] = the lane's 8 channels of
+                // a head.  q and k live until the softmax weights are known (16 registers), then v; x2 waits in the wave's LDS tile.
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int st = 0; st < 8; ++st) stage_strip(&x1[4 * st], 16 * st);
+                __builtin_amdgcn_sched_barrier(0);
+                auto q_group = [&](auto gg, float (&dst)[32]) {
+                    constexpr int gq = decltype(gg)::value;
+                    b16_static_for<4>([&](auto ss) {
+                        constexpr int sp = decltype(ss)::value;
+                        f32x4 qh0, qh1;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) qh0[r] = qh1[r] = 0.f;
+                        b16_static_for<KQC>([&](auto cc) {
+                            constexpr int c = decltype(cc)::value;
+                            constexpr int pg = sp * 2 * KQC + 2 * c;
+                            if constexpr (pg % 8 == 0) stage_top();
+                            consume2(std::integral_constant<int, pg % 8>{}, bqh[c], bql[c], qh0, qh1);
+                            if constexpr (pg % 8 == 6) stage_end();
+                        });
+                        const f32x4 ba = par4(B16P_BQ + gq * 128 + 32 * sp + 4 * g), bb = par4(B16P_BQ + gq * 128 + 32 * sp + 16 + 4 * g);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            dst[8 * sp + e] = fmaf(qh0[e], a.inv_q, ba[e]);
+                            dst[8 * sp + 4 + e] = fmaf(qh1[e], a.inv_q, bb[e]);
+                        }
+                    });
+                };
+                float wgt[4][4];
+                {
+                    float qv[32], kv[32];
+                    q_group(std::integral_constant<int, 0>{}, qv);
+                    q_group(std::integral_constant<int, 1>{}, kv);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float q[8], k[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { q[e] = qv[8 * c + e]; k[e] = kv[8 * c + e]; }
+                        sib_weights(q, k, wgt[c]);
+                    }
+                }
+                B16_STAMP(8);
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- the self-edge block (second parameter set, the stages that follow in the stream): sibling attention on the way in
+                h16x8 bm2h[4], bm2l[4];
+                {
+                    float vvv[32];
+                    q_group(std::integral_constant<int, 2>{}, vvv);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float vv[8], o[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) vv[e] = vvv[8 * c + e];
+                        sib_apply(wgt[c], vv, o);
+                        split8u_g(o, bm2h[c], bm2l[c], guard);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int st = 0; st < 8; ++st) unstage_strip(&x1[4 * st], 16 * st);
+                proj_stage(bm2h, bm2l, B16P2_BP, a.inv_p2);
+                __builtin_amdgcn_sched_barrier(0);
+                B16_STAMP(9);
+                if (a.x_out2) {
+#pragma unroll
+                    for (int st = 0; st < 8; ++st) stage_strip(&x1[4 * st], 16 * st);
+                    flush_rows(a.x_out2, 128, 0, t0);
+                }
+                h16x8 b2h[KQC], b2l[KQC];
+                {
+                    float ln[32];
+                    layer_norm(x1, B16P2_GQ, B16P2_BQN, a.epsq2, ln);
+                    if (a.ln_out2) {
+#pragma unroll
+                        for (int st = 0; st < 8; ++st) stage_strip(&ln[4 * st], 16 * st);
+                        flush_rows(a.ln_out2, 128, 0, t0, a.ln_out2_map);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) split8u_g(&ln[8 * c], b2h[c], b2l[c], guard);
+                }
+                {
+                    const float *e = a.extra2 + (tc / a.extra2_div) * a.extra2_ld;
+                    const float4 v0 = ldg4(e + 4 * g), v1 = ldg4(e + 16 + 4 * g);
+                    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    split8u_g(v, b2h[4], b2l[4], guard);
+                }
+                if (a.q_out2) emit_q(b2h, b2l, B16P2_BQ, a.inv_q2, a.kv16_2, a.q_out2, a.NQ2, false);
+                B16_STAMP(10);
+            } else {
+                if (a.q_out) emit_q(bqh, bql, B16P_BQ, a.inv_q, a.kv16, a.q_out, a.NQ, true);
             }
         }
         if constexpr ((DBG & 32) != 0) {
@@ -623,10 +765,10 @@ extern "C" int nmrf_debug_realtime_mark(void *dst, void *stream) {
 }
 #endif
 
-template <bool MLP, int KQC, int DBG = 0>
+template <bool MLP, int KQC, int DBG = 0, bool FUSE = false>
 static int launch_nmp_block16(const NmpBlock16Args &a, hipStream_t st) {
 #ifdef NMRF_DEBUG_PROBES
-    if constexpr (DBG == 0) {
+    if constexpr (DBG == 0 && !FUSE) {
         if (g_b16_stamps) {
             NmpBlock16Args b = a;
             b.stamps = g_b16_stamps;
@@ -650,9 +792,9 @@ static int launch_nmp_block16(const NmpBlock16Args &a, hipStream_t st) {
     static int n_cu_dev[NMRF_MAX_DEV] = {};
     const int dev = nmrf_cur_device();
     if (dev < 0) return NMRF_ELAUNCH;
-    const size_t lds = (size_t)B16_PAR_OFF + B16P_FLOATS * sizeof(float);
+    const size_t lds = (size_t)B16_PAR_OFF + (FUSE ? B16P2_FLOATS : B16P_FLOATS) * sizeof(float);
     if (!attr_set_dev[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(nmp_block16_kernel<MLP, KQC, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(nmp_block16_kernel<MLP, KQC, DBG, FUSE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024) != hipSuccess)
             return NMRF_ELAUNCH;
         attr_set_dev[dev] = true;
@@ -663,7 +805,7 @@ static int launch_nmp_block16(const NmpBlock16Args &a, hipStream_t st) {
         n_cu_dev[dev] = prop.multiProcessorCount;
     }
     const int grid = a.n_tiles < n_cu_dev[dev] ? a.n_tiles : n_cu_dev[dev];
-    hipLaunchKernelGGL((nmp_block16_kernel<MLP, KQC, DBG>), dim3(grid), dim3(B16_THR), lds, st, a);
+    hipLaunchKernelGGL((nmp_block16_kernel<MLP, KQC, DBG, FUSE>), dim3(grid), dim3(B16_THR), lds, st, a);
     return nmrf_launch_status();
 }
 
@@ -689,7 +831,8 @@ extern "C" int nmrf_nmp_block16_f32(const float *x, const float *msg, const floa
     if (total_stages != want || total_stages < 1) return NMRF_EINVAL;
     NmpBlock16Args a{x, msg, attn_qkv, reinterpret_cast<const b16_u32x4 *>(stream_w), total_stages, bp, ln2_g, ln2_b, b1, b2, lnq_g, lnq_b, extra,
                      extra_ld, extra_div, bq, x_out, q_out, ln_out, ln_out_map, T, (int)ceil_div64(T, B16_TOK), eps2, epsq, NQ,
-                     inv_scales[0], inv_scales[1], inv_scales[2], inv_scales[3], nullptr, range_flag, kv16 ? 1 : 0};
+                     inv_scales[0], inv_scales[1], inv_scales[2], inv_scales[3], nullptr, range_flag, kv16 ? 1 : 0,
+                     nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0, 0};
     hipStream_t st = (hipStream_t)stream;
     const int kqc = KQ / 32;
     if (has_mlp) {
@@ -708,6 +851,36 @@ extern "C" int nmrf_nmp_block16_f32(const float *x, const float *msg, const floa
         }
     }
     return NMRF_EINVAL;
+}
+
+// A full block and the self-edge block behind it in one launch (the FUSE form of the kernel): x, msg [T,128] (the window attention's
+// output) -> proj + residual + MLP -> LayerNorm | extra -> q | k | v of the self-edge attention (kept in registers) -> the 4 x 4 sibling
+// attention -> proj2 + residual -> LayerNorm2 | extra2 -> q_out2 [T, NQ2] (kv16_2: k | v as split fp16 pairs), x_out2 [T,128].
+// stream_w: the first block's stream (4 + 32 + 15 stages, nmrf_nmp_block16_f32 with has_mlp, KQ = 160, NQ = 384) followed by the second's
+// (4 + NQ2 / 128 * 5 stages: KQ = 160, no MLP); inv_scales: HOST array of 6 floats -- proj, fc1, fc2, q of the first block, proj, q of
+// the second.  T a multiple of 4 (four sibling labels per pixel).  Same bits as the two launches.
+extern "C" int nmrf_nmp_block16_pair_f32(const float *x, const float *msg, const void *stream_w, int total_stages, const float *bp,
+                                         const float *ln2_g, const float *ln2_b, float eps2, const float *b1, const float *b2,
+                                         const float *lnq_g, const float *lnq_b, float epsq, const float *extra, int extra_ld, int extra_div,
+                                         const float *bq, const float *bp2, const float *lnq2_g, const float *lnq2_b, float epsq2,
+                                         const float *extra2, int extra2_ld, int extra2_div, const float *bq2, int NQ2, int64_t T,
+                                         const float *inv_scales, float *x_out2, float *q_out2, float *ln_out2, const int *ln_out2_map,
+                                         int kv16_2, int *range_flag, void *stream) {
+    if (!x || !msg || !stream_w || !inv_scales || !ln2_g || !ln2_b || !b1 || !b2 || !lnq_g || !lnq_b || !lnq2_g || !lnq2_b || !extra || !extra2)
+        return NMRF_ENULL;
+    if (T < 4 || (T & 3) || ceil_div64(T, B16_TOK) > 0x7fffffff) return NMRF_EINVAL;
+    if (extra_ld < 32 || (extra_ld & 3) || extra_div < 1 || extra2_ld < 32 || (extra2_ld & 3) || extra2_div < 1) return NMRF_EINVAL;
+    if (q_out2 && (NQ2 < 128 || (NQ2 & 127) || NQ2 > 512)) return NMRF_EINVAL;
+    if (kv16_2 && (!q_out2 || NQ2 != 384)) return NMRF_EINVAL;
+    if (!q_out2 && !ln_out2 && !x_out2) return NMRF_ENULL;
+    const int want = 4 + 32 + 15 + 4 + (q_out2 ? (NQ2 / 128) * 5 : 0);
+    if (total_stages != want) return NMRF_EINVAL;
+    NmpBlock16Args a{x, msg, nullptr, reinterpret_cast<const b16_u32x4 *>(stream_w), total_stages, bp, ln2_g, ln2_b, b1, b2, lnq_g, lnq_b, extra,
+                     extra_ld, extra_div, bq, nullptr, nullptr, nullptr, nullptr, T, (int)ceil_div64(T, B16_TOK), eps2, epsq, 384,
+                     inv_scales[0], inv_scales[1], inv_scales[2], inv_scales[3], nullptr, range_flag, 0,
+                     bp2, lnq2_g, lnq2_b, extra2, bq2, extra2_ld, extra2_div, x_out2, q_out2, ln_out2, ln_out2_map, epsq2, inv_scales[4],
+                     inv_scales[5], NQ2, kv16_2 ? 1 : 0};
+    return launch_nmp_block16<true, 5, 0, true>(a, (hipStream_t)stream);
 }
 
 #ifdef NMRF_DEBUG_PROBES

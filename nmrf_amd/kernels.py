@@ -583,6 +583,36 @@ def refine_head_epilogue(tgt, stream, stages, inv_scales, biases, disp_curr, out
     return disp, pred
 
 
+@_on_device
+def nmp_block_pair(x, msg, stream, stages, inv_scales, bp, mlp, q, bp2, q2, want_x=True, ln_out=None, ln_out_map=None):
+    """nmrf_nmp_block16_pair_f32: a full block (proj + MLP -> the self-edge q | k | v) and the self-edge block behind it in one launch.
+    stream / inv_scales: the two launches' weight streams back to back, 6 floats.  mlp = (ln2_gamma, ln2_beta, eps, b1, b2);
+    q / q2 = dict(g, b, eps, extra, extra_div, bias[, nq, kv16, ln_out]) of the first / second block.  Returns what the second launch
+    would: (x_out | None, q_out | None, ln_out | None)."""
+    _chk(x, msg, bp, bp2)
+    _chk(stream, dtype=torch.int32)
+    t = x.shape[0]
+    ln2_g, ln2_b, eps2, b1, b2 = mlp
+    _chk(ln2_g, ln2_b, b1, b2, q["g"], q["b"], q["extra"], q.get("bias"), q2["g"], q2["b"], q2["extra"], q2.get("bias"))
+    nq2, want_ln = q2.get("nq", 0), q2.get("ln_out", False)
+    x_out = torch.empty_like(x) if want_x else None
+    q_out = torch.empty(t, nq2, device=x.device, dtype=torch.float32) if nq2 else None
+    if ln_out is None and want_ln:
+        ln_out = torch.empty_like(x)
+    flops = 2.0 * t * (128 * 128 + 2 * 128 * 512 + 160 * 384 + 128 * 128 + 160 * nq2)
+    _hb("nmp_block_pair", row="A10 (N3)", bound="mfma", split=True, flops=flops, bytes=4.0 * t * (2 * 128 + 32 + 128 + nq2),
+        label="nmp_block16_kernel<true,5,FUSE> (full block + the self-edge block behind it in one launch)",
+        pmc=["nmp_block16_kernel<true, 5, 0, true>"])
+    _lib.check(_lib.load().nmrf_nmp_block16_pair_f32(
+        _p(x), _p(msg), _p(stream), stages, _p(bp), _p(ln2_g), _p(ln2_b), float(eps2), _p(b1), _p(b2),
+        _p(q["g"]), _p(q["b"]), float(q["eps"]), _p(q["extra"]), q["extra"].shape[-1], q.get("extra_div", 1), _p(q.get("bias")),
+        _p(bp2), _p(q2["g"]), _p(q2["b"]), float(q2["eps"]), _p(q2["extra"]), q2["extra"].shape[-1], q2.get("extra_div", 1),
+        _p(q2.get("bias")), nq2, t, inv_scales, _p(x_out), _p(q_out), _p(ln_out), _p(ln_out_map), int(bool(q2.get("kv16", False))),
+        _rf(x), _stream()), "nmp_block_pair")
+    _he("nmp_block_pair")
+    return x_out, q_out, ln_out
+
+
 def heads_wta_stream(w1, w2, w3, ws):
     """Weight stream of heads_wta: the pairs of W1, Ws, W2, W3 (the score layer runs on layer 1's operand, right behind it).
     -> (int32 [96, 512], 12, 1/scales of W1, W2, W3, Ws)"""

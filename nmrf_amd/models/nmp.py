@@ -199,6 +199,38 @@ class _ChainLauncher:
                            row_add=row_add, relu_out=relu_out)
 
 
+class _PairLauncher:
+    """A full block's launch site and the self-edge block's behind it as ONE launch (nmrf_nmp_block16_pair_f32): the two weight
+    streams back to back, rebuilt when a parameter of either changes."""
+
+    def __init__(self, first, second):
+        self.a, self.b = first, second
+        self.cache = _FusedCache()
+
+    def _build(self):
+        import ctypes
+        sa, na, ia, bqa, nqa = self.a._build()
+        sb, nb, ib, bqb, nqb = self.b._build()
+        inv = (ctypes.c_float * 6)(ia[0], ia[1], ia[2], ia[3], ib[0], ib[3])
+        return torch.cat((sa, sb)).contiguous(), na + nb, inv, bqa, bqb, nqb
+
+    @staticmethod
+    def ok(first, second):
+        return (first.proj is not None and first.mlp is not None and first.kq == 160 and len(first.nxt_linears) == 3
+                and all(l.out_features == 128 for l in first.nxt_linears) and second.proj is not None and second.mlp is None
+                and second.kq == 160 and second.nxt_norm is not None and not second.ln_out)
+
+    def __call__(self, x, msg, extra, extra_div=1, want_x=True):
+        a, b = self.a, self.b
+        stream, stages, inv, bqa, bqb, nqb = self.cache.get(a._params() + b._params(), self._build)
+        n2, m = a.mlp
+        mlp = (n2.weight, n2.bias, n2.eps, m.fc1.bias, m.fc2.bias)
+        q = dict(g=a.nxt_norm.weight, b=a.nxt_norm.bias, eps=a.nxt_norm.eps, extra=extra, extra_div=extra_div, bias=bqa)
+        q2 = dict(g=b.nxt_norm.weight, b=b.nxt_norm.bias, eps=b.nxt_norm.eps, extra=extra, extra_div=extra_div, bias=bqb, nq=nqb,
+                  kv16=b.kv16 and nqb == 384)
+        return K.nmp_block_pair(x, msg, stream, stages, inv, a.proj.bias, mlp, q, b.proj.bias, q2, want_x=want_x)
+
+
 def _pad_maps(dims, win, device, cache):
     """int32 row maps between the dense token grid (b, h, w, n) and the grid zero-padded to a multiple of `win` (top = pad // 2,
     NMP.py:745-762): (pdims, to_padded [T], to_dense [Tp] with -1 at pad tokens), or (dims, None, None) when nothing is padded."""
@@ -639,7 +671,24 @@ class Inference(nn.Module):
                     self._launch.append(_BlockLauncher(m.proj, mlp))
         _, qkv, _ = self._launch[0](x, None, enc, 1, want_x=False)
         ln = None
+        # a window block and the self-edge block behind it run as one launch (the self-edge q | k | v stay on the CU) where the pair has
+        # the shipped shape; the training-mode intermediates need the window block's own output, so they take the two launches
+        if not hasattr(self, "_pairs"):
+            self._pairs = {}
+            for i, (kind, m) in enumerate(self._sites):
+                if (kind == "win" and i + 2 < len(self._sites) and self._sites[i + 1][0] == "self" and n == 4
+                        and self._sites[i + 1][1].num_heads == 4 and _PairLauncher.ok(self._launch[i + 1], self._launch[i + 2])):
+                    self._pairs[i] = _PairLauncher(self._launch[i + 1], self._launch[i + 2])
+        skip = False
         for i, (kind, m) in enumerate(self._sites):
+            if skip:                                     # this self-edge site ran inside the previous launch
+                skip = False
+                continue
+            if kind == "win" and collect is None and i in self._pairs and _split():
+                msg = m.attn(qkv, pdims, n > 1, checked=True, kv16=self._site_kv16[i])
+                x, qkv, ln = self._pairs[i](x, msg, enc, 1)
+                skip = True
+                continue
             attn_qkv = None
             if kind == "self" and n == 4 and m.num_heads == 4 and qkv.shape[1] == 384 and i + 1 < len(self._sites):
                 msg, attn_qkv = None, qkv               # the 4 x 4 self-edge attention is evaluated inside the block kernel

@@ -692,6 +692,39 @@ def test_nmp_block_with_self_edge_attention_on_the_way_in(t_):
     report("attn block vs two launches (q)", qo.cpu(), qo2.cpu().double(), 5e-6, 1e-6)
 
 
+@pytest.mark.parametrize("t_,kv16", [(128, True), (1000, True), (29952, True), (516, False)])
+def test_nmp_block_pair_equals_the_two_launches(t_, kv16):
+    """nmrf_nmp_block16_pair_f32 (a full block and the self-edge block behind it in one launch, the self-edge q | k | v kept in
+    registers) against the two launches it replaces: the same bits in x_out and in the window q | k | v (plain or kv16 rows)."""
+    import ctypes
+    kk = K()
+    d = lambda v: None if v is None else v.to(DEV)
+    x, msg = rnd(t_, 128, seed=1, scale=2.0), rnd(t_, 128, seed=2, scale=1.5)
+    enc = rnd(t_, 32, seed=3)
+    enc[:, 31] = 0.0
+    wp, bp = rnd(128, 128, seed=4, scale=0.1), rnd(128, seed=5, scale=0.2)
+    w1, b1 = rnd(512, 128, seed=6, scale=0.1), rnd(512, seed=7, scale=0.2)
+    w2, b2 = rnd(128, 512, seed=8, scale=0.05), rnd(128, seed=9, scale=0.2)
+    g2, be2 = 1.0 + 0.1 * rnd(128, seed=10), 0.1 * rnd(128, seed=11)
+    gq, bqn = 1.0 + 0.1 * rnd(128, seed=12), 0.1 * rnd(128, seed=13)
+    wq, bq = rnd(384, 159, seed=14, scale=0.1), rnd(384, seed=15)
+    wpb, bpb = rnd(128, 128, seed=16, scale=0.1), rnd(128, seed=17, scale=0.2)
+    gqb, bqnb = 1.0 + 0.1 * rnd(128, seed=18), 0.1 * rnd(128, seed=19)
+    wqb, bqb = rnd(384, 159, seed=20, scale=0.1), rnd(384, seed=21)
+    sa, na, ia = kk.block_stream16(d(wp), d(w1), d(w2), d(wq), 160)
+    sb, nb, ib = kk.block_stream16(d(wpb), None, None, d(wqb), 160)
+    mlp = (d(g2), d(be2), 1e-5, d(b1), d(b2))
+    qa = dict(g=d(gq), b=d(bqn), eps=1e-5, extra=d(enc), extra_div=1, bias=d(bq), kq=160, nq=384, ln_out=False)
+    qb = dict(g=d(gqb), b=d(bqnb), eps=1e-5, extra=d(enc), extra_div=1, bias=d(bqb), kq=160, nq=384, ln_out=False, kv16=kv16)
+    x1, q1, _ = kk.nmp_block(d(x), sa, na, ia, d(msg), d(bp), mlp, qa)
+    x2, q2, _ = kk.nmp_block(x1, sb, nb, ib, None, d(bpb), None, qb, want_x=True, attn_qkv=q1)
+    inv = (ctypes.c_float * 6)(ia[0], ia[1], ia[2], ia[3], ib[0], ib[3])
+    xf, qf, _ = kk.nmp_block_pair(d(x), d(msg), torch.cat((sa, sb)).contiguous(), na + nb, inv, d(bp), mlp, qa, d(bpb), qb)
+    assert torch.equal(xf.cpu(), x2.cpu()), f"x_out: max|d| = {float((xf - x2).abs().max())}"
+    same = torch.equal(qf.cpu().view(torch.int32), q2.cpu().view(torch.int32))
+    assert same, f"q_out: {int((qf.cpu().view(torch.int32) != q2.cpu().view(torch.int32)).sum())} of {qf.numel()} words differ"
+
+
 @pytest.mark.parametrize("kind,t_,n_out", [(0, 300, 128), (0, 29328, 128), (1, 1000, 128), (2, 517, 64), (2, 300, 16), (2, 4097, 1),
                                            (3, 777, 64), (3, 40001, 64)])
 def test_mlp_chain_fused(kind, t_, n_out):

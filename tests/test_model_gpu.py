@@ -183,6 +183,26 @@ def test_hot_path_with_and_without_the_fused_heads_launch():
         assert torch.equal(fused[k], plain[k]), k
 
 
+def test_hot_path_with_and_without_the_block_pair_launches():
+    """The inference stage runs every window block and the self-edge block behind it as one launch (nmrf_nmp_block16_pair_f32); with
+    the pairs switched off (two launches per pair, the training-mode form) the hot path must return the same bits."""
+    from nmrf_amd.utils.hashinit import synthetic_pair
+    l, r, _ = synthetic_pair(120, 264, seed=777)
+    model = build_product(320, DEV)
+    f4, f8 = _features(model, l[None], r[None])
+    fl, fr = [f8[:1].contiguous(), f4[:1].contiguous()], [f8[1:].contiguous(), f4[1:].contiguous()]
+    with torch.no_grad():
+        fused = model.hot_path(fl, fr, (120, 264))
+        assert len(model.inference._pairs) == 4, "the shipped inference stage has four (window block, self-edge block) pairs"
+        saved, model.inference._pairs = model.inference._pairs, {}
+        try:
+            plain = model.hot_path(fl, fr, (120, 264))
+        finally:
+            model.inference._pairs = saved
+    for k in ("disp", "disp_pred", "proposal"):
+        assert torch.equal(fused[k], plain[k]), k
+
+
 def test_driver_pipeline_matches_direct_calls():
     """The pipelined batched driver (N1) returns, per pair and in order, what model(sample) returns: uint8 host images through
     one captured hipGraph per shape (short final batch padded), float images, and eager launches all agree with direct calls."""
