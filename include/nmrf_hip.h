@@ -255,7 +255,9 @@ int nmrf_nmp_block16_f32(const float *x, const float *msg, const float *attn_qkv
  * the first block's q | k | v never leave the registers, the 4 x 4 sibling attention runs on them, then the second parameter set
  * (bp2, lnq2_*, extra2, bq2) with the stages that follow in the same weight stream.  stream_w = the two launches' streams back to
  * back (51 + 4 + 5 NQ2 / 128 stages); inv_scales: HOST array of 6 floats (proj, fc1, fc2, q of the first block; proj, q of the second).
- * T a multiple of 4.  Outputs as the second launch's (x_out2, q_out2 [kv16_2], ln_out2 through ln_out2_map).  Same bits. */
+ * T a multiple of 4.  Outputs as the second launch's (x_out2, q_out2 [kv16_2], ln_out2 through ln_out2_map).  Same bits.
+ * msg == NULL (with bp, ln2_*, b1, b2 NULL): the first block is a q stage alone -- the launch that opens the inference stage -- and
+ * stream_w holds its 15 stages in front of the second block's. */
 int nmrf_nmp_block16_pair_f32(const float *x, const float *msg, const void *stream_w, int total_stages, const float *bp,
                               const float *ln2_g, const float *ln2_b, float eps2, const float *b1, const float *b2,
                               const float *lnq_g, const float *lnq_b, float epsq, const float *extra, int extra_ld, int extra_div,

@@ -101,13 +101,13 @@ struct NmpBlock16Args {
 
 // MLP: run fc1-GELU-fc2.  KQC: 32-deep k chunks of the q stage's operand [LNq(x2) | extra]: 0 none, 4 = LayerNorm only,
 // 5 = + 32 side columns (Fourier31 + 0), 6 = + 64 context columns.
-// FUSE (MLP, KQC == 5, NQ == 384, four sibling labels): the launch continues with the self-edge block that follows in the layer
+// FUSE (KQC == 5, NQ == 384, four sibling labels; with or without proj / MLP in front): the launch continues with the self-edge block that follows in the layer
 // sequence (NMP.py:90-108, 337-364) -- this block's q | k | v never leave the registers, the 4 x 4 sibling attention runs on them,
 // then proj + residual -> LayerNorm | enc -> the window attention's q | k | v with the second parameter set and the stages that
 // follow in the same weight stream.  One launch, one x round trip and one [T,384] round trip less per layer.
 template <bool MLP, int KQC, int DBG = 0, bool FUSE = false>          // DBG: timing experiments of the debug build (wrong results)
 __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args a) {
-    static_assert(!FUSE || (MLP && KQC == 5), "FUSE: a full block whose q stage feeds a self-edge block");
+    static_assert(!FUSE || KQC == 5, "FUSE: a block whose q stage (LayerNorm | 32 side columns) feeds a self-edge block");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     b16_u32x4 *ring = reinterpret_cast<b16_u32x4 *>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -856,6 +856,7 @@ extern "C" int nmrf_nmp_block16_f32(const float *x, const float *msg, const floa
 // A full block and the self-edge block behind it in one launch (the FUSE form of the kernel): x, msg [T,128] (the window attention's
 // output) -> proj + residual + MLP -> LayerNorm | extra -> q | k | v of the self-edge attention (kept in registers) -> the 4 x 4 sibling
 // attention -> proj2 + residual -> LayerNorm2 | extra2 -> q_out2 [T, NQ2] (kv16_2: k | v as split fp16 pairs), x_out2 [T,128].
+// (msg == NULL, no bp / ln2 / b1 / b2: the first block is its q stage alone -- the entry of the inference stage -- 15 stages.)
 // stream_w: the first block's stream (4 + 32 + 15 stages, nmrf_nmp_block16_f32 with has_mlp, KQ = 160, NQ = 384) followed by the second's
 // (4 + NQ2 / 128 * 5 stages: KQ = 160, no MLP); inv_scales: HOST array of 6 floats -- proj, fc1, fc2, q of the first block, proj, q of
 // the second.  T a multiple of 4 (four sibling labels per pixel).  Same bits as the two launches.
@@ -866,21 +867,23 @@ extern "C" int nmrf_nmp_block16_pair_f32(const float *x, const float *msg, const
                                          const float *extra2, int extra2_ld, int extra2_div, const float *bq2, int NQ2, int64_t T,
                                          const float *inv_scales, float *x_out2, float *q_out2, float *ln_out2, const int *ln_out2_map,
                                          int kv16_2, int *range_flag, void *stream) {
-    if (!x || !msg || !stream_w || !inv_scales || !ln2_g || !ln2_b || !b1 || !b2 || !lnq_g || !lnq_b || !lnq2_g || !lnq2_b || !extra || !extra2)
-        return NMRF_ENULL;
+    if (!x || !stream_w || !inv_scales || !lnq_g || !lnq_b || !lnq2_g || !lnq2_b || !extra || !extra2) return NMRF_ENULL;
+    const bool full = msg != nullptr;                 // msg == NULL: the first block is a q stage alone (no proj, no MLP: the stage's entry)
+    if (full && (!ln2_g || !ln2_b || !b1 || !b2)) return NMRF_ENULL;
+    if (!full && (ln2_g || ln2_b || b1 || b2 || bp)) return NMRF_EINVAL;
     if (T < 4 || (T & 3) || ceil_div64(T, B16_TOK) > 0x7fffffff) return NMRF_EINVAL;
     if (extra_ld < 32 || (extra_ld & 3) || extra_div < 1 || extra2_ld < 32 || (extra2_ld & 3) || extra2_div < 1) return NMRF_EINVAL;
     if (q_out2 && (NQ2 < 128 || (NQ2 & 127) || NQ2 > 512)) return NMRF_EINVAL;
     if (kv16_2 && (!q_out2 || NQ2 != 384)) return NMRF_EINVAL;
     if (!q_out2 && !ln_out2 && !x_out2) return NMRF_ENULL;
-    const int want = 4 + 32 + 15 + 4 + (q_out2 ? (NQ2 / 128) * 5 : 0);
+    const int want = (full ? 4 + 32 : 0) + 15 + 4 + (q_out2 ? (NQ2 / 128) * 5 : 0);
     if (total_stages != want) return NMRF_EINVAL;
     NmpBlock16Args a{x, msg, nullptr, reinterpret_cast<const b16_u32x4 *>(stream_w), total_stages, bp, ln2_g, ln2_b, b1, b2, lnq_g, lnq_b, extra,
                      extra_ld, extra_div, bq, nullptr, nullptr, nullptr, nullptr, T, (int)ceil_div64(T, B16_TOK), eps2, epsq, 384,
                      inv_scales[0], inv_scales[1], inv_scales[2], inv_scales[3], nullptr, range_flag, 0,
                      bp2, lnq2_g, lnq2_b, extra2, bq2, extra2_ld, extra2_div, x_out2, q_out2, ln_out2, ln_out2_map, epsq2, inv_scales[4],
                      inv_scales[5], NQ2, kv16_2 ? 1 : 0};
-    return launch_nmp_block16<true, 5, 0, true>(a, (hipStream_t)stream);
+    return full ? launch_nmp_block16<true, 5, 0, true>(a, (hipStream_t)stream) : launch_nmp_block16<false, 5, 0, true>(a, (hipStream_t)stream);
 }
 
 #ifdef NMRF_DEBUG_PROBES

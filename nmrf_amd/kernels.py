@@ -592,24 +592,24 @@ def nmp_block_pair(x, msg, stream, stages, inv_scales, bp, mlp, q, bp2, q2, want
     _chk(x, msg, bp, bp2)
     _chk(stream, dtype=torch.int32)
     t = x.shape[0]
-    ln2_g, ln2_b, eps2, b1, b2 = mlp
+    ln2_g, ln2_b, eps2, b1, b2 = mlp if mlp is not None else (None, None, 0.0, None, None)     # (msg is None: a q stage alone in front)
     _chk(ln2_g, ln2_b, b1, b2, q["g"], q["b"], q["extra"], q.get("bias"), q2["g"], q2["b"], q2["extra"], q2.get("bias"))
     nq2, want_ln = q2.get("nq", 0), q2.get("ln_out", False)
     x_out = torch.empty_like(x) if want_x else None
     q_out = torch.empty(t, nq2, device=x.device, dtype=torch.float32) if nq2 else None
     if ln_out is None and want_ln:
         ln_out = torch.empty_like(x)
-    flops = 2.0 * t * (128 * 128 + 2 * 128 * 512 + 160 * 384 + 128 * 128 + 160 * nq2)
-    _hb("nmp_block_pair", row="A10 (N3)", bound="mfma", split=True, flops=flops, bytes=4.0 * t * (2 * 128 + 32 + 128 + nq2),
+    flops = 2.0 * t * ((128 * 128 + 2 * 128 * 512 if msg is not None else 0) + 160 * 384 + 128 * 128 + 160 * nq2)
+    _hb("nmp_block_pair" if msg is not None else "nmp_block_pair_entry", row="A10 (N3)", bound="mfma", split=True, flops=flops, bytes=4.0 * t * (2 * 128 + 32 + 128 + nq2),
         label="nmp_block16_kernel<true,5,FUSE> (full block + the self-edge block behind it in one launch)",
-        pmc=["nmp_block16_kernel<true, 5, 0, true>"])
+        pmc=["nmp_block16_kernel<true, 5, 0, true>" if msg is not None else "nmp_block16_kernel<false, 5, 0, true>"])
     _lib.check(_lib.load().nmrf_nmp_block16_pair_f32(
         _p(x), _p(msg), _p(stream), stages, _p(bp), _p(ln2_g), _p(ln2_b), float(eps2), _p(b1), _p(b2),
         _p(q["g"]), _p(q["b"]), float(q["eps"]), _p(q["extra"]), q["extra"].shape[-1], q.get("extra_div", 1), _p(q.get("bias")),
         _p(bp2), _p(q2["g"]), _p(q2["b"]), float(q2["eps"]), _p(q2["extra"]), q2["extra"].shape[-1], q2.get("extra_div", 1),
         _p(q2.get("bias")), nq2, t, inv_scales, _p(x_out), _p(q_out), _p(ln_out), _p(ln_out_map), int(bool(q2.get("kv16", False))),
         _rf(x), _stream()), "nmp_block_pair")
-    _he("nmp_block_pair")
+    _he("nmp_block_pair" if msg is not None else "nmp_block_pair_entry")
     return x_out, q_out, ln_out
 
 

@@ -216,19 +216,23 @@ class _PairLauncher:
 
     @staticmethod
     def ok(first, second):
-        return (first.proj is not None and first.mlp is not None and first.kq == 160 and len(first.nxt_linears) == 3
+        # (first.proj is None and first.mlp is None: the launch that opens the stage -- a q stage alone)
+        return ((first.proj is None) == (first.mlp is None) and first.kq == 160 and len(first.nxt_linears) == 3
                 and all(l.out_features == 128 for l in first.nxt_linears) and second.proj is not None and second.mlp is None
                 and second.kq == 160 and second.nxt_norm is not None and not second.ln_out)
 
     def __call__(self, x, msg, extra, extra_div=1, want_x=True):
         a, b = self.a, self.b
         stream, stages, inv, bqa, bqb, nqb = self.cache.get(a._params() + b._params(), self._build)
-        n2, m = a.mlp
-        mlp = (n2.weight, n2.bias, n2.eps, m.fc1.bias, m.fc2.bias)
+        mlp = None
+        if a.mlp is not None:
+            n2, m = a.mlp
+            mlp = (n2.weight, n2.bias, n2.eps, m.fc1.bias, m.fc2.bias)
         q = dict(g=a.nxt_norm.weight, b=a.nxt_norm.bias, eps=a.nxt_norm.eps, extra=extra, extra_div=extra_div, bias=bqa)
         q2 = dict(g=b.nxt_norm.weight, b=b.nxt_norm.bias, eps=b.nxt_norm.eps, extra=extra, extra_div=extra_div, bias=bqb, nq=nqb,
                   kv16=b.kv16 and nqb == 384)
-        return K.nmp_block_pair(x, msg, stream, stages, inv, a.proj.bias, mlp, q, b.proj.bias, q2, want_x=want_x)
+        return K.nmp_block_pair(x, msg, stream, stages, inv, None if a.proj is None else a.proj.bias, mlp, q, b.proj.bias, q2,
+                                want_x=want_x)
 
 
 def _pad_maps(dims, win, device, cache):
@@ -669,7 +673,6 @@ class Inference(nn.Module):
                     self._launch.append(_BlockLauncher(m.proj, mlp, self.norm, (), 128, ln_out=True))
                 else:
                     self._launch.append(_BlockLauncher(m.proj, mlp))
-        _, qkv, _ = self._launch[0](x, None, enc, 1, want_x=False)
         ln = None
         # a window block and the self-edge block behind it run as one launch (the self-edge q | k | v stay on the CU) where the pair has
         # the shipped shape; the training-mode intermediates need the window block's own output, so they take the two launches
@@ -679,7 +682,16 @@ class Inference(nn.Module):
                 if (kind == "win" and i + 2 < len(self._sites) and self._sites[i + 1][0] == "self" and n == 4
                         and self._sites[i + 1][1].num_heads == 4 and _PairLauncher.ok(self._launch[i + 1], self._launch[i + 2])):
                     self._pairs[i] = _PairLauncher(self._launch[i + 1], self._launch[i + 2])
+            # ... and the stage's opening launch (a q stage alone) with the first self-edge block
+            if (len(self._sites) > 1 and self._sites[0][0] == "self" and n == 4 and self._sites[0][1].num_heads == 4
+                    and _PairLauncher.ok(self._launch[0], self._launch[1])):
+                self._pairs[-1] = _PairLauncher(self._launch[0], self._launch[1])
         skip = False
+        if collect is None and -1 in self._pairs and _split():
+            x, qkv, ln = self._pairs[-1](x, None, enc, 1)
+            skip = True
+        else:
+            _, qkv, _ = self._launch[0](x, None, enc, 1, want_x=False)
         for i, (kind, m) in enumerate(self._sites):
             if skip:                                     # this self-edge site ran inside the previous launch
                 skip = False

@@ -723,6 +723,13 @@ def test_nmp_block_pair_equals_the_two_launches(t_, kv16):
     assert torch.equal(xf.cpu(), x2.cpu()), f"x_out: max|d| = {float((xf - x2).abs().max())}"
     same = torch.equal(qf.cpu().view(torch.int32), q2.cpu().view(torch.int32))
     assert same, f"q_out: {int((qf.cpu().view(torch.int32) != q2.cpu().view(torch.int32)).sum())} of {qf.numel()} words differ"
+    # the stage's opening pair: the first block is its q stage alone (no message, no MLP)
+    so, no, io = kk.block_stream16(None, None, None, d(wq), 160)
+    _, q1o, _ = kk.nmp_block(d(x), so, no, io, None, None, None, qa, want_x=False)
+    x2o, q2o, _ = kk.nmp_block(d(x), sb, nb, ib, None, d(bpb), None, qb, want_x=True, attn_qkv=q1o)
+    invo = (ctypes.c_float * 6)(io[0], io[1], io[2], io[3], ib[0], ib[3])
+    xfo, qfo, _ = kk.nmp_block_pair(d(x), None, torch.cat((so, sb)).contiguous(), no + nb, invo, None, None, qa, d(bpb), qb)
+    assert torch.equal(xfo.cpu(), x2o.cpu()) and torch.equal(qfo.cpu().view(torch.int32), q2o.cpu().view(torch.int32))
 
 
 @pytest.mark.parametrize("kind,t_,n_out", [(0, 300, 128), (0, 29328, 128), (1, 1000, 128), (2, 517, 64), (2, 300, 16), (2, 4097, 1),

@@ -193,7 +193,7 @@ def test_hot_path_with_and_without_the_block_pair_launches():
     fl, fr = [f8[:1].contiguous(), f4[:1].contiguous()], [f8[1:].contiguous(), f4[1:].contiguous()]
     with torch.no_grad():
         fused = model.hot_path(fl, fr, (120, 264))
-        assert len(model.inference._pairs) == 4, "the shipped inference stage has four (window block, self-edge block) pairs"
+        assert len(model.inference._pairs) == 5, "four (window block, self-edge block) pairs and the stage's opening pair"
         saved, model.inference._pairs = model.inference._pairs, {}
         try:
             plain = model.hot_path(fl, fr, (120, 264))
