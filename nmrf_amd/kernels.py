@@ -551,7 +551,8 @@ def mlp_chain(kind, x, k1, stream, stages, inv_scales, biases, n_out, extra=None
         _hb(name + "_n%d" % n_out, row="A6/A9/A11/A13/A14 (N3)", bound="mfma", flops=2.0 * t * widths, bytes=4.0 * t * (k1 + n_out), split=True,
             label="mlp_chain_kernel kind %d (%s, split-fp16 MFMA)" % (kind, ("ffn 160->128->128", "seed embed 36->128->128|32->128",
                                                                             "head 128->128->128->%d" % n_out, "Linear 128->%d" % n_out)[kind]),
-            pmc=["mlp_chain_kernel"])
+            pmc=["mlp_chain_kernel<%s" % {0: "10, 4, 2, true, 0, 0, 0,", 1: "3, 4, 2, true, 0, 10, 4,", 2: "8, 4, 1, true, 1, 8, %d," % (2 if n_out > 32 else 1),
+                                          3: "8, %d, 0, false, 0, 0, 0," % (2 if n_out > 32 else 1)}[kind]])
     _lib.check(_lib.load().nmrf_mlp_chain_f32(kind, _p(x), ld, k1, _p(stream), stages, _p(b[0]), _p(b[1]), _p(b[2]), _p(extra),
                                               0 if extra is None else extra.shape[-1], inv_scales, t, _p(out), out.shape[-1], n_out,
                                               _p(out_map), _p(row_add), 0 if row_add is None else row_add.shape[-1], int(bool(relu_out)),
@@ -637,7 +638,7 @@ def heads_wta(tgt, stream, stages, inv_scales, biases, labels, b, h, w, n=4):
     out = torch.empty(b, 2 * h, 2 * w, device=tgt.device, dtype=torch.float32)
     _hb("heads_wta", row="A11/A12 (N3)", bound="mfma", flops=2.0 * t * (2 * 128 * 128 + 2 * 128 * 64), bytes=4.0 * t * 129 + 4.0 * out.numel(), split=True,
         label="mlp_chain_kernel WTA form (head 128->128->128->64 + score 128->64 + winner-take-all + medians, split-fp16 MFMA)",
-        pmc=["mlp_chain_kernel<8, 4, 1, true, 1, 8, 2, true>"])
+        pmc=["mlp_chain_kernel<8, 4, 1, true, 1, 8, 2, true, false>"])
     b1, b2, b3, bs = biases
     _lib.check(_lib.load().nmrf_heads_wta_f32(_p(tgt), b, h, w, n, _p(stream), stages, _p(b1), _p(b2), _p(b3), _p(bs), inv_scales,
                                               _p(labels), _p(out), _rf(tgt), _stream()), "heads_wta")
@@ -689,7 +690,7 @@ def nmp_block(x, stream, stages, inv_scales, msg=None, bp=None, mlp=None, q=None
                 "LN+fc1+GELU+fc2 " if mlp is not None else "", ("LN+%d->%d" % (kq, nq)) if nq else ("final LN" if want_ln else ""),
                 tokens_per_wave),
             pmc=["nmp_block_kernel<%s, %d, 1, 4, false, 0>" % ("true" if mlp is not None else "false", kq // 16) if tokens_per_wave == 32
-                 else "nmp_block16_kernel<%s, %d, 0>" % ("true" if mlp is not None else "false", (kq + 31) // 32)])
+                 else "nmp_block16_kernel<%s, %d, 0, false>" % ("true" if mlp is not None else "false", (kq + 31) // 32)])
     head = (_p(stream), stages, _p(bp), _p(ln2_g), _p(ln2_b), float(eps2), _p(b1), _p(b2), _p(lq_g), _p(lq_b), float(epsq), _p(extra), ld,
             div, _p(bq), int(mlp is not None), kq, nq, t, inv_scales, _p(x_out), _p(q_out), _p(ln_out), _p(ln_out_map))
     kv16 = int(bool(q is not None and q.get("kv16", False)))
