@@ -52,6 +52,7 @@ def parse(argv=None):
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL result gather at N>1")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find mode)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the result gather even at N=1 (smoke)")
+    ap.add_argument("--config4", action="store_true", help="also measure BASELINE config 4's per-GPU shard (batch 8) at N=1 (always on at N>1)")
     ap.add_argument("--sync-gather", action="store_true", help="gather on the compute stream inside every step (round-2 behaviour)")
     ap.add_argument("--lib", default=None, help="same-box A/B runs (tools/gpu_ab.sh): another build of libnmrf_hip.so (same ABI, checked at load)")
     args = ap.parse_args(argv)
@@ -247,6 +248,13 @@ def run_plumbing(args, rank, world):
         elapsed = float(tt.item())
     want = torch.stack([(lambda p: (p[0].mean(0) - p[1].mean(0)).abs())(synthetic_pair(h, w, seed=1000 + i)[:2]) for i in range(world * b)])
     ok = bool(torch.equal(out, want))                       # every rank holds all disparities, in rank order
+    # the config-4 leg of the GPU path (8 pairs per rank, contiguous split of the 8 * world job, same gather): plumbing only
+    lo4, hi4 = shard_range(8 * world, rank, world)
+    p4 = [synthetic_pair(h, w, seed=1000 + i)[:2] for i in range(lo4, hi4)]
+    a4, b4 = torch.stack([p[0] for p in p4]), torch.stack([p[1] for p in p4])
+    out4 = gath.submit((a4.mean(1) - b4.mean(1)).abs())
+    want4 = torch.stack([(lambda p: (p[0].mean(0) - p[1].mean(0)).abs())(synthetic_pair(h, w, seed=1000 + i)[:2]) for i in range(8 * world)])
+    ok4 = bool(torch.equal(out4, want4))
     if rank == 0:
         print(json.dumps({"metric": "stereo pairs/sec at %dx%d" % (args.width, args.height), "value": None,
                           "unit": "stereo pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -255,10 +263,12 @@ def run_plumbing(args, rank, world):
                           "config": {"workload": "PLUMBING ONLY: no GPU on this host, stand-in forward on %d gloo ranks (launcher, batch "
                                                  "split, result gather); not a measurement" % world,
                                      "global_batch": world * b, "parallelism": "batch-shard x%d" % world, "launch": "cpu stand-in",
-                                     "result_gather": world > 1, "gather_correct": ok}}), flush=True)
+                                     "result_gather": world > 1, "gather_correct": ok},
+                          "config4": {"workload": "PLUMBING ONLY: 8 pairs per rank x %d" % world, "value": None, "global_batch": 8 * world,
+                                      "gather_correct": ok4}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
-    if not ok:
+    if not (ok and ok4):
         raise SystemExit("gathered result differs from the single-process result")
 
 
@@ -279,6 +289,10 @@ def run(args):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
+    numa = None
+    if world > 1:                                            # one process per GPU: host threads + pinned rings on the GPU's NUMA node
+        from nmrf_amd.parallel import pin_to_gpu_numa       # (N = 1 keeps every core: the cpu_baseline leg wants them)
+        numa = pin_to_gpu_numa(local_rank)
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -306,9 +320,6 @@ def run(args):
     timer = KernelTimer()
     K.kernel_hook = timer
 
-    def forward():
-        return model(sample)["disp"]
-
     overlapped = OverlappedGather(single_rank_too=args.force_dist)      # the gather rides a side stream behind the next step's compute
 
     def gather(disp):
@@ -320,12 +331,17 @@ def run(args):
             return gather_disparity(disp) if args.sync_gather else overlapped.submit(disp)
         return disp
 
-    def step():
-        return gather(forward())
+    def timed_region(smp, steps, warmup):
+        """`warmup` untimed steps (+ the hipGraph capture), then EXACTLY `steps` steps between barrier + synchronize on both sides;
+        the MAX over ranks.  Returns (elapsed s, graph or None, the graph's static output, forward, step)."""
+        def forward():
+            return model(smp)["disp"]
 
-    graph = None
-    with torch.no_grad():
-        for _ in range(max(args.warmup, 1)):
+        def step():
+            return gather(forward())
+
+        graph, static_out = None, None
+        for _ in range(max(warmup, 1)):
             step()
         torch.cuda.synchronize()
         if not args.no_graph:
@@ -343,41 +359,71 @@ def run(args):
             K.kernel_hook = timer
 
         if graph is not None:
-            def run():
+            def run_step():
                 graph.replay()
                 return gather(static_out)
         else:
-            run = step
+            run_step = step
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            run()
+        for _ in range(steps):
+            run_step()
         overlapped.finish()                                   # every gather of the timed steps has landed inside the timed region
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
-        elapsed = time.perf_counter() - t0
+        dt = time.perf_counter() - t0
         if use_dist:
-            tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            elapsed = float(tt.item())
-        # the collective alone ("report the gather time separately"): 10 back-to-back all-gathers of one step's output
+            dt = float(tt.item())
+        return dt, graph, static_out, forward, step
+
+    def gather_alone_ms(d0):
+        """the collective alone ("report the gather time separately"): 10 back-to-back all-gathers of one step's output"""
+        alone = (lambda t: overlapped.submit(t)) if world == 1 else gather_disparity      # (1-rank group: same RCCL call)
+        alone(d0)
+        torch.cuda.synchronize()
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        g0.record()
+        for _ in range(10):
+            alone(d0)
+        overlapped.finish()
+        g1.record()
+        torch.cuda.synchronize()
+        return g0.elapsed_time(g1) / 10
+
+    with torch.no_grad():
+        elapsed, graph, static_out, forward, step = timed_region(sample, args.steps, args.warmup)
         gather_ms = None
         if use_dist and not args.no_gather:
-            d0 = static_out if graph is not None else forward()
-            alone = (lambda t: overlapped.submit(t)) if world == 1 else gather_disparity      # (1-rank group: same RCCL call)
-            alone(d0)
-            torch.cuda.synchronize()
-            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            g0.record()
-            for _ in range(10):
-                alone(d0)
-            overlapped.finish()
-            g1.record()
-            torch.cuda.synchronize()
-            gather_ms = g0.elapsed_time(g1) / 10
+            gather_ms = gather_alone_ms(static_out if graph is not None else forward())
+
+        # BASELINE config 4 (KITTI 1242x375, batch 64 over 8 GPUs = 8 pairs per GPU, nmrf/utils/evaluation.py:61-69's contiguous
+        # split): measured NEXT TO the default weak-scaling line whenever the job has more than one rank (or --config4), never in
+        # its place -- `value` stays the default line's.  Same timed_region, same gather, its own hipGraph at batch 8.
+        config4 = None
+        if (world > 1 or args.config4) and b != 8 and args.backbone == "resnet":
+            try:
+                from nmrf_amd.parallel import shard_range
+                lo, hi = shard_range(8 * world, rank, world)
+                prs = [synthetic_pair(args.height, args.width, seed=1000 + i)[:2] for i in range(lo, hi)]
+                smp8 = {"img1": torch.stack([p[0] for p in prs]).to(dev), "img2": torch.stack([p[1] for p in prs]).to(dev)}
+                k4 = max(3, args.steps // 4)
+                dt4, g4, so4, fwd4, _ = timed_region(smp8, k4, 2)
+                gms4 = gather_alone_ms(so4 if g4 is not None else fwd4()) if (use_dist and not args.no_gather) else None
+                config4 = {"workload": "KITTI %dx%d, global batch %d = 8 pairs per GPU x %d (BASELINE config 4%s)" % (
+                               args.width, args.height, 8 * world, world, "" if world == 8 else ": its per-GPU shard at this N"),
+                           "value": round(8 * world * k4 / dt4, 3), "unit": "stereo pairs/s", "steps": k4, "warmup": 2,
+                           "ms_per_step": round(dt4 / k4 * 1e3, 3), "global_batch": 8 * world,
+                           "launch": "hipGraph" if g4 is not None else "eager",
+                           "gather_ms_alone": None if gms4 is None else round(gms4, 4),
+                           "gather_bytes_per_rank_per_step": 8 * args.height * args.width * 4}
+                del smp8, g4, so4
+            except Exception as e:                              # never at the expense of the default line
+                config4 = {"error": repr(e)}
 
         # dominant hand-written kernel, timed live with HIP events on its launching stream (eager launches,
         # same inputs, right after the timed region so clocks/caches are in the same state)
@@ -546,10 +592,12 @@ def run(args):
                        "global_batch": world * b, "parallelism": "batch-shard x%d" % world,
                        "launch": "hipGraph" if graph is not None else "eager",
                        "result_gather": bool(use_dist and not args.no_gather),
+                       "numa_pinning_rank0": numa,
                        "gather": None if gather_ms is None else {
                            "ms_alone": round(gather_ms, 4), "placement": "on the compute stream" if args.sync_gather else
                            "side stream behind the next step (nmrf_amd.parallel.OverlappedGather); all gathers complete inside the timed region"}},
             "hot_path_ms": None if hp_ms is None else round(hp_ms, 3),
+            "config4": config4,
             "roofline": roof,
             "other_kernels": others,
         }

@@ -147,8 +147,10 @@ int nmrf_window_attn_f32(const float *qkv, const float *table, int B, int Hp, in
                          int win, int shift, int sibling_mask, int kv16, float *out, int *range_flag, void *stream);
 /* (kv16 != 0: the k | v thirds of qkv hold split fp16 operand pairs, see nmrf_nmp_block16_f32; win == 6, N == 4, range_flag == NULL:
  *  the range of such rows was checked by their producer.  In this form the q . E_k[rel] / k . E_q[rel] terms (NMP.py:255-268) run on the
- *  fp16 matrix pipe with the table staged x 2^10 as split fp16 pairs: |table| must stay below 32 -- a parameter, checked by the CALLER;
- *  rows in a configuration the pre-split kernel does not cover return NMRF_EINVAL instead of being read as floats.) */
+ *  fp16 matrix pipe with the table staged x 2^10 as split fp16 pairs: |table| must stay below 32 -- a parameter, checked by the CALLER.
+ *  kv16 == 2: the same rows, the same kernel, but those relative-position terms on the VALU in fp32 -- no bound on the table; the
+ *  form a caller selects for a checkpoint whose table exceeds 32 (nmrf_amd.kernels.window_attn does, once per parameter version).
+ *  Rows in a configuration the pre-split kernel does not cover return NMRF_EINVAL instead of being read as floats.) */
 
 /* A8/A11/A14  narrow prediction-head layers: out[T,N] = act(x[T,K] w[N,K]^T + bias), N <= 64, K % 4 == 0, K <= 512
  * (LDS: 32*(K+4) + 8*npt*K floats <= 64 KiB), act 0 = identity, 1 = ReLU; bias may be NULL.

@@ -120,7 +120,9 @@ __global__ __launch_bounds__(256, PB == 2 ? 4 : 3) void msda_fwd_d8_kernel(const
                 for (int k = 0; k < 4; ++k) offs[k] = base + (unsigned)(yc[k >> 1] * Ww + xc[k & 1]) * (unsigned)(M * 8);
             }
             if (tw4) {
-                const float lh = h_im - hf, lw = w_im - wf;
+                // (!inside includes non-finite locations -- the comparisons above are false for NaN: the fractions are then zeroed as
+                // well, so that such a point contributes exactly 0 like in msda_fwd_kernel instead of 0 * NaN)
+                const float lh = inside ? h_im - hf : 0.f, lw = inside ? w_im - wf : 0.f;
                 const float wy[2] = {inside && h0 >= 0 ? 1 - lh : 0.f, inside && h0 + 1 < Hh ? lh : 0.f};
                 const float wx[2] = {w0 >= 0 ? 1 - lw : 0.f, w0 + 1 < Ww ? lw : 0.f};
 #pragma unroll

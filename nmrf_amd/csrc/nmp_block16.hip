@@ -146,6 +146,8 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
         // The eight parameter vectors are requested TOGETHER: written as `Par[i] = src ? src[i] : 0` one vector after the other, every
         // vector was its own uniform branch + load + full wait -- eight serial L2 round trips at the head of every launch
         // (tools/isa_scan.py).  A NULL vector reads the head of the weight stream instead (always >= 2 KB) and is zeroed afterwards.
+        // (one `tid < ns[k]` pass per vector: the longest fixed vector, b1, has 512 entries; only bq has a strided tail loop)
+        static_assert(B16_THR >= 512, "the parameter prologue loads b1 (512 floats) and the NULL-vector dummy reads in ONE pass of B16_THR threads");
         const float *dummy = reinterpret_cast<const float *>(a.stream);
         const float *srcs[8] = {a.bp, a.ln2_g, a.ln2_b, a.b1, a.b2, a.lnq_g, a.lnq_b, a.bq};
         const int offs[8] = {B16P_BP, B16P_G2, B16P_B2N, B16P_B1, B16P_B2, B16P_GQ, B16P_BQN, B16P_BQ};

@@ -953,6 +953,9 @@ extern "C" int nmrf_window_attn_f32(const float *qkv, const float *table, int B,
 #ifdef NMRF_DEBUG_PROBES
         if (win == 6 && N == 4 && kv16 && g_window_pack1 == 11) return launch_window_fast<5, 6, 4, 1, 3, 1, true, true, true>(qkv, table, g, B, out, st);   // A/B: ONE window per block
 #endif
+        // kv16 == 2: phase 0 (the relative-position dot products) on the VALU in fp32 -- for a table with an entry >= 32 in magnitude,
+        // which the x 2^10 fp16 staging of the matrix-pipe form (P0M) cannot hold; same key tiles, ~4 us slower per launch
+        if (win == 6 && N == 4 && kv16 == 2) return launch_window_fast<5, 6, 4, 2, 3, 1, true>(qkv, table, g, B, out, st);
         if (win == 6 && N == 4 && kv16) return launch_window_fast<5, 6, 4, 2, 3, 1, true, true>(qkv, table, g, B, out, st);
         if (win == 6 && N == 4) return launch_window_fast<5, 6, 4, 2, 3>(qkv, table, g, B, out, st);   // inference windows
 #ifdef NMRF_DEBUG_PROBES

@@ -287,14 +287,22 @@ class StereoStream:
     def run(self, pairs):
         """pairs: iterable of (key, left [3,H,W], right [3,H,W]) (uint8 or float32, 0..255) -> yields (key, disparity [H,W] CPU
         tensor) in input order."""
-        prev_check = None if self._range_model is None else self._range_model.range_check
-        if self._range_model is not None:
-            self._range_model.range_check = False
+        # The per-forward range check (a host sync) is deferred to the stream's own check while a run is active.  Runs are COUNTED on
+        # the model (two streams interleaved on one model, or a generator that is dropped half-way and collected later, must not
+        # restore the wrong value): the caller's setting is saved by the first active run and restored by the last one to end.
+        m = self._range_model
+        if m is not None:
+            if getattr(m, "_stream_runs", 0) == 0:
+                m._range_check_saved = m.range_check
+            m._stream_runs = getattr(m, "_stream_runs", 0) + 1
+            m.range_check = False
         try:
             yield from (self._run_threaded(pairs) if self.threaded else self._run_inline(pairs))
         finally:
-            if self._range_model is not None:
-                self._range_model.range_check = prev_check
+            if m is not None:
+                m._stream_runs -= 1
+                if m._stream_runs == 0:
+                    m.range_check = m._range_check_saved
 
     def _slot(self, i):
         """batch i -> (lane, ring slot of that lane's plan).  The producer is at most `inflight` + 1 batches ahead of the batch being

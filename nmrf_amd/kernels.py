@@ -344,17 +344,37 @@ def self_attn(qkv, n, heads):
     return out
 
 
+_TABLE_OK = {}
+
+
+def _table_fits_fp16(table):
+    key = (table.data_ptr(), table._version, str(table.device), tuple(table.shape))
+    ok = _TABLE_OK.get(key)
+    if ok is None:
+        if len(_TABLE_OK) > 256:
+            _TABLE_OK.clear()
+        with torch.no_grad():
+            ok = _TABLE_OK[key] = bool(torch.isfinite(table).all() and float(table.abs().max()) < 32.0)
+    return ok
+
+
 @_on_device
 def window_attn(qkv, table, b, hp, wp, n, heads, win, shift, sibling_mask, checked=False, kv16=False):
     """checked: the producer of qkv range-checked it (no scan pass).  kv16: the k | v thirds of qkv are split fp16 operand pairs
-    (nmp_block(q=dict(kv16=True)) / to_kv16; 6 x 6 windows of four labels; implies checked)."""
+    (nmp_block(q=dict(kv16=True)) / to_kv16; 6 x 6 windows of four labels; implies checked).  The kv16 kernel contracts q / k with
+    the table on the fp16 matrix pipe (table staged x 2^10 as split fp16, window_attn.hip P0M): that form needs |table| < 32, checked
+    HERE once per parameter version (one read-back) for every caller; a table beyond it (or non-finite) takes the same kernel with
+    the relative-position dot products on the VALU in fp32 (kv16 = 2 at the C ABI) instead of returning inf / NaN."""
     _chk(qkv, table)
+    if kv16:
+        kv16 = 1 if _table_fits_fp16(table) else 2
     t, c3 = qkv.shape
     c = c3 // 3
     assert t == b * hp * wp * n
     out = torch.empty(t, c, device=qkv.device, dtype=torch.float32)
     tw = win * win * n                                 # reference form: 5 contractions of tw^2 x 32 MACs per (window, head)
-    fast = {(6, 4): ("window_attn_fast_kernel<5, 6, 4, 2, 3, false, 1, true, true, false>" if kv16 else
+    fast = {(6, 4): ("window_attn_fast_kernel<5, 6, 4, 2, 3, false, 1, true, true, false>" if kv16 == 1 else
+                     "window_attn_fast_kernel<5, 6, 4, 2, 3, false, 1, true, false, false>" if kv16 else
                      "window_attn_fast_kernel<5, 6, 4, 2, 3, false, 1, false, false, false>"),
             (4, 1): "window_attn_fast_kernel<1, 4, 1, 4, 3,"}
     _hb("window_attn_w%d_n%d" % (win, n), row="A10" if n > 1 else "A13", bound="mfma", split=True,

@@ -332,17 +332,6 @@ class WindowAttention(nn.Module):
         range-checked it (include/nmrf_hip.h, "fp16 range"); otherwise the entry point scans it first.  kv16: ... and wrote its
         k | v thirds as split fp16 operand pairs."""
         b, hp, wp, n = dims
-        if kv16:
-            # the kv16 kernel contracts q / k with the table on the fp16 matrix pipe, table staged x 2^10 as split fp16 (window_attn.hip,
-            # P0M): entries must stay below 32 in magnitude.  Checked once per parameter version (one read-back), like the fp16 range
-            # guard of the activations it raises instead of returning inf / NaN.
-            if not hasattr(self, "_tab_ok"):
-                self._tab_ok = _FusedCache()
-            t = self.relative_position_enc_table
-            if not self._tab_ok.get((t,), lambda: bool(torch.isfinite(t).all() and float(t.abs().max()) < 32.0)):
-                from .._lib import NmrfHipError
-                raise NmrfHipError("relative_position_enc_table has an entry >= 32 in magnitude (or non-finite): outside the fp16 range "
-                                   "of the window kernel's table operand")
         return K.window_attn(qkv, self.relative_position_enc_table, b, hp, wp, n, self.num_heads,
                              self.window_size[0], self.shift_size, sibling_mask, checked=checked, kv16=kv16)
 

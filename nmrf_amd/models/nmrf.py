@@ -117,7 +117,9 @@ class NMRF(nn.Module):
             raise NotImplementedError("training-mode forward: CNN backbone only (the Swin-T trunk has stochastic depth in training mode)")
         if self.training and not getattr(self, "_warned_train", False):
             import warnings
-            warnings.warn("nmrf_amd: model.train() runs the training-mode FORWARD only (forward-only HIP kernels, no autograd graph)")
+            warnings.warn("nmrf_amd: the model is in TRAINING mode (nn.Module's default after build_model -- call model.eval() for "
+                          "inference): this runs the training-mode FORWARD only -- no padding / un-padding, aux_outputs returned, forward-only "
+                          "HIP kernels, no autograd graph")
             self._warned_train = True
         if self.device.type != "cuda":
             raise RuntimeError("the NMRF hot path runs on an MI355X through libnmrf_hip.so; there is no CPU "
@@ -133,7 +135,9 @@ class NMRF(nn.Module):
             b = image1.shape[0]
             hp, wp = h0 + (-h0) % self.divis_by, w0 + (-w0) % self.divis_by
             if self.training and (hp, wp) != (h0, w0):
-                raise ValueError("training mode does not pad its input (NMRF.py:203-205): %dx%d is not a multiple of %d" % (h0, w0, self.divis_by))
+                raise ValueError("the model is in TRAINING mode, which does not pad its input (NMRF.py:203-205): %dx%d is not a multiple of "
+                                 "%d -- did you forget model.eval()?  (build_model returns the module in nn.Module's default training "
+                                 "state, as the reference's does; inference.py:150 calls .eval())" % (h0, w0, self.divis_by))
             stem = enc.conv1
             if (enc.fused and image1.shape[1] == 3 and hp % 2 == 0 and wp % 2 == 0 and stem.weight.shape[0] % 64 == 0
                     and tuple(stem.weight.shape[1:]) == (3, 7, 7) and stem.stride == (2, 2) and stem.padding == (3, 3)):

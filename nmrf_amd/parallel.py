@@ -3,6 +3,8 @@ batch is split contiguously across one-process-per-GPU ranks (same rule as the r
 InferenceSampler, nmrf/utils/evaluation.py:61-69); weights are replicated; the ONLY collective is the
 gather of the finished disparity maps (RCCL all-gather over xGMI on GPUs, gloo on CPU in the tests).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -95,3 +97,46 @@ class OverlappedGather:
                 slot["work"] = None
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
+
+
+def _parse_cpulist(text):
+    """'0-23,96-119' -> sorted list of CPU ids (the format of /sys/devices/system/node/node*/cpulist)."""
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return sorted(cpus)
+
+
+def pin_to_gpu_numa(device_index, sysfs="/sys", pci=None):
+    """Bind this rank's host threads to the NUMA node its GPU hangs off (one process per GPU: the pinned H2D / D2H rings of
+    nmrf_amd.driver.StereoStream are then allocated and touched on the memory next to the device, and the launch thread does not
+    migrate across sockets).  Call BEFORE the pinned allocations.  The node comes from the GPU's PCI address
+    (/sys/bus/pci/devices/<domain:bus:dev.fn>/numa_node), its CPUs from /sys/devices/system/node/node<N>/cpulist, intersected with
+    the CPUs this process may already use (a container's cpuset).  Best effort and never fatal: returns a record of what was done
+    ({"pinned": False, "why": ...} when the topology is not exposed -- single-socket hosts report numa_node -1)."""
+    rec = {"pinned": False, "device": int(device_index)}
+    try:
+        if not hasattr(os, "sched_setaffinity"):
+            return dict(rec, why="no sched_setaffinity on this platform")
+        if pci is None:                                       # (pci: the address given by the caller -- tests)
+            p = torch.cuda.get_device_properties(device_index)
+            pci = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+        addr = pci
+        rec["pci"] = addr
+        with open(os.path.join(sysfs, "bus/pci/devices", addr, "numa_node")) as f:
+            node = int(f.read().strip())
+        rec["numa_node"] = node
+        if node < 0:
+            return dict(rec, why="numa_node -1 (single node / not exposed)")
+        with open(os.path.join(sysfs, "devices/system/node/node%d/cpulist" % node)) as f:
+            cpus = set(_parse_cpulist(f.read()))
+        allowed = cpus & set(os.sched_getaffinity(0))
+        if not allowed:
+            return dict(rec, why="no allowed CPU on node %d" % node)
+        os.sched_setaffinity(0, allowed)
+        return dict(rec, pinned=True, cpus=len(allowed))
+    except Exception as e:                                   # missing sysfs entry, no such attribute, permission: leave the affinity alone
+        return dict(rec, why="%s: %s" % (type(e).__name__, e))

@@ -73,6 +73,7 @@ def test_bench_launches_its_own_workers():
     rec = recs[0]
     assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["valid"] is False and rec["value"] is None
     assert rec["config"]["global_batch"] == 6 and rec["config"]["result_gather"] and rec["config"]["gather_correct"]
+    assert rec["config4"]["global_batch"] == 16 and rec["config4"]["gather_correct"]        # config 4's leg: 8 pairs per rank
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="plumbing mode is what bench.py does on a host WITHOUT a GPU")
@@ -84,3 +85,36 @@ def test_bench_under_torchrun_and_loud_failure_without_gpu():
     assert len(recs) == 1 and recs[0]["n_gpus"] == 2 and recs[0]["config"]["gather_correct"]
     r, recs = _bench(["bench.py", "--steps", "1", "--warmup", "1"])          # N=1 has nothing to fall back to: no line, an error
     assert r.returncode != 0 and not recs and "needs an MI355X" in r.stderr
+
+
+def test_numa_pinning_from_a_sysfs_tree(tmp_path):
+    """nmrf_amd.parallel.pin_to_gpu_numa: GPU PCI address -> numa_node -> that node's cpulist, intersected with the CPUs the
+    process may use; -1 / missing entries leave the affinity alone and say why.  Runs in a child process (it changes affinity)."""
+    import subprocess
+    import sys
+    allowed = sorted(os.sched_getaffinity(0))
+    root = tmp_path / "sys"
+    dev = root / "bus/pci/devices/0000:c5:00.0"
+    dev.mkdir(parents=True)
+    (dev / "numa_node").write_text("1\n")
+    node = root / "devices/system/node/node1"
+    node.mkdir(parents=True)
+    first = allowed[0]
+    (node / "cpulist").write_text("%d-%d,%d\n" % (first, first, 10 ** 6))          # one CPU we own + one that does not exist
+    single = root / "bus/pci/devices/0000:05:00.0"
+    single.mkdir(parents=True)
+    (single / "numa_node").write_text("-1\n")
+    code = ("import os, json, sys; sys.path.insert(0, %r); from nmrf_amd.parallel import pin_to_gpu_numa, _parse_cpulist;"
+            "assert _parse_cpulist('0-2,8,10-11') == [0, 1, 2, 8, 10, 11];"
+            "a = pin_to_gpu_numa(0, sysfs=%r, pci='0000:05:00.0'); b0 = sorted(os.sched_getaffinity(0));"
+            "m = pin_to_gpu_numa(0, sysfs=%r, pci='0000:aa:00.0');"
+            "b = pin_to_gpu_numa(0, sysfs=%r, pci='0000:c5:00.0');"
+            "print(json.dumps([a, b0, m, b, sorted(os.sched_getaffinity(0))]))") % (
+                os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(root), str(root), str(root))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    import json
+    a, b0, m, b, after = json.loads(r.stdout.strip().splitlines()[-1])
+    assert a["pinned"] is False and a["numa_node"] == -1 and b0 == allowed
+    assert m["pinned"] is False and "why" in m
+    assert b["pinned"] is True and b["numa_node"] == 1 and b["cpus"] == 1 and after == [first]

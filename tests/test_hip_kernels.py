@@ -662,6 +662,63 @@ def test_window_attention_on_kv16_rows(shift):
     report("window attention on kv16 rows", c.cpu(), a.cpu().double(), 3e-6, 1e-6)
 
 
+@pytest.mark.parametrize("scale,form", [(0.3, 1), (12.0, 1), (12.0, 2), (45.0, 2)])
+def test_window_attention_kv16_table_magnitude_and_valu_fallback(scale, form):
+    """the kv16 window kernel stages its relative-position table x 2^10 as split fp16 for the matrix-pipe form of the
+    rel-pos dot products (needs |table| < 32).  Tables with entries of 10 ... 30 through both forms (kv16 = 1: matrix pipe, 2: VALU
+    fp32) against the oracle, and a table beyond 32 (entries up to 45): the Python entry point must pick the VALU form by itself
+    and return finite, correct rows instead of inf / NaN.  q is scaled down so that the logits stay in a range where the softmax
+    has more than one live term."""
+    kk = K()
+    b, hp, wp, n = 1, 12, 12, 4
+    qkv = rnd(b * hp * wp * n, 384, seed=43, scale=1.0)
+    qkv[:, :256] *= 0.05                                            # q, k small: logits = q.k + q.E_k + k.E_q stay O(10) for |E| ~ 30
+    table = rnd(121, 384, seed=44, scale=scale)
+    assert float(table.abs().max()) > 0.9 * scale
+    from nmrf_amd import kernels as KK
+    assert KK._table_fits_fp16(table.to(DEV)) == (scale < 32)
+    rows = kk.to_kv16(qkv.to(DEV))
+    if scale < 32:
+        import ctypes
+        from nmrf_amd import _lib
+        out = torch.empty(qkv.shape[0], 128, device=DEV)
+        tab = table.to(DEV)
+        p = lambda x: ctypes.c_void_p(x.data_ptr())
+        _lib.check(_lib.load().nmrf_window_attn_f32(p(rows), p(tab), b, hp, wp, n, 128, 4, 6, 3, 1, form, p(out), None,
+                                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "window_attn")
+        got = out.cpu()
+    else:
+        got = kk.window_attn(rows, table.to(DEV), b, hp, wp, n, 4, 6, 3, True, kv16=True).cpu()      # picks kv16 = 2 itself
+    assert torch.isfinite(got).all()
+    ref = O.window_attention(qkv.double().view(b, hp, wp, n, 384), table.double(), (b, hp, wp, n), 6, 3, 4, True)
+    report("window attention, |table| <= %g, form %d" % (scale, form), got, ref.reshape(-1, 128), 2e-5 * max(1.0, scale / 4), 1e-5)
+
+
+def test_msda_forward_non_finite_locations_contribute_zero():
+    """a sampling location that is inf / NaN (an overflowed offset) must contribute exactly 0 in the fast path
+    (msda_fwd_d8_kernel) as it does in the generic kernel -- not 0 * NaN.  Shape family of the neck (8 heads x 8 channels, one
+    level, 4 points) = fast path; the same operands with 3 points = generic kernel."""
+    h, w, lq = 12, 20, 96
+    value = rnd(2, h * w, 8, 8, seed=51)
+    shapes, start = torch.tensor([[h, w]]), torch.tensor([0])
+    for pts in (4, 3):
+        loc = rnd(2, lq, 8, 1, pts, 2, seed=52).abs()
+        wgt = torch.softmax(rnd(2, lq, 8, 1, pts, seed=53), -1)
+        clean = K().msda_forward(value.to(DEV), shapes.to(DEV), start.to(DEV), loc.to(DEV), wgt.to(DEV)).cpu()
+        bad = loc.clone()
+        bad[0, 5, 2, 0, 1, 0] = float("inf")
+        bad[1, 7, 3, 0, 0, 1] = float("nan")
+        bad[0, 9, 0, 0, 2, :] = float("-inf")
+        got = K().msda_forward(value.to(DEV), shapes.to(DEV), start.to(DEV), bad.to(DEV), wgt.to(DEV)).cpu()
+        assert torch.isfinite(got).all(), "points=%d: non-finite output" % pts
+        # the expected rows: the same call with the bad points' attention weights zeroed and their locations made harmless
+        w0 = wgt.clone()
+        w0[0, 5, 2, 0, 1] = 0; w0[1, 7, 3, 0, 0] = 0; w0[0, 9, 0, 0, 2] = 0
+        want = K().msda_forward(value.to(DEV), shapes.to(DEV), start.to(DEV), loc.to(DEV), w0.to(DEV)).cpu()
+        report("msda with non-finite locations (points=%d)" % pts, got, want.double(), 1e-6)
+        assert not torch.equal(clean, got)
+
+
 @pytest.mark.parametrize("t_", [64, 516, 29952, 40004])
 def test_nmp_block_with_self_edge_attention_on_the_way_in(t_):
     """The self-edge block (BasicAttention, NMP.py:90-108) with the 4 x 4 sibling attention evaluated inside the block kernel

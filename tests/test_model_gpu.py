@@ -32,21 +32,32 @@ def _oracle_chain_side(oout):
 def _oracle_features(g):
     """Backbone features computed by the oracle on CPU (stock convs): the GPU hot path is then fed the
     exact same activations the reference saw, so seeds can be required bit-exact."""
-    w, cfg = oracle_weights(int(g["max_disp"])), oracle_cfg(int(g["max_disp"]))
-    from tests.util import golden_images
-    with torch.no_grad():
+    w, cfg = oracle_weights(int(g["max_disp"]), weights=_weights_of(g)), oracle_cfg(int(g["max_disp"]))
+    from tests.util import golden_images, operand_range
+    with torch.no_grad(), operand_range() as rng:
         out = O.forward(w, cfg, *golden_images(g), return_stages=True)
+    out["operand_range"] = rng.summary()
     st = out["stages"]
     return w, cfg, out, ([st["fmap8_l"], st["fmap4_l"]], [st["fmap8_r"], st["fmap4_r"]])
 
 
-@pytest.mark.parametrize("name", ["e2e_a", "e2e_b", "e2e_c", "e2e_d"])
+def _weights_of(g):
+    """e2e_t was captured from the TRAINED reference (tools/gen_trained_golden.py), every other fixture from the hash fill."""
+    return "trained" if "train_steps" in g else "hash"
+
+
+@pytest.mark.parametrize("name", ["e2e_a", "e2e_b", "e2e_c", "e2e_d", "e2e_t"])
 def test_hot_path_from_reference_features(name):
+    """e2e_t: the same chain on the TRAINED reference checkpoint (tests/golden/trained_sd.npz through load_state_dict), with the
+    largest |activation| each split-fp16 stage saw printed beside the 65 520 limit of csrc/split_mfma.h."""
     g = golden(name)
     w, cfg, oout, (fl, fr) = _oracle_features(g)
-    model = build_product(int(g["max_disp"]), DEV)
+    model = build_product(int(g["max_disp"]), DEV, weights=_weights_of(g))
     with torch.no_grad():
         out, cand = _gpu_chain_side(model, [f.to(DEV) for f in fl], [f.to(DEV) for f in fr], g["disp"].shape[-2:])
+    assert model.check_range()
+    from tests.conftest import record_note
+    record_note("%s (%s weights): largest |operand| of the oracle's linears / convolutions: %s" % (name, _weights_of(g), oout["operand_range"]))
     report("prob", out["prob"].cpu(), t(g["prob"]), 5e-6 if name != "e2e_d" else 1.5e-5)     # e2e_d: 17 x 129 x 2 pixels, measured 7e-6
     seeds = out["initial_proposal"].cpu().long()
     assert torch.equal(seeds, t(g["seeds"]).long()), \
@@ -161,7 +172,8 @@ def test_full_forward_vs_oracle_mid_size():
         o4, o8 = O.cnn_backbone(torch.cat(O.pad_images(l[None], r[None], 8)[:2], 0), w, "backbone")
     report("encoder 1/4", f4.cpu(), o4, 2e-4, 1e-4)
     report("encoder 1/8", f8.cpu(), o8, 2e-4, 1e-4)
-    out, _, _ = _hot_path_vs_oracle("full_forward_120x264 (hot path from the GPU encoder features)", model, (f4, f8), (120, 264), 320)
+    out, _, _ = _hot_path_vs_oracle("full_forward_120x264 (hot path from the GPU encoder features)", model, (f4, f8), (120, 264), 320,
+                                    exact_seeds=False)
     d = (out["disp"] - got["disp"]).abs()
     assert float(d.median()) < 1e-3, "model(sample) and encoder + hot_path disagree"
 
@@ -291,11 +303,9 @@ def test_middlebury_half_res_size_runs():
 @pytest.mark.parametrize("h,w", [(375, 1242), (540, 960)])
 def test_full_size_properties(h, w):
     """BASELINE sizes (KITTI, SceneFlow): properties that hold at any size.
-    * per-image independence of the whole model: a batch of two different pairs ~= the two pairs run alone,
-      in either order.  Not required bit-exact end to end: the two 1x1 down-sampling shortcuts of the encoder still run on
-      rocBLAS, which may pick a batch-size-dependent reduction order, and that fp32 noise is amplified by the 2^14
-      Fourier band; seeds must agree on >= 99.9 % of pixels and the disparity on average to 1e-2 px.  (The
-      hand-written kernels ARE bit-exact under batching: test_hip_kernels_are_batch_invariant.)
+    * per-image independence of the whole model: a batch of two different pairs == the two pairs run alone, in either order,
+      BIT FOR BIT (no library kernel is left in the CNN configuration since round 4; the hand-written kernels are batch-invariant:
+      test_hip_kernels_are_batch_invariant)
     * probabilities sum to 1, seeds are distinct in-range bins, strong seeds are local maxima of prob
     * outputs are finite, non-negative, and of the un-padded size."""
     from nmrf_amd.utils.hashinit import synthetic_pair
@@ -307,11 +317,10 @@ def test_full_size_properties(h, w):
         both = model({"img1": img1, "img2": img2})
         swapped = model({"img1": img1.flip(0), "img2": img2.flip(0)})
         solo = model({"img1": img1[:1], "img2": img2[:1]})
-    for a, b in ((both["initial_proposal"].flip(0), swapped["initial_proposal"]),
-                 (both["initial_proposal"][:1], solo["initial_proposal"])):
-        assert (a != b).any(-1).float().mean() < 1e-3
-    for a, b in ((both["disp"].flip(0), swapped["disp"]), (both["disp"][:1], solo["disp"])):
-        assert float((a - b).abs().mean()) < 1e-2
+    _assert_batch_equals_solo("%dx%d, image 0 of 2" % (w, h), both, solo, 0, 2)
+    _assert_batch_equals_solo("%dx%d, image 1 of 2 vs image 0 of the swapped batch" % (w, h), both,
+                              {k: (v.reshape(2, -1, *v.shape[1:])[:1].reshape(-1, *v.shape[1:]) if k == "prob" else v[:1])
+                               for k, v in swapped.items() if torch.is_tensor(v)}, 1, 2)
     d = 40
     prob = both["prob"]
     assert torch.allclose(prob.sum(-1), torch.ones_like(prob[:, 0]), atol=1e-5)
@@ -380,8 +389,14 @@ def test_hip_kernels_are_batch_invariant():
 # --------------------------------------------------------------------------------------------------------------------
 # BASELINE.json configs 2-5 at their stated workloads: whole-model runs on the GPU + oracle-subset parity
 # --------------------------------------------------------------------------------------------------------------------
-def _hot_path_vs_oracle(tag, model, feats, out_hw, max_disp, opts=(), pick=0, prob_tol=1.5e-5, **gate):
-    """GPU hot path and CPU oracle hot path from the SAME encoder features (one image `pick` of the batch)."""
+def _hot_path_vs_oracle(tag, model, feats, out_hw, max_disp, opts=(), pick=0, prob_tol=1.5e-5, exact_seeds=True, fp64_floor=False,
+                        **gate):
+    """GPU hot path and CPU oracle hot path from the SAME encoder features (one image `pick` of the batch).
+    exact_seeds (the BASELINE-size runs): "NMS indices bit-exact" is asserted outright -- the explained-by-prob-noise escape of
+    seeds_explained_by_prob_noise measured 0 pixels on every such run and is only kept for the small mid-size case.
+    fp64_floor: also run the oracle in fp64 from the same features and print what fp32 arithmetic itself does to this input (the
+    oracle's fp32 vs its fp64: decisions differing, raw EPE) beside the GPU's numbers -- the "reference does not meet 1e-3
+    against itself" argument of tests/util.py, re-measured on the input under test instead of cited."""
     f4, f8 = feats
     b = f4.shape[0] // 2
     sel = [pick, b + pick]
@@ -397,11 +412,42 @@ def _hot_path_vs_oracle(tag, model, feats, out_hw, max_disp, opts=(), pick=0, pr
         # probabilities at full size: fp32 summation order of the 64-channel (Swin: 32) correlation means, amplified by the three
         # conv1d layers; measured on the MI355X 5e-6 ... 7e-6 (CNN features) and 1.8e-5 (Swin-T features, larger magnitudes)
         mism = seeds_explained_by_prob_noise(tag, got, want, cfg.eps, prob_tol)
+        if exact_seeds:
+            assert mism == 0, "%s: %d pixels with different label seeds (NMS indices must be bit-exact)" % (tag, mism)
         if mism:            # candidates tied within the noise of prob: the oracle continues from the GPU's choice there
             want = O.hot_path(w, cfg, f8s.cpu(), f4s.cpu(), None, out_hw, stages={}, seeds=got["initial_proposal"].cpu().long())
         report(tag + " proposal", got["proposal"].cpu(), want["proposal"], 2e-4)
         st = check_chain(tag, cand, _oracle_chain_side(want), lambda dq: O.refine_from(w, cfg, dq, l4, r4, out_hw)[0], **gate)
+        if fp64_floor:
+            from tests.conftest import record_note
+            from tests.util import disp_stats
+            w64 = {k: v.double() if v.is_floating_point() else v for k, v in w.items()}
+            o64 = O.hot_path(w64, cfg, f8s.cpu().double(), f4s.cpu().double(), None, out_hw, stages={})
+            s32, s64 = want["stages"]["score"].double(), o64["stages"]["score"].double()
+            flips = int((s32.max(-1).indices != s64.max(-1).indices).sum())
+            raw = disp_stats(want["disp"], o64["disp"])
+            gflips = int((cand["score"].double().max(-1).indices != s64.max(-1).indices).sum())
+            graw = disp_stats(cand["disp"], o64["disp"])
+            record_note("%s | fp64 floor of this input: the fp32 oracle (the reference's arithmetic) vs fp64: %d decisions differ, raw EPE "
+                        "%.2e px, max %.1f; the GPU vs fp64: %d decisions, raw EPE %.2e; the GPU vs the fp32 oracle: %d decisions, raw EPE "
+                        "%.2e" % (tag, flips, raw["epe"], raw["max"], gflips, graw["epe"], st["wta_flips"], st["raw_epe"]))
     return got, st, mism
+
+
+def _assert_batch_equals_solo(tag, batch_out, solo_out, i, b):
+    """Image i of a batch of b against the same pair run alone: every kernel of the CNN configuration is this library's and is
+    batch-invariant (fixed per-wave summation order, no cross-image reduction: test_hip_kernels_are_batch_invariant), so the whole
+    model must return the SAME BITS -- probabilities, seeds, proposals, disparity.  A failure names the first output that differs."""
+    bad = []
+    for k in ("prob", "initial_proposal", "proposal", "disp_pred", "disp"):
+        x, y = batch_out[k], solo_out[k]
+        if x.shape[0] == b * y.shape[0]:                         # (prob: [B * pixels, D])
+            x = x.reshape(b, -1, *x.shape[1:])[i].reshape(y.shape)
+        else:
+            x = x[i:i + 1]
+        if not torch.equal(x, y):
+            bad.append("%s: %d of %d values differ, max |d| %.3g" % (k, int((x != y).sum()), x.numel(), float((x.float() - y.float()).abs().max())))
+    assert not bad, "%s: batched and solo runs are not bit-equal -- %s" % (tag, "; ".join(bad))
 
 
 def _features(model, img1, img2):
@@ -422,7 +468,7 @@ def test_hot_path_vs_oracle_at_baseline_size(name, h, w):
     model = build_product(320, DEV)
     l, r, _ = synthetic_pair(h, w, seed=1000)
     feats = _features(model, l[None], r[None])
-    _hot_path_vs_oracle("hot path vs oracle %s %dx%d" % (name, w, h), model, feats, (h, w), 320)
+    _hot_path_vs_oracle("hot path vs oracle %s %dx%d" % (name, w, h), model, feats, (h, w), 320, fp64_floor=True)
 
 
 def test_config3_sceneflow_batch32():
@@ -446,10 +492,7 @@ def test_config3_sceneflow_batch32():
     record_note("config 3 (960x540, batch 32): peak allocated %.1f GiB" % peak)
     with torch.no_grad():
         for i in (0, 31):
-            solo = model({"img1": img1[i:i + 1], "img2": img2[i:i + 1]})
-            mism = float((solo["initial_proposal"] != out["initial_proposal"][i:i + 1]).any(-1).float().mean())
-            d = (solo["disp"] - out["disp"][i:i + 1]).abs()
-            assert mism < 1e-3 and float(d.mean()) < 1e-2, (i, mism, float(d.mean()))
+            _assert_batch_equals_solo("config 3, image %d of 32" % i, out, model({"img1": img1[i:i + 1], "img2": img2[i:i + 1]}), i, b)
     feats = _features(model, img1, img2)
     _hot_path_vs_oracle("config 3 image 5 of 32 vs oracle", model, feats, (h, w), 320, pick=5)
 
@@ -470,9 +513,7 @@ def test_config4_local_shard_kitti_batch8():
         out = model({"img1": img1, "img2": img2})
         solo = model({"img1": img1[2:3], "img2": img2[2:3]})
     assert out["disp"].shape == (8, h, w) and torch.isfinite(out["disp"]).all()
-    mism = float((solo["initial_proposal"] != out["initial_proposal"][2:3]).any(-1).float().mean())
-    d = (solo["disp"] - out["disp"][2:3]).abs()
-    assert mism < 1e-3 and float(d.mean()) < 1e-2, (mism, float(d.mean()))
+    _assert_batch_equals_solo("config 4 shard, image 2 of 8", out, solo, 2, 8)
     feats = _features(model, img1, img2)
     _hot_path_vs_oracle("config 4 shard image 2 of 8 vs oracle", model, feats, (h, w), 320, pick=2)
 
@@ -662,3 +703,14 @@ def test_driver_two_forwards_in_flight():
     k0, d0 = next(gen)
     gen.close()
     assert k0 == 0 and torch.equal(d0, one[0]) and model.range_check is True
+    # two streams interleaved on ONE model, ended in the order they were started, and one that is never exhausted:
+    # the caller's range_check comes back when the LAST active run ends, not a stale False saved by the second stream
+    ga = StereoStream(model, DEV, batch=1).run(iter(many))
+    next(ga)
+    gb = StereoStream(model, DEV, batch=1).run(iter(many))
+    next(gb)
+    assert model.range_check is False
+    ga.close()
+    assert model.range_check is False                                   # gb still active
+    gb.close()
+    assert model.range_check is True

@@ -105,14 +105,19 @@ def test_refinement_stage_from_reference_disparity(run_a):
     report("disp", disp, t(g["disp"]), 1e-4)
 
 
-@pytest.mark.parametrize("name", ["e2e_a", "e2e_b", "e2e_c", "e2e_d"])
+def _weights_of(g):
+    """e2e_t holds the outputs of the TRAINED reference (tools/gen_trained_golden.py; weights tests/golden/trained_sd.npz)."""
+    return "trained" if "train_steps" in g else "hash"
+
+
+@pytest.mark.parametrize("name", ["e2e_a", "e2e_b", "e2e_c", "e2e_d", "e2e_t"])
 def test_end_to_end_outputs(name):
     """Whole forward vs the reference.  Seeds are bit-exact, probabilities 2e-6, proposals 5e-5; the final disparity is held to
     the contract of BASELINE.json (EPE within 1e-3 px; measured 3e-5 ... 1.2e-4) plus a median and an outlier bound, because
     label noise of 1e-6 is amplified ~1e3x by the top Fourier band before the winner-take-all and can flip the odd pixel
     (e2e_d: one 0.27 px pixel in 280 704; DESIGN.md, 'error amplification')."""
     g = golden(name)
-    w, cfg = oracle_weights(int(g["max_disp"])), oracle_cfg(int(g["max_disp"]))
+    w, cfg = oracle_weights(int(g["max_disp"]), weights=_weights_of(g)), oracle_cfg(int(g["max_disp"]))
     with torch.no_grad():
         out = O.forward(w, cfg, *_imgs(g))
     report("prob", out["prob"], t(g["prob"]), 2e-6)
@@ -124,14 +129,14 @@ def test_end_to_end_outputs(name):
     assert st["epe"] < 1e-3 and st["median"] < 2e-4 and st["frac_gt_0p5"] < 2e-3, st       # the CPU oracle meets the raw contract
 
 
-@pytest.mark.parametrize("name", ["e2e_a", "e2e_b"])
+@pytest.mark.parametrize("name", ["e2e_a", "e2e_b", "e2e_t"])
 def test_wta_inputs_vs_reference_captures(name):
     """The tensors entering the winner-take-all (NMRF.py:218-228): the oracle's candidates / scores against forward-hook captures
     of the reference's infer_head / infer_score_head outputs, and the decision itself: same winner except at near-ties
     (reference margin <= 1e-4; e2e_a has one such pixel of 5 824 even between the reference and this CPU oracle)."""
     from tests.util import unshuffle_heads
     g = golden(name)
-    w, cfg = oracle_weights(int(g["max_disp"])), oracle_cfg(int(g["max_disp"]))
+    w, cfg = oracle_weights(int(g["max_disp"]), weights=_weights_of(g)), oracle_cfg(int(g["max_disp"]))
     with torch.no_grad():
         out = O.forward(w, cfg, *_imgs(g), return_stages=True)
     st = out["stages"]

@@ -35,10 +35,25 @@ def make_cfg(max_disp=320, opts=()):
     return cfg
 
 
-def build_product(max_disp=320, device="cpu", opts=()):
-    """The nmrf_amd model with the closed-form hash weights (same fill the goldens were made with)."""
+@functools.lru_cache(maxsize=None)
+def trained_state_dict():
+    """tests/golden/trained_sd.npz: the state dict of the REFERENCE after tools/gen_trained_golden.py trained it on CPU (its own
+    initialisation, its own Criterion / optimizer groups / schedule): weights with structure, not the hash fill."""
+    with np.load(os.path.join(GOLDEN, "trained_sd.npz")) as z:
+        return {k: torch.from_numpy(np.ascontiguousarray(z[k])) for k in z.files}
+
+
+def build_product(max_disp=320, device="cpu", opts=(), weights="hash"):
+    """The nmrf_amd model with the closed-form hash weights (same fill the goldens were made with), or -- weights="trained" --
+    with the trained reference checkpoint of tests/golden/trained_sd.npz through load_state_dict (inference.py:148-150)."""
     model = build_model(make_cfg(max_disp, opts))[0].eval()
     sd = model.state_dict()
+    if weights == "trained":
+        new = trained_state_dict()
+        missing = [k for k, v in sd.items() if torch.is_floating_point(v) and k not in new]
+        assert not missing, "trained_sd.npz lacks %s" % missing[:5]
+        model.load_state_dict({k: new.get(k, v) for k, v in sd.items()}, strict=True)
+        return model.to(device)
     new = hash_state_dict(sd)
     with torch.no_grad():
         for k, v in new.items():
@@ -47,10 +62,41 @@ def build_product(max_disp=320, device="cpu", opts=()):
 
 
 @functools.lru_cache(maxsize=None)
-def oracle_weights(max_disp=320, opts=()):
+def oracle_weights(max_disp=320, opts=(), weights="hash"):
     """Flat weight dict for the oracle: keys/shapes come from the product model's state dict."""
+    if weights == "trained":
+        return dict(trained_state_dict())
     model = build_model(make_cfg(max_disp, opts))[0]
     return hash_state_dict(model.state_dict())
+
+
+class operand_range:
+    """Context manager: the largest |value| entering or leaving any linear / convolution the ORACLE runs inside the block (the
+    operands the HIP path splits into fp16 pairs: activations in, and q | k | v / hidden rows out), by kind.  For the range
+    account of csrc/split_mfma.h (|operand| < 65 520) on weights with structure."""
+
+    def __enter__(self):
+        import torch.nn.functional as F
+        self.F, self.saved, self.max = F, {}, {}
+        for name in ("linear", "conv2d", "conv1d"):
+            fn = getattr(F, name)
+            self.saved[name] = fn
+
+            def wrapped(x, *a, _fn=fn, _name=name, **k):
+                y = _fn(x, *a, **k)
+                m = max(float(x.detach().abs().max()), float(y.detach().abs().max())) if x.numel() and y.numel() else 0.0
+                self.max[_name] = max(self.max.get(_name, 0.0), m)
+                return y
+            setattr(F, name, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self.saved.items():
+            setattr(self.F, name, fn)
+        return False
+
+    def summary(self):
+        return ", ".join("%s %.3g" % kv for kv in sorted(self.max.items())) + " (limit 65520)"
 
 
 def oracle_cfg(max_disp=320, **kw):
