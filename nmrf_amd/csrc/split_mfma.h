@@ -67,7 +67,15 @@ __device__ __forceinline__ void split_mma(h16x8 ah, h16x8 al, h16x8 bh, h16x8 bl
 // whatever their magnitude; activations are used as they are.  Half the accumulator registers, no combine step.
 __device__ __forceinline__ void split2u(f32x2 a, h16x2 &hi, h16x2 &lo) {
     hi = __builtin_convertvector(a, h16x2);
+#ifdef NMRF_SCALAR_SPLIT
+    // A/B build (tools/build_ab_nopk.sh): the same two subtractions as plain v_sub_f32 instead of one v_pk_add_f32 -- a packed fp32
+    // instruction beside MFMAs costs more than its issue slot (MI355X_MICROARCH.md, "price of one filler beside MFMAs")
+    const float b0 = (float)hi[0], b1 = (float)hi[1];
+    const float l0 = a[0] - b0, l1 = a[1] - b1;
+    lo = h16x2{(_Float16)l0, (_Float16)l1};
+#else
     lo = __builtin_convertvector(a - __builtin_convertvector(hi, f32x2), h16x2);
+#endif
 }
 __device__ __forceinline__ void split8u(const float *v, h16x8 &hi, h16x8 &lo) {
 #pragma unroll

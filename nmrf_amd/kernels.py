@@ -348,13 +348,18 @@ _TABLE_OK = {}
 
 
 def _table_fits_fp16(table):
-    key = (table.data_ptr(), table._version, str(table.device), tuple(table.shape))
-    ok = _TABLE_OK.get(key)
-    if ok is None:
-        if len(_TABLE_OK) > 256:
-            _TABLE_OK.clear()
-        with torch.no_grad():
-            ok = _TABLE_OK[key] = bool(torch.isfinite(table).all() and float(table.abs().max()) < 32.0)
+    """|table| < 32 and finite, read back once per (tensor object, version).  Keyed on the object's id WITH a weak reference to it: a
+    (data_ptr, version) key alone is not an identity -- a new tensor allocated at a freed table's address would inherit its verdict."""
+    import weakref
+    ent = _TABLE_OK.get(id(table))
+    if ent is not None and ent[0]() is table and ent[1] == (table._version, table.data_ptr()):
+        return ent[2]
+    if len(_TABLE_OK) > 256:
+        for k in [k for k, e in _TABLE_OK.items() if e[0]() is None]:
+            del _TABLE_OK[k]
+    with torch.no_grad():
+        ok = bool(torch.isfinite(table).all() and float(table.abs().max()) < 32.0)
+    _TABLE_OK[id(table)] = (weakref.ref(table), (table._version, table.data_ptr()), ok)
     return ok
 
 
