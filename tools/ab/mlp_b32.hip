@@ -62,7 +62,9 @@ __device__ __forceinline__ void mv_static_for(F &&f) {
 // PIPE 0: GELU of a group in front of its fc2 stage (the product's order; the compiler may move it)
 // PIPE 1: GELU halves placed inside the neighbouring MFMA stages
 // PIPE 2: ... and interleaved with them by sched_group_barrier (1 MFMA, VPM VALU) x 12 per sub-step
-template <int PIPE>
+// DIST: how many stages a weight fetch is issued ahead of its commit to the ring (product: 1 -- the global load of stage g + 3 is issued
+// at the end of stage g and its data is needed at the end of stage g + 1; DIST staging register sets of 16 VGPRs)
+template <int PIPE, int DIST = 1>
 __global__ __launch_bounds__(MV_THR, 1) void mlp_b32_kernel(MlpvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     mv_u32x4 *ring = reinterpret_cast<mv_u32x4 *>(smem);
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(MV_THR, 1) void mlp_b32_kernel(MlpvArgs a) {
     auto par4 = [&](int off) { return *reinterpret_cast<const f32x4 *>(Par + off); };
 
     // ---- weight ring (protocol of csrc/split_stream.h; 256 threads move 4 x 16 B per stage) ----------------------------------------
-    mv_u32x4 R[4];
+    mv_u32x4 R[DIST][4];
     int src_stage = 0, wr_slot = 0, rd_slot = 0;
     const mv_u32x4 *my_stream = a.stream + (size_t)(blockIdx.x % a.copies) * a.copy_stride_u4;
     auto fetch_into = [&](mv_u32x4 (&Rx)[4]) {
@@ -108,8 +110,12 @@ __global__ __launch_bounds__(MV_THR, 1) void mlp_b32_kernel(MlpvArgs a) {
         have_barrier = false;
     };
     auto stage_end = [&]() {
-        commit_from(R);
-        fetch_into(R);
+        commit_from(R[0]);                                   // the oldest request (issued DIST stages ago)
+#pragma unroll
+        for (int d = 0; d + 1 < DIST; ++d)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) R[d][i] = R[d + 1][i];   // (register renaming after unrolling: no moves survive when DIST == 1)
+        fetch_into(R[DIST - 1]);
         rd_slot = (rd_slot == MV_RING - 1) ? 0 : rd_slot + 1;
         cur = nxt;
         nxt = ring + ((rd_slot == MV_RING - 1) ? 0 : rd_slot + 1) * MV_STAGE_U4;
@@ -153,7 +159,9 @@ __global__ __launch_bounds__(MV_THR, 1) void mlp_b32_kernel(MlpvArgs a) {
     };
     {
         mv_u32x4 Ra[4], Rb[4];
-        fetch_into(Ra); fetch_into(Rb); fetch_into(R);
+        fetch_into(Ra); fetch_into(Rb);
+#pragma unroll
+        for (int d = 0; d < DIST; ++d) fetch_into(R[d]);
         commit_from(Ra); commit_from(Rb);
     }
     __syncthreads();
@@ -325,12 +333,12 @@ __global__ __launch_bounds__(MV_THR, 1) void mlp_b32_kernel(MlpvArgs a) {
     split_guard_commit(guard, a.range_flag);
 }
 
-template <int PIPE>
+template <int PIPE, int DIST = 1>
 static int launch(const MlpvArgs &a, hipStream_t st) {
     static bool attr_set = false;
     static int n_cu = 0;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_b32_kernel<PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp_b32_kernel<PIPE, DIST>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
             hipSuccess)
             return -1;
         attr_set = true;
@@ -343,7 +351,7 @@ static int launch(const MlpvArgs &a, hipStream_t st) {
         n_cu = prop.multiProcessorCount;
     }
     const int grid = a.n_tiles < n_cu ? a.n_tiles : n_cu;
-    hipLaunchKernelGGL((mlp_b32_kernel<PIPE>), dim3(grid), dim3(MV_THR), MV_LDS, st, a);
+    hipLaunchKernelGGL((mlp_b32_kernel<PIPE, DIST>), dim3(grid), dim3(MV_THR), MV_LDS, st, a);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -361,6 +369,10 @@ extern "C" int mlp_b32_f32(int pipe, const float *x, const void *stream_w, int t
         case 0: return launch<0>(a, st);
         case 1: return launch<1>(a, st);
         case 2: return launch<2>(a, st);
+        case 10: return launch<0, 2>(a, st);                 // pipe 0 with the fetch 2 / 3 / 4 stages ahead
+        case 20: return launch<0, 3>(a, st);
+        case 30: return launch<0, 4>(a, st);
+        case 22: return launch<2, 3>(a, st);
     }
     return -4;
 }

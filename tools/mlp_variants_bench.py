@@ -109,7 +109,8 @@ def main():
             return run
         forms = [("product", prod), ("r2-32tok", r2), ("b32/p0", b32(0)), ("b32/p1", b32(1)), ("b32/p2", b32(2)),
                  ("p0 x8", b32(0, 8)), ("p0 x32", b32(0, 32)), ("p0 x256", b32(0, 256)), ("p0 x32+4K", b32(0, 32, 4096 + 256)),
-                 ("p2 x32", b32(2, 32)), ("p2 x256", b32(2, 256))]
+                 ("p2 x32", b32(2, 32)), ("p2 x256", b32(2, 256)),
+                 ("p0 dist2", b32(10)), ("p0 dist3", b32(20)), ("p0 dist4", b32(30)), ("p2 dist3", b32(22))]
         base_us, base_out = None, None
         for name, fn in forms:
             try:
