@@ -40,7 +40,7 @@ const char *nmrf_strerror(int code);
  * in a separate pass when range_flag != NULL; pass NULL when qkv was produced by nmrf_nmp_block16_f32, which range-checks its q_out. */
 int nmrf_range_scan_f32(const float *x, int64_t n, int *range_flag, void *stream);   /* n % 4 == 0, x 16-byte aligned */
 /* ABI version of this header; bumps on any signature change. */
-int nmrf_abi_version(void);   /* currently 23 */
+int nmrf_abi_version(void);   /* currently 24 */
 
 /* A2  group-wise correlation volume.
  * replaces build_correlation_volume + the permute of DPN.forward
@@ -399,6 +399,36 @@ int nmrf_selftest_mfma_f16split(const float *A, const float *Bm, int K, int mode
 /* Self-test of the LDS-DMA path (global_load_lds_dwordx4) the weight streams use: dst[t] = src[t ^ 65] within each
  * 256-float4 block, routed through LDS.  n_float4 % 256 == 0. */
 int nmrf_selftest_lds_dma(const float *src, float *dst, int n_float4, void *stream);
+
+/* ---- N4, first slice: the pieces of a backward pass through the token-linear chains (csrc/backward.hip) -------------
+ * The reference differentiates its whole forward with autograd (nmrf/models/NMRF.py:387-429 losses, main.py:413-430 step).  Here the
+ * FORWARD of a chain / block is the product's fused launch and the backward is composed from these entry points by
+ * nmrf_amd/models/autograd_ops.py (torch.autograd.Function): dgrad / wgrad of an nn.Linear as one strided GEMM on the split-operand
+ * fp16 MFMA (fp32-grade products, fp32 accumulate), bias gradients as column sums, the activation derivatives, LayerNorm backward.
+ * Every reduction over tokens is "per-part partial sums + nmrf_sum_partials_f32 in fixed order": deterministic.
+ *
+ * C[M,N] = op(A)[M,K] . op(B)[K,N]: element (i,k) of op(A) at A[i*sa_i + k*sa_k], element (k,j) of op(B) at B[k*sb_k + j*sb_j].
+ *   dgrad   dx = dy . W       : A = dy [T,N] (sa_i = N, sa_k = 1), B = W [N,K] (sb_k = K, sb_j = 1)            (torch: grad_input of F.linear)
+ *   wgrad   dW = dy^T . x     : A = dy (sa_i = 1, sa_k = N), B = x [T,K] (sb_k = K, sb_j = 1), reduction over the T tokens
+ *   forward y  = x . W^T      : A = x [T,K] (sa_i = K, sa_k = 1), B = W (sb_k = 1, sb_j = K)                   (recomputation of saved-for-backward values)
+ * splits > 1: the K range is cut into `splits` parts, part s writes its product to C + s*split_stride (>= M*ldc); the caller sums them.
+ * range_flag: the fp16 range guard of the split operands (see the top of this header), may be NULL. */
+int nmrf_gemm_split_f32(const float *A, int64_t sa_i, int64_t sa_k, const float *B, int64_t sb_k, int64_t sb_j, int M, int N, int K,
+                        float *C, int ldc, int splits, int64_t split_stride, int *range_flag, void *stream);
+/* out[i] = sum_{s < S} parts[s*stride + i], s ascending (i < n). */
+int nmrf_sum_partials_f32(const float *parts, int S, int64_t n, int64_t stride, float *out, void *stream);
+/* parts[b][n] = sum of x[t][n] over the rows_per_block rows of block b (b < ceil(T / rows_per_block)): the bias gradient's first pass. */
+int nmrf_colsum_partials_f32(const float *x, int64_t T, int N, int rows_per_block, float *parts, void *stream);
+/* pre_out = pre_in + bias (bias, pre_out may be NULL; pre_out may alias pre_in); act_out (may be NULL) = act(pre_in + bias):
+ * act 0 identity, 1 ReLU, 2 GELU(erf) with the forward kernels' own gelu_fast (nn.ReLU / nn.GELU of NMP.py:54-66, timm Mlp). */
+int nmrf_bias_act_f32(const float *pre_in, const float *bias, int64_t T, int N, int act, float *pre_out, float *act_out, void *stream);
+/* dx = dy * act'(pre): act 1 ReLU (pre > 0), 2 GELU(erf): Phi(pre) + pre * phi(pre). */
+int nmrf_act_bwd_f32(const float *pre, const float *dy, int64_t n, int act, float *dx, void *stream);
+/* nn.LayerNorm over the last dimension, C in {64, 128, 256, 512} (NMP.py: every norm of the path has C = 128). */
+int nmrf_layernorm_f32(const float *x, const float *g, const float *b, int64_t T, int C, float eps, float *y, void *stream);
+/* its backward: dx [T,C]; part_dg / part_db [4*blocks][C]: per-wave partial sums of dy*xhat and dy (then nmrf_sum_partials_f32). */
+int nmrf_layernorm_bwd_f32(const float *x, const float *g, const float *dy, int64_t T, int C, float eps, int blocks, float *dx,
+                           float *part_dg, float *part_db, void *stream);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnmrf_hip.so")      # (tools may point this at another build BEFORE the first load(): bench.py --lib)
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -66,6 +66,13 @@ PROTOTYPES = {
     "nmrf_selftest_mfma_f32": [_P, _P, _I, _P, _P],
     "nmrf_selftest_mfma_f16split": [_P, _P, _I, _I, _P, _P],
     "nmrf_selftest_lds_dma": [_P, _P, _I, _P],
+    "nmrf_gemm_split_f32": [_P, _L, _L, _P, _L, _L, _I, _I, _I, _P, _I, _I, _L, _P, _P],
+    "nmrf_sum_partials_f32": [_P, _I, _L, _L, _P, _P],
+    "nmrf_colsum_partials_f32": [_P, _L, _I, _I, _P, _P],
+    "nmrf_bias_act_f32": [_P, _P, _L, _I, _I, _P, _P, _P],
+    "nmrf_act_bwd_f32": [_P, _P, _L, _I, _P, _P],
+    "nmrf_layernorm_f32": [_P, _P, _P, _L, _I, _F, _P, _P],
+    "nmrf_layernorm_bwd_f32": [_P, _P, _P, _L, _I, _F, _I, _P, _P, _P, _P],
 }
 
 # exported only by libnmrf_hip_debug.so (include/nmrf_hip_debug.h): reference kernels for A/B runs, never launched by the product

@@ -1095,3 +1095,100 @@ def msda_backward(value, shapes, lvl_start, loc, w, grad_out):
     _lib.check(fn(_p(value), _p(shapes), _p(lvl_start), _p(loc), _p(w), _p(grad_out), b, s, m, d, l, lq, p, _p(gv), _p(gl),
                   _p(gw), _stream()), "msda_backward")
     return gv, gl, gw
+
+
+# ---- N4, first slice: the pieces of a backward pass through the token-linear chains (csrc/backward.hip, include/nmrf_hip.h) -------------
+def _gemm(a, sa_i, sa_k, b, sb_k, sb_j, m, n, k, splits=1):
+    """C[m,n] = op(A) . op(B) on the split-fp16 MFMA with explicit element strides; splits > 1: K split + fixed-order sum."""
+    _chk(a, b)
+    out = torch.empty(m, n, device=a.device, dtype=torch.float32)
+    if splits <= 1:
+        _lib.check(_lib.load().nmrf_gemm_split_f32(_p(a), sa_i, sa_k, _p(b), sb_k, sb_j, m, n, k, _p(out), n, 1, 0, _rf(a), _stream()), "gemm_split")
+        return out
+    parts = torch.empty(splits, m, n, device=a.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_gemm_split_f32(_p(a), sa_i, sa_k, _p(b), sb_k, sb_j, m, n, k, _p(parts), n, splits, m * n, _rf(a), _stream()),
+               "gemm_split")
+    _lib.check(_lib.load().nmrf_sum_partials_f32(_p(parts), splits, m * n, m * n, _p(out), _stream()), "sum_partials")
+    return out
+
+
+@_on_device
+def linear_forward(x, w):
+    """x [T,K] . w [N,K]^T -> [T,N] (no bias): the recomputation of a saved-for-backward pre-activation."""
+    t, k = x.shape
+    return _gemm(x, k, 1, w, 1, k, t, w.shape[0], k)
+
+
+@_on_device
+def linear_dgrad(dy, w):
+    """dy [T,N], w [N,K] -> dx [T,K] = dy . w."""
+    t, n = dy.shape
+    return _gemm(dy, n, 1, w, w.shape[1], 1, t, w.shape[1], n)
+
+
+@_on_device
+def linear_wgrad(dy, x):
+    """dy [T,N], x [T,K] -> dW [N,K] = dy^T . x (reduction over the T tokens, split into <= 256 deterministic parts)."""
+    t, n = dy.shape
+    k = x.shape[1]
+    tiles = ((n + 31) // 32) * ((k + 31) // 32)
+    splits = max(1, min(256, (t + 511) // 512, max(1, 2048 // tiles)))
+    return _gemm(dy, 1, n, x, k, 1, n, k, t, splits=splits)
+
+
+@_on_device
+def bias_grad(dy):
+    """dy [T,N] -> [N] column sums (two deterministic passes)."""
+    _chk(dy)
+    t, n = dy.shape
+    rpb = max(64, (t + 1023) // 1024)
+    nb = (t + rpb - 1) // rpb
+    parts = torch.empty(nb, n, device=dy.device, dtype=torch.float32)
+    out = torch.empty(n, device=dy.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_colsum_partials_f32(_p(dy), t, n, rpb, _p(parts), _stream()), "colsum_partials")
+    _lib.check(_lib.load().nmrf_sum_partials_f32(_p(parts), nb, n, n, _p(out), _stream()), "sum_partials")
+    return out
+
+
+@_on_device
+def bias_act(pre, bias, act, want_pre=True):
+    """(pre + bias, act(pre + bias)); act 0 identity, 1 ReLU, 2 GELU(erf)."""
+    _chk(pre, bias)
+    t, n = pre.shape
+    pre_out = torch.empty_like(pre) if want_pre else None
+    act_out = torch.empty_like(pre) if act else None
+    _lib.check(_lib.load().nmrf_bias_act_f32(_p(pre), _p(bias), t, n, act, _p(pre_out), _p(act_out), _stream()), "bias_act")
+    return pre_out, (act_out if act else pre_out)
+
+
+@_on_device
+def act_backward(pre, dy, act):
+    _chk(pre, dy)
+    dx = torch.empty_like(dy)
+    _lib.check(_lib.load().nmrf_act_bwd_f32(_p(pre), _p(dy), dy.numel(), act, _p(dx), _stream()), "act_bwd")
+    return dx
+
+
+@_on_device
+def layer_norm(x, g, b, eps):
+    _chk(x, g, b)
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().nmrf_layernorm_f32(_p(x), _p(g), _p(b), x.shape[0], x.shape[1], float(eps), _p(y), _stream()), "layernorm")
+    return y
+
+
+@_on_device
+def layer_norm_backward(x, g, dy, eps):
+    """-> (dx [T,C], dg [C], db [C])"""
+    _chk(x, g, dy)
+    t, c = x.shape
+    blocks = max(1, min(512, (t + 31) // 32))
+    dx = torch.empty_like(x)
+    pg = torch.empty(4 * blocks, c, device=x.device, dtype=torch.float32)
+    pb = torch.empty_like(pg)
+    _lib.check(_lib.load().nmrf_layernorm_bwd_f32(_p(x), _p(g), _p(dy), t, c, float(eps), blocks, _p(dx), _p(pg), _p(pb), _stream()), "layernorm_bwd")
+    dg = torch.empty(c, device=x.device, dtype=torch.float32)
+    db = torch.empty_like(dg)
+    _lib.check(_lib.load().nmrf_sum_partials_f32(_p(pg), 4 * blocks, c, c, _p(dg), _stream()), "sum_partials")
+    _lib.check(_lib.load().nmrf_sum_partials_f32(_p(pb), 4 * blocks, c, c, _p(db), _stream()), "sum_partials")
+    return dx, dg, db

@@ -1,0 +1,116 @@
+"""N4, first slice: torch.autograd.Functions over the HIP kernels, so that a loss evaluated on the training-mode forward
+can be differentiated with respect to the parameters that sit between the last attention kernel of a stage and the loss.
+
+The reference differentiates its whole forward with autograd (nmrf/models/NMRF.py:387-429, main.py:413-430) and detaches the two
+discrete hand-overs between stages (`labels_curr`, NMRF.py:215; `disp_curr`, NMRF.py:231).  The gradients of the three prediction heads
+(`infer_head`, `infer_score_head`, `refine_head`), of the two stage-final LayerNorms and of a stage's LAST message-passing block therefore
+depend only on tensors the forward already holds -- the per-layer token rows -- and not on a backward of the attention kernels, which
+this build does not have (their autograd would be the next slice).
+
+Every Function's FORWARD is the product's fused launch (the same bits the forward-only path returns); its backward recomputes the
+intermediates from the saved inputs and composes dgrad / wgrad / bias / activation / LayerNorm pieces of csrc/backward.hip
+(nmrf_amd.kernels.linear_dgrad, linear_wgrad, bias_grad, act_backward, layer_norm_backward): split-operand fp16 MFMA GEMMs with fp32
+accumulation, deterministic token reductions.  The only torch arithmetic in a backward is the addition of two gradient tensors where a
+residual branch joins (plumbing, as in autograd's own AccumulateGrad)."""
+import torch
+
+from .. import kernels as K
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b.  fwd(x) -> y is the product's launch for this layer."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, fwd):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _c(dy)
+        dx = K.linear_dgrad(dy, w) if ctx.needs_input_grad[0] else None
+        return dx, K.linear_wgrad(dy, x), (K.bias_grad(dy) if ctx.has_bias else None), None
+
+
+class MlpHeadFn(torch.autograd.Function):
+    """y = L3(relu(L2(relu(L1 x))))  (MLP of NMP.py:54-66: the prediction heads).  fwd(x) -> y: the fused chain launch."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, w3, b3, fwd):
+        ctx.save_for_backward(x, w1, b1, w2, b2, w3)
+        return fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, b1, w2, b2, w3 = ctx.saved_tensors
+        dy = _c(dy)
+        p1, a1 = K.bias_act(K.linear_forward(x, w1), b1, 1)              # recomputed, not saved: [T,128] rows twice
+        p2, a2 = K.bias_act(K.linear_forward(a1, w2), b2, 1)
+        dw3, db3 = K.linear_wgrad(dy, a2), K.bias_grad(dy)
+        d2 = K.act_backward(p2, K.linear_dgrad(dy, w3), 1)
+        dw2, db2 = K.linear_wgrad(d2, a1), K.bias_grad(d2)
+        d1 = K.act_backward(p1, K.linear_dgrad(d2, w2), 1)
+        dw1, db1 = K.linear_wgrad(d1, x), K.bias_grad(d1)
+        dx = K.linear_dgrad(d1, w1) if ctx.needs_input_grad[0] else None
+        return dx, dw1, db1, dw2, db2, dw3, db3, None
+
+
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm over the last dimension (the stage-final `norm` of Inference / Refinement, NMP.py:777-798, 879-898)."""
+
+    @staticmethod
+    def forward(ctx, x, g, b, eps):
+        ctx.save_for_backward(x, g)
+        ctx.eps = eps
+        return K.layer_norm(x, g, b, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g = ctx.saved_tensors
+        dx, dg, db = K.layer_norm_backward(x, g, _c(dy), ctx.eps)
+        return (dx if ctx.needs_input_grad[0] else None), dg, db, None
+
+
+class BlockFn(torch.autograd.Function):
+    """One message-passing block without its q stage (SwinNMP / CSWinNMP.forward_pre, NMP.py:337-364, 537-574):
+           x1 = x + proj(msg);   x2 = x1 + fc2(gelu(fc1(LayerNorm2(x1))))
+    fwd() -> x2 is the product's fused nmp_block16 launch on the same operands."""
+
+    @staticmethod
+    def forward(ctx, x, msg, wp, bp, g2, b2n, w1, b1, w2, b2, eps, fwd):
+        ctx.save_for_backward(x, msg, wp, bp, g2, b2n, w1, b1, w2)
+        ctx.eps = eps
+        return fwd()
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, msg, wp, bp, g2, b2n, w1, b1, w2 = ctx.saved_tensors
+        dy = _c(dy)
+        _, proj = K.bias_act(K.linear_forward(msg, wp), bp, 0)
+        x1 = x + proj
+        ln = K.layer_norm(x1, g2, b2n, ctx.eps)
+        p, h = K.bias_act(K.linear_forward(ln, w1), b1, 2)
+        dw2, db2 = K.linear_wgrad(dy, h), K.bias_grad(dy)
+        dp = K.act_backward(p, K.linear_dgrad(dy, w2), 2)
+        dw1, db1 = K.linear_wgrad(dp, ln), K.bias_grad(dp)
+        dx1_ln, dg2, db2n = K.layer_norm_backward(x1, g2, K.linear_dgrad(dp, w1), ctx.eps)
+        dx1 = dy + dx1_ln                                              # the residual branch joins
+        dwp, dbp = K.linear_wgrad(dx1, msg), K.bias_grad(dx1)
+        dmsg = K.linear_dgrad(dx1, wp) if ctx.needs_input_grad[1] else None
+        return (dx1 if ctx.needs_input_grad[0] else None), dmsg, dwp, dbp, dg2, db2n, dw1, db1, dw2, db2, None, None
+
+
+def refine_epilogue_torch(delta16, disp_curr, training_hw=None):
+    """relu(disp_curr + delta) pixel-shuffled 4x4 (NMRF.py:238-245) as differentiable torch views for the training-mode loss:
+    delta16 [B*H4*W4, 16], disp_curr [B,H4,W4] -> (disp = 4 * disp_pred, disp_pred [B, 4*H4, 4*W4]).  (No un-padding: the training-mode
+    forward does not pad, NMRF.py:203-205.)"""
+    b, h4, w4 = disp_curr.shape
+    pred = torch.relu(disp_curr.reshape(b, h4, w4, 1) + delta16.view(b, h4, w4, 16))
+    pred = pred.view(b, h4, w4, 4, 4).permute(0, 1, 3, 2, 4).reshape(b, 4 * h4, 4 * w4)
+    return pred * 4, pred

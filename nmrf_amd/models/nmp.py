@@ -640,6 +640,11 @@ class Inference(nn.Module):
         keep = None
         if collect is not None and to_dense is not None:
             keep = (to_dense >= 0).nonzero().squeeze(1)
+        # keep_pre_norm (set by NMRF.enable_grad_slice): the training-mode forward also keeps every layer's residual stream BEFORE the
+        # stage-final LayerNorm on the dense grid (`_pre_norm`), the saved input of that norm's backward (models/autograd_ops.py)
+        keep_pre = collect is not None and getattr(self, "keep_pre_norm", False)
+        if keep_pre:
+            self._pre_norm = []
         n = pdims[3]
         if not hasattr(self, "_launch"):
             sites = []                                                   # (kind, module) in execution order
@@ -700,17 +705,23 @@ class Inference(nn.Module):
             last = i + 1 == len(self._sites)
             if last and self.norm is not None and to_dense is not None:       # final norm, cropped to the dense grid on the way out
                 ln = torch.empty(t_dense, self.dim, device=x.device)
-                self._launch[i + 1](x, msg, enc, 1, want_x=False, ln_out=ln, ln_out_map=to_dense)
+                xo, _, _ = self._launch[i + 1](x, msg, enc, 1, want_x=keep_pre, ln_out=ln, ln_out_map=to_dense)
                 if collect is not None:
                     collect.append(ln)
+                if keep_pre:
+                    self._pre_norm.append(xo.index_select(0, keep).contiguous())
                 return ln
-            x, qkv, ln = self._launch[i + 1](x, msg, enc, 1, want_x=not last or self.norm is None, attn_qkv=attn_qkv)
+            x, qkv, ln = self._launch[i + 1](x, msg, enc, 1, want_x=not last or self.norm is None or keep_pre, attn_qkv=attn_qkv)
             if collect is not None and kind == "win":
+                xd = None
+                if not last or keep_pre:
+                    xd = (x if keep is None else x.index_select(0, keep)).contiguous()
+                if keep_pre:
+                    self._pre_norm.append(xd)
                 if last:
                     collect.append(ln)
                 else:
-                    xd = x if keep is None else x.index_select(0, keep)
-                    collect.append(K.ln_concat(xd.contiguous(), self.norm.weight, self.norm.bias, ld=self.dim, eps=self.norm.eps))
+                    collect.append(K.ln_concat(xd, self.norm.weight, self.norm.bias, ld=self.dim, eps=self.norm.eps))
         if to_dense is not None:
             keep = (to_dense >= 0).nonzero().squeeze(1)
             return (ln if self.norm is not None else x).index_select(0, keep)

@@ -161,6 +161,54 @@ class NMRF(nn.Module):
             K.check_range(self.device)
         return out
 
+    def enable_grad_slice(self, on=True):
+        """N4, first slice: in training mode, build an autograd graph over the part of the forward that lies between the last
+        attention kernel of a stage and the outputs -- the stage-final LayerNorms and the three prediction heads on every layer's
+        rows (models/autograd_ops.py: forward = the fused HIP launches, backward = csrc/backward.hip) -- so that
+        `Criterion(model(sample)).backward()` leaves the REFERENCE's gradients in `.grad` of those 18 tensors (`labels_curr` and
+        `disp_curr` are detached by the reference too, NMRF.py:215,231).  Every other parameter gets no gradient: the attention /
+        convolution kernels are forward-only (the next slice).  Off by default; eval mode ignores it."""
+        self.grad_slice = bool(on)
+        self.inference.keep_pre_norm = self.refinement.keep_pre_norm = bool(on)
+        return self
+
+    def _tail_with_grad(self, labels_curr, dims8, heads4, tok4, out_hw, prob, label_seeds):
+        """The tail of hot_path in training mode with grad_slice: norms + heads of every layer under autograd."""
+        from .autograd_ops import LayerNormFn, LinearFn, MlpHeadFn, refine_epilogue_torch
+        from .nmp import _ChainLauncher
+        b, h8, w8, n = dims8
+        if not hasattr(self, "_score"):
+            self._score = _ChainLauncher(3, (self.infer_score_head,), (128,), self.infer_score_head.out_features)
+        un = lambda x: x.reshape(b, h8, w8, n, 8, 8).permute(0, 1, 4, 2, 5, 3).reshape(b, h8 * 8, w8 * 8, n)
+        lab = labels_curr.reshape(-1, 1)
+
+        def head(mlp, rows):
+            l = mlp.layers
+            return MlpHeadFn.apply(rows, l[0].weight, l[0].bias, l[1].weight, l[1].bias, l[2].weight, l[2].bias, lambda t: mlp(t))
+
+        with torch.enable_grad():
+            nm = self.inference.norm
+            aux, delta, score = [], None, None
+            for pre in self.inference._pre_norm:
+                rows = LayerNormFn.apply(pre, nm.weight, nm.bias, nm.eps)
+                delta = head(self.infer_head, rows)
+                score = LinearFn.apply(rows, self.infer_score_head.weight, self.infer_score_head.bias, lambda t: self._score(t, 128))
+                aux.append({"disp_pred": un(torch.relu(lab + delta)), "logits_pred": un(0.25 * score)})
+            disp_curr = K.wta_median(delta.detach().contiguous(), score.detach().contiguous(), labels_curr.reshape(-1).contiguous(), b, h8, w8, n)
+            fmap1, fmap2, fmap1_gw, fmap2_gw = heads4
+            with torch.no_grad():
+                self.refinement(disp_curr, fmap1, fmap2, fmap1_gw, fmap2_gw, token_major=tok4)
+            nm4 = self.refinement.norm
+            preds = []
+            for pre in self.refinement._pre_norm:
+                rows = LayerNormFn.apply(pre, nm4.weight, nm4.bias, nm4.eps)
+                preds.append(refine_epilogue_torch(head(self.refine_head, rows), disp_curr))
+        out = {"proposal": labels_curr.reshape(b, -1, n), "prob": prob, "initial_proposal": label_seeds.reshape(b, -1, n),
+               "disp": preds[-1][0], "disp_pred": preds[-1][1]}
+        if self.aux_loss:
+            out["aux_outputs"] = aux + [{"disp_pred": p[1]} for p in preds[:-1]]
+        return out
+
     def check_range(self):
         """Raise NmrfHipError if an activation left the fp16 range of the split-operand kernels since the last check (syncs)."""
         return K.check_range(self.device)
@@ -247,6 +295,10 @@ class NMRF(nn.Module):
         tgt_all = self.inference(labels_curr, fmap1, fmap2, fmap1_gw, fmap2_gw, token_major=tok8)    # [1 | layers, P, N, C]
         tgt = tgt_all[-1].reshape(-1, self.inference.dim)
         b, h8, w8 = fmap1_list[0].shape[0], fmap1_list[0].shape[2], fmap1_list[0].shape[3]
+        if self.training and getattr(self, "grad_slice", False) and stages is None:
+            if not (self.inference.return_intermediate and self.refinement.return_intermediate):
+                raise NotImplementedError("grad_slice: the training-mode forward with NMP.RETURN_INTERMEDIATE (the reference's default)")
+            return self._tail_with_grad(labels_curr, (b, h8, w8, n), heads4, tok4, (h0, w0), prob, label_seeds)
         from .nmp import _ChainLauncher, _FusedCache, _split
         hl = self.infer_head.layers
         if (stages is None and not self.training and _split() and n == 4 and len(hl) == 3

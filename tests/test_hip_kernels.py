@@ -1141,3 +1141,124 @@ def test_conv1x1_strided_shortcut(b, ci, co, h, w, stride, bias):
     got = kk.conv1x1(x.to(DEV), kk.pack_conv1x1(wt.to(DEV)), ci, stride, None if bs is None else bs.to(DEV)).cpu()
     ref = F.conv2d(x.double(), wt.double(), None if bs is None else bs.double(), stride)
     report("conv1x1 stride %d" % stride, got, ref, 2e-5, 1e-5)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# N4, first slice: backward pieces (csrc/backward.hip) and the autograd Functions over the fused forward launches
+# --------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("t_,n,k", [(64, 128, 128), (777, 64, 128), (5000, 512, 128), (33, 16, 128), (1030, 128, 512), (40000, 128, 128)])
+def test_backward_gemm_pieces_vs_fp64(t_, n, k):
+    """dgrad / wgrad / forward of an nn.Linear as the strided split-fp16 GEMM (nmrf_gemm_split_f32), bias gradient as column sums:
+    against fp64 matmuls; wgrad's K-split reduction is deterministic (two runs: same bits)."""
+    kk = K()
+    x, w, dy = rnd(t_, k, seed=1, scale=1.5), rnd(n, k, seed=2, scale=0.2), rnd(t_, n, seed=3)
+    xd, wd, dyd = x.double(), w.double(), dy.double()
+    tol = lambda ref: 2e-5 + 1e-5 * ref.abs().max()
+    y = kk.linear_forward(x.to(DEV), w.to(DEV)).cpu()
+    report("linear_forward", y, xd @ wd.T, float(tol(xd @ wd.T)))
+    dx = kk.linear_dgrad(dy.to(DEV), w.to(DEV)).cpu()
+    report("linear_dgrad", dx, dyd @ wd, float(tol(dyd @ wd)))
+    ref_w = dyd.T @ xd
+    dw = kk.linear_wgrad(dy.to(DEV), x.to(DEV))
+    report("linear_wgrad", dw.cpu(), ref_w, float(2e-5 + 3e-6 * ref_w.abs().max() + 1e-7 * t_ ** 0.5))
+    assert torch.equal(dw, kk.linear_wgrad(dy.to(DEV), x.to(DEV))), "wgrad must be deterministic"
+    db = kk.bias_grad(dy.to(DEV))
+    report("bias_grad", db.cpu(), dyd.sum(0), float(2e-5 + 2e-6 * dyd.sum(0).abs().max() + 1e-7 * t_ ** 0.5))   # fp32 sums of t_ terms
+    assert torch.equal(db, kk.bias_grad(dy.to(DEV)))
+
+
+@pytest.mark.parametrize("t_,c", [(64, 128), (1000, 128), (333, 64), (50, 512)])
+def test_backward_elementwise_pieces_vs_fp64(t_, c):
+    kk = K()
+    x, dy = rnd(t_, c, seed=5, scale=2.0), rnd(t_, c, seed=6)
+    g, b = 1.0 + 0.2 * rnd(c, seed=7), 0.1 * rnd(c, seed=8)
+    xd = x.double().requires_grad_(True)
+    gd, bd = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    yref = F.layer_norm(xd, (c,), gd, bd, 1e-5)
+    yref.backward(dy.double())
+    report("layer_norm", kk.layer_norm(x.to(DEV), g.to(DEV), b.to(DEV), 1e-5).cpu(), yref.detach(), 5e-6)
+    dx, dg, db = kk.layer_norm_backward(x.to(DEV), g.to(DEV), dy.to(DEV), 1e-5)
+    report("layer_norm dx", dx.cpu(), xd.grad, 1e-5)
+    report("layer_norm dg", dg.cpu(), gd.grad, 2e-5 + 1e-6 * t_ ** 0.5)
+    report("layer_norm db", db.cpu(), bd.grad, 2e-5 + 1e-6 * t_ ** 0.5)
+    for act, fn in ((1, F.relu), (2, F.gelu)):
+        pd = x.double().requires_grad_(True)
+        fn(pd).backward(dy.double())
+        report("act %d backward" % act, kk.act_backward(x.to(DEV), dy.to(DEV), act).cpu(), pd.grad, 2e-6)
+        bias = 0.3 * rnd(c, seed=9)
+        pre, a = kk.bias_act(x.to(DEV), bias.to(DEV), act)
+        report("bias_act pre", pre.cpu(), x.double() + bias.double(), 1e-6)
+        report("bias_act out", a.cpu(), fn(x.double() + bias.double()), 2e-6)
+
+
+@pytest.mark.parametrize("t_", [64, 1000])
+def test_autograd_functions_match_fp64_autograd(t_):
+    """The four Functions of nmrf_amd/models/autograd_ops.py (forward = the product's fused launch, backward = csrc/backward.hip)
+    against torch autograd of the same mathematics in fp64 -- what the oracle's functions are made of (oracle/nmrf_oracle.py: F.linear,
+    F.relu, F.gelu, F.layer_norm) -- on a 64-token case (and 1 000 tokens): every gradient <= 1e-4 relative to its largest entry."""
+    from nmrf_amd.models.autograd_ops import BlockFn, LayerNormFn, LinearFn, MlpHeadFn
+    from nmrf_amd.models.nmp import MLP, _ChainLauncher
+    kk = K()
+    dev = lambda v: v.to(DEV).requires_grad_(True)
+
+    def compare(tag, got, want):
+        for name, gt, wt in zip(tag[1], got, want):
+            scale = float(wt.abs().max())
+            report("%s d%s" % (tag[0], name), gt.cpu(), wt, 1e-4 * scale + 1e-7)
+
+    # --- prediction head (MLP 128 -> 128 -> 128 -> 64) and a single Linear (the score head)
+    torch.manual_seed(0)
+    mlp = MLP(128, 128, 64, 3)
+    for i, l in enumerate(mlp.layers):
+        l.weight.data = rnd(*l.weight.shape, seed=20 + i, scale=0.15)
+        l.bias.data = rnd(*l.bias.shape, seed=30 + i, scale=0.1)
+    mlp = mlp.to(DEV)
+    x, gy = rnd(t_, 128, seed=1, scale=1.5), rnd(t_, 64, seed=2)
+    xg = dev(x)
+    ps = [p for l in mlp.layers for p in (l.weight, l.bias)]
+    y = MlpHeadFn.apply(xg, *ps, lambda t: mlp(t))
+    assert torch.equal(y, mlp(x.to(DEV)))                         # the forward IS the fused chain launch
+    got = torch.autograd.grad(y, [xg] + ps, gy.to(DEV))
+    xd = x.double().requires_grad_(True)
+    pd = [p.detach().cpu().double().requires_grad_(True) for p in ps]
+    yd = F.linear(F.relu(F.linear(F.relu(F.linear(xd, pd[0], pd[1])), pd[2], pd[3])), pd[4], pd[5])
+    report("head forward", y.detach().cpu(), yd.detach(), 2e-5, 1e-5)
+    compare(("head", ["x", "w1", "b1", "w2", "b2", "w3", "b3"]), got, torch.autograd.grad(yd, [xd] + pd, gy.double()))
+
+    lin = torch.nn.Linear(128, 64)
+    lin.weight.data, lin.bias.data = rnd(64, 128, seed=40, scale=0.2), rnd(64, seed=41, scale=0.1)
+    lin = lin.to(DEV)
+    score = _ChainLauncher(3, (lin,), (128,), 64)
+    xg = dev(x)
+    y = LinearFn.apply(xg, lin.weight, lin.bias, lambda t: score(t, 128))
+    got = torch.autograd.grad(y, [xg, lin.weight, lin.bias], gy.to(DEV))
+    xd = x.double().requires_grad_(True)
+    wd_, bd_ = lin.weight.detach().cpu().double().requires_grad_(True), lin.bias.detach().cpu().double().requires_grad_(True)
+    yd = F.linear(xd, wd_, bd_)
+    report("linear forward", y.detach().cpu(), yd.detach(), 2e-5, 1e-5)
+    compare(("linear", ["x", "w", "b"]), got, torch.autograd.grad(yd, [xd, wd_, bd_], gy.double()))
+
+    # --- stage-final LayerNorm
+    g, b = dev(1.0 + 0.2 * rnd(128, seed=50)), dev(0.1 * rnd(128, seed=51))
+    xg, g128 = dev(x), rnd(t_, 128, seed=52)
+    y = LayerNormFn.apply(xg, g, b, 1e-5)
+    got = torch.autograd.grad(y, [xg, g, b], g128.to(DEV))
+    xd, gd, bd = x.double().requires_grad_(True), g.detach().cpu().double().requires_grad_(True), b.detach().cpu().double().requires_grad_(True)
+    compare(("norm", ["x", "g", "b"]), got, torch.autograd.grad(F.layer_norm(xd, (128,), gd, bd, 1e-5), [xd, gd, bd], g128.double()))
+
+    # --- a whole block: x1 = x + proj(msg); x2 = x1 + fc2(gelu(fc1(LN2(x1))))
+    msg = rnd(t_, 128, seed=60, scale=1.2)
+    names = ["x", "msg", "wp", "bp", "g2", "b2n", "w1", "b1", "w2", "b2"]
+    vals = [x, msg, rnd(128, 128, seed=61, scale=0.1), rnd(128, seed=62, scale=0.2), 1.0 + 0.1 * rnd(128, seed=63), 0.1 * rnd(128, seed=64),
+            rnd(512, 128, seed=65, scale=0.15), rnd(512, seed=66, scale=0.1), rnd(128, 512, seed=67, scale=0.08), rnd(128, seed=68, scale=0.1)]
+    tg = [dev(v) for v in vals]
+    stream, stages, inv = kk.block_stream16(tg[2].detach(), tg[6].detach(), tg[8].detach(), None, 0)
+    fwd = lambda: kk.nmp_block(tg[0].detach(), stream, stages, inv, tg[1].detach(), tg[3].detach(),
+                               (tg[4].detach(), tg[5].detach(), 1e-5, tg[7].detach(), tg[9].detach()), None, want_x=True)[0]
+    y = BlockFn.apply(*tg, 1e-5, fwd)
+    got = torch.autograd.grad(y, tg, g128.to(DEV))
+    td = [v.double().requires_grad_(True) for v in vals]
+    x1 = td[0] + F.linear(td[1], td[2], td[3])
+    yd = x1 + F.linear(F.gelu(F.linear(F.layer_norm(x1, (128,), td[4], td[5], 1e-5), td[6], td[7])), td[8], td[9])
+    report("block forward", y.detach().cpu(), yd.detach(), 2e-5, 1e-5)
+    compare(("block", names), got, torch.autograd.grad(yd, td, g128.double()))

@@ -714,3 +714,53 @@ def test_driver_two_forwards_in_flight():
     assert model.range_check is False                                   # gb still active
     gb.close()
     assert model.range_check is True
+
+
+def test_training_backward_slice_matches_reference_gradients():
+    """N4, first slice: model.train() + enable_grad_slice(): the loss of one training step (main.py:413-420: sum_k weight_dict[k] *
+    loss_dict[k] of the reference's Criterion, restated in nmrf_amd.models.criterion) is differentiated through the prediction heads and
+    the stage-final LayerNorms on the HIP kernels (models/autograd_ops.py, csrc/backward.hip) and `.grad` of those 18 tensors equals the
+    REFERENCE's own autograd gradients (tests/golden/e2e_train.npz `grad/*`, tools/gen_golden.py:run_train) -- the forward fed with
+    the features the reference saw, so the label seeds are bit-exact.  Parameters behind an attention kernel get no gradient."""
+    from nmrf_amd.models.criterion import build_criterion
+    from tests.conftest import record_note
+    from tests.util import golden_images, make_cfg
+    g = golden("e2e_train")
+    md = int(g["max_disp"])
+    w, cfg = oracle_weights(md), oracle_cfg(md)
+    img1, img2 = golden_images(g)
+    with torch.no_grad():
+        st = O.forward(w, cfg, img1, img2, return_stages=True, training=True)["stages"]
+    fl, fr = [st["fmap8_l"].to(DEV), st["fmap4_l"].to(DEV)], [st["fmap8_r"].to(DEV), st["fmap4_r"].to(DEV)]
+    model = build_product(md, DEV).train().enable_grad_slice()
+    with torch.no_grad():                                    # (model(sample) runs under no_grad too; the slice re-enables grad itself)
+        out = model.hot_path(fl, fr, tuple(g["disp"].shape[-2:]))
+    assert torch.equal(out["initial_proposal"].cpu().long(), t(g["seeds"]).long())
+    assert out["disp_pred"].requires_grad and out["aux_outputs"][0]["logits_pred"].requires_grad
+    report("disp_pred", out["disp_pred"].detach().cpu(), t(g["disp_pred"]), 4e-4)
+    crit = build_criterion(make_cfg(md))
+    losses = crit(out, {"disp": t(g["gt"]).to(DEV), "valid": t(g["valid"]).to(DEV)})
+    total = sum(losses[k] * crit.weight_dict[k] for k in losses if k in crit.weight_dict)
+    assert abs(float(total) - float(g["loss_total"])) <= 2e-4 * abs(float(g["loss_total"])), (float(total), float(g["loss_total"]))
+    model.zero_grad(set_to_none=True)
+    total.backward()
+    worst = {}
+    named = dict(model.named_parameters())
+    for key in [k for k in g if k.startswith("grad/")]:
+        name = key[5:]
+        want, got = t(g[key]), named[name].grad
+        assert got is not None, name + ": no gradient"
+        scale = float(want.abs().max())
+        err = float((got.cpu().double() - want.double()).abs().max())
+        worst[name] = err / max(scale, 1e-6)
+        # relative to the tensor's largest entry; the score head's bias gradient is zero in exact arithmetic (softmax shift invariance).
+        # Not tighter than 1e-2: the loss is L1 (SOLVER.LOSS_TYPE), whose derivative sign(pred - gt) / count flips at every pixel where
+        # the GPU's and the reference's prediction (1e-4 apart) straddle the target -- measured 2e-3 of the largest entry
+        assert err <= 1e-2 * scale + 2e-6, (name, err, scale)
+    record_note("training backward slice: %d parameter gradients vs the reference's autograd, worst max|d| / max|ref| = %.1e (%s)" % (
+        len(worst), max(worst.values()), max(worst, key=worst.get)))
+    no_grad = [n for n, p in named.items() if p.grad is None]
+    assert "inference.layers.4.nmp.mlp.fc2.weight" in no_grad and "dpn.mlp.0.weight" in no_grad       # forward-only kernels behind them
+    # eval mode is untouched by the switch
+    ev = model.eval()({"img1": img1, "img2": img2})
+    assert not ev["disp"].requires_grad and "aux_outputs" not in ev

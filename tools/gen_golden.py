@@ -145,6 +145,20 @@ def run_train():
             d["aux%d_%s" % (i, k)] = _np(v)
     for k, v in losses.items():
         d["loss/" + k] = _np(torch.as_tensor(v))
+    # the reference's own parameter gradients of one training step's loss (main.py:413-420: sum_k weight_dict[k] * loss_dict[k], backward):
+    # the three prediction heads and the two stage-final LayerNorms -- every parameter between the last attention kernel of a stage
+    # and the loss (labels_curr and disp_curr are detached by the reference, NMRF.py:215,231: these gradients do not cross the stages)
+    model.zero_grad(set_to_none=True)
+    out_g = model({"img1": img1.clone().float(), "img2": img2.clone().float()})
+    loss_g = crit(out_g, {"disp": gt, "valid": valid})
+    total = sum(loss_g[k] * crit.weight_dict[k] for k in loss_g if k in crit.weight_dict)
+    total.backward()
+    d["loss_total"] = _np(total)
+    for name, p in model.named_parameters():
+        if name.startswith(("infer_head.", "infer_score_head.", "refine_head.", "inference.norm.", "refinement.norm.")):
+            d["grad/" + name] = _np(p.grad)
+    for k in ("disp", "disp_pred"):
+        assert np.array_equal(_np(out_g[k]), d[k]), k                    # the same forward with and without no_grad
     path = os.path.join(OUT, "e2e_train.npz")
     np.savez_compressed(path, **d)
     print("e2e_train", {k: v.shape for k, v in d.items() if hasattr(v, "shape")}, os.path.getsize(path) // 1024, "KiB")
