@@ -710,8 +710,12 @@ class Inference(nn.Module):
                     collect.append(ln)
                 if keep_pre:
                     self._pre_norm.append(xo.index_select(0, keep).contiguous())
+                    self._last_block = (x, msg, xo, m, keep)        # the last block's operands on the padded grid (autograd_ops.BlockFn)
                 return ln
+            x_in = x
             x, qkv, ln = self._launch[i + 1](x, msg, enc, 1, want_x=not last or self.norm is None or keep_pre, attn_qkv=attn_qkv)
+            if keep_pre and last and kind == "win":
+                self._last_block = (x_in, msg, x, m, keep)
             if collect is not None and kind == "win":
                 xd = None
                 if not last or keep_pre:

@@ -165,7 +165,8 @@ class NMRF(nn.Module):
         """N4, first slice: in training mode, build an autograd graph over the part of the forward that lies between the last
         attention kernel of a stage and the outputs -- the stage-final LayerNorms and the three prediction heads on every layer's
         rows (models/autograd_ops.py: forward = the fused HIP launches, backward = csrc/backward.hip) -- so that
-        `Criterion(model(sample)).backward()` leaves the REFERENCE's gradients in `.grad` of those 18 tensors (`labels_curr` and
+        `Criterion(model(sample)).backward()` leaves the REFERENCE's gradients in `.grad` of those 18 tensors + the 16 of the two stages'
+        LAST message-passing blocks (proj, norm2, fc1, fc2: autograd_ops.BlockFn) (`labels_curr` and
         `disp_curr` are detached by the reference too, NMRF.py:215,231).  Every other parameter gets no gradient: the attention /
         convolution kernels are forward-only (the next slice).  Off by default; eval mode ignores it."""
         self.grad_slice = bool(on)
@@ -186,10 +187,22 @@ class NMRF(nn.Module):
             l = mlp.layers
             return MlpHeadFn.apply(rows, l[0].weight, l[0].bias, l[1].weight, l[1].bias, l[2].weight, l[2].bias, lambda t: mlp(t))
 
+        def last_rows(stage):
+            """The last layer's residual stream as a function of that layer's OWN block parameters (proj, norm2, fc1, fc2): its
+            operands x, msg are constants of the backward (msg comes out of a forward-only attention kernel), its output is the
+            fused launch's -- the rows every earlier layer contributed stay detached."""
+            from .autograd_ops import BlockFn
+            x_in, msg, x_out, m, keep = stage._last_block
+            y = BlockFn.apply(x_in, msg, m.proj.weight, m.proj.bias, m.norm2.weight, m.norm2.bias, m.mlp.fc1.weight, m.mlp.fc1.bias,
+                              m.mlp.fc2.weight, m.mlp.fc2.bias, m.norm2.eps, lambda: x_out)
+            return y if keep is None else y.index_select(0, keep)
+
         with torch.enable_grad():
             nm = self.inference.norm
             aux, delta, score = [], None, None
-            for pre in self.inference._pre_norm:
+            pres = list(self.inference._pre_norm)
+            pres[-1] = last_rows(self.inference)
+            for pre in pres:
                 rows = LayerNormFn.apply(pre, nm.weight, nm.bias, nm.eps)
                 delta = head(self.infer_head, rows)
                 score = LinearFn.apply(rows, self.infer_score_head.weight, self.infer_score_head.bias, lambda t: self._score(t, 128))
@@ -200,7 +213,9 @@ class NMRF(nn.Module):
                 self.refinement(disp_curr, fmap1, fmap2, fmap1_gw, fmap2_gw, token_major=tok4)
             nm4 = self.refinement.norm
             preds = []
-            for pre in self.refinement._pre_norm:
+            pres = list(self.refinement._pre_norm)
+            pres[-1] = last_rows(self.refinement)
+            for pre in pres:
                 rows = LayerNormFn.apply(pre, nm4.weight, nm4.bias, nm4.eps)
                 preds.append(refine_epilogue_torch(head(self.refine_head, rows), disp_curr))
         out = {"proposal": labels_curr.reshape(b, -1, n), "prob": prob, "initial_proposal": label_seeds.reshape(b, -1, n),

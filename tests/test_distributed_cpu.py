@@ -118,3 +118,39 @@ def test_numa_pinning_from_a_sysfs_tree(tmp_path):
     assert a["pinned"] is False and a["numa_node"] == -1 and b0 == allowed
     assert m["pinned"] is False and "why" in m
     assert b["pinned"] is True and b["numa_node"] == 1 and b["cpus"] == 1 and after == [first]
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nmrf_amd.train import allreduce_gradients
+        torch.manual_seed(0)
+        ps = [torch.nn.Parameter(torch.zeros(3, 5)), torch.nn.Parameter(torch.zeros(7)), torch.nn.Parameter(torch.zeros(2, 2))]
+        ps[2].requires_grad_(False)                                   # frozen: not part of the bucket
+        ps[0].grad = torch.full((3, 5), float(rank + 1))
+        if rank == 0:
+            ps[1].grad = torch.arange(7.0)                             # rank 1 has no gradient for this one: zeros
+        n = allreduce_gradients(ps)
+        ok = (n == 22 and torch.allclose(ps[0].grad, torch.full((3, 5), 1.5)) and torch.allclose(ps[1].grad, torch.arange(7.0) / 2)
+              and ps[2].grad is None)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_bucket_allreduce_world2():
+    """nmrf_amd.train.allreduce_gradients: the DDP gradient average of main.py:334-339 as one flat bucket (gloo here, RCCL on GPUs)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
+    from nmrf_amd.train import allreduce_gradients
+    assert allreduce_gradients([torch.nn.Parameter(torch.zeros(2))]) == 0           # no process group: identity

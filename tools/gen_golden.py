@@ -155,7 +155,9 @@ def run_train():
     total.backward()
     d["loss_total"] = _np(total)
     for name, p in model.named_parameters():
-        if name.startswith(("infer_head.", "infer_score_head.", "refine_head.", "inference.norm.", "refinement.norm.")):
+        last = ("inference.layers.4.nmp.", "refinement.layers.4.nmp.")          # + the LAST block of either stage: proj, norm2, mlp
+        if name.startswith(("infer_head.", "infer_score_head.", "refine_head.", "inference.norm.", "refinement.norm.")) or (
+                name.startswith(last) and name.split(".nmp.")[1].split(".")[0] in ("proj", "norm2", "mlp")):
             d["grad/" + name] = _np(p.grad)
     for k in ("disp", "disp_pred"):
         assert np.array_equal(_np(out_g[k]), d[k]), k                    # the same forward with and without no_grad
