@@ -3,7 +3,7 @@
 # Outputs under gpurun_out/.   TAG=r02a tools/gpu_round.sh [quick]
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
 REPO=$(pwd)
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 mkdir -p gpurun_out
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 rm -f gpurun_out/e2e_stats.jsonl
@@ -16,6 +16,8 @@ if [ -z "$LEAN" ]; then      # LEAN=1: tests, smoke, bench and the kernel trace 
 ( timeout 600 python tools/kernel_bench.py --iters 20 --which window,stripe,refine,block 2>&1 | grep -v stamp | tail -60 ) > gpurun_out/kernel_bench_block.log
 fi
 if [ "$1" != "quick" ]; then
+  # the RCCL path on the one GPU of the box (1-rank group, the gather in the loop) + BASELINE config 4's per-GPU shard as its own record
+  ( timeout 600 python bench.py --steps 20 --warmup 5 --force-dist --config4 --no-cpu-baseline --no-stream-figure 2>&1 | grep '^{' | tail -1 ) > gpurun_out/bench_config4.log
   # the other BASELINE configs: bench lines kept under profiles/
   ( timeout 600 python bench.py --steps 10 --warmup 3 --infer-layers 4 --no-cpu-baseline 2>&1 | tail -2 ) > gpurun_out/bench_infer4.log
   ( timeout 600 python bench.py --steps 5 --warmup 2 --batch 8 --no-cpu-baseline 2>&1 | tail -2 ) > gpurun_out/bench_kitti_b8.log
