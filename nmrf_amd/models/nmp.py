@@ -474,10 +474,14 @@ class Propagation(nn.Module):
                 else:
                     self._launch.append(_BlockLauncher(m.proj, (m.norm2, m.mlp)))
         _, qkv, _ = self._launch[0](x, None, ctx, n, want_x=False)
+        keep_pre = self.training and getattr(self, "keep_pre_norm", False)      # NMRF.enable_grad_slice: see Inference._run_blocks
         for i, m in enumerate(L):
             msg = K.stripe_attn(qkv, m.attns[0].get_v.weight, m.attns[1].get_v.weight, b, h, wd, n, kv16=kv16)
             last = i + 1 == len(L)
-            x, qkv, ln = self._launch[i + 1](x, msg, ctx, n, want_x=not last or self.norm is None)
+            x_in = x
+            x, qkv, ln = self._launch[i + 1](x, msg, ctx, n, want_x=not last or self.norm is None or keep_pre)
+            if last and keep_pre:
+                self._last_block = (x_in, msg, x, m, None)
         return ln if self.norm is not None else x
 
     def __init__(self, embed_dim, cost_group, layers, norm=None):

@@ -165,12 +165,13 @@ class NMRF(nn.Module):
         """N4, first slice: in training mode, build an autograd graph over the part of the forward that lies between the last
         attention kernel of a stage and the outputs -- the stage-final LayerNorms and the three prediction heads on every layer's
         rows (models/autograd_ops.py: forward = the fused HIP launches, backward = csrc/backward.hip) -- so that
-        `Criterion(model(sample)).backward()` leaves the REFERENCE's gradients in `.grad` of those 18 tensors + the 16 of the two stages'
-        LAST message-passing blocks (proj, norm2, fc1, fc2: autograd_ops.BlockFn) (`labels_curr` and
+        `Criterion(model(sample)).backward()` leaves the REFERENCE's gradients in `.grad` of those tensors + those of the LAST
+        message-passing block of the propagation, inference and refinement stage (proj, norm2, fc1, fc2: autograd_ops.BlockFn) + the
+        proposal head and the propagation's final norm: 50 tensors (`labels_curr` and
         `disp_curr` are detached by the reference too, NMRF.py:215,231).  Every other parameter gets no gradient: the attention /
         convolution kernels are forward-only (the next slice).  Off by default; eval mode ignores it."""
         self.grad_slice = bool(on)
-        self.inference.keep_pre_norm = self.refinement.keep_pre_norm = bool(on)
+        self.inference.keep_pre_norm = self.refinement.keep_pre_norm = self.dpn.propagation.keep_pre_norm = bool(on)
         return self
 
     def _tail_with_grad(self, labels_curr, dims8, heads4, tok4, out_hw, prob, label_seeds):
@@ -198,6 +199,13 @@ class NMRF(nn.Module):
             return y if keep is None else y.index_select(0, keep)
 
         with torch.enable_grad():
+            # disparity proposals (DPN.py:131-132): labels = relu(prop_head(norm(last propagation block)) + seeds) as a function of the
+            # propagation stage's last block, its final norm and the head -- the loss_prop branch of the Criterion
+            prop = self.dpn.propagation
+            mem = last_rows(prop)
+            if prop.norm is not None:
+                mem = LayerNormFn.apply(mem, prop.norm.weight, prop.norm.bias, prop.norm.eps)
+            proposal = torch.relu(head(self.dpn.prop_head, mem).view(-1, n) + label_seeds.reshape(-1, n)).reshape(b, -1, n)
             nm = self.inference.norm
             aux, delta, score = [], None, None
             pres = list(self.inference._pre_norm)
@@ -218,7 +226,7 @@ class NMRF(nn.Module):
             for pre in pres:
                 rows = LayerNormFn.apply(pre, nm4.weight, nm4.bias, nm4.eps)
                 preds.append(refine_epilogue_torch(head(self.refine_head, rows), disp_curr))
-        out = {"proposal": labels_curr.reshape(b, -1, n), "prob": prob, "initial_proposal": label_seeds.reshape(b, -1, n),
+        out = {"proposal": proposal, "prob": prob, "initial_proposal": label_seeds.reshape(b, -1, n),
                "disp": preds[-1][0], "disp_pred": preds[-1][1]}
         if self.aux_loss:
             out["aux_outputs"] = aux + [{"disp_pred": p[1]} for p in preds[:-1]]

@@ -154,11 +154,26 @@ def run_train():
     total = sum(loss_g[k] * crit.weight_dict[k] for k in loss_g if k in crit.weight_dict)
     total.backward()
     d["loss_total"] = _np(total)
-    for name, p in model.named_parameters():
-        last = ("inference.layers.4.nmp.", "refinement.layers.4.nmp.")          # + the LAST block of either stage: proj, norm2, mlp
-        if name.startswith(("infer_head.", "infer_score_head.", "refine_head.", "inference.norm.", "refinement.norm.")) or (
-                name.startswith(last) and name.split(".nmp.")[1].split(".")[0] in ("proj", "norm2", "mlp")):
+
+    def in_slice(name, heads, last):
+        return name.startswith(heads) or (name.startswith(last) and name.split(".nmp.")[1].split(".")[0] in ("proj", "norm2", "mlp"))
+    for name, p in model.named_parameters():                          # + the LAST block of either NMP stage: proj, norm2, mlp
+        if in_slice(name, ("infer_head.", "infer_score_head.", "refine_head.", "inference.norm.", "refinement.norm."),
+                    ("inference.layers.4.nmp.", "refinement.layers.4.nmp.")):
             d["grad/" + name] = _np(p.grad)
+    # The proposal loss: Criterion.forward returns it as 'loss_prop' while the weight_dict of NMRF.py:432-447 names it 'proposal_disp',
+    # so main.py:416's `if k in weight_dict` leaves it OUT of the trained loss and the propagation stage gets no gradient in the
+    # reference's own step (checked: .grad is None).  Its gradient is still well defined: differentiated on its own here, for the
+    # proposal head, the propagation's final norm and its last block.
+    prop_names = [n for n, p in model.named_parameters()
+                  if in_slice(n, ("dpn.prop_head.", "dpn.propagation.norm."), ("dpn.propagation.layers.4.nmp.",))]
+    assert all(dict(model.named_parameters())[n].grad is None for n in prop_names)
+    model.zero_grad(set_to_none=True)
+    out_p = model({"img1": img1.clone().float(), "img2": img2.clone().float()})
+    loss_p = crit(out_p, {"disp": gt, "valid": valid})["loss_prop"]
+    loss_p.backward()
+    for n in prop_names:
+        d["grad_prop/" + n] = _np(dict(model.named_parameters())[n].grad)
     for k in ("disp", "disp_pred"):
         assert np.array_equal(_np(out_g[k]), d[k]), k                    # the same forward with and without no_grad
     path = os.path.join(OUT, "e2e_train.npz")
