@@ -430,6 +430,13 @@ int nmrf_layernorm_f32(const float *x, const float *g, const float *b, int64_t T
 int nmrf_layernorm_bwd_f32(const float *x, const float *g, const float *dy, int64_t T, int C, float eps, int blocks, float *dx,
                            float *part_dg, float *part_db, void *stream);
 
+/* Backward of nmrf_window_attn_f32 on fp32 q | k | v rows (WindowAttention.forward, nmrf/models/NMP.py:185-289 -- what the reference's
+ * autograd differentiates): dout [B,Hp,Wp,N,C] -> dqkv [B,Hp,Wp,N,3C] (every element written) and the gradient of the relative-position
+ * table as one part per (image, window), dtab_parts [B * (Hp/win)*(Wp/win)][(2 win - 1)^2][3C] (sum with nmrf_sum_partials_f32: fixed
+ * order).  scratch: 2 * B * heads * windows * (win*win*N)^2 floats (P and dS of every window).  win*win*N <= 256; same masks as the forward. */
+int nmrf_window_attn_bwd_f32(const float *qkv, const float *table, const float *dout, int B, int Hp, int Wp, int N, int C, int heads,
+                             int win, int shift, int sibling_mask, float *dqkv, float *dtab_parts, float *scratch, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -237,3 +237,196 @@ extern "C" int nmrf_layernorm_bwd_f32(const float *x, const float *g, const floa
     }
     return nmrf_launch_status();
 }
+
+// ---- (shifted-)window attention with relative-position q / k / v embeddings: backward -----------------------------------------------
+// Forward (WindowAttention.forward, nmrf/models/NMP.py:185-289; restated in oracle/nmrf_oracle.py:window_attention): per window and head,
+// tokens i, j of the window on the rolled grid, r = rel(pixel_i, pixel_j), (eq | ek | ev) = the head's 96 columns of table row r,
+//     logit_ij = s (q_i . k_j + q_i . ek_r + k_j . eq_r)   (-inf: sibling labels of the query's pixel; other Swin region when shifted)
+//     p = softmax_j(logit),   out_i = sum_j p_ij (v_j + ev_r)
+// Backward, given dout: with dp_ij = dout_i . (v_j + ev_r), D_i = sum_j p_ij dp_ij, ds_ij = p_ij (dp_ij - D_i):
+//     dq_i = s sum_j ds_ij (k_j + ek_r)      dk_j = s sum_i ds_ij (q_i + eq_r)      dv_j = sum_i p_ij dout_i
+//     dek_r += s ds_ij q_i                   deq_r += s ds_ij k_j                    dev_r += p_ij dout_i
+// One workgroup per (window, head, image); P and ds of the window live in a global scratch (2 x Tw^2 floats per workgroup), the table
+// gradient leaves as one part per (image, window) -- summed in fixed order by nmrf_sum_partials_f32: deterministic.  Correctness first:
+// one thread per query row / key column / table entry, fp32 VALU arithmetic (this is 5 x Tw^2 x 32 MACs per window and head).
+struct WinBwdArgs {
+    const float *qkv, *table, *dout;
+    float *dqkv, *dtab_parts, *scratch;
+    int Hp, Wp, N, C, heads, win, shift, sibling;
+    float scale;
+};
+
+#define WB_LD 33          // LDS row stride of the [Tw][32] tiles (one thread per row: conflict-free)
+
+__global__ __launch_bounds__(256) void window_attn_bwd_kernel(WinBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float wb_smem[];
+    const int win = a.win, N = a.N, W2 = win * win, Tw = W2 * N, span = 2 * win - 1, R = span * span;
+    float *Q = wb_smem, *Kt = Q + Tw * WB_LD, *V = Kt + Tw * WB_LD, *dO = V + Tw * WB_LD;
+    float *Eq = dO + Tw * WB_LD, *Ek = Eq + R * WB_LD, *Ev = Ek + R * WB_LD;
+    int *rowoff = reinterpret_cast<int *>(Ev + R * WB_LD);                    // [Tw] token index on the (un-rolled) grid
+    int *reg = rowoff + Tw;                                                    // [Tw] Swin region of the token's pixel
+    const int tid = threadIdx.x;
+    const int nwx = a.Wp / win, nwin = nwx * (a.Hp / win);
+    const int w = blockIdx.x, head = blockIdx.y, bimg = blockIdx.z;
+    const int wi = w / nwx, wj = w % nwx;
+    const int ld = 3 * a.C;
+    const float s = a.scale;
+    for (int i = tid; i < Tw; i += 256) {
+        const int pt = i / N, n = i - pt * N, pa = pt / win, pb = pt - pa * win;
+        const int Yr = wi * win + pa, Xr = wj * win + pb;                      // rolled grid
+        int Y = Yr + a.shift, X = Xr + a.shift;
+        Y = Y >= a.Hp ? Y - a.Hp : Y;
+        X = X >= a.Wp ? X - a.Wp : X;
+        rowoff[i] = ((bimg * a.Hp + Y) * a.Wp + X) * N + n;
+        const int fy = Yr < a.Hp - win ? 0 : (Yr < a.Hp - a.shift ? 1 : 2), fx = Xr < a.Wp - win ? 0 : (Xr < a.Wp - a.shift ? 1 : 2);
+        reg[i] = a.shift ? fy * 3 + fx : 0;
+    }
+    __syncthreads();
+    for (int e = tid; e < Tw * 32; e += 256) {
+        const int i = e >> 5, c = e & 31;
+        const float *row = a.qkv + (size_t)rowoff[i] * ld + head * 32 + c;
+        Q[i * WB_LD + c] = row[0];
+        Kt[i * WB_LD + c] = row[a.C];
+        V[i * WB_LD + c] = row[2 * a.C];
+        dO[i * WB_LD + c] = a.dout[(size_t)rowoff[i] * a.C + head * 32 + c];
+    }
+    for (int e = tid; e < R * 32; e += 256) {
+        const int r = e >> 5, c = e & 31;
+        const float *row = a.table + (size_t)r * ld + head * 96 + c;
+        Eq[r * WB_LD + c] = row[0];
+        Ek[r * WB_LD + c] = row[32];
+        Ev[r * WB_LD + c] = row[64];
+    }
+    __syncthreads();
+    float *P = a.scratch + ((size_t)(bimg * a.heads + head) * nwin + w) * 2 * Tw * Tw, *dS = P + (size_t)Tw * Tw;
+    auto rel = [&](int i, int j) {
+        const int pi = i / N, pj = j / N;
+        return (pi / win - pj / win + win - 1) * span + (pi % win - pj % win + win - 1);
+    };
+    auto masked = [&](int i, int j) {
+        if (a.sibling && N > 1 && i / N == j / N && i != j) return true;
+        return reg[i] != reg[j];
+    };
+    // ---- phase 1: one thread per query row ----------------------------------------------------------------------------------------------
+    for (int i = tid; i < Tw; i += 256) {
+        const float *q = Q + i * WB_LD, *go = dO + i * WB_LD;
+        float m = -INFINITY;
+        for (int j = 0; j < Tw; ++j) {
+            float l = -INFINITY;
+            if (!masked(i, j)) {
+                const float *k = Kt + j * WB_LD;
+                const int r = rel(i, j);
+                const float *ek = Ek + r * WB_LD, *eq = Eq + r * WB_LD;
+                float acc = 0.f;
+                for (int c = 0; c < 32; ++c) acc = fmaf(q[c], k[c] + ek[c], fmaf(k[c], eq[c], acc));
+                l = acc * s;
+            }
+            P[(size_t)i * Tw + j] = l;
+            m = fmaxf(m, l);
+        }
+        float Z = 0.f;
+        for (int j = 0; j < Tw; ++j) {
+            const float l = P[(size_t)i * Tw + j];
+            const float e = l == -INFINITY ? 0.f : expf(l - m);
+            P[(size_t)i * Tw + j] = e;
+            Z += e;
+        }
+        const float rz = 1.0f / Z;
+        float D = 0.f;
+        for (int j = 0; j < Tw; ++j) {
+            const float p = P[(size_t)i * Tw + j] * rz;
+            P[(size_t)i * Tw + j] = p;
+            float dp = 0.f;
+            if (p != 0.f) {
+                const float *v = V + j * WB_LD, *ev = Ev + rel(i, j) * WB_LD;
+                for (int c = 0; c < 32; ++c) dp = fmaf(go[c], v[c] + ev[c], dp);
+            }
+            dS[(size_t)i * Tw + j] = dp;
+            D = fmaf(p, dp, D);
+        }
+        float dq[32];
+        for (int c = 0; c < 32; ++c) dq[c] = 0.f;
+        for (int j = 0; j < Tw; ++j) {
+            const float ds = P[(size_t)i * Tw + j] * (dS[(size_t)i * Tw + j] - D);
+            dS[(size_t)i * Tw + j] = ds;
+            if (ds != 0.f) {
+                const float *k = Kt + j * WB_LD, *ek = Ek + rel(i, j) * WB_LD;
+                for (int c = 0; c < 32; ++c) dq[c] = fmaf(ds, k[c] + ek[c], dq[c]);
+            }
+        }
+        float *o = a.dqkv + (size_t)rowoff[i] * ld + head * 32;
+        for (int c = 0; c < 32; ++c) o[c] = dq[c] * s;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- phase 2: one thread per key column ---------------------------------------------------------------------------------------------
+    for (int j = tid; j < Tw; j += 256) {
+        float dk[32], dv[32];
+        for (int c = 0; c < 32; ++c) dk[c] = dv[c] = 0.f;
+        for (int i = 0; i < Tw; ++i) {
+            const float ds = dS[(size_t)i * Tw + j], p = P[(size_t)i * Tw + j];
+            if (p == 0.f && ds == 0.f) continue;
+            const float *q = Q + i * WB_LD, *go = dO + i * WB_LD, *eq = Eq + rel(i, j) * WB_LD;
+            for (int c = 0; c < 32; ++c) {
+                dk[c] = fmaf(ds, q[c] + eq[c], dk[c]);
+                dv[c] = fmaf(p, go[c], dv[c]);
+            }
+        }
+        float *o = a.dqkv + (size_t)rowoff[j] * ld + head * 32;
+        for (int c = 0; c < 32; ++c) {
+            o[a.C + c] = dk[c] * s;
+            o[2 * a.C + c] = dv[c];
+        }
+    }
+    // ---- phase 3: one thread per (table row, channel): every (query pixel, key pixel) pair with that offset, every label pair ------------
+    float *part = a.dtab_parts + ((size_t)bimg * nwin + w) * R * ld + head * 96;
+    for (int e = tid; e < R * 32; e += 256) {
+        const int r = e >> 5, c = e & 31;
+        const int da = r / span - (win - 1), db = r % span - (win - 1);        // query pixel - key pixel
+        float geq = 0.f, gek = 0.f, gev = 0.f;
+        for (int pa = 0; pa < win; ++pa) {
+            const int ka = pa - da;
+            if (ka < 0 || ka >= win) continue;
+            for (int pb = 0; pb < win; ++pb) {
+                const int kb = pb - db;
+                if (kb < 0 || kb >= win) continue;
+                const int i0 = (pa * win + pb) * N, j0 = (ka * win + kb) * N;
+                for (int n = 0; n < N; ++n)
+                    for (int n2 = 0; n2 < N; ++n2) {
+                        const int i = i0 + n, j = j0 + n2;
+                        const float ds = dS[(size_t)i * Tw + j], p = P[(size_t)i * Tw + j];
+                        gek = fmaf(ds, Q[i * WB_LD + c], gek);
+                        geq = fmaf(ds, Kt[j * WB_LD + c], geq);
+                        gev = fmaf(p, dO[i * WB_LD + c], gev);
+                    }
+            }
+        }
+        part[(size_t)r * ld + c] = geq * s;
+        part[(size_t)r * ld + 32 + c] = gek * s;
+        part[(size_t)r * ld + 64 + c] = gev;
+    }
+}
+
+// qkv [B,Hp,Wp,N,3C] fp32 rows, table [(2 win - 1)^2, 3C], dout [B,Hp,Wp,N,C] -> dqkv (every element written), dtab_parts
+// [B * windows][(2 win - 1)^2][3C] (sum them with nmrf_sum_partials_f32), scratch: 2 * B * heads * windows * Tw^2 floats.
+extern "C" int nmrf_window_attn_bwd_f32(const float *qkv, const float *table, const float *dout, int B, int Hp, int Wp, int N, int C, int heads,
+                                        int win, int shift, int sibling_mask, float *dqkv, float *dtab_parts, float *scratch, void *stream) {
+    if (!qkv || !table || !dout || !dqkv || !dtab_parts || !scratch) return NMRF_ENULL;
+    if (B < 1 || N < 1 || win < 1 || Hp % win || Wp % win || shift < 0 || shift >= win || heads * 32 != C) return NMRF_EINVAL;
+    const int Tw = win * win * N, R = (2 * win - 1) * (2 * win - 1);
+    if (Tw > 256) return NMRF_EINVAL;
+    const size_t lds = ((size_t)(4 * Tw + 3 * R) * WB_LD + 2 * Tw) * sizeof(float);
+    if (lds > 160 * 1024) return NMRF_EINVAL;
+    static bool attr_set_dev[NMRF_MAX_DEV] = {};
+    const int dev = nmrf_cur_device();
+    if (dev < 0) return NMRF_ELAUNCH;
+    if (!attr_set_dev[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(window_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+            hipSuccess)
+            return NMRF_ELAUNCH;
+        attr_set_dev[dev] = true;
+    }
+    WinBwdArgs a{qkv, table, dout, dqkv, dtab_parts, scratch, Hp, Wp, N, C, heads, win, shift, sibling_mask ? 1 : 0, 1.0f / sqrtf(32.0f)};
+    hipLaunchKernelGGL(window_attn_bwd_kernel, dim3((Hp / win) * (Wp / win), heads, B), dim3(256), lds, (hipStream_t)stream, a);
+    return nmrf_launch_status();
+}

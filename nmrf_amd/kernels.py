@@ -1192,3 +1192,22 @@ def layer_norm_backward(x, g, dy, eps):
     _lib.check(_lib.load().nmrf_sum_partials_f32(_p(pg), 4 * blocks, c, c, _p(dg), _stream()), "sum_partials")
     _lib.check(_lib.load().nmrf_sum_partials_f32(_p(pb), 4 * blocks, c, c, _p(db), _stream()), "sum_partials")
     return dx, dg, db
+
+
+@_on_device
+def window_attn_backward(qkv, table, dout, b, hp, wp, n, heads, win, shift, sibling_mask):
+    """Backward of window_attn on fp32 rows: -> (dqkv [T,3C], dtable [(2 win - 1)^2, 3C])."""
+    _chk(qkv, table, dout)
+    t, c3 = qkv.shape
+    c = c3 // 3
+    assert t == b * hp * wp * n and dout.shape == (t, c)
+    nwin = (hp // win) * (wp // win)
+    tw, r = win * win * n, (2 * win - 1) ** 2
+    dqkv = torch.empty_like(qkv)
+    parts = torch.empty(b * nwin, r, c3, device=qkv.device, dtype=torch.float32)
+    scratch = torch.empty(2 * b * heads * nwin * tw * tw, device=qkv.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_window_attn_bwd_f32(_p(qkv), _p(table), _p(dout), b, hp, wp, n, c, heads, win, shift, int(bool(sibling_mask)),
+                                                    _p(dqkv), _p(parts), _p(scratch), _stream()), "window_attn_bwd")
+    dtab = torch.empty(r, c3, device=qkv.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_sum_partials_f32(_p(parts), b * nwin, r * c3, r * c3, _p(dtab), _stream()), "sum_partials")
+    return dqkv, dtab

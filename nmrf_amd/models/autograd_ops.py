@@ -106,6 +106,64 @@ class BlockFn(torch.autograd.Function):
         return (dx1 if ctx.needs_input_grad[0] else None), dmsg, dwp, dbp, dg2, db2n, dw1, db1, dw2, db2, None, None
 
 
+class WindowAttnFn(torch.autograd.Function):
+    """(Shifted-)window attention with relative-position embeddings on fp32 q | k | v rows (WindowAttention.forward, NMP.py:185-289).
+    fwd() -> the forward kernel's output on the same operands (or the tensor the fused forward already produced)."""
+
+    @staticmethod
+    def forward(ctx, qkv, table, geom, fwd):
+        ctx.save_for_backward(qkv, table)
+        ctx.geom = geom                                              # (b, hp, wp, n, heads, win, shift, sibling_mask)
+        return fwd()
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, table = ctx.saved_tensors
+        dqkv, dtab = K.window_attn_backward(qkv, table, _c(dout), *ctx.geom)
+        return (dqkv if ctx.needs_input_grad[0] else None), dtab, None, None
+
+
+class QkvFn(torch.autograd.Function):
+    """The q | k | v projection of a message-passing block on [LayerNorm1(x) | extra] (SwinNMP.get_qkv_input + qkv, NMP.py:343-349):
+    y = [LN(x) | extra] W^T + b with W [3C, C + E] (columns past a linear's own width are zero in the fused weight).  fwd() -> y."""
+
+    @staticmethod
+    def forward(ctx, x, extra, g, b, w, bias, eps, fwd):
+        ctx.save_for_backward(x, extra, g, b, w)
+        ctx.eps = eps
+        return fwd()
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, extra, g, b, w = ctx.saved_tensors
+        dy = _c(dy)
+        c = x.shape[1]
+        cat = torch.cat((K.layer_norm(x, g, b, ctx.eps), extra[:, : w.shape[1] - c]), 1).contiguous()      # (plumbing: the operand rows)
+        dw, dbias = K.linear_wgrad(dy, cat), K.bias_grad(dy)
+        dcat = K.linear_dgrad(dy, w)
+        dx, dg, db = K.layer_norm_backward(x, g, dcat[:, :c].contiguous(), ctx.eps)
+        return (dx if ctx.needs_input_grad[0] else None), None, dg, db, dw, dbias, None, None
+
+
+class FfnFn(torch.autograd.Function):
+    """timm Mlp: y = fc2(gelu(fc1 x))  (Inference.ffn / Refinement.ffn, NMP.py:675, 735-741).  fwd(x) -> y: the fused chain launch."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, fwd):
+        ctx.save_for_backward(x, w1, b1, w2)
+        return fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, b1, w2 = ctx.saved_tensors
+        dy = _c(dy)
+        p, h = K.bias_act(K.linear_forward(x, w1), b1, 2)
+        dw2, db2 = K.linear_wgrad(dy, h), K.bias_grad(dy)
+        dp = K.act_backward(p, K.linear_dgrad(dy, w2), 2)
+        dx = K.linear_dgrad(dp, w1) if ctx.needs_input_grad[0] else None
+        return dx, K.linear_wgrad(dp, x), K.bias_grad(dp), dw2, db2, None
+
+
 def refine_epilogue_torch(delta16, disp_curr, training_hw=None):
     """relu(disp_curr + delta) pixel-shuffled 4x4 (NMRF.py:238-245) as differentiable torch views for the training-mode loss:
     delta16 [B*H4*W4, 16], disp_curr [B,H4,W4] -> (disp = 4 * disp_pred, disp_pred [B, 4*H4, 4*W4]).  (No un-padding: the training-mode

@@ -1262,3 +1262,32 @@ def test_autograd_functions_match_fp64_autograd(t_):
     yd = x1 + F.linear(F.gelu(F.linear(F.layer_norm(x1, (128,), td[4], td[5], 1e-5), td[6], td[7])), td[8], td[9])
     report("block forward", y.detach().cpu(), yd.detach(), 2e-5, 1e-5)
     compare(("block", names), got, torch.autograd.grad(yd, td, g128.double()))
+
+
+@pytest.mark.parametrize("b,hp,wp,n,win,shift,sib", [(1, 8, 12, 1, 4, 0, False), (2, 8, 8, 1, 4, 2, False), (1, 12, 12, 4, 6, 0, True),
+                                                      (1, 12, 18, 4, 6, 3, True), (1, 6, 6, 2, 6, 3, True)])
+def test_window_attention_backward_vs_oracle_autograd(b, hp, wp, n, win, shift, sib):
+    """nmrf_window_attn_bwd_f32 against torch autograd of the oracle's window_attention in fp64 (oracle/nmrf_oracle.py: the restatement
+    of WindowAttention.forward, NMP.py:185-289): dq | dk | dv and the gradient of the relative-position table, regular and shifted
+    windows, with and without the sibling mask, 1 / 2 / 4 labels; deterministic (two runs: same bits)."""
+    kk = K()
+    tkn = b * hp * wp * n
+    qkv = rnd(tkn, 384, seed=hp * wp + shift, scale=1.2)
+    table = rnd((2 * win - 1) ** 2, 384, seed=win, scale=0.4)
+    gout = rnd(tkn, 128, seed=9)
+    qd, td = qkv.double().requires_grad_(True), table.double().requires_grad_(True)
+    ref = O.window_attention(qd.view(b, hp, wp, n, 384), td, (b, hp, wp, n), win, shift, 4, sib).reshape(tkn, 128)
+    gq, gt = torch.autograd.grad(ref, [qd, td], gout.double())
+    dqkv, dtab = kk.window_attn_backward(qkv.to(DEV), table.to(DEV), gout.to(DEV), b, hp, wp, n, 4, win, shift, sib)
+    report("window attention dqkv", dqkv.cpu(), gq, 1e-5 * float(gq.abs().max()) + 1e-7)
+    report("window attention dtable", dtab.cpu(), gt, 1e-5 * float(gt.abs().max()) + 1e-7)
+    d2, t2 = kk.window_attn_backward(qkv.to(DEV), table.to(DEV), gout.to(DEV), b, hp, wp, n, 4, win, shift, sib)
+    assert torch.equal(dqkv, d2) and torch.equal(dtab, t2)
+    # through the Function: forward = the product kernel, backward = the above
+    from nmrf_amd.models.autograd_ops import WindowAttnFn
+    qg, tg = qkv.to(DEV).requires_grad_(True), table.to(DEV).requires_grad_(True)
+    y = WindowAttnFn.apply(qg, tg, (b, hp, wp, n, 4, win, shift, sib),
+                           lambda: kk.window_attn(qg.detach(), tg.detach(), b, hp, wp, n, 4, win, shift, sib))
+    report("window attention forward", y.detach().cpu(), ref.detach(), 2e-5, 1e-5)
+    g1, g2 = torch.autograd.grad(y, [qg, tg], gout.to(DEV))
+    assert torch.equal(g1, dqkv) and torch.equal(g2, dtab)
