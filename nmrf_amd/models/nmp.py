@@ -612,6 +612,11 @@ class Inference(nn.Module):
                 enc = K.fourier_embed(labels_flat, self.normalizer, 32, out=ebuf, out_map=to_p)
             x = self._ffn(wcc, 160) if to_p is None else self._ffn(wcc, 160, out=xbuf, out_map=to_p)
             t_dense = dims[0] * dims[1] * dims[2] * dims[3]
+            if collect is not None and getattr(self, "keep_pre_norm", False):
+                # the tape of the training-mode forward (NMRF.enable_grad_slice): every tensor a backward through the WHOLE stage needs --
+                # the ffn operand, the Fourier rows and, appended by _run_blocks, each layer's residual stream, q | k | v and message
+                # (clones of the persistent padded grids: the next forward overwrites them)
+                self._tape = {"wcc": wcc, "enc": enc.clone(), "x": [x.clone()], "qkv": [], "msg": [], "pdims": pdims, "to_p": to_p}
             return self._run_blocks(x, enc, pdims, to_d, t_dense, collect)
         if collect is not None:
             raise NotImplementedError("return_intermediate is implemented on the fused block path (128-wide tokens, shipped head shapes)")
@@ -690,6 +695,9 @@ class Inference(nn.Module):
             skip = True
         else:
             _, qkv, _ = self._launch[0](x, None, enc, 1, want_x=False)
+        tape = getattr(self, "_tape", None) if keep_pre else None
+        if tape is not None:
+            tape["qkv"].append(qkv)
         for i, (kind, m) in enumerate(self._sites):
             if skip:                                     # this self-edge site ran inside the previous launch
                 skip = False
@@ -715,11 +723,19 @@ class Inference(nn.Module):
                 if keep_pre:
                     self._pre_norm.append(xo.index_select(0, keep).contiguous())
                     self._last_block = (x, msg, xo, m, keep)        # the last block's operands on the padded grid (autograd_ops.BlockFn)
+                    if tape is not None:
+                        tape["msg"].append(msg)
+                        tape["x"].append(xo)
                 return ln
             x_in = x
             x, qkv, ln = self._launch[i + 1](x, msg, enc, 1, want_x=not last or self.norm is None or keep_pre, attn_qkv=attn_qkv)
             if keep_pre and last and kind == "win":
                 self._last_block = (x_in, msg, x, m, keep)
+            if tape is not None:
+                tape["msg"].append(msg)
+                tape["x"].append(x)
+                if qkv is not None:
+                    tape["qkv"].append(qkv)
             if collect is not None and kind == "win":
                 xd = None
                 if not last or keep_pre:

@@ -174,6 +174,35 @@ class NMRF(nn.Module):
         self.inference.keep_pre_norm = self.refinement.keep_pre_norm = self.dpn.propagation.keep_pre_norm = bool(on)
         return self
 
+    @staticmethod
+    def _stage_rows_with_grad(stage):
+        """The residual stream of EVERY layer of a window-only stage (the refinement: one label per pixel, no self-edge sites) on the
+        dense grid, as an autograd graph over ALL of the stage's parameters: ffn -> per layer [norm1 | enc -> qkv -> window attention
+        (relative-position table) -> proj + residual + norm2 + MLP].  Every Function's forward value is the tensor the fused forward
+        already produced (the tape of Inference._run); backward = csrc/backward.hip.  None when the stage is not of that shape."""
+        from .autograd_ops import BlockFn, FfnFn, QkvFn, WindowAttnFn
+        tape = getattr(stage, "_tape", None)
+        if tape is None or any(kind != "win" for kind, _ in stage._sites) or len(tape["qkv"]) != len(stage._sites):
+            return None
+        b, hp, wp, n = tape["pdims"]
+        to_p = tape["to_p"]
+        keep = None if to_p is None else to_p.long()
+        x0 = tape["x"][0]
+        ffn = stage.ffn
+        xd = FfnFn.apply(tape["wcc"], ffn.fc1.weight, ffn.fc1.bias, ffn.fc2.weight, ffn.fc2.bias,
+                         lambda t: x0 if keep is None else x0.index_select(0, keep))
+        xg = xd if keep is None else torch.zeros_like(x0).index_copy(0, keep, xd)          # (the zero-padded grid, NMP.py:745-762)
+        rows = []
+        for i, (_, m) in enumerate(stage._sites):
+            qkv_i, msg_i, x_next = tape["qkv"][i], tape["msg"][i], tape["x"][i + 1]
+            qkv = QkvFn.apply(xg, tape["enc"], m.norm1.weight, m.norm1.bias, m.qkv.weight, m.qkv.bias, m.norm1.eps, lambda v=qkv_i: v)
+            geom = (b, hp, wp, n, m.attn.num_heads, m.attn.window_size[0], m.attn.shift_size, n > 1)
+            msg = WindowAttnFn.apply(qkv, m.attn.relative_position_enc_table, geom, lambda v=msg_i: v)
+            xg = BlockFn.apply(xg, msg, m.proj.weight, m.proj.bias, m.norm2.weight, m.norm2.bias, m.mlp.fc1.weight, m.mlp.fc1.bias,
+                               m.mlp.fc2.weight, m.mlp.fc2.bias, m.norm2.eps, lambda v=x_next: v)
+            rows.append(xg if keep is None else xg.index_select(0, keep))
+        return rows
+
     def _tail_with_grad(self, labels_curr, dims8, heads4, tok4, out_hw, prob, label_seeds):
         """The tail of hot_path in training mode with grad_slice: norms + heads of every layer under autograd."""
         from .autograd_ops import LayerNormFn, LinearFn, MlpHeadFn, refine_epilogue_torch
@@ -221,8 +250,10 @@ class NMRF(nn.Module):
                 self.refinement(disp_curr, fmap1, fmap2, fmap1_gw, fmap2_gw, token_major=tok4)
             nm4 = self.refinement.norm
             preds = []
-            pres = list(self.refinement._pre_norm)
-            pres[-1] = last_rows(self.refinement)
+            pres = self._stage_rows_with_grad(self.refinement)
+            if pres is None:
+                pres = list(self.refinement._pre_norm)
+                pres[-1] = last_rows(self.refinement)
             for pre in pres:
                 rows = LayerNormFn.apply(pre, nm4.weight, nm4.bias, nm4.eps)
                 preds.append(refine_epilogue_torch(head(self.refine_head, rows), disp_curr))

@@ -1,6 +1,6 @@
 """N4, first slice: one optimisation step over the part of the model whose gradients this build can produce on the MI355X
-(nmrf_amd.models.NMRF.enable_grad_slice: the three prediction heads, the two stage-final LayerNorms and the last message-passing block
-of the propagation, the inference and the refinement stage, the proposal head -- 50 tensors), shaped like the reference's training loop (main.py:403-430):
+(nmrf_amd.models.NMRF.enable_grad_slice: the three prediction heads, the WHOLE refinement stage, the inference stage's final norm and
+last message-passing block, and -- behind the proposal loss -- the proposal head, the propagation's final norm and last block: 111 tensors), shaped like the reference's training loop (main.py:403-430):
 
     model.train(); loss_dict = criterion(model(sample), sample); losses = sum_k weight_dict[k] * loss_dict[k]
     param.grad = None; losses.backward(); clip_grad_norm_(GRAD_CLIP); optimizer.step()
@@ -11,14 +11,14 @@ GPU, weights replicated, batch sharded as in nmrf_amd.parallel).  Everything els
 import torch
 import torch.distributed as dist
 
-SLICE_PREFIXES = ("infer_head.", "infer_score_head.", "refine_head.", "inference.norm.", "refinement.norm.", "dpn.prop_head.",
-                  "dpn.propagation.norm.")
+SLICE_PREFIXES = ("infer_head.", "infer_score_head.", "refine_head.", "inference.norm.", "refinement.", "dpn.prop_head.",
+                  "dpn.propagation.norm.")           # "refinement.": the WHOLE refinement stage (window attention backward, round 5)
 LAST_BLOCK_PARTS = ("proj", "norm2", "mlp")
 
 
 def slice_parameters(model):
     """[(name, parameter)] the gradient slice reaches, in named_parameters() order."""
-    last = ("inference.layers.%d.nmp." % (len(model.inference.layers) - 1), "refinement.layers.%d.nmp." % (len(model.refinement.layers) - 1),
+    last = ("inference.layers.%d.nmp." % (len(model.inference.layers) - 1),
             "dpn.propagation.layers.%d.nmp." % (len(model.dpn.propagation.layers) - 1))
     out = []
     for name, p in model.named_parameters():
