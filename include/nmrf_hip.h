@@ -437,6 +437,10 @@ int nmrf_layernorm_bwd_f32(const float *x, const float *g, const float *dy, int6
 int nmrf_window_attn_bwd_f32(const float *qkv, const float *table, const float *dout, int B, int Hp, int Wp, int N, int C, int heads,
                              int win, int shift, int sibling_mask, float *dqkv, float *dtab_parts, float *scratch, void *stream);
 
+/* Backward of nmrf_self_attn_f32 (the per-pixel self-edge attention over the N sibling labels, BasicAttention.forward_pre, NMP.py:97-103):
+ * qkv [T,3C] fp32, dout [T,C] -> dqkv [T,3C].  T % N == 0, N in {1, 2, 4}, heads*32 == C. */
+int nmrf_self_attn_bwd_f32(const float *qkv, const float *dout, int64_t T, int N, int C, int heads, float *dqkv, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -430,3 +430,94 @@ extern "C" int nmrf_window_attn_bwd_f32(const float *qkv, const float *table, co
     hipLaunchKernelGGL(window_attn_bwd_kernel, dim3((Hp / win) * (Wp / win), heads, B), dim3(256), lds, (hipStream_t)stream, a);
     return nmrf_launch_status();
 }
+
+// ---- per-pixel self-edge attention over the N sibling labels: backward ------------------------------------------------------------------
+// Forward (BasicAttention.forward_pre, nmrf/models/NMP.py:97-103; nmrf_self_attn_f32): per pixel and head, tokens n, m of the pixel,
+//     p = softmax_m(s q_n . k_m),  out_n = sum_m p_nm v_m.      One thread per (pixel, head): the N x N matrices in registers, q / k / v /
+// dout rows streamed twice from global (L1-resident: 4 x N x 32 floats).  N <= 4.
+template <int N>
+__global__ __launch_bounds__(256) void self_attn_bwd_kernel(const float *__restrict__ qkv, const float *__restrict__ dout, int64_t pixels, int C,
+                                                            int heads, float s, float *__restrict__ dqkv) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= pixels * heads) return;
+    const int head = (int)(idx % heads);
+    const int64_t t0 = (idx / heads) * N;
+    const int ld = 3 * C;
+    const float *base = qkv + t0 * ld + head * 32;
+    const float *gbase = dout + t0 * C + head * 32;
+    float l[N][N], dp[N][N];
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int m = 0; m < N; ++m) l[n][m] = dp[n][m] = 0.f;
+    for (int c = 0; c < 32; c += 4) {
+        float4 q[N], k[N], v[N], g[N];
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            q[n] = ldg4(base + (size_t)n * ld + c);
+            k[n] = ldg4(base + (size_t)n * ld + C + c);
+            v[n] = ldg4(base + (size_t)n * ld + 2 * C + c);
+            g[n] = ldg4(gbase + (size_t)n * C + c);
+        }
+#pragma unroll
+        for (int n = 0; n < N; ++n)
+#pragma unroll
+            for (int m = 0; m < N; ++m) {
+                l[n][m] += q[n].x * k[m].x + q[n].y * k[m].y + q[n].z * k[m].z + q[n].w * k[m].w;
+                dp[n][m] += g[n].x * v[m].x + g[n].y * v[m].y + g[n].z * v[m].z + g[n].w * v[m].w;
+            }
+    }
+    float p[N][N], ds[N][N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        float mx = -INFINITY, z = 0.f, d = 0.f;
+#pragma unroll
+        for (int m = 0; m < N; ++m) mx = fmaxf(mx, l[n][m] * s);
+#pragma unroll
+        for (int m = 0; m < N; ++m) { p[n][m] = expf(l[n][m] * s - mx); z += p[n][m]; }
+        const float rz = 1.0f / z;
+#pragma unroll
+        for (int m = 0; m < N; ++m) { p[n][m] *= rz; d = fmaf(p[n][m], dp[n][m], d); }
+#pragma unroll
+        for (int m = 0; m < N; ++m) ds[n][m] = p[n][m] * (dp[n][m] - d) * s;
+    }
+    float *obase = dqkv + t0 * ld + head * 32;
+    for (int c = 0; c < 32; c += 4) {
+        float4 q[N], k[N], g[N];
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            q[n] = ldg4(base + (size_t)n * ld + c);
+            k[n] = ldg4(base + (size_t)n * ld + C + c);
+            g[n] = ldg4(gbase + (size_t)n * C + c);
+        }
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            float4 dq = {0.f, 0.f, 0.f, 0.f}, dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < N; ++m) {
+                dq.x = fmaf(ds[n][m], k[m].x, dq.x); dq.y = fmaf(ds[n][m], k[m].y, dq.y); dq.z = fmaf(ds[n][m], k[m].z, dq.z); dq.w = fmaf(ds[n][m], k[m].w, dq.w);
+                dk.x = fmaf(ds[m][n], q[m].x, dk.x); dk.y = fmaf(ds[m][n], q[m].y, dk.y); dk.z = fmaf(ds[m][n], q[m].z, dk.z); dk.w = fmaf(ds[m][n], q[m].w, dk.w);
+                dv.x = fmaf(p[m][n], g[m].x, dv.x); dv.y = fmaf(p[m][n], g[m].y, dv.y); dv.z = fmaf(p[m][n], g[m].z, dv.z); dv.w = fmaf(p[m][n], g[m].w, dv.w);
+            }
+            stg4(obase + (size_t)n * ld + c, dq);
+            stg4(obase + (size_t)n * ld + C + c, dk);
+            stg4(obase + (size_t)n * ld + 2 * C + c, dv);
+        }
+    }
+}
+
+// qkv [T,3C] fp32 (q | k | v), dout [T,C] -> dqkv [T,3C]; T a multiple of N, N in {1, 2, 4}, heads * 32 == C.
+extern "C" int nmrf_self_attn_bwd_f32(const float *qkv, const float *dout, int64_t T, int N, int C, int heads, float *dqkv, void *stream) {
+    if (!qkv || !dout || !dqkv) return NMRF_ENULL;
+    if (T < 1 || (N != 1 && N != 2 && N != 4) || T % N || heads * 32 != C || (C & 3)) return NMRF_EINVAL;
+    const int64_t pixels = T / N, items = pixels * heads;
+    const float s = 1.0f / sqrtf(32.0f);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)ceil_div64(items, 256));
+    switch (N) {
+        case 1: hipLaunchKernelGGL(self_attn_bwd_kernel<1>, grid, dim3(256), 0, st, qkv, dout, pixels, C, heads, s, dqkv); break;
+        case 2: hipLaunchKernelGGL(self_attn_bwd_kernel<2>, grid, dim3(256), 0, st, qkv, dout, pixels, C, heads, s, dqkv); break;
+        case 4: hipLaunchKernelGGL(self_attn_bwd_kernel<4>, grid, dim3(256), 0, st, qkv, dout, pixels, C, heads, s, dqkv); break;
+    }
+    return nmrf_launch_status();
+}

@@ -1211,3 +1211,28 @@ def window_attn_backward(qkv, table, dout, b, hp, wp, n, heads, win, shift, sibl
     dtab = torch.empty(r, c3, device=qkv.device, dtype=torch.float32)
     _lib.check(_lib.load().nmrf_sum_partials_f32(_p(parts), b * nwin, r * c3, r * c3, _p(dtab), _stream()), "sum_partials")
     return dqkv, dtab
+
+
+@_on_device
+def self_attn_backward(qkv, dout, n, heads):
+    """Backward of self_attn: qkv [T,3C] fp32, dout [T,C] -> dqkv [T,3C]."""
+    _chk(qkv, dout)
+    t, c3 = qkv.shape
+    dqkv = torch.empty_like(qkv)
+    _lib.check(_lib.load().nmrf_self_attn_bwd_f32(_p(qkv), _p(dout), t, n, c3 // 3, heads, _p(dqkv), _stream()), "self_attn_bwd")
+    return dqkv
+
+
+def from_kv16(qkv):
+    """The inverse of to_kv16 (torch views and bit operations -- plumbing): rows whose k | v thirds are split fp16 pairs -> fp32 rows with
+    k = hi + lo, v = hi + lo (the value the attention kernels multiply: up to 2^-22 relative of what the producer split)."""
+    t = qkv.shape[0]
+    out = qkv.clone()
+    words = qkv.view(torch.int32)
+    half = lambda w16: (w16 & 0xffff).to(torch.int16).view(torch.float16).float()
+    kw = words[:, 128:256].reshape(t, 4, 32)                                   # per head: 16 words of hi halves, 16 words of lo halves
+    unpack = lambda w: torch.stack((half(w), half(w >> 16)), -1).reshape(t, 4, 32)
+    out[:, 128:256] = (unpack(kw[..., :16]) + unpack(kw[..., 16:])).reshape(t, 128)
+    vw = words[:, 256:384]
+    out[:, 256:384] = half(vw) + half(vw >> 16)
+    return out

@@ -124,25 +124,65 @@ class WindowAttnFn(torch.autograd.Function):
 
 
 class QkvFn(torch.autograd.Function):
-    """The q | k | v projection of a message-passing block on [LayerNorm1(x) | extra] (SwinNMP.get_qkv_input + qkv, NMP.py:343-349):
-    y = [LN(x) | extra] W^T + b with W [3C, C + E] (columns past a linear's own width are zero in the fused weight).  fwd() -> y."""
+    """The q | k | v projection of a message-passing block on [LayerNorm1(x) | extra]: one fused linear (SwinNMP.qkv, NMP.py:343-349) or
+    three (BasicAttention / CSWinNMP q, k on [LN(x) | extra], v on LN(x) alone, NMP.py:90-96): y = cat_i([LN(x) | extra][:, :K_i] W_i^T + b_i).
+    Arguments after fwd: w_1, b_1, w_2, b_2, ... (W_i [N_i, K_i], K_i <= C + E).  fwd() -> y (the fused launch's q_out, fp32 rows)."""
 
     @staticmethod
-    def forward(ctx, x, extra, g, b, w, bias, eps, fwd):
-        ctx.save_for_backward(x, extra, g, b, w)
+    def forward(ctx, x, extra, g, b, eps, fwd, *wb):
+        ctx.save_for_backward(x, extra, g, b, *wb[0::2])
         ctx.eps = eps
+        ctx.has_bias = [bb is not None for bb in wb[1::2]]
         return fwd()
 
     @staticmethod
     def backward(ctx, dy):
-        x, extra, g, b, w = ctx.saved_tensors
+        x, extra, g, b, *ws = ctx.saved_tensors
         dy = _c(dy)
         c = x.shape[1]
-        cat = torch.cat((K.layer_norm(x, g, b, ctx.eps), extra[:, : w.shape[1] - c]), 1).contiguous()      # (plumbing: the operand rows)
-        dw, dbias = K.linear_wgrad(dy, cat), K.bias_grad(dy)
-        dcat = K.linear_dgrad(dy, w)
+        kmax = max(w.shape[1] for w in ws)
+        cat = torch.cat((K.layer_norm(x, g, b, ctx.eps), extra[:, : kmax - c]), 1).contiguous()        # (plumbing: the operand rows)
+        wf = torch.cat([w if w.shape[1] == kmax else torch.nn.functional.pad(w, (0, kmax - w.shape[1])) for w in ws], 0).contiguous()
+        dwf, dbf = K.linear_wgrad(dy, cat), K.bias_grad(dy)
+        dcat = K.linear_dgrad(dy, wf)
         dx, dg, db = K.layer_norm_backward(x, g, dcat[:, :c].contiguous(), ctx.eps)
-        return (dx if ctx.needs_input_grad[0] else None), None, dg, db, dw, dbias, None, None
+        grads, r0 = [], 0
+        for w, hb in zip(ws, ctx.has_bias):
+            n = w.shape[0]
+            grads += [dwf[r0:r0 + n, : w.shape[1]].contiguous(), dbf[r0:r0 + n].contiguous() if hb else None]
+            r0 += n
+        return ((dx if ctx.needs_input_grad[0] else None), None, dg, db, None, None, *grads)
+
+
+class SelfAttnFn(torch.autograd.Function):
+    """Per-pixel self-edge attention over the N sibling labels (BasicAttention.forward_pre, NMP.py:97-103) on fp32 q | k | v rows."""
+
+    @staticmethod
+    def forward(ctx, qkv, n, heads):
+        ctx.save_for_backward(qkv)
+        ctx.n, ctx.heads = n, heads
+        return K.self_attn(qkv, n, heads)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (qkv,) = ctx.saved_tensors
+        return K.self_attn_backward(qkv, _c(dout), ctx.n, ctx.heads), None, None
+
+
+class ProjFn(torch.autograd.Function):
+    """x + proj(msg): a block without MLP (the self-edge block, NMP.py:104-108).  fwd() -> the fused launch's x_out."""
+
+    @staticmethod
+    def forward(ctx, x, msg, wp, bp, fwd):
+        ctx.save_for_backward(msg, wp)
+        return fwd()
+
+    @staticmethod
+    def backward(ctx, dy):
+        msg, wp = ctx.saved_tensors
+        dy = _c(dy)
+        dmsg = K.linear_dgrad(dy, wp) if ctx.needs_input_grad[1] else None
+        return (dy if ctx.needs_input_grad[0] else None), dmsg, K.linear_wgrad(dy, msg), K.bias_grad(dy), None
 
 
 class FfnFn(torch.autograd.Function):

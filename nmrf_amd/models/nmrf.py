@@ -176,28 +176,39 @@ class NMRF(nn.Module):
 
     @staticmethod
     def _stage_rows_with_grad(stage):
-        """The residual stream of EVERY layer of a window-only stage (the refinement: one label per pixel, no self-edge sites) on the
-        dense grid, as an autograd graph over ALL of the stage's parameters: ffn -> per layer [norm1 | enc -> qkv -> window attention
-        (relative-position table) -> proj + residual + norm2 + MLP].  Every Function's forward value is the tensor the fused forward
-        already produced (the tape of Inference._run); backward = csrc/backward.hip.  None when the stage is not of that shape."""
-        from .autograd_ops import BlockFn, FfnFn, QkvFn, WindowAttnFn
+        """The residual stream of EVERY layer of an NMP stage (inference: self-edge + window sites, four labels per pixel; refinement:
+        window sites, one label) on the dense grid, as an autograd graph over ALL of the stage's parameters:
+            ffn -> per site [norm1 | enc -> q | k | v -> attention (siblings / windows with the relative-position table) -> proj + residual
+                             (+ norm2 + MLP at window sites)].
+        Every Function's forward value is the tensor the fused forward already produced (the tape of Inference._run; the sibling
+        attention, evaluated inside the block kernel there, is re-run by its own kernel); backward = csrc/backward.hip.  q | k | v rows
+        that the forward wrote as split fp16 pairs for the window kernel (kv16) are decoded to the fp32 values those kernels multiply.
+        None when the forward did not record a tape."""
+        from .autograd_ops import BlockFn, FfnFn, ProjFn, QkvFn, SelfAttnFn, WindowAttnFn
         tape = getattr(stage, "_tape", None)
-        if tape is None or any(kind != "win" for kind, _ in stage._sites) or len(tape["qkv"]) != len(stage._sites):
+        if tape is None or len(tape["qkv"]) != len(stage._sites) or len(tape["x"]) != len(stage._sites) + 1:
             return None
         b, hp, wp, n = tape["pdims"]
         to_p = tape["to_p"]
         keep = None if to_p is None else to_p.long()
-        x0 = tape["x"][0]
+        x0, enc = tape["x"][0], tape["enc"]
         ffn = stage.ffn
         xd = FfnFn.apply(tape["wcc"], ffn.fc1.weight, ffn.fc1.bias, ffn.fc2.weight, ffn.fc2.bias,
                          lambda t: x0 if keep is None else x0.index_select(0, keep))
         xg = xd if keep is None else torch.zeros_like(x0).index_copy(0, keep, xd)          # (the zero-padded grid, NMP.py:745-762)
         rows = []
-        for i, (_, m) in enumerate(stage._sites):
-            qkv_i, msg_i, x_next = tape["qkv"][i], tape["msg"][i], tape["x"][i + 1]
-            qkv = QkvFn.apply(xg, tape["enc"], m.norm1.weight, m.norm1.bias, m.qkv.weight, m.qkv.bias, m.norm1.eps, lambda v=qkv_i: v)
+        for i, (kind, m) in enumerate(stage._sites):
+            qkv_i, x_next = tape["qkv"][i], tape["x"][i + 1]
+            if kind == "win" and stage._site_kv16[i]:
+                qkv_i = K.from_kv16(qkv_i)
+            wb = [t for l in ((m.q, m.k, m.v) if hasattr(m, "q") else (m.qkv,)) for t in (l.weight, l.bias)]
+            qkv = QkvFn.apply(xg, enc, m.norm1.weight, m.norm1.bias, m.norm1.eps, lambda v=qkv_i: v, *wb)
+            if kind == "self":
+                msg = SelfAttnFn.apply(qkv, n, m.num_heads)
+                xg = ProjFn.apply(xg, msg, m.proj.weight, m.proj.bias, lambda v=x_next: v)
+                continue
             geom = (b, hp, wp, n, m.attn.num_heads, m.attn.window_size[0], m.attn.shift_size, n > 1)
-            msg = WindowAttnFn.apply(qkv, m.attn.relative_position_enc_table, geom, lambda v=msg_i: v)
+            msg = WindowAttnFn.apply(qkv, m.attn.relative_position_enc_table, geom, lambda v=tape["msg"][i]: v)
             xg = BlockFn.apply(xg, msg, m.proj.weight, m.proj.bias, m.norm2.weight, m.norm2.bias, m.mlp.fc1.weight, m.mlp.fc1.bias,
                                m.mlp.fc2.weight, m.mlp.fc2.bias, m.norm2.eps, lambda v=x_next: v)
             rows.append(xg if keep is None else xg.index_select(0, keep))
@@ -237,8 +248,10 @@ class NMRF(nn.Module):
             proposal = torch.relu(head(self.dpn.prop_head, mem).view(-1, n) + label_seeds.reshape(-1, n)).reshape(b, -1, n)
             nm = self.inference.norm
             aux, delta, score = [], None, None
-            pres = list(self.inference._pre_norm)
-            pres[-1] = last_rows(self.inference)
+            pres = self._stage_rows_with_grad(self.inference)
+            if pres is None:
+                pres = list(self.inference._pre_norm)
+                pres[-1] = last_rows(self.inference)
             for pre in pres:
                 rows = LayerNormFn.apply(pre, nm.weight, nm.bias, nm.eps)
                 delta = head(self.infer_head, rows)

@@ -1,6 +1,6 @@
 """N4, first slice: one optimisation step over the part of the model whose gradients this build can produce on the MI355X
-(nmrf_amd.models.NMRF.enable_grad_slice: the three prediction heads, the WHOLE refinement stage, the inference stage's final norm and
-last message-passing block, and -- behind the proposal loss -- the proposal head, the propagation's final norm and last block: 111 tensors), shaped like the reference's training loop (main.py:403-430):
+(nmrf_amd.models.NMRF.enable_grad_slice: the three prediction heads, the WHOLE inference and refinement stages, and -- behind the proposal
+loss -- the proposal head, the propagation's final norm and last block: 222 of the model's 351 tensors), shaped like the reference's training loop (main.py:403-430):
 
     model.train(); loss_dict = criterion(model(sample), sample); losses = sum_k weight_dict[k] * loss_dict[k]
     param.grad = None; losses.backward(); clip_grad_norm_(GRAD_CLIP); optimizer.step()
@@ -11,15 +11,14 @@ GPU, weights replicated, batch sharded as in nmrf_amd.parallel).  Everything els
 import torch
 import torch.distributed as dist
 
-SLICE_PREFIXES = ("infer_head.", "infer_score_head.", "refine_head.", "inference.norm.", "refinement.", "dpn.prop_head.",
-                  "dpn.propagation.norm.")           # "refinement.": the WHOLE refinement stage (window attention backward, round 5)
+SLICE_PREFIXES = ("infer_head.", "infer_score_head.", "refine_head.", "inference.", "refinement.", "dpn.prop_head.",
+                  "dpn.propagation.norm.")           # "inference." / "refinement.": the WHOLE stages (attention backward kernels, round 5)
 LAST_BLOCK_PARTS = ("proj", "norm2", "mlp")
 
 
 def slice_parameters(model):
     """[(name, parameter)] the gradient slice reaches, in named_parameters() order."""
-    last = ("inference.layers.%d.nmp." % (len(model.inference.layers) - 1),
-            "dpn.propagation.layers.%d.nmp." % (len(model.dpn.propagation.layers) - 1))
+    last = ("dpn.propagation.layers.%d.nmp." % (len(model.dpn.propagation.layers) - 1),)
     out = []
     for name, p in model.named_parameters():
         if name.startswith(SLICE_PREFIXES) or (name.startswith(last) and name.split(".nmp.")[1].split(".")[0] in LAST_BLOCK_PARTS):

@@ -1291,3 +1291,22 @@ def test_window_attention_backward_vs_oracle_autograd(b, hp, wp, n, win, shift, 
     report("window attention forward", y.detach().cpu(), ref.detach(), 2e-5, 1e-5)
     g1, g2 = torch.autograd.grad(y, [qg, tg], gout.to(DEV))
     assert torch.equal(g1, dqkv) and torch.equal(g2, dtab)
+
+
+@pytest.mark.parametrize("t_,n", [(64, 4), (1000, 4), (30, 2), (17, 1)])
+def test_self_attention_backward_vs_fp64_autograd(t_, n):
+    """nmrf_self_attn_bwd_f32 against fp64 autograd of softmax(q k^T / sqrt(32)) v over the n sibling labels of a pixel, 4 heads."""
+    kk = K()
+    qkv, gout = rnd(t_, 384, seed=3, scale=1.3), rnd(t_, 128, seed=4)
+    qd = qkv.double().requires_grad_(True)
+    q, k, v = (qd[:, i * 128:(i + 1) * 128].view(t_ // n, n, 4, 32).transpose(1, 2) for i in range(3))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / 32 ** 0.5, -1) @ v).transpose(1, 2).reshape(t_, 128)
+    (gq,) = torch.autograd.grad(ref, [qd], gout.double())
+    got = kk.self_attn_backward(qkv.to(DEV), gout.to(DEV), n, 4)
+    report("self attention dqkv", got.cpu(), gq, 1e-5 * float(gq.abs().max()) + 1e-7)
+    from nmrf_amd.models.autograd_ops import SelfAttnFn
+    qg = qkv.to(DEV).requires_grad_(True)
+    y = SelfAttnFn.apply(qg, n, 4)
+    report("self attention forward", y.detach().cpu(), ref.detach(), 2e-5, 1e-5)
+    assert torch.equal(torch.autograd.grad(y, [qg], gout.to(DEV))[0], got)
+    assert float((kk.from_kv16(kk.to_kv16(qkv.to(DEV))) - qkv.to(DEV)).abs().max()) <= 2.0 ** -21 * float(qkv.abs().max())

@@ -159,8 +159,10 @@ def run_train():
         return name.startswith(heads) or (name.startswith(last) and name.split(".nmp.")[1].split(".")[0] in ("proj", "norm2", "mlp"))
     for name, p in model.named_parameters():                          # + the LAST block of either NMP stage: proj, norm2, mlp
         # (round 5, later: EVERY parameter of the refinement stage -- its window attention has a backward kernel now)
-        if name.startswith("refinement.") or in_slice(name, ("infer_head.", "infer_score_head.", "refine_head.", "inference.norm."),
-                                                      ("inference.layers.4.nmp.",)):
+        # ... and of the inference stage: sibling + window attention backward; stored for its ffn, final norm and layers 0 and 4 (the
+        # fixture would grow by 4 MB for the other three; the test asserts that they do get gradients)
+        if name.startswith(("refinement.", "infer_head.", "infer_score_head.", "refine_head.", "inference.norm.", "inference.ffn.",
+                            "inference.layers.0.", "inference.layers.4.")):
             d["grad/" + name] = _np(p.grad)
     # The proposal loss: Criterion.forward returns it as 'loss_prop' while the weight_dict of NMRF.py:432-447 names it 'proposal_disp',
     # so main.py:416's `if k in weight_dict` leaves it OUT of the trained loss and the propagation stage gets no gradient in the
