@@ -1,17 +1,18 @@
-"""N4, first slice: torch.autograd.Functions over the HIP kernels, so that a loss evaluated on the training-mode forward
-can be differentiated with respect to the parameters that sit between the last attention kernel of a stage and the loss.
+"""N4: torch.autograd.Functions over the HIP kernels, so that a loss evaluated on the training-mode forward can be
+differentiated with respect to every parameter behind the `labels_curr` hand-over.
 
 The reference differentiates its whole forward with autograd (nmrf/models/NMRF.py:387-429, main.py:413-430) and detaches the two
-discrete hand-overs between stages (`labels_curr`, NMRF.py:215; `disp_curr`, NMRF.py:231).  The gradients of the three prediction heads
-(`infer_head`, `infer_score_head`, `refine_head`), of the two stage-final LayerNorms and of a stage's LAST message-passing block therefore
-depend only on tensors the forward already holds -- the per-layer token rows -- and not on a backward of the attention kernels, which
-this build does not have (their autograd would be the next slice).
+discrete hand-overs between stages (`labels_curr`, NMRF.py:215; `disp_curr`, NMRF.py:231).  Everything from the inference stage's ffn to
+the outputs therefore depends only on tensors the forward already holds.  The Functions here cover that part completely: FfnFn (timm Mlp),
+QkvFn (LayerNorm | extra -> one or three linears), SelfAttnFn (sibling labels of a pixel), WindowAttnFn ((shifted) windows with the
+relative-position q / k / v embeddings), ProjFn / BlockFn (proj + residual [+ norm2 + MLP]), LayerNormFn, MlpHeadFn / LinearFn (the heads).
+What has no backward yet: the propagation's stripe attention, the seed stage (cost volume, conv1d filter, NMS), warp + correlation with
+respect to the feature maps, the convolutions.
 
-Every Function's FORWARD is the product's fused launch (the same bits the forward-only path returns); its backward recomputes the
-intermediates from the saved inputs and composes dgrad / wgrad / bias / activation / LayerNorm pieces of csrc/backward.hip
-(nmrf_amd.kernels.linear_dgrad, linear_wgrad, bias_grad, act_backward, layer_norm_backward): split-operand fp16 MFMA GEMMs with fp32
-accumulation, deterministic token reductions.  The only torch arithmetic in a backward is the addition of two gradient tensors where a
-residual branch joins (plumbing, as in autograd's own AccumulateGrad)."""
+Every Function's FORWARD is the product's fused launch (or the tensor that launch already produced: the same bits the forward-only path
+returns); its backward recomputes what it needs from the saved inputs and composes the pieces of csrc/backward.hip: split-operand fp16
+MFMA GEMMs for dgrad / wgrad (fp32 accumulation), attention backward kernels in fp32, deterministic reductions over tokens and windows.
+The only torch arithmetic in a backward is plumbing: concatenating operand rows, adding two gradients where a residual branch joins."""
 import torch
 
 from .. import kernels as K

@@ -162,14 +162,14 @@ class NMRF(nn.Module):
         return out
 
     def enable_grad_slice(self, on=True):
-        """N4, first slice: in training mode, build an autograd graph over the part of the forward that lies between the last
-        attention kernel of a stage and the outputs -- the stage-final LayerNorms and the three prediction heads on every layer's
-        rows (models/autograd_ops.py: forward = the fused HIP launches, backward = csrc/backward.hip) -- so that
-        `Criterion(model(sample)).backward()` leaves the REFERENCE's gradients in `.grad` of those tensors + those of the LAST
-        message-passing block of the propagation, inference and refinement stage (proj, norm2, fc1, fc2: autograd_ops.BlockFn) + the
-        proposal head and the propagation's final norm: 50 tensors (`labels_curr` and
-        `disp_curr` are detached by the reference too, NMRF.py:215,231).  Every other parameter gets no gradient: the attention /
-        convolution kernels are forward-only (the next slice).  Off by default; eval mode ignores it."""
+        """N4 (round 5): in training mode, build an autograd graph over everything from the `labels_curr` hand-over to the outputs -- the
+        WHOLE inference and refinement stages (ffn, every layer's norm1 / q | k | v / sibling or window attention with its
+        relative-position table / proj / norm2 / MLP, the stage-final norms) and the three prediction heads -- plus, behind the proposal
+        loss, the propagation stage's last block, final norm and `prop_head` (models/autograd_ops.py: every Function's forward value is
+        the fused HIP launch's, backward = csrc/backward.hip).  The reference detaches `labels_curr` and `disp_curr` (NMRF.py:215,231), so
+        `Criterion(model(sample)).backward()` leaves the REFERENCE's own gradients in `.grad` of those 206 tensors (222 with
+        `weight_dict['loss_prop']`).  Everything in front of the hand-over -- encoder, matching heads, cost volume, seed filter, the
+        propagation's stripe attention -- stays forward-only: `.grad is None`, loudly.  Off by default; eval mode ignores it."""
         self.grad_slice = bool(on)
         self.inference.keep_pre_norm = self.refinement.keep_pre_norm = self.dpn.propagation.keep_pre_norm = bool(on)
         return self
