@@ -417,6 +417,9 @@ int nmrf_gemm_split_f32(const float *A, int64_t sa_i, int64_t sa_k, const float 
                         float *C, int ldc, int splits, int64_t split_stride, int *range_flag, void *stream);
 /* out[i] = sum_{s < S} parts[s*stride + i], s ascending (i < n). */
 int nmrf_sum_partials_f32(const float *parts, int S, int64_t n, int64_t stride, float *out, void *stream);
+/* The same in groups: out[g*n + i] = sum over the parts s in [g*group, min(S, (g+1)*group)) -- a caller with many parts reduces in rounds
+ * (a fixed tree: deterministic) instead of one long serial chain per element. */
+int nmrf_sum_partials_grouped_f32(const float *parts, int S, int64_t n, int64_t stride, int group, float *out, void *stream);
 /* parts[b][n] = sum of x[t][n] over the rows_per_block rows of block b (b < ceil(T / rows_per_block)): the bias gradient's first pass. */
 int nmrf_colsum_partials_f32(const float *x, int64_t T, int N, int rows_per_block, float *parts, void *stream);
 /* pre_out = pre_in + bias (bias, pre_out may be NULL; pre_out may alias pre_in); act_out (may be NULL) = act(pre_in + bias):

@@ -71,21 +71,29 @@ extern "C" int nmrf_gemm_split_f32(const float *A, int64_t sa_i, int64_t sa_k, c
     return nmrf_launch_status();
 }
 
-// out[i] = sum_s parts[s*stride + i], s in ascending order (the deterministic second pass of every split reduction here)
-__global__ __launch_bounds__(256) void sum_partials_kernel(const float *__restrict__ parts, int S, int64_t n, int64_t stride, float *__restrict__ out) {
+// out[g*n + i] = sum of parts[s*stride + i] over the `group` parts s of group g, s ascending (the deterministic second pass of every
+// split reduction here; a caller with many parts reduces in rounds of `group`: a fixed tree, same bits every run)
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float *__restrict__ parts, int S, int64_t n, int64_t stride, int group,
+                                                           float *__restrict__ out) {
+    const int s0 = blockIdx.y * group, s1 = min(S, s0 + group);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float s = 0.f;
-        for (int k = 0; k < S; ++k) s += parts[(int64_t)k * stride + i];
-        out[i] = s;
+        for (int k = s0; k < s1; ++k) s += parts[(int64_t)k * stride + i];
+        out[(int64_t)blockIdx.y * n + i] = s;
     }
 }
-extern "C" int nmrf_sum_partials_f32(const float *parts, int S, int64_t n, int64_t stride, float *out, void *stream) {
+extern "C" int nmrf_sum_partials_grouped_f32(const float *parts, int S, int64_t n, int64_t stride, int group, float *out, void *stream) {
     if (!parts || !out) return NMRF_ENULL;
-    if (S < 1 || n < 1 || stride < n) return NMRF_EINVAL;
+    if (S < 1 || n < 1 || stride < n || group < 1) return NMRF_EINVAL;
+    const int groups = (S + group - 1) / group;
+    if (groups > 65535) return NMRF_EINVAL;
     int64_t blocks = ceil_div64(n, 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, parts, S, n, stride, out);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)blocks, (unsigned)groups), dim3(256), 0, (hipStream_t)stream, parts, S, n, stride, group, out);
     return nmrf_launch_status();
+}
+extern "C" int nmrf_sum_partials_f32(const float *parts, int S, int64_t n, int64_t stride, float *out, void *stream) {
+    return nmrf_sum_partials_grouped_f32(parts, S, n, stride, S < 1 ? 1 : S, out, stream);
 }
 
 // bias gradient: parts[b][n] = sum over the rows of block b of x[t][n]   (then nmrf_sum_partials_f32 over b)

@@ -1098,6 +1098,21 @@ def msda_backward(value, shapes, lvl_start, loc, w, grad_out):
 
 
 # ---- N4, first slice: the pieces of a backward pass through the token-linear chains (csrc/backward.hip, include/nmrf_hip.h) -------------
+def _sum_parts(parts, n, out=None):
+    """parts [S, n] (contiguous) -> [n]: rounds of 32 parts per group (nmrf_sum_partials_grouped_f32), a fixed reduction tree."""
+    s_ = parts.shape[0]
+    cur = parts
+    while s_ > 32:
+        g = (s_ + 31) // 32
+        nxt = torch.empty(g, n, device=parts.device, dtype=torch.float32)
+        _lib.check(_lib.load().nmrf_sum_partials_grouped_f32(_p(cur), s_, n, n, 32, _p(nxt), _stream()), "sum_partials")
+        cur, s_ = nxt, g
+    if out is None:
+        out = torch.empty(n, device=parts.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_sum_partials_grouped_f32(_p(cur), s_, n, n, s_, _p(out), _stream()), "sum_partials")
+    return out
+
+
 def _gemm(a, sa_i, sa_k, b, sb_k, sb_j, m, n, k, splits=1):
     """C[m,n] = op(A) . op(B) on the split-fp16 MFMA with explicit element strides; splits > 1: K split + fixed-order sum."""
     _chk(a, b)
@@ -1108,7 +1123,7 @@ def _gemm(a, sa_i, sa_k, b, sb_k, sb_j, m, n, k, splits=1):
     parts = torch.empty(splits, m, n, device=a.device, dtype=torch.float32)
     _lib.check(_lib.load().nmrf_gemm_split_f32(_p(a), sa_i, sa_k, _p(b), sb_k, sb_j, m, n, k, _p(parts), n, splits, m * n, _rf(a), _stream()),
                "gemm_split")
-    _lib.check(_lib.load().nmrf_sum_partials_f32(_p(parts), splits, m * n, m * n, _p(out), _stream()), "sum_partials")
+    _sum_parts(parts.view(splits, m * n), m * n, out=out.view(-1))
     return out
 
 
@@ -1144,10 +1159,8 @@ def bias_grad(dy):
     rpb = max(64, (t + 1023) // 1024)
     nb = (t + rpb - 1) // rpb
     parts = torch.empty(nb, n, device=dy.device, dtype=torch.float32)
-    out = torch.empty(n, device=dy.device, dtype=torch.float32)
     _lib.check(_lib.load().nmrf_colsum_partials_f32(_p(dy), t, n, rpb, _p(parts), _stream()), "colsum_partials")
-    _lib.check(_lib.load().nmrf_sum_partials_f32(_p(parts), nb, n, n, _p(out), _stream()), "sum_partials")
-    return out
+    return _sum_parts(parts, n)
 
 
 @_on_device
@@ -1187,11 +1200,7 @@ def layer_norm_backward(x, g, dy, eps):
     pg = torch.empty(4 * blocks, c, device=x.device, dtype=torch.float32)
     pb = torch.empty_like(pg)
     _lib.check(_lib.load().nmrf_layernorm_bwd_f32(_p(x), _p(g), _p(dy), t, c, float(eps), blocks, _p(dx), _p(pg), _p(pb), _stream()), "layernorm_bwd")
-    dg = torch.empty(c, device=x.device, dtype=torch.float32)
-    db = torch.empty_like(dg)
-    _lib.check(_lib.load().nmrf_sum_partials_f32(_p(pg), 4 * blocks, c, c, _p(dg), _stream()), "sum_partials")
-    _lib.check(_lib.load().nmrf_sum_partials_f32(_p(pb), 4 * blocks, c, c, _p(db), _stream()), "sum_partials")
-    return dx, dg, db
+    return dx, _sum_parts(pg, c), _sum_parts(pb, c)
 
 
 @_on_device
@@ -1208,9 +1217,7 @@ def window_attn_backward(qkv, table, dout, b, hp, wp, n, heads, win, shift, sibl
     scratch = torch.empty(2 * b * heads * nwin * tw * tw, device=qkv.device, dtype=torch.float32)
     _lib.check(_lib.load().nmrf_window_attn_bwd_f32(_p(qkv), _p(table), _p(dout), b, hp, wp, n, c, heads, win, shift, int(bool(sibling_mask)),
                                                     _p(dqkv), _p(parts), _p(scratch), _stream()), "window_attn_bwd")
-    dtab = torch.empty(r, c3, device=qkv.device, dtype=torch.float32)
-    _lib.check(_lib.load().nmrf_sum_partials_f32(_p(parts), b * nwin, r * c3, r * c3, _p(dtab), _stream()), "sum_partials")
-    return dqkv, dtab
+    return dqkv, _sum_parts(parts.view(b * nwin, r * c3), r * c3).view(r, c3)
 
 
 @_on_device

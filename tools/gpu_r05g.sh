@@ -1,0 +1,6 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+( timeout 900 python -m pytest tests -m gpu -q --tb=short -rf -p no:cacheprovider -k "backward or autograd or training or train_steps" 2>&1 | tail -12 ) > gpurun_out/pytest_n4.log
+cat gpurun_out/pytest_n4.log | cut -c1-300
+bash tools/gpu_r05f.sh
