@@ -444,6 +444,14 @@ int nmrf_window_attn_bwd_f32(const float *qkv, const float *table, const float *
  * qkv [T,3C] fp32, dout [T,C] -> dqkv [T,3C].  T % N == 0, N in {1, 2, 4}, heads*32 == C. */
 int nmrf_self_attn_bwd_f32(const float *qkv, const float *dout, int64_t T, int N, int C, int heads, float *dqkv, void *stream);
 
+/* Backward of nmrf_stripe_attn_f32 on fp32 q | k | v rows (CSWinAttention.forward + get_rpe, nmrf/models/NMP.py:429-505): dout
+ * [B,H,W,N,128] -> dqkv [B,H,W,N,384] (every element written) and, per stripe, the gradients of the (previous, centre, next) LePE taps of
+ * that axis' 64 channels: dtap_v_parts [B*W][64][3] (centre COLUMN of attns.0.get_v.weight), dtap_h_parts [B*H][64][3] (centre ROW of
+ * attns.1.get_v.weight) -- sum the parts with nmrf_sum_partials_f32; the other six taps of either kernel have gradient 0 (they only see the
+ * zero padding of a width-1 stripe).  scratch: 2 * B * 2 * max(W * (H N)^2, H * (W N)^2) floats.  The two axes run one after the other. */
+int nmrf_stripe_attn_bwd_f32(const float *qkv, const float *lepe_v, const float *lepe_h, const float *dout, int B, int H, int W, int N,
+                             float *dqkv, float *dtap_v_parts, float *dtap_h_parts, float *scratch, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,7 @@ PROTOTYPES = {
     "nmrf_layernorm_bwd_f32": [_P, _P, _P, _L, _I, _F, _I, _P, _P, _P, _P],
     "nmrf_window_attn_bwd_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "nmrf_self_attn_bwd_f32": [_P, _P, _L, _I, _I, _I, _P, _P],
+    "nmrf_stripe_attn_bwd_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
 }
 
 # exported only by libnmrf_hip_debug.so (include/nmrf_hip_debug.h): reference kernels for A/B runs, never launched by the product

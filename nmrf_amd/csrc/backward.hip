@@ -529,3 +529,166 @@ extern "C" int nmrf_self_attn_bwd_f32(const float *qkv, const float *dout, int64
     }
     return nmrf_launch_status();
 }
+
+// ---- cross-stripe (CSWin, split size 1) attention with LePE: backward --------------------------------------------------------------------
+// Forward (CSWinAttention.forward / get_rpe, nmrf/models/NMP.py:429-505; oracle/nmrf_oracle.py:stripe_attention): channel half `axis` of
+// q | k | v (axis 0: channels 0..63, vertical stripes = columns; axis 1: channels 64..127, horizontal stripes = rows), 2 heads of 32;
+// per stripe and head, tokens i, j = (pixel along the stripe, label):
+//     p = softmax_j(s q_i . k_j)  (-inf between different labels of one pixel),   out_i = sum_j p_ij v_j + rpe_i
+//     rpe[p, n] = tc * v[p, n] + tm * sum_k v[p - 1, k] + tp * sum_k v[p + 1, k]     (tm, tc, tp: the centre column / row of the depthwise 3x3)
+// Backward: the attention part as in window_attn_bwd_kernel (P and dS in a global scratch, one thread per query row, then per key column;
+// q / k / v / dout rows come from global memory -- a stripe has up to W * N tokens); LePE: dv += tc * dout + tm * sum dout[p + 1] + tp *
+// sum dout[p - 1], and per (stripe, head, image) partial sums of the three tap gradients.
+struct StripeBwdArgs {
+    const float *qkv, *lepe, *dout;
+    float *dqkv, *dtap_parts, *scratch;
+    int H, W, N, axis;
+    float scale;
+};
+
+__global__ __launch_bounds__(256) void stripe_attn_bwd_kernel(StripeBwdArgs a) {
+    const int N = a.N, L = a.axis == 0 ? a.H : a.W, Ts = L * N;
+    const int stripe = blockIdx.x, head = blockIdx.y, bimg = blockIdx.z;
+    const int n_stripes = gridDim.x;
+    const int coff = a.axis * 64 + head * 32;
+    const int ld = 384, C = 128;
+    const float s = a.scale;
+    const int tid = threadIdx.x;
+    auto row_of = [&](int t) -> size_t {                       // global token row of stripe token t = (pixel p, label n)
+        const int p = t / N, n = t - p * N;
+        const int y = a.axis == 0 ? p : stripe, x = a.axis == 0 ? stripe : p;
+        return ((size_t)(bimg * a.H + y) * a.W + x) * N + n;
+    };
+    float *P = a.scratch + ((size_t)(bimg * 2 + head) * n_stripes + stripe) * 2 * Ts * Ts, *dS = P + (size_t)Ts * Ts;
+    // ---- phase 1: one thread per query row ----------------------------------------------------------------------------------------------
+    for (int i = tid; i < Ts; i += 256) {
+        const size_t ri = row_of(i);
+        float q[32], go[32];
+        for (int c = 0; c < 32; c += 4) {
+            const float4 a4 = ldg4(a.qkv + ri * ld + coff + c), g4 = ldg4(a.dout + ri * C + coff + c);
+            q[c] = a4.x; q[c + 1] = a4.y; q[c + 2] = a4.z; q[c + 3] = a4.w;
+            go[c] = g4.x; go[c + 1] = g4.y; go[c + 2] = g4.z; go[c + 3] = g4.w;
+        }
+        float m = -INFINITY;
+        for (int j = 0; j < Ts; ++j) {
+            float l = -INFINITY;
+            if (!(i / N == j / N && i != j)) {
+                const float *k = a.qkv + row_of(j) * ld + C + coff;
+                float acc = 0.f;
+                for (int c = 0; c < 32; ++c) acc = fmaf(q[c], k[c], acc);
+                l = acc * s;
+            }
+            P[(size_t)i * Ts + j] = l;
+            m = fmaxf(m, l);
+        }
+        float Z = 0.f;
+        for (int j = 0; j < Ts; ++j) {
+            const float l = P[(size_t)i * Ts + j];
+            const float e = l == -INFINITY ? 0.f : expf(l - m);
+            P[(size_t)i * Ts + j] = e;
+            Z += e;
+        }
+        const float rz = 1.0f / Z;
+        float D = 0.f;
+        for (int j = 0; j < Ts; ++j) {
+            const float p = P[(size_t)i * Ts + j] * rz;
+            P[(size_t)i * Ts + j] = p;
+            float dp = 0.f;
+            if (p != 0.f) {
+                const float *v = a.qkv + row_of(j) * ld + 2 * C + coff;
+                for (int c = 0; c < 32; ++c) dp = fmaf(go[c], v[c], dp);
+            }
+            dS[(size_t)i * Ts + j] = dp;
+            D = fmaf(p, dp, D);
+        }
+        float dq[32];
+        for (int c = 0; c < 32; ++c) dq[c] = 0.f;
+        for (int j = 0; j < Ts; ++j) {
+            const float ds = P[(size_t)i * Ts + j] * (dS[(size_t)i * Ts + j] - D);
+            dS[(size_t)i * Ts + j] = ds;
+            if (ds != 0.f) {
+                const float *k = a.qkv + row_of(j) * ld + C + coff;
+                for (int c = 0; c < 32; ++c) dq[c] = fmaf(ds, k[c], dq[c]);
+            }
+        }
+        float *o = a.dqkv + ri * ld + coff;
+        for (int c = 0; c < 32; ++c) o[c] = dq[c] * s;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- phase 2: one thread per key column: dk, dv (attention + LePE) ---------------------------------------------------------------------
+    const float *taps = a.lepe + (size_t)(head * 32) * 9;      // channel ch of the half: taps[ch * 9 + 3 * dy + dx]
+    const int t_m = a.axis == 0 ? 1 : 3, t_c = 4, t_p = a.axis == 0 ? 7 : 5;      // centre column (dy = 0, 1, 2) / centre row (dx = 0, 1, 2)
+    for (int j = tid; j < Ts; j += 256) {
+        float dk[32], dv[32];
+        for (int c = 0; c < 32; ++c) dk[c] = dv[c] = 0.f;
+        for (int i = 0; i < Ts; ++i) {
+            const float ds = dS[(size_t)i * Ts + j], p = P[(size_t)i * Ts + j];
+            if (p == 0.f && ds == 0.f) continue;
+            const size_t ri = row_of(i);
+            const float *q = a.qkv + ri * ld + coff, *go = a.dout + ri * C + coff;
+            for (int c = 0; c < 32; ++c) {
+                dk[c] = fmaf(ds, q[c], dk[c]);
+                dv[c] = fmaf(p, go[c], dv[c]);
+            }
+        }
+        const int pj = j / N;
+        const float *gj = a.dout + row_of(j) * C + coff;
+        for (int c = 0; c < 32; ++c) {
+            float e = taps[c * 9 + t_c] * gj[c];
+            if (pj + 1 < L) {                                  // v[pj] is the "previous" pixel of pj + 1: weight tm there
+                float sum = 0.f;
+                for (int n = 0; n < N; ++n) sum += a.dout[row_of((pj + 1) * N + n) * C + coff + c];
+                e = fmaf(taps[c * 9 + t_m], sum, e);
+            }
+            if (pj > 0) {                                      // ... and the "next" pixel of pj - 1: weight tp there
+                float sum = 0.f;
+                for (int n = 0; n < N; ++n) sum += a.dout[row_of((pj - 1) * N + n) * C + coff + c];
+                e = fmaf(taps[c * 9 + t_p], sum, e);
+            }
+            dv[c] += e;
+        }
+        float *o = a.dqkv + row_of(j) * ld + coff;
+        for (int c = 0; c < 32; ++c) {
+            o[C + c] = dk[c] * s;
+            o[2 * C + c] = dv[c];
+        }
+    }
+    // ---- phase 3: the three tap gradients of this head's 32 channels, summed over the stripe's tokens (threads 0 .. 31) ----------------------
+    if (tid < 32) {
+        const int c = tid;
+        float gm = 0.f, gc = 0.f, gp = 0.f;
+        for (int p = 0; p < L; ++p) {
+            float vprev = 0.f, vnext = 0.f;
+            for (int n = 0; n < N; ++n) {
+                if (p > 0) vprev += a.qkv[row_of((p - 1) * N + n) * ld + 2 * C + coff + c];
+                if (p + 1 < L) vnext += a.qkv[row_of((p + 1) * N + n) * ld + 2 * C + coff + c];
+            }
+            for (int n = 0; n < N; ++n) {
+                const size_t r = row_of(p * N + n);
+                const float g = a.dout[r * C + coff + c];
+                gc = fmaf(g, a.qkv[r * ld + 2 * C + coff + c], gc);
+                gm = fmaf(g, vprev, gm);
+                gp = fmaf(g, vnext, gp);
+            }
+        }
+        float *part = a.dtap_parts + (((size_t)bimg * n_stripes + stripe) * 64 + head * 32 + c) * 3;
+        part[0] = gm; part[1] = gc; part[2] = gp;
+    }
+}
+
+// qkv [B,H,W,N,384] fp32 rows, lepe_v / lepe_h [64,1,3,3] (attns.0 / attns.1 get_v.weight), dout [B,H,W,N,128] -> dqkv (every element
+// written); dtap_v_parts [B*W][64][3], dtap_h_parts [B*H][64][3]: per stripe the gradients of the (previous, centre, next) taps of the 64
+// channels of that axis (sum over the parts; the other six taps of a 3x3 kernel only ever see the zero padding of a width-1 stripe:
+// gradient 0).  scratch: 2 * B * 2 * max(W * (H N)^2, H * (W N)^2) floats.
+extern "C" int nmrf_stripe_attn_bwd_f32(const float *qkv, const float *lepe_v, const float *lepe_h, const float *dout, int B, int H, int W, int N,
+                                        float *dqkv, float *dtap_v_parts, float *dtap_h_parts, float *scratch, void *stream) {
+    if (!qkv || !lepe_v || !lepe_h || !dout || !dqkv || !dtap_v_parts || !dtap_h_parts || !scratch) return NMRF_ENULL;
+    if (B < 1 || H < 1 || W < 1 || N < 1 || B > 65535) return NMRF_EINVAL;
+    const float scale = 1.0f / sqrtf(32.0f);
+    StripeBwdArgs av{qkv, lepe_v, dout, dqkv, dtap_v_parts, scratch, H, W, N, 0, scale};
+    hipLaunchKernelGGL(stripe_attn_bwd_kernel, dim3(W, 2, B), dim3(256), 0, (hipStream_t)stream, av);
+    StripeBwdArgs ah{qkv, lepe_h, dout, dqkv, dtap_h_parts, scratch, H, W, N, 1, scale};
+    hipLaunchKernelGGL(stripe_attn_bwd_kernel, dim3(H, 2, B), dim3(256), 0, (hipStream_t)stream, ah);
+    return nmrf_launch_status();
+}

@@ -1243,3 +1243,22 @@ def from_kv16(qkv):
     vw = words[:, 256:384]
     out[:, 256:384] = half(vw) + half(vw >> 16)
     return out
+
+
+@_on_device
+def stripe_attn_backward(qkv, lepe_v, lepe_h, dout, b, h, w, n):
+    """Backward of stripe_attn on fp32 rows: -> (dqkv [T,384], dlepe_v [64,1,3,3], dlepe_h [64,1,3,3])."""
+    _chk(qkv, lepe_v, lepe_h, dout)
+    t = qkv.shape[0]
+    assert t == b * h * w * n and qkv.shape[1] == 384 and dout.shape == (t, 128)
+    dqkv = torch.empty_like(qkv)
+    pv = torch.empty(b * w, 64 * 3, device=qkv.device, dtype=torch.float32)
+    ph = torch.empty(b * h, 64 * 3, device=qkv.device, dtype=torch.float32)
+    scratch = torch.empty(2 * b * 2 * max(w * (h * n) ** 2, h * (w * n) ** 2), device=qkv.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_stripe_attn_bwd_f32(_p(qkv), _p(lepe_v), _p(lepe_h), _p(dout), b, h, w, n, _p(dqkv), _p(pv), _p(ph), _p(scratch),
+                                                    _stream()), "stripe_attn_bwd")
+    gv, gh = _sum_parts(pv, 192).view(64, 3), _sum_parts(ph, 192).view(64, 3)
+    dlv, dlh = torch.zeros_like(lepe_v), torch.zeros_like(lepe_h)
+    dlv[:, 0, :, 1] = gv                                     # centre column: taps over dy
+    dlh[:, 0, 1, :] = gh                                     # centre row: taps over dx
+    return dqkv, dlv, dlh

@@ -170,6 +170,22 @@ class SelfAttnFn(torch.autograd.Function):
         return K.self_attn_backward(qkv, _c(dout), ctx.n, ctx.heads), None, None
 
 
+class StripeAttnFn(torch.autograd.Function):
+    """Cross-stripe attention with LePE on fp32 q | k | v rows (CSWinAttention.forward, NMP.py:429-505).  fwd() -> the message rows."""
+
+    @staticmethod
+    def forward(ctx, qkv, lepe_v, lepe_h, geom, fwd):
+        ctx.save_for_backward(qkv, lepe_v, lepe_h)
+        ctx.geom = geom                                              # (b, h, w, n)
+        return fwd()
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, lepe_v, lepe_h = ctx.saved_tensors
+        dqkv, dlv, dlh = K.stripe_attn_backward(qkv, lepe_v.contiguous(), lepe_h.contiguous(), _c(dout), *ctx.geom)
+        return (dqkv if ctx.needs_input_grad[0] else None), dlv, dlh, None, None
+
+
 class ProjFn(torch.autograd.Function):
     """x + proj(msg): a block without MLP (the self-edge block, NMP.py:104-108).  fwd() -> the fused launch's x_out."""
 

@@ -1310,3 +1310,31 @@ def test_self_attention_backward_vs_fp64_autograd(t_, n):
     report("self attention forward", y.detach().cpu(), ref.detach(), 2e-5, 1e-5)
     assert torch.equal(torch.autograd.grad(y, [qg], gout.to(DEV))[0], got)
     assert float((kk.from_kv16(kk.to_kv16(qkv.to(DEV))) - qkv.to(DEV)).abs().max()) <= 2.0 ** -21 * float(qkv.abs().max())
+
+
+@pytest.mark.parametrize("b,h,w,n", [(1, 5, 9, 4), (2, 7, 4, 4), (1, 3, 70, 4), (1, 6, 6, 1)])
+def test_stripe_attention_backward_vs_oracle_autograd(b, h, w, n):
+    """nmrf_stripe_attn_bwd_f32 against fp64 autograd of the oracle's stripe attention (both axes, sibling mask, LePE): dq | dk | dv and
+    the gradients of the two depthwise 3x3 LePE kernels (only their centre column / row is ever non-zero); deterministic."""
+    kk = K()
+    tkn = b * h * w * n
+    qkv = rnd(tkn, 384, seed=h * w, scale=1.1)
+    lv, lh = rnd(64, 1, 3, 3, seed=5, scale=0.5), rnd(64, 1, 3, 3, seed=6, scale=0.5)
+    gout = rnd(tkn, 128, seed=7)
+    qd, lvd, lhd = qkv.double().requires_grad_(True), lv.double().requires_grad_(True), lh.double().requires_grad_(True)
+    outs = []
+    for axis, lw in ((0, lvd), (1, lhd)):
+        sl = slice(axis * 64, (axis + 1) * 64)
+        sp = lambda t3: t3[:, sl].reshape(b, h, w, n, 2, 32)
+        o = O.stripe_attention(sp(qd[:, :128]), sp(qd[:, 128:256]), sp(qd[:, 256:]), lw, axis, 32 ** -0.5)
+        outs.append(o.reshape(b, h, w, n, 64))
+    ref = torch.cat(outs, -1).reshape(tkn, 128)
+    fwd = kk.stripe_attn(qkv.to(DEV), lv.to(DEV), lh.to(DEV), b, h, w, n)
+    report("stripe attention forward", fwd.cpu(), ref.detach(), 2e-5, 1e-5)
+    gq, glv, glh = torch.autograd.grad(ref, [qd, lvd, lhd], gout.double())
+    dqkv, dlv, dlh = kk.stripe_attn_backward(qkv.to(DEV), lv.to(DEV), lh.to(DEV), gout.to(DEV), b, h, w, n)
+    report("stripe attention dqkv", dqkv.cpu(), gq, 1e-5 * float(gq.abs().max()) + 1e-7)
+    report("stripe attention dlepe_v", dlv.cpu(), glv, 1e-5 * float(glv.abs().max()) + 1e-6)
+    report("stripe attention dlepe_h", dlh.cpu(), glh, 1e-5 * float(glh.abs().max()) + 1e-6)
+    again = kk.stripe_attn_backward(qkv.to(DEV), lv.to(DEV), lh.to(DEV), gout.to(DEV), b, h, w, n)
+    assert all(torch.equal(x, y) for x, y in zip((dqkv, dlv, dlh), again))
