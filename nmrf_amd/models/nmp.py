@@ -475,6 +475,9 @@ class Propagation(nn.Module):
                     self._launch.append(_BlockLauncher(m.proj, (m.norm2, m.mlp)))
         _, qkv, _ = self._launch[0](x, None, ctx, n, want_x=False)
         keep_pre = self.training and getattr(self, "keep_pre_norm", False)      # NMRF.enable_grad_slice: see Inference._run_blocks
+        tape = getattr(self, "_tape", None) if keep_pre else None
+        if tape is not None:
+            tape.update(x=[x], qkv=[qkv], msg=[], dims=dims, ctx=ctx, kv16=kv16)
         for i, m in enumerate(L):
             msg = K.stripe_attn(qkv, m.attns[0].get_v.weight, m.attns[1].get_v.weight, b, h, wd, n, kv16=kv16)
             last = i + 1 == len(L)
@@ -482,6 +485,11 @@ class Propagation(nn.Module):
             x, qkv, ln = self._launch[i + 1](x, msg, ctx, n, want_x=not last or self.norm is None or keep_pre)
             if last and keep_pre:
                 self._last_block = (x_in, msg, x, m, None)
+            if tape is not None:
+                tape["msg"].append(msg)
+                tape["x"].append(x)
+                if qkv is not None:
+                    tape["qkv"].append(qkv)
         return ln if self.norm is not None else x
 
     def __init__(self, embed_dim, cost_group, layers, norm=None):
@@ -519,6 +527,8 @@ class Propagation(nn.Module):
             if not hasattr(self, "_embed"):
                 self._embed = _ChainLauncher(1, (self.cost_encoder[0], self.cost_encoder[2], self.proj), (48, 128, 160), 128)
             x = self._embed(cost, cost.shape[1], extra=enc)
+            if self.training and getattr(self, "keep_pre_norm", False):
+                self._tape = {"cost": cost, "enc": enc}          # (NMRF.enable_grad_slice: the seed embedding's operands; _forward_blocks adds the rest)
             return self._forward_blocks(x, ctx, dims).unsqueeze(0), (label_seed.float() if seeds_f is None else seeds_f)
         if feats is None:
             cost, enc = K.seed_features(cost_volume, label_seed, 3.14 / 64)

@@ -214,6 +214,38 @@ class NMRF(nn.Module):
             rows.append(xg if keep is None else xg.index_select(0, keep))
         return rows
 
+    @staticmethod
+    def _propagation_rows_with_grad(prop):
+        """The propagation stage's output rows (before its final norm) as an autograd graph over ALL of its parameters: the seed embedding
+        (cost_encoder on the 9 x 4 cost taps, proj on [features | Fourier]) and five layers of [norm1 | context -> q, k, v -> cross-stripe
+        attention with LePE -> proj + residual + norm2 + MLP].  Forward values from the tape of Propagation.forward (kv16 rows decoded),
+        backward = csrc/backward.hip.  The label seeds (integer NMS output), the cost taps and the context rows are constants: their
+        producers -- seed stage, DPN context convs -- are forward-only.  None without a tape."""
+        from .autograd_ops import BlockFn, FfnFn, LinearFn, QkvFn, StripeAttnFn
+        tape = getattr(prop, "_tape", None)
+        if tape is None or "x" not in tape or len(tape["qkv"]) != len(prop.layers):
+            return None
+        b, h, wd, n = tape["dims"]
+        ce0, ce2 = prop.cost_encoder[0], prop.cost_encoder[2]
+        cost = tape["cost"][:, : ce0.in_features].contiguous()
+
+        def encoder(t):                                               # (the fused seed-embedding chain does not materialise this layer)
+            _, hid = K.bias_act(K.linear_forward(t, ce0.weight), ce0.bias, 2)
+            return K.bias_act(K.linear_forward(hid, ce2.weight), ce2.bias, 0)[1]
+        feat = FfnFn.apply(cost, ce0.weight, ce0.bias, ce2.weight, ce2.bias, encoder)
+        cat = torch.cat((feat, tape["enc"][:, : prop.proj.in_features - feat.shape[1]]), 1)
+        x = LinearFn.apply(cat, prop.proj.weight, None, lambda t, v=tape["x"][0]: v)
+        ctx_tok = tape["ctx"].repeat_interleave(n, 0).contiguous()    # the context row of a pixel, once per label (NMP.py:548)
+        for i, layer in enumerate(prop.layers):
+            m = layer.nmp
+            qkv_i = K.from_kv16(tape["qkv"][i]) if tape["kv16"] else tape["qkv"][i]
+            wb = [t for l in (m.q, m.k, m.v) for t in (l.weight, l.bias)]
+            qkv = QkvFn.apply(x, ctx_tok, m.norm1.weight, m.norm1.bias, m.norm1.eps, lambda v=qkv_i: v, *wb)
+            msg = StripeAttnFn.apply(qkv, m.attns[0].get_v.weight, m.attns[1].get_v.weight, (b, h, wd, n), lambda v=tape["msg"][i]: v)
+            x = BlockFn.apply(x, msg, m.proj.weight, m.proj.bias, m.norm2.weight, m.norm2.bias, m.mlp.fc1.weight, m.mlp.fc1.bias,
+                              m.mlp.fc2.weight, m.mlp.fc2.bias, m.norm2.eps, lambda v=tape["x"][i + 1]: v)
+        return x
+
     def _tail_with_grad(self, labels_curr, dims8, heads4, tok4, out_hw, prob, label_seeds):
         """The tail of hot_path in training mode with grad_slice: norms + heads of every layer under autograd."""
         from .autograd_ops import LayerNormFn, LinearFn, MlpHeadFn, refine_epilogue_torch
@@ -242,7 +274,9 @@ class NMRF(nn.Module):
             # disparity proposals (DPN.py:131-132): labels = relu(prop_head(norm(last propagation block)) + seeds) as a function of the
             # propagation stage's last block, its final norm and the head -- the loss_prop branch of the Criterion
             prop = self.dpn.propagation
-            mem = last_rows(prop)
+            mem = self._propagation_rows_with_grad(prop)
+            if mem is None:
+                mem = last_rows(prop)
             if prop.norm is not None:
                 mem = LayerNormFn.apply(mem, prop.norm.weight, prop.norm.bias, prop.norm.eps)
             proposal = torch.relu(head(self.dpn.prop_head, mem).view(-1, n) + label_seeds.reshape(-1, n)).reshape(b, -1, n)

@@ -1,6 +1,7 @@
 """N4, first slice: one optimisation step over the part of the model whose gradients this build can produce on the MI355X
-(nmrf_amd.models.NMRF.enable_grad_slice: the three prediction heads, the WHOLE inference and refinement stages, and -- behind the proposal
-loss -- the proposal head, the propagation's final norm and last block: 222 of the model's 351 tensors), shaped like the reference's training loop (main.py:403-430):
+(nmrf_amd.models.NMRF.enable_grad_slice: the WHOLE inference and refinement stages with their three heads, and -- behind the proposal
+loss -- the WHOLE propagation stage with its head: 309 of the model's 351 tensors; the rest is the encoder, the matching heads, the DPN context
+convolutions and the seed filter), shaped like the reference's training loop (main.py:403-430):
 
     model.train(); loss_dict = criterion(model(sample), sample); losses = sum_k weight_dict[k] * loss_dict[k]
     param.grad = None; losses.backward(); clip_grad_norm_(GRAD_CLIP); optimizer.step()
@@ -11,19 +12,13 @@ GPU, weights replicated, batch sharded as in nmrf_amd.parallel).  Everything els
 import torch
 import torch.distributed as dist
 
-SLICE_PREFIXES = ("infer_head.", "infer_score_head.", "refine_head.", "inference.", "refinement.", "dpn.prop_head.",
-                  "dpn.propagation.norm.")           # "inference." / "refinement.": the WHOLE stages (attention backward kernels, round 5)
-LAST_BLOCK_PARTS = ("proj", "norm2", "mlp")
+# the WHOLE inference, refinement and propagation stages (attention backward kernels, round 5) and the four prediction heads
+SLICE_PREFIXES = ("infer_head.", "infer_score_head.", "refine_head.", "inference.", "refinement.", "dpn.prop_head.", "dpn.propagation.")
 
 
 def slice_parameters(model):
     """[(name, parameter)] the gradient slice reaches, in named_parameters() order."""
-    last = ("dpn.propagation.layers.%d.nmp." % (len(model.dpn.propagation.layers) - 1),)
-    out = []
-    for name, p in model.named_parameters():
-        if name.startswith(SLICE_PREFIXES) or (name.startswith(last) and name.split(".nmp.")[1].split(".")[0] in LAST_BLOCK_PARTS):
-            out.append((name, p))
-    return out
+    return [(name, p) for name, p in model.named_parameters() if name.startswith(SLICE_PREFIXES)]
 
 
 def build_slice_optimizer(model, cfg):

@@ -744,7 +744,7 @@ def test_training_backward_slice_matches_reference_gradients():
     """N4, first slice: model.train() + enable_grad_slice(): the loss of one training step (main.py:413-420: sum_k weight_dict[k] *
     loss_dict[k] of the reference's Criterion, restated in nmrf_amd.models.criterion) is differentiated through the prediction heads and
     the stage-final LayerNorms -- and through the LAST message-passing block of either stage (proj, norm2, fc1, fc2) -- on the HIP kernels
-    (models/autograd_ops.py, csrc/backward.hip) and `.grad` of EVERY parameter of the inference and refinement stages and the heads (206 tensors: ffn, per layer norm1 / q | k | v / relative-position table / proj / norm2 / MLP through FfnFn, QkvFn, SelfAttnFn, WindowAttnFn, ProjFn, BlockFn; 137 of them stored in the fixture) -- (and, for the proposal loss differentiated alone, of 16 more in the propagation stage) equals the REFERENCE's own autograd gradients (tests/golden/e2e_train.npz `grad/*`, tools/gen_golden.py:run_train) -- the forward fed with
+    (models/autograd_ops.py, csrc/backward.hip) and `.grad` of EVERY parameter of the inference and refinement stages and the heads (206 tensors: ffn, per layer norm1 / q | k | v / relative-position table / proj / norm2 / MLP through FfnFn, QkvFn, SelfAttnFn, WindowAttnFn, ProjFn, BlockFn; 137 of them stored in the fixture) -- (and, for the proposal loss differentiated alone, of the whole propagation stage and its head: 103 more, 49 stored) equals the REFERENCE's own autograd gradients (tests/golden/e2e_train.npz `grad/*`, tools/gen_golden.py:run_train) -- the forward fed with
     the features the reference saw, so the label seeds are bit-exact.  Parameters behind an attention kernel get no gradient."""
     from nmrf_amd.models.criterion import build_criterion
     from tests.conftest import record_note
@@ -798,11 +798,10 @@ def test_training_backward_slice_matches_reference_gradients():
     # The proposal loss is NOT part of the reference's trained loss (Criterion returns 'loss_prop', weight_dict names 'proposal_disp':
     # main.py:416 drops it), so after the step's backward the propagation slice has no gradient -- here as in the reference ...
     prop = [k[len("grad_prop/"):] for k in g if k.startswith("grad_prop/")]
-    assert len(prop) == 16 and all(named[n].grad is None for n in prop)
+    assert len(prop) == 49 and all(named[n].grad is None for n in prop)
     no_grad = [n for n, p in named.items() if p.grad is None]
     # forward-only kernels behind these: an earlier layer's block, the last layer's attention projections, the seed stage
-    for name in ("dpn.mlp.0.weight", "dpn.propagation.layers.3.nmp.mlp.fc2.weight", "dpn.propagation.layers.4.nmp.q.weight",
-                 "concatconv.0.weight", "backbone.conv1.weight"):
+    for name in ("dpn.mlp.0.weight", "dpn.proj.0.weight", "concatconv.0.weight", "gw.3.weight", "backbone.conv1.weight"):
         assert name in no_grad, name
     # ... and differentiated on its own it gives the reference's gradients for the proposal head, the propagation's final norm and its
     # last block (what a user who adds 'loss_prop' to the weight_dict trains)
@@ -811,6 +810,8 @@ def test_training_backward_slice_matches_reference_gradients():
     worst = compare("grad_prop/", 1e-2)
     record_note("training backward slice, proposal loss alone: %d parameter gradients, worst %.1e (%s)" % (
         len(worst), max(worst.values()), max(worst, key=worst.get)))
+    missing = [n for n, p in named.items() if n.startswith(("dpn.propagation.", "dpn.prop_head.")) and p.grad is None]
+    assert not missing, missing                                        # EVERY parameter of the propagation stage and its head
     # eval mode is untouched by the switch
     ev = model.eval()({"img1": img1, "img2": img2})
     assert not ev["disp"].requires_grad and "aux_outputs" not in ev
@@ -818,7 +819,7 @@ def test_training_backward_slice_matches_reference_gradients():
 
 def test_train_steps_on_the_gradient_slice_reduce_the_loss():
     """nmrf_amd.train.train_step (the shape of main.py:413-430 on the gradient slice): a few AdamW steps on one 56x104 pair lower the
-    weighted loss; exactly the 206 tensors the reference's loss reaches move (222 once 'loss_prop' is given a weight), everything else is frozen and bit-unchanged."""
+    weighted loss; exactly the 206 tensors the reference's loss reaches move (309 once 'loss_prop' is given a weight), everything else is frozen and bit-unchanged."""
     from nmrf_amd.models.criterion import build_criterion
     from nmrf_amd.train import build_slice_optimizer, slice_parameters, train_step
     from tests.conftest import record_note
@@ -828,7 +829,7 @@ def test_train_steps_on_the_gradient_slice_reduce_the_loss():
     cfg = make_cfg(md)
     model = build_product(md, DEV).train().enable_grad_slice()
     crit = build_criterion(cfg)
-    assert len(slice_parameters(model)) == 222                      # 206 that the reference's loss reaches + 16 behind 'loss_prop'
+    assert len(slice_parameters(model)) == 309                      # 206 that the reference's loss reaches + 103 behind 'loss_prop'
     opt = build_slice_optimizer(model, cfg)
     before = {k: v.detach().clone() for k, v in model.named_parameters()}
     img1, img2 = golden_images(g)

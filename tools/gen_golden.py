@@ -168,8 +168,10 @@ def run_train():
     # so main.py:416's `if k in weight_dict` leaves it OUT of the trained loss and the propagation stage gets no gradient in the
     # reference's own step (checked: .grad is None).  Its gradient is still well defined: differentiated on its own here, for the
     # proposal head, the propagation's final norm and its last block.
+    # (round 5, later: the whole propagation stage has a backward -- stored for the seed embedding, layers 0 and 4, the norm and the head)
     prop_names = [n for n, p in model.named_parameters()
-                  if in_slice(n, ("dpn.prop_head.", "dpn.propagation.norm."), ("dpn.propagation.layers.4.nmp.",))]
+                  if n.startswith(("dpn.prop_head.", "dpn.propagation.norm.", "dpn.propagation.cost_encoder.", "dpn.propagation.proj.",
+                                   "dpn.propagation.layers.0.", "dpn.propagation.layers.4."))]
     assert all(dict(model.named_parameters())[n].grad is None for n in prop_names)
     model.zero_grad(set_to_none=True)
     out_p = model({"img1": img1.clone().float(), "img2": img2.clone().float()})
