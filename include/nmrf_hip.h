@@ -452,6 +452,15 @@ int nmrf_self_attn_bwd_f32(const float *qkv, const float *dout, int64_t T, int N
 int nmrf_stripe_attn_bwd_f32(const float *qkv, const float *lepe_v, const float *lepe_h, const float *dout, int B, int H, int W, int N,
                              float *dqkv, float *dtap_v_parts, float *dtap_h_parts, float *scratch, void *stream);
 
+/* Backward pieces of the seed filter (DPN.mlp: three Conv1d(kernel 5, padding 2) along the disparity axis + softmax, DPN.py:32-38,117-119):
+ * a Conv1d over D is an nn.Linear on 5-tap columns, col[(p, d)][c*5 + t] = A[(p, d + t - 2)][c] (zero outside the row) with the weight
+ * [O][C][5] flattened, so dgrad / wgrad are nmrf_gemm_split_f32 on `col`.  nmrf_unfold5_f32 builds col [P*D, 5C] from rows (p, d) x C
+ * (src_pcd == 0) or from the cost volume's [P][C][D] (src_pcd != 0); nmrf_fold5_f32 is its adjoint, dA[(p, e)][c] = sum_t dcol[(p, e - t +
+ * 2)][c*5 + t]; nmrf_softmax_bwd_f32: dz = p (dp - sum_d p dp) over rows of D <= 64. */
+int nmrf_unfold5_f32(const float *src, int64_t P, int C, int D, int src_pcd, float *col, void *stream);
+int nmrf_fold5_f32(const float *dcol, int64_t P, int C, int D, float *dA, void *stream);
+int nmrf_softmax_bwd_f32(const float *prob, const float *dprob, int64_t P, int D, float *dz, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

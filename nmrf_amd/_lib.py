@@ -77,6 +77,9 @@ PROTOTYPES = {
     "nmrf_window_attn_bwd_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "nmrf_self_attn_bwd_f32": [_P, _P, _L, _I, _I, _I, _P, _P],
     "nmrf_stripe_attn_bwd_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "nmrf_unfold5_f32": [_P, _L, _I, _I, _I, _P, _P],
+    "nmrf_fold5_f32": [_P, _L, _I, _I, _P, _P],
+    "nmrf_softmax_bwd_f32": [_P, _P, _L, _I, _P, _P],
 }
 
 # exported only by libnmrf_hip_debug.so (include/nmrf_hip_debug.h): reference kernels for A/B runs, never launched by the product

@@ -692,3 +692,72 @@ extern "C" int nmrf_stripe_attn_bwd_f32(const float *qkv, const float *lepe_v, c
     hipLaunchKernelGGL(stripe_attn_bwd_kernel, dim3(H, 2, B), dim3(256), 0, (hipStream_t)stream, ah);
     return nmrf_launch_status();
 }
+
+// ---- the seed filter (DPN.mlp: three Conv1d(k = 5, pad 2) along the disparity axis + softmax, DPN.py:32-38,117-119) as linears ----------
+// A Conv1d over D is a Linear on 5-tap columns: col[(p, d)][c * 5 + t] = A[(p, d + t - 2)][c] (zero outside 0 <= d + t - 2 < D), weight
+// [O][C][5] flattened -- so its backward is the dgrad / wgrad GEMM above plus the two data movements here and the softmax backward.
+// src_pcd != 0: the source is [P][C][D] (the cost volume's layout), else rows (p, d) x C.
+__global__ __launch_bounds__(256) void unfold5_kernel(const float *__restrict__ src, int64_t P, int C, int D, int src_pcd, float *__restrict__ col) {
+    const int64_t total = P * D * C * 5;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int t = (int)(idx % 5);
+        const int c = (int)((idx / 5) % C);
+        const int64_t pd = idx / (5 * C);
+        const int d = (int)(pd % D);
+        const int64_t p = pd / D;
+        const int e = d + t - 2;
+        float v = 0.f;
+        if (e >= 0 && e < D) v = src_pcd ? src[(p * C + c) * D + e] : src[(p * D + e) * C + c];
+        col[idx] = v;
+    }
+}
+// dA[(p, e)][c] = sum_t dcol[(p, e - t + 2)][c * 5 + t]   (t ascending: fixed order)
+__global__ __launch_bounds__(256) void fold5_kernel(const float *__restrict__ dcol, int64_t P, int C, int D, float *__restrict__ dA) {
+    const int64_t total = P * D * C;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        const int64_t pe = idx / C;
+        const int e = (int)(pe % D);
+        const int64_t p = pe / D;
+        float s = 0.f;
+        for (int t = 0; t < 5; ++t) {
+            const int d = e - t + 2;
+            if (d >= 0 && d < D) s += dcol[((p * D + d) * C + c) * 5 + t];
+        }
+        dA[idx] = s;
+    }
+}
+// dz = p * (dp - sum_d p dp), one wave per row of D <= 64 entries
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float *__restrict__ prob, const float *__restrict__ dprob, int64_t P, int D,
+                                                          float *__restrict__ dz) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < P; r += (int64_t)gridDim.x * 4) {
+        const float p = lane < D ? prob[r * D + lane] : 0.f, g = lane < D ? dprob[r * D + lane] : 0.f;
+        const float dot = wave_sum(p * g);
+        if (lane < D) dz[r * D + lane] = p * (g - dot);
+    }
+}
+extern "C" int nmrf_unfold5_f32(const float *src, int64_t P, int C, int D, int src_pcd, float *col, void *stream) {
+    if (!src || !col) return NMRF_ENULL;
+    if (P < 1 || C < 1 || D < 1) return NMRF_EINVAL;
+    int64_t blocks = ceil_div64(P * D * C * 5, 256 * 4);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(unfold5_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, P, C, D, src_pcd, col);
+    return nmrf_launch_status();
+}
+extern "C" int nmrf_fold5_f32(const float *dcol, int64_t P, int C, int D, float *dA, void *stream) {
+    if (!dcol || !dA) return NMRF_ENULL;
+    if (P < 1 || C < 1 || D < 1) return NMRF_EINVAL;
+    int64_t blocks = ceil_div64(P * D * C, 256 * 4);
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(fold5_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dcol, P, C, D, dA);
+    return nmrf_launch_status();
+}
+extern "C" int nmrf_softmax_bwd_f32(const float *prob, const float *dprob, int64_t P, int D, float *dz, void *stream) {
+    if (!prob || !dprob || !dz) return NMRF_ENULL;
+    if (P < 1 || D < 1 || D > 64) return NMRF_EINVAL;
+    int64_t blocks = ceil_div64(P, 4 * 4);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, prob, dprob, P, D, dz);
+    return nmrf_launch_status();
+}

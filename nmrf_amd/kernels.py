@@ -1262,3 +1262,28 @@ def stripe_attn_backward(qkv, lepe_v, lepe_h, dout, b, h, w, n):
     dlv[:, 0, :, 1] = gv                                     # centre column: taps over dy
     dlh[:, 0, 1, :] = gh                                     # centre row: taps over dx
     return dqkv, dlv, dlh
+
+
+@_on_device
+def unfold5(src, p, c, d, src_pcd=False):
+    """5-tap columns of a Conv1d(kernel 5, padding 2) over the disparity axis: src rows (p, d) x c (or [p][c][d]) -> [p*d, 5c]."""
+    _chk(src)
+    col = torch.empty(p * d, 5 * c, device=src.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_unfold5_f32(_p(src), p, c, d, int(bool(src_pcd)), _p(col), _stream()), "unfold5")
+    return col
+
+
+@_on_device
+def fold5(dcol, p, c, d):
+    _chk(dcol)
+    out = torch.empty(p * d, c, device=dcol.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_fold5_f32(_p(dcol), p, c, d, _p(out), _stream()), "fold5")
+    return out
+
+
+@_on_device
+def softmax_backward(prob, dprob):
+    _chk(prob, dprob)
+    dz = torch.empty_like(prob)
+    _lib.check(_lib.load().nmrf_softmax_bwd_f32(_p(prob), _p(dprob), prob.shape[0], prob.shape[1], _p(dz), _stream()), "softmax_bwd")
+    return dz

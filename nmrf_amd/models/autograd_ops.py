@@ -186,6 +186,36 @@ class StripeAttnFn(torch.autograd.Function):
         return (dqkv if ctx.needs_input_grad[0] else None), dlv, dlh, None, None
 
 
+class DpnFilterFn(torch.autograd.Function):
+    """The seed filter: prob = softmax_D(conv1d(relu(conv1d(relu(conv1d(cost volume)))))) (DPN.mlp, DPN.py:32-38,117-119), differentiated
+    with respect to its six parameters (the cost volume is a constant here: its producers -- correlation, encoder -- are forward-only).
+    fwd() -> prob of the fused kernel.  Each Conv1d(kernel 5, padding 2) over D is a Linear on 5-tap columns (K.unfold5)."""
+
+    @staticmethod
+    def forward(ctx, cv, w0, b0, w2, b2, w4, b4, fwd):
+        prob = fwd()
+        ctx.save_for_backward(cv, w0, b0, w2, b2, w4, prob)
+        return prob
+
+    @staticmethod
+    def backward(ctx, dprob):
+        cv, w0, b0, w2, b2, w4, prob = ctx.saved_tensors
+        p, g, d = cv.shape
+        f = lambda w: w.reshape(w.shape[0], -1).contiguous()                     # [O, C, 5] -> [O, 5C] (c-major, tap-minor: unfold5's order)
+        col0 = K.unfold5(cv, p, g, d, src_pcd=True)
+        y1, a1 = K.bias_act(K.linear_forward(col0, f(w0)), b0, 1)
+        col1 = K.unfold5(a1, p, w0.shape[0], d)
+        y2, a2 = K.bias_act(K.linear_forward(col1, f(w2)), b2, 1)
+        col2 = K.unfold5(a2, p, w2.shape[0], d)
+        dz = K.softmax_backward(prob, _c(dprob)).reshape(p * d, 1)
+        dw4, db4 = K.linear_wgrad(dz, col2), K.bias_grad(dz)
+        dy2 = K.act_backward(y2, K.fold5(K.linear_dgrad(dz, f(w4)), p, w2.shape[0], d), 1)
+        dw2, db2 = K.linear_wgrad(dy2, col1), K.bias_grad(dy2)
+        dy1 = K.act_backward(y1, K.fold5(K.linear_dgrad(dy2, f(w2)), p, w0.shape[0], d), 1)
+        dw0, db0 = K.linear_wgrad(dy1, col0), K.bias_grad(dy1)
+        return None, dw0.view_as(w0), db0, dw2.view_as(w2), db2, dw4.view_as(w4), db4, None
+
+
 class ProjFn(torch.autograd.Function):
     """x + proj(msg): a block without MLP (the self-edge block, NMP.py:104-108).  fwd() -> the fused launch's x_out."""
 

@@ -247,9 +247,9 @@ class NMRF(nn.Module):
                               m.mlp.fc2.weight, m.mlp.fc2.bias, m.norm2.eps, lambda v=tape["x"][i + 1]: v)
         return x
 
-    def _tail_with_grad(self, labels_curr, dims8, heads4, tok4, out_hw, prob, label_seeds):
+    def _tail_with_grad(self, labels_curr, dims8, heads4, tok4, out_hw, prob, label_seeds, cv_rows):
         """The tail of hot_path in training mode with grad_slice: norms + heads of every layer under autograd."""
-        from .autograd_ops import LayerNormFn, LinearFn, MlpHeadFn, refine_epilogue_torch
+        from .autograd_ops import DpnFilterFn, LayerNormFn, LinearFn, MlpHeadFn, refine_epilogue_torch
         from .nmp import _ChainLauncher
         b, h8, w8, n = dims8
         if not hasattr(self, "_score"):
@@ -272,6 +272,10 @@ class NMRF(nn.Module):
             return y if keep is None else y.index_select(0, keep)
 
         with torch.enable_grad():
+            # the matching distribution as a function of the seed filter's parameters (the `init` loss of the Criterion, NMRF.py:300-330)
+            fm = self.dpn.mlp
+            prob = DpnFilterFn.apply(cv_rows.contiguous(), fm[0].weight, fm[0].bias, fm[2].weight, fm[2].bias, fm[4].weight, fm[4].bias,
+                                     lambda v=prob: v)
             # disparity proposals (DPN.py:131-132): labels = relu(prop_head(norm(last propagation block)) + seeds) as a function of the
             # propagation stage's last block, its final norm and the head -- the loss_prop branch of the Criterion
             prop = self.dpn.propagation
@@ -387,7 +391,7 @@ class NMRF(nn.Module):
                     t.record_stream(main)
 
         cost_volume = K.cost_volume(fmap1_list[0], fmap2_list[0], self.max_disp // 8, self.dpn.cost_group)
-        _, prob, label_seeds, labels = self.dpn(cost_volume, fmap1_list, context=context, context_ready=ctx_ready)
+        cv_rows, prob, label_seeds, labels = self.dpn(cost_volume, fmap1_list, context=context, context_ready=ctx_ready)      # cv_rows [P,G,D]
         labels_curr = labels[-1]                                            # [P, N]
         if overlap:
             main.wait_stream(side)
@@ -400,7 +404,7 @@ class NMRF(nn.Module):
         if self.training and getattr(self, "grad_slice", False) and stages is None:
             if not (self.inference.return_intermediate and self.refinement.return_intermediate):
                 raise NotImplementedError("grad_slice: the training-mode forward with NMP.RETURN_INTERMEDIATE (the reference's default)")
-            return self._tail_with_grad(labels_curr, (b, h8, w8, n), heads4, tok4, (h0, w0), prob, label_seeds)
+            return self._tail_with_grad(labels_curr, (b, h8, w8, n), heads4, tok4, (h0, w0), prob, label_seeds, cv_rows)
         from .nmp import _ChainLauncher, _FusedCache, _split
         hl = self.infer_head.layers
         if (stages is None and not self.training and _split() and n == 4 and len(hl) == 3

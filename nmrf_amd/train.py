@@ -1,7 +1,7 @@
 """N4, first slice: one optimisation step over the part of the model whose gradients this build can produce on the MI355X
 (nmrf_amd.models.NMRF.enable_grad_slice: the WHOLE inference and refinement stages with their three heads, and -- behind the proposal
-loss -- the WHOLE propagation stage with its head: 309 of the model's 351 tensors; the rest is the encoder, the matching heads, the DPN context
-convolutions and the seed filter), shaped like the reference's training loop (main.py:403-430):
+loss -- the WHOLE propagation stage with its head, and the seed filter: 315 of the model's 351 tensors; the rest is the encoder, the
+matching heads and the DPN context convolutions), shaped like the reference's training loop (main.py:403-430):
 
     model.train(); loss_dict = criterion(model(sample), sample); losses = sum_k weight_dict[k] * loss_dict[k]
     param.grad = None; losses.backward(); clip_grad_norm_(GRAD_CLIP); optimizer.step()
@@ -13,7 +13,8 @@ import torch
 import torch.distributed as dist
 
 # the WHOLE inference, refinement and propagation stages (attention backward kernels, round 5) and the four prediction heads
-SLICE_PREFIXES = ("infer_head.", "infer_score_head.", "refine_head.", "inference.", "refinement.", "dpn.prop_head.", "dpn.propagation.")
+SLICE_PREFIXES = ("infer_head.", "infer_score_head.", "refine_head.", "inference.", "refinement.", "dpn.prop_head.", "dpn.propagation.",
+                  "dpn.mlp.")                        # + the seed filter (Conv1d x 3 + softmax: the `init` loss)
 
 
 def slice_parameters(model):

@@ -1338,3 +1338,32 @@ def test_stripe_attention_backward_vs_oracle_autograd(b, h, w, n):
     report("stripe attention dlepe_h", dlh.cpu(), glh, 1e-5 * float(glh.abs().max()) + 1e-6)
     again = kk.stripe_attn_backward(qkv.to(DEV), lv.to(DEV), lh.to(DEV), gout.to(DEV), b, h, w, n)
     assert all(torch.equal(x, y) for x, y in zip((dqkv, dlv, dlh), again))
+
+
+@pytest.mark.parametrize("p,d", [(7, 16), (300, 40), (33, 48)])
+def test_seed_filter_backward_vs_oracle_autograd(p, d):
+    """DpnFilterFn (forward = the fused filter + softmax kernel; backward = unfold5 / split-fp16 GEMMs / fold5 / softmax_bwd) against fp64
+    autograd of the oracle's dpn_filter_softmax (three Conv1d(k 5, pad 2) + ReLU + softmax over D): the six parameter gradients."""
+    from nmrf_amd.models.autograd_ops import DpnFilterFn
+    kk = K()
+    cv = rnd(p, 4, d, seed=p, scale=1.0)
+    names = ["dpn.mlp.0.weight", "dpn.mlp.0.bias", "dpn.mlp.2.weight", "dpn.mlp.2.bias", "dpn.mlp.4.weight", "dpn.mlp.4.bias"]
+    shapes = [(8, 4, 5), (8,), (16, 8, 5), (16,), (1, 16, 5), (1,)]
+    ws = [rnd(*sh, seed=70 + i, scale=0.6) for i, sh in enumerate(shapes)]
+    gout = rnd(p, d, seed=80)
+    wd = {n: w.double().requires_grad_(True) for n, w in zip(names, ws)}
+    ref = O.dpn_filter_softmax(cv.double(), wd)
+    gref = torch.autograd.grad(ref, [wd[n] for n in names], gout.double())
+    wg = [w.to(DEV).requires_grad_(True) for w in ws]
+    cvd = cv.to(DEV)
+    prob = DpnFilterFn.apply(cvd, *wg, lambda: kk.dpn_filter_softmax(cvd, *[w.detach() for w in wg]))
+    report("seed filter forward", prob.detach().cpu(), ref.detach(), 3e-6)
+    got = torch.autograd.grad(prob, wg, gout.to(DEV))
+    for n, g1, g2 in zip(names, got, gref):
+        # (the last bias shifts every logit of a row alike: its gradient is 0 in exact arithmetic, fp32 sums of p * d terms leave ~1e-7)
+        report("seed filter d" + n, g1.cpu(), g2, 2e-5 * float(g2.abs().max()) + 2e-6)
+    # unfold5 / fold5 are adjoint: <unfold(a), c> == <a, fold(c)>
+    a, c = rnd(p * d, 8, seed=1).to(DEV), rnd(p * d, 40, seed=2).to(DEV)
+    lhs = float((kk.unfold5(a, p, 8, d).double() * c.double()).sum())
+    rhs = float((a.double() * kk.fold5(c, p, 8, d).double()).sum())
+    assert abs(lhs - rhs) <= 1e-6 * max(1.0, abs(lhs)), (lhs, rhs)             # (fold5 adds its five taps in fp32)

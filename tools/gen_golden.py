@@ -162,7 +162,7 @@ def run_train():
         # ... and of the inference stage: sibling + window attention backward; stored for its ffn, final norm and layers 0 and 4 (the
         # fixture would grow by 4 MB for the other three; the test asserts that they do get gradients)
         if name.startswith(("refinement.", "infer_head.", "infer_score_head.", "refine_head.", "inference.norm.", "inference.ffn.",
-                            "inference.layers.0.", "inference.layers.4.")):
+                            "inference.layers.0.", "inference.layers.4.", "dpn.mlp.")):         # dpn.mlp: the seed filter (the `init` loss)
             d["grad/" + name] = _np(p.grad)
     # The proposal loss: Criterion.forward returns it as 'loss_prop' while the weight_dict of NMRF.py:432-447 names it 'proposal_disp',
     # so main.py:416's `if k in weight_dict` leaves it OUT of the trained loss and the propagation stage gets no gradient in the
