@@ -165,11 +165,11 @@ class NMRF(nn.Module):
         """N4 (round 5): in training mode, build an autograd graph over the three message-passing stages and their heads -- the WHOLE
         propagation, inference and refinement stages (seed embedding / ffn, every layer's norm1 / q | k | v / stripe, sibling or window
         attention with its LePE kernels or relative-position table / proj / norm2 / MLP, the stage-final norms) and `prop_head`,
-        `infer_head`, `infer_score_head`, `refine_head`: 309 of 351 tensors (models/autograd_ops.py: every Function's forward value is the
+        `infer_head`, `infer_score_head`, `refine_head`: 315 of 351 tensors (models/autograd_ops.py: every Function's forward value is the
         fused HIP launch's, backward = csrc/backward.hip).  The reference detaches `labels_curr` and `disp_curr` (NMRF.py:215,231), so
         `Criterion(model(sample)).backward()` leaves the REFERENCE's own gradients in `.grad` of the 206 tensors behind the hand-over; the
         propagation stage is reached by the proposal loss only, which carries no weight in the reference's weight_dict (add
-        `weight_dict['loss_prop']` to train it).  Encoder, matching heads, DPN context convolutions and the seed filter stay forward-only:
+        `weight_dict['loss_prop']` to train it).  Encoder, matching heads and DPN context convolutions stay forward-only:
         `.grad is None`, loudly.  Off by default; eval mode ignores it."""
         self.grad_slice = bool(on)
         self.inference.keep_pre_norm = self.refinement.keep_pre_norm = self.dpn.propagation.keep_pre_norm = bool(on)
