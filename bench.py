@@ -296,7 +296,9 @@ def run(args):
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        # (only a rank started without a launcher gets here without MASTER_PORT: `--force-dist` at N = 1 -- a FREE port, not a fixed one:
+        # a store of a previous run on the same port in TIME_WAIT made one such run of a gpu_round.sh fail to rendezvous)
+        os.environ.setdefault("MASTER_PORT", str(_free_port()) if world == 1 else "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from nmrf_amd import kernels as K
