@@ -40,7 +40,7 @@ const char *nmrf_strerror(int code);
  * in a separate pass when range_flag != NULL; pass NULL when qkv was produced by nmrf_nmp_block16_f32, which range-checks its q_out. */
 int nmrf_range_scan_f32(const float *x, int64_t n, int *range_flag, void *stream);   /* n % 4 == 0, x 16-byte aligned */
 /* ABI version of this header; bumps on any signature change. */
-int nmrf_abi_version(void);   /* currently 24 */
+int nmrf_abi_version(void);   /* currently 25 */
 
 /* A2  group-wise correlation volume.
  * replaces build_correlation_volume + the permute of DPN.forward
@@ -460,6 +460,22 @@ int nmrf_stripe_attn_bwd_f32(const float *qkv, const float *lepe_v, const float 
 int nmrf_unfold5_f32(const float *src, int64_t P, int C, int D, int src_pcd, float *col, void *stream);
 int nmrf_fold5_f32(const float *dcol, int64_t P, int C, int D, float *dA, void *stream);
 int nmrf_softmax_bwd_f32(const float *prob, const float *dprob, int64_t P, int D, float *dz, void *stream);
+
+/* ---- N4, towards the feature maps: the backward of the three kernels that read the convolutional maps (the convolutions themselves --
+ * encoder, matching heads, DPN context -- run on stock PyTorch-ROCm autograd in training mode: north_star keeps them there).
+ * nmrf_cost_volume_bwd_f32: backward of nmrf_cost_volume_f32 (build_correlation_volume, nmrf/models/submodule.py:4-23): dcv [B*H*W, G, D]
+ *   -> df1, df2 [B,C,H,W], gather form (one thread per map element, fixed summation order over d).
+ * nmrf_seed_taps_bwd_f32: backward of the 9 cost taps of nmrf_seed_features_f32 (Propagation.sample_cost, NMP.py:619-634): dcost rows
+ *   [(p, n)][ldc >= 9 G] -> dcv [P, G, D]; clamped taps that alias the same bin add up (what index_select's backward does).
+ * nmrf_warp_corr_concat_bwd_f32: backward of nmrf_warp_corr_concat_f32 (Inference.sample_fmap / corr, NMP.py:683-741) for NCHW maps:
+ *   drow [T, 2 Cf + Gr] -> df1, df2 [B,Cf,H,W], dg1, dg2 [B,Cg,H,W].  The labels are constants (NMP.py:694 builds the grid under no_grad;
+ *   NMRF.py:215,232 detach them); the bilinear weights along x are the forward's, the ~1e-7 share of the neighbouring row (H6) is dropped. */
+int nmrf_cost_volume_bwd_f32(const float *f1, const float *f2, const float *dcv, int B, int C, int H, int W, int D, int G, float *df1,
+                             float *df2, void *stream);
+int nmrf_seed_taps_bwd_f32(const float *dcost, const int64_t *seeds, int64_t P, int N, int G, int D, int ldc, float *dcv, void *stream);
+int nmrf_warp_corr_concat_bwd_f32(const float *labels, const float *drow, const float *f1, const float *f2, const float *g1,
+                                  const float *g2, int B, int H, int W, int N, int Cf, int Cg, int Gr, float *df1, float *df2, float *dg1,
+                                  float *dg2, void *stream);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnmrf_hip.so")      # (tools may point this at another build BEFORE the first load(): bench.py --lib)
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -80,6 +80,9 @@ PROTOTYPES = {
     "nmrf_unfold5_f32": [_P, _L, _I, _I, _I, _P, _P],
     "nmrf_fold5_f32": [_P, _L, _I, _I, _P, _P],
     "nmrf_softmax_bwd_f32": [_P, _P, _L, _I, _P, _P],
+    "nmrf_cost_volume_bwd_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "nmrf_seed_taps_bwd_f32": [_P, _P, _L, _I, _I, _I, _I, _P, _P],
+    "nmrf_warp_corr_concat_bwd_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
 }
 
 # exported only by libnmrf_hip_debug.so (include/nmrf_hip_debug.h): reference kernels for A/B runs, never launched by the product

@@ -761,3 +761,178 @@ extern "C" int nmrf_softmax_bwd_f32(const float *prob, const float *dprob, int64
     hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, prob, dprob, P, D, dz);
     return nmrf_launch_status();
 }
+
+// ---- backward towards the feature maps (the stock-PyTorch convolutions take over from there: north_star keeps the backbone on stock ROCm) ---
+// (1) group-wise correlation volume (submodule.py:4-23): cv[(b,y,x)][g][d] = mean_c f1[b,g*cpg+c,y,x] * f2[b,g*cpg+c,y,x-d] (x >= d)
+//     df1[b,ch,y,x] = (1/cpg) sum_{d <= x} dcv[(b,y,x)][g][d] f2[b,ch,y,x-d];   df2[b,ch,y,x'] = (1/cpg) sum_{x'+d < W} dcv[(b,y,x'+d)][g][d] f1[b,ch,y,x'+d]
+__global__ __launch_bounds__(256) void cost_volume_bwd_kernel(const float *__restrict__ f1, const float *__restrict__ f2, const float *__restrict__ dcv,
+                                                              int B, int C, int H, int W, int D, int G, float *__restrict__ df1,
+                                                              float *__restrict__ df2) {
+    const int64_t total = (int64_t)B * C * H * W;
+    const int cpg = C / G;
+    const float inv = 1.0f / (float)cpg;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int x = (int)(idx % W);
+        const int y = (int)((idx / W) % H);
+        const int ch = (int)((idx / ((int64_t)W * H)) % C);
+        const int b = (int)(idx / ((int64_t)W * H * C));
+        const int g = ch / cpg;
+        const float *r1 = f1 + (((int64_t)b * C + ch) * H + y) * W, *r2 = f2 + (((int64_t)b * C + ch) * H + y) * W;
+        const float *drow = dcv + ((int64_t)(b * H + y) * W) * G * D + (int64_t)g * D;       // + x * G * D + d
+        float a1 = 0.f, a2 = 0.f;
+        for (int d = 0; d < D; ++d) {
+            if (d <= x) a1 = fmaf(drow[(int64_t)x * G * D + d], r2[x - d], a1);
+            if (x + d < W) a2 = fmaf(drow[(int64_t)(x + d) * G * D + d], r1[x + d], a2);
+        }
+        df1[idx] = a1 * inv;
+        df2[idx] = a2 * inv;
+    }
+}
+extern "C" int nmrf_cost_volume_bwd_f32(const float *f1, const float *f2, const float *dcv, int B, int C, int H, int W, int D, int G,
+                                        float *df1, float *df2, void *stream) {
+    if (!f1 || !f2 || !dcv || !df1 || !df2) return NMRF_ENULL;
+    if (B < 1 || C < 1 || H < 1 || W < 1 || D < 1 || G < 1 || C % G) return NMRF_EINVAL;
+    int64_t blocks = ceil_div64((int64_t)B * C * H * W, 256);
+    if (blocks > 65535 * 8) blocks = 65535 * 8;
+    hipLaunchKernelGGL(cost_volume_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, f1, f2, dcv, B, C, H, W, D, G, df1, df2);
+    return nmrf_launch_status();
+}
+
+// (2) the cost taps of the seed embedding (Propagation.sample_cost, NMP.py:619-634): cost[(p,n)][g*9+t] = cv[p][g][clamp(seed_n - 4 + t, 0, D-1)]
+//     dcv[p][g][d] = sum over the labels n and taps t that read bin d  (one thread per (p, g, d): fixed order)
+__global__ __launch_bounds__(256) void seed_taps_bwd_kernel(const float *__restrict__ dcost, const int64_t *__restrict__ seeds, int64_t P, int N, int G, int D,
+                                                            int ldc, float *__restrict__ dcv) {
+    const int64_t total = P * G * D;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int d = (int)(idx % D), g = (int)((idx / D) % G);
+        const int64_t p = idx / ((int64_t)D * G);
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const int sd = (int)seeds[p * N + n];
+            for (int t = 0; t < 9; ++t) {
+                int e = sd - 4 + t;
+                e = e < 0 ? 0 : (e > D - 1 ? D - 1 : e);
+                if (e == d) s += dcost[(p * N + n) * ldc + g * 9 + t];
+            }
+        }
+        dcv[idx] = s;
+    }
+}
+extern "C" int nmrf_seed_taps_bwd_f32(const float *dcost, const int64_t *seeds, int64_t P, int N, int G, int D, int ldc, float *dcv, void *stream) {
+    if (!dcost || !seeds || !dcv) return NMRF_ENULL;
+    if (P < 1 || N < 1 || G < 1 || D < 1 || ldc < G * 9) return NMRF_EINVAL;
+    int64_t blocks = ceil_div64(P * G * D, 256);
+    if (blocks > 65535 * 8) blocks = 65535 * 8;
+    hipLaunchKernelGGL(seed_taps_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dcost, seeds, P, N, G, D, ldc, dcv);
+    return nmrf_launch_status();
+}
+
+// (3) warp + correlation + concat (Inference.sample_fmap / corr, NMP.py:683-741): rows [left f1 (Cf) | f2 warped at x - label (Cf) | group corr (Gr)],
+//     corr_g = mean_c g1[g*cpg+c] * warp(g2)[g*cpg+c].  Labels are constants (the reference detaches them).  The sampling is bilinear along x
+//     (ix of the reference's float round trip; the ~1e-7 share of the adjacent row that round trip leaks -- SURVEY H6 -- is not differentiated).
+//     LEFT maps: one thread per (b, ch, y, x): df1 = sum_n drow[t][ch]; dg1 = sum_n dcorr[t][g] * warp(g2)[ch] / cpg.
+//     RIGHT maps: one wave per (b, y, xd), lanes = channels: the wave walks the W * N tokens of the row (uniform), and where a token's
+//     sample touches xd every lane adds its channel's share -- a gather, deterministic.
+__device__ __forceinline__ void wc_tap(float label, int x, int W, int &x0, float &w0, float &w1) {
+#pragma clang fp contract(off)
+    const float gx = 2.0f * ((float)x + (-label)) / (float)(W - 1) - 1.0f;
+    const float ix = (gx + 1.0f) * ((float)(W - 1) / 2.0f);
+    float x0f = floorf(ix);
+    w1 = ix - x0f;
+    w0 = 1.0f - w1;
+    x0f = fminf(fmaxf(x0f, -2.0f), (float)W);
+    x0 = (int)x0f;
+}
+struct WcBwdArgs {
+    const float *labels, *drow, *f1, *f2, *g1, *g2;     // maps NCHW; drow [T, 2 Cf + Gr]
+    float *df1, *df2, *dg1, *dg2;
+    int B, H, W, N, Cf, Cg, Gr;
+};
+__global__ __launch_bounds__(256) void warp_corr_bwd_left_kernel(WcBwdArgs a) {
+    const int64_t plane = (int64_t)a.H * a.W, total = (int64_t)a.B * (a.Cf + a.Cg) * plane;
+    const int ld = 2 * a.Cf + a.Gr, cpg = a.Cg / a.Gr;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int x = (int)(idx % a.W), y = (int)((idx / a.W) % a.H);
+        const int chall = (int)((idx / plane) % (a.Cf + a.Cg));
+        const int b = (int)(idx / (plane * (a.Cf + a.Cg)));
+        const int64_t t0 = (((int64_t)b * a.H + y) * a.W + x) * a.N;
+        float s = 0.f;
+        if (chall < a.Cf) {
+            for (int n = 0; n < a.N; ++n) s += a.drow[(t0 + n) * ld + chall];
+            a.df1[((int64_t)b * a.Cf + chall) * plane + (int64_t)y * a.W + x] = s;
+        } else {
+            const int ch = chall - a.Cf, g = ch / cpg;
+            const float *row2 = a.g2 + ((int64_t)b * a.Cg + ch) * plane + (int64_t)y * a.W;
+            for (int n = 0; n < a.N; ++n) {
+                int x0; float w0, w1;
+                wc_tap(a.labels[t0 + n], x, a.W, x0, w0, w1);
+                float v = 0.f;
+                if (x0 >= 0 && x0 <= a.W - 1) v = w0 * row2[x0];
+                if (x0 + 1 >= 0 && x0 + 1 <= a.W - 1) v = fmaf(w1, row2[x0 + 1], v);
+                s = fmaf(a.drow[(t0 + n) * ld + 2 * a.Cf + g], v, s);
+            }
+            a.dg1[((int64_t)b * a.Cg + ch) * plane + (int64_t)y * a.W + x] = s / (float)cpg;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void warp_corr_bwd_right_kernel(WcBwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t plane = (int64_t)a.H * a.W, items = (int64_t)a.B * plane;
+    const int ld = 2 * a.Cf + a.Gr, cpg = a.Cg / a.Gr;
+    const int nchunk = (a.Cf + a.Cg + 63) / 64;            // channel chunks of 64 lanes: the Cf channels of f2 first, then the Cg of g2
+    for (int64_t it = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); it < items; it += (int64_t)gridDim.x * 4) {
+        const int xd = (int)(it % a.W), y = (int)((it / a.W) % a.H), b = (int)(it / plane);
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        const int64_t trow = (((int64_t)b * a.H + y) * a.W) * a.N;
+        for (int x = 0; x < a.W; ++x)
+            for (int n = 0; n < a.N; ++n) {
+                int x0; float w0, w1;
+                wc_tap(a.labels[trow + (int64_t)x * a.N + n], x, a.W, x0, w0, w1);
+                float wgt;
+                if (x0 == xd) wgt = w0;
+                else if (x0 + 1 == xd) wgt = w1;
+                else continue;                              // (wave-uniform: the weight depends on (x, n, xd) only)
+                const float *dr = a.drow + (trow + (int64_t)x * a.N + n) * ld;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int chall = 64 * k + lane;
+                    if (k < nchunk && chall < a.Cf + a.Cg) {
+                        float up;
+                        if (chall < a.Cf) up = dr[a.Cf + chall];
+                        else {
+                            const int ch = chall - a.Cf;
+                            up = dr[2 * a.Cf + ch / cpg] * a.g1[((int64_t)b * a.Cg + ch) * plane + (int64_t)y * a.W + x] / (float)cpg;
+                        }
+                        acc[k] = fmaf(wgt, up, acc[k]);
+                    }
+                }
+            }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int chall = 64 * k + lane;
+            if (k < nchunk && chall < a.Cf + a.Cg) {
+                if (chall < a.Cf) a.df2[((int64_t)b * a.Cf + chall) * plane + (int64_t)y * a.W + xd] = acc[k];
+                else a.dg2[((int64_t)b * a.Cg + (chall - a.Cf)) * plane + (int64_t)y * a.W + xd] = acc[k];
+            }
+        }
+    }
+}
+// labels [B*H*W*N] (constants), drow [T, 2 Cf + Gr] = the gradient of nmrf_warp_corr_concat_f32's rows, maps [B,C,H,W] (NCHW) ->
+// df1, df2 [B,Cf,H,W], dg1, dg2 [B,Cg,H,W].  Cf + Cg <= 512, Cg % Gr == 0.
+extern "C" int nmrf_warp_corr_concat_bwd_f32(const float *labels, const float *drow, const float *f1, const float *f2, const float *g1,
+                                             const float *g2, int B, int H, int W, int N, int Cf, int Cg, int Gr, float *df1, float *df2,
+                                             float *dg1, float *dg2, void *stream) {
+    if (!labels || !drow || !f1 || !f2 || !g1 || !g2 || !df1 || !df2 || !dg1 || !dg2) return NMRF_ENULL;
+    if (B < 1 || H < 1 || W < 2 || N < 1 || Cf < 1 || Cg < 1 || Gr < 1 || Cg % Gr || Cf + Cg > 512) return NMRF_EINVAL;
+    WcBwdArgs a{labels, drow, f1, f2, g1, g2, df1, df2, dg1, dg2, B, H, W, N, Cf, Cg, Gr};
+    hipStream_t st = (hipStream_t)stream;
+    int64_t bl = ceil_div64((int64_t)B * (Cf + Cg) * H * W, 256);
+    if (bl > 65535 * 8) bl = 65535 * 8;
+    hipLaunchKernelGGL(warp_corr_bwd_left_kernel, dim3((unsigned)bl), dim3(256), 0, st, a);
+    int64_t br = ceil_div64((int64_t)B * H * W, 4);
+    if (br > 65535 * 8) br = 65535 * 8;
+    hipLaunchKernelGGL(warp_corr_bwd_right_kernel, dim3((unsigned)br), dim3(256), 0, st, a);
+    return nmrf_launch_status();
+}

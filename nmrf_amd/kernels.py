@@ -1287,3 +1287,40 @@ def softmax_backward(prob, dprob):
     dz = torch.empty_like(prob)
     _lib.check(_lib.load().nmrf_softmax_bwd_f32(_p(prob), _p(dprob), prob.shape[0], prob.shape[1], _p(dz), _stream()), "softmax_bwd")
     return dz
+
+
+@_on_device
+def cost_volume_backward(f1, f2, dcv, num_disp, groups):
+    """Backward of cost_volume: f1, f2 [B,C,H,W], dcv [B*H*W, G, D] -> (df1, df2)."""
+    _chk(f1, f2, dcv)
+    b, c, h, w = f1.shape
+    assert dcv.shape == (b * h * w, groups, num_disp)
+    df1, df2 = torch.empty_like(f1), torch.empty_like(f2)
+    _lib.check(_lib.load().nmrf_cost_volume_bwd_f32(_p(f1), _p(f2), _p(dcv), b, c, h, w, num_disp, groups, _p(df1), _p(df2), _stream()),
+               "cost_volume_bwd")
+    return df1, df2
+
+
+@_on_device
+def seed_taps_backward(dcost, seeds, g, d):
+    """Backward of seed_features' cost taps: dcost [P*N, ldc >= 9 g], seeds [P, N] int64 -> dcv [P, g, d]."""
+    _chk(dcost)
+    _chk(seeds, dtype=torch.int64)
+    p, n = seeds.shape
+    assert dcost.shape[0] == p * n and dcost.shape[1] >= 9 * g
+    dcv = torch.empty(p, g, d, device=dcost.device, dtype=torch.float32)
+    _lib.check(_lib.load().nmrf_seed_taps_bwd_f32(_p(dcost), _p(seeds), p, n, g, d, dcost.shape[1], _p(dcv), _stream()), "seed_taps_bwd")
+    return dcv
+
+
+@_on_device
+def warp_corr_concat_backward(labels, drow, f1, f2, g1, g2, n, groups=32):
+    """Backward of warp_corr_concat (NCHW maps): drow [T, 2 Cf + groups] -> (df1, df2, dg1, dg2)."""
+    _chk(labels, drow, f1, f2, g1, g2)
+    b, cf, h, w = f1.shape
+    cg = g1.shape[1]
+    assert labels.numel() == b * h * w * n and drow.shape == (b * h * w * n, 2 * cf + groups)
+    out = [torch.empty_like(t) for t in (f1, f2, g1, g2)]
+    _lib.check(_lib.load().nmrf_warp_corr_concat_bwd_f32(_p(labels), _p(drow), _p(f1), _p(f2), _p(g1), _p(g2), b, h, w, n, cf, cg, groups,
+                                                         *[_p(t) for t in out], _stream()), "warp_corr_concat_bwd")
+    return tuple(out)

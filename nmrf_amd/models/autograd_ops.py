@@ -152,7 +152,11 @@ class QkvFn(torch.autograd.Function):
             n = w.shape[0]
             grads += [dwf[r0:r0 + n, : w.shape[1]].contiguous(), dbf[r0:r0 + n].contiguous() if hb else None]
             r0 += n
-        return ((dx if ctx.needs_input_grad[0] else None), None, dg, db, None, None, *grads)
+        dextra = None
+        if ctx.needs_input_grad[1]:                                  # (the context rows of the propagation stage: DPN.proj is trainable)
+            dextra = torch.zeros_like(extra)
+            dextra[:, : kmax - c] = dcat[:, c:]
+        return ((dx if ctx.needs_input_grad[0] else None), dextra, dg, db, None, None, *grads)
 
 
 class SelfAttnFn(torch.autograd.Function):
@@ -188,7 +192,7 @@ class StripeAttnFn(torch.autograd.Function):
 
 class DpnFilterFn(torch.autograd.Function):
     """The seed filter: prob = softmax_D(conv1d(relu(conv1d(relu(conv1d(cost volume)))))) (DPN.mlp, DPN.py:32-38,117-119), differentiated
-    with respect to its six parameters (the cost volume is a constant here: its producers -- correlation, encoder -- are forward-only).
+    with respect to its six parameters and, when it carries a graph (CostVolumeFn: the full training mode), the cost volume.
     fwd() -> prob of the fused kernel.  Each Conv1d(kernel 5, padding 2) over D is a Linear on 5-tap columns (K.unfold5)."""
 
     @staticmethod
@@ -213,7 +217,10 @@ class DpnFilterFn(torch.autograd.Function):
         dw2, db2 = K.linear_wgrad(dy2, col1), K.bias_grad(dy2)
         dy1 = K.act_backward(y1, K.fold5(K.linear_dgrad(dy2, f(w2)), p, w0.shape[0], d), 1)
         dw0, db0 = K.linear_wgrad(dy1, col0), K.bias_grad(dy1)
-        return None, dw0.view_as(w0), db0, dw2.view_as(w2), db2, dw4.view_as(w4), db4, None
+        dcv = None
+        if ctx.needs_input_grad[0]:                                  # rows (p, d) x G -> the volume's [P, G, D]
+            dcv = K.fold5(K.linear_dgrad(dy1, f(w0)), p, g, d).view(p, d, g).permute(0, 2, 1).contiguous()
+        return dcv, dw0.view_as(w0), db0, dw2.view_as(w2), db2, dw4.view_as(w4), db4, None
 
 
 class ProjFn(torch.autograd.Function):
@@ -259,3 +266,54 @@ def refine_epilogue_torch(delta16, disp_curr, training_hw=None):
     pred = torch.relu(disp_curr.reshape(b, h4, w4, 1) + delta16.view(b, h4, w4, 16))
     pred = pred.view(b, h4, w4, 4, 4).permute(0, 1, 3, 2, 4).reshape(b, 4 * h4, 4 * w4)
     return pred * 4, pred
+
+
+class CostVolumeFn(torch.autograd.Function):
+    """Group-wise correlation volume of the 1/8 maps (build_correlation_volume, submodule.py:4-23) -> [B*H*W, G, D].  fwd() -> the volume the
+    forward built (K.cost_volume).  Backward = nmrf_cost_volume_bwd_f32; from there the encoder is stock PyTorch autograd."""
+
+    @staticmethod
+    def forward(ctx, f1, f2, num_disp, groups, fwd):
+        ctx.save_for_backward(f1, f2)
+        ctx.dg = (num_disp, groups)
+        return fwd()
+
+    @staticmethod
+    def backward(ctx, dcv):
+        f1, f2 = ctx.saved_tensors
+        df1, df2 = K.cost_volume_backward(_c(f1), _c(f2), _c(dcv), *ctx.dg)
+        return df1, df2, None, None, None
+
+
+class SeedTapsFn(torch.autograd.Function):
+    """The 9 cost taps around every label seed (Propagation.sample_cost, NMP.py:619-634) as a function of the cost volume [P, G, D]; the
+    seeds are integer NMS output.  fwd() -> the [P*N, 9 G] rows the seed kernel gathered."""
+
+    @staticmethod
+    def forward(ctx, cv, seeds, fwd):
+        ctx.save_for_backward(seeds)
+        ctx.gd = cv.shape[1:]
+        return fwd()
+
+    @staticmethod
+    def backward(ctx, dcost):
+        (seeds,) = ctx.saved_tensors
+        return K.seed_taps_backward(_c(dcost), seeds, *ctx.gd), None, None
+
+
+class WarpCorrFn(torch.autograd.Function):
+    """[left features | right features warped at x - label | group correlation] rows of a message-passing stage (Inference.sample_fmap /
+    corr, NMP.py:683-741) as a function of the four matching-head maps (NCHW); the labels are constants (NMP.py:694, NMRF.py:215,232).
+    fwd() -> the rows the forward built (K.warp_corr_concat)."""
+
+    @staticmethod
+    def forward(ctx, f1, f2, g1, g2, labels, n, groups, fwd):
+        ctx.save_for_backward(f1, f2, g1, g2, labels)
+        ctx.ng = (n, groups)
+        return fwd()
+
+    @staticmethod
+    def backward(ctx, drow):
+        f1, f2, g1, g2, labels = ctx.saved_tensors
+        grads = K.warp_corr_concat_backward(_c(labels), _c(drow), _c(f1), _c(f2), _c(g1), _c(g2), *ctx.ng)
+        return (*grads, None, None, None, None)

@@ -139,14 +139,23 @@ class NMRF(nn.Module):
                                  "%d -- did you forget model.eval()?  (build_model returns the module in nn.Module's default training "
                                  "state, as the reference's does; inference.py:150 calls .eval())" % (h0, w0, self.divis_by))
             stem = enc.conv1
-            if (enc.fused and image1.shape[1] == 3 and hp % 2 == 0 and wp % 2 == 0 and stem.weight.shape[0] % 64 == 0
+            if self._grad_full():
+                # N4, the whole model: the encoder on stock PyTorch-ROCm autograd (its stock branch: models/backbone.py:_hip_ok), fed by
+                # the same staging kernel; the hot path below attaches its own Functions to these maps
+                x = K.prep_images(image1.contiguous(), image2.contiguous(), hp, wp)
+                with torch.enable_grad():
+                    feats = enc(x, normalized=True)[::-1]
+                    fmap1_list, fmap2_list = [f[:b] for f in feats], [f[b:] for f in feats]
+                self._joint_feats = feats
+            elif (enc.fused and image1.shape[1] == 3 and hp % 2 == 0 and wp % 2 == 0 and stem.weight.shape[0] % 64 == 0
                     and tuple(stem.weight.shape[1:]) == (3, 7, 7) and stem.stride == (2, 2) and stem.padding == (3, 3)):
                 # the stem (7x7 / stride 2) runs as a 4x4 convolution over the 2x2 space-to-depth image: staged in that layout
                 feats = enc(K.prep_images_s2d(image1.contiguous(), image2.contiguous(), hp, wp), normalized="s2d")[::-1]
             else:
                 feats = enc(K.prep_images(image1.contiguous(), image2.contiguous(), hp, wp), normalized=True)[::-1]
-            self._joint_feats = feats
-            fmap1_list, fmap2_list = [f[:b] for f in feats], [f[b:] for f in feats]
+            if not self._grad_full():
+                self._joint_feats = feats
+                fmap1_list, fmap2_list = [f[:b] for f in feats], [f[b:] for f in feats]
         else:
             image1, image2 = image1.float(), image2.float()
             if not self.training:
@@ -161,7 +170,10 @@ class NMRF(nn.Module):
             K.check_range(self.device)
         return out
 
-    def enable_grad_slice(self, on=True):
+    def _grad_full(self):
+        return bool(self.training and getattr(self, "grad_slice", False) and getattr(self, "grad_full", False))
+
+    def enable_grad_slice(self, on=True, full=False):
         """N4 (round 5): in training mode, build an autograd graph over the three message-passing stages and their heads -- the WHOLE
         propagation, inference and refinement stages (seed embedding / ffn, every layer's norm1 / q | k | v / stripe, sibling or window
         attention with its LePE kernels or relative-position table / proj / norm2 / MLP, the stage-final norms) and `prop_head`,
@@ -170,13 +182,19 @@ class NMRF(nn.Module):
         `Criterion(model(sample)).backward()` leaves the REFERENCE's own gradients in `.grad` of the 206 tensors behind the hand-over; the
         propagation stage is reached by the proposal loss only, which carries no weight in the reference's weight_dict (add
         `weight_dict['loss_prop']` to train it).  Encoder, matching heads and DPN context convolutions stay forward-only:
-        `.grad is None`, loudly.  Off by default; eval mode ignores it."""
+        `.grad is None`, loudly.  Off by default; eval mode ignores it.
+        full=True: the WHOLE model.  The convolutional modules -- encoder, `concatconv`, `gw`, `dpn.proj` -- run on stock PyTorch-ROCm
+        autograd in the training-mode forward (north_star keeps them on stock ROCm; the fused forward-only conv kernels serve eval mode),
+        and the three kernels that read their maps get a backward (autograd_ops.CostVolumeFn / SeedTapsFn / WarpCorrFn; the seed filter and
+        the propagation's q | k return the gradient of the cost volume and of the context rows): every parameter's `.grad` is the
+        reference's."""
         self.grad_slice = bool(on)
+        self.grad_full = bool(on and full)
         self.inference.keep_pre_norm = self.refinement.keep_pre_norm = self.dpn.propagation.keep_pre_norm = bool(on)
         return self
 
     @staticmethod
-    def _stage_rows_with_grad(stage):
+    def _stage_rows_with_grad(stage, maps=None, labels=None):
         """The residual stream of EVERY layer of an NMP stage (inference: self-edge + window sites, four labels per pixel; refinement:
         window sites, one label) on the dense grid, as an autograd graph over ALL of the stage's parameters:
             ffn -> per site [norm1 | enc -> q | k | v -> attention (siblings / windows with the relative-position table) -> proj + residual
@@ -184,8 +202,9 @@ class NMRF(nn.Module):
         Every Function's forward value is the tensor the fused forward already produced (the tape of Inference._run; the sibling
         attention, evaluated inside the block kernel there, is re-run by its own kernel); backward = csrc/backward.hip.  q | k | v rows
         that the forward wrote as split fp16 pairs for the window kernel (kv16) are decoded to the fp32 values those kernels multiply.
-        None when the forward did not record a tape."""
-        from .autograd_ops import BlockFn, FfnFn, ProjFn, QkvFn, SelfAttnFn, WindowAttnFn
+        maps = (fmap1, fmap2, fmap1_gw, fmap2_gw) NCHW with a graph + the (constant) labels: the stage's input rows become a function of
+        them (WarpCorrFn).  None when the forward did not record a tape."""
+        from .autograd_ops import BlockFn, FfnFn, ProjFn, QkvFn, SelfAttnFn, WarpCorrFn, WindowAttnFn
         tape = getattr(stage, "_tape", None)
         if tape is None or len(tape["qkv"]) != len(stage._sites) or len(tape["x"]) != len(stage._sites) + 1:
             return None
@@ -194,7 +213,10 @@ class NMRF(nn.Module):
         keep = None if to_p is None else to_p.long()
         x0, enc = tape["x"][0], tape["enc"]
         ffn = stage.ffn
-        xd = FfnFn.apply(tape["wcc"], ffn.fc1.weight, ffn.fc1.bias, ffn.fc2.weight, ffn.fc2.bias,
+        wcc = tape["wcc"]
+        if maps is not None:
+            wcc = WarpCorrFn.apply(*maps, labels.reshape(-1).contiguous(), n, stage.cost_group, lambda v=wcc: v)
+        xd = FfnFn.apply(wcc, ffn.fc1.weight, ffn.fc1.bias, ffn.fc2.weight, ffn.fc2.bias,
                          lambda t: x0 if keep is None else x0.index_select(0, keep))
         xg = xd if keep is None else torch.zeros_like(x0).index_copy(0, keep, xd)          # (the zero-padded grid, NMP.py:745-762)
         rows = []
@@ -216,19 +238,22 @@ class NMRF(nn.Module):
         return rows
 
     @staticmethod
-    def _propagation_rows_with_grad(prop):
+    def _propagation_rows_with_grad(prop, cv=None, seeds=None, context=None):
         """The propagation stage's output rows (before its final norm) as an autograd graph over ALL of its parameters: the seed embedding
         (cost_encoder on the 9 x 4 cost taps, proj on [features | Fourier]) and five layers of [norm1 | context -> q, k, v -> cross-stripe
         attention with LePE -> proj + residual + norm2 + MLP].  Forward values from the tape of Propagation.forward (kv16 rows decoded),
         backward = csrc/backward.hip.  The label seeds (integer NMS output), the cost taps and the context rows are constants: their
-        producers -- seed stage, DPN context convs -- are forward-only.  None without a tape."""
-        from .autograd_ops import BlockFn, FfnFn, LinearFn, QkvFn, StripeAttnFn
+        producers -- seed stage, DPN context convs -- are forward-only -- unless handed in with a graph: cv [P,G,D] (+ the int64 seeds) makes
+        the cost taps a function of the volume (SeedTapsFn), context [B,Cctx,H,W] the q | k operand rows one of DPN.proj.  None without a tape."""
+        from .autograd_ops import BlockFn, FfnFn, LinearFn, QkvFn, SeedTapsFn, StripeAttnFn
         tape = getattr(prop, "_tape", None)
         if tape is None or "x" not in tape or len(tape["qkv"]) != len(prop.layers):
             return None
         b, h, wd, n = tape["dims"]
         ce0, ce2 = prop.cost_encoder[0], prop.cost_encoder[2]
         cost = tape["cost"][:, : ce0.in_features].contiguous()
+        if cv is not None:
+            cost = SeedTapsFn.apply(cv, seeds, lambda v=cost: v)
 
         def encoder(t):                                               # (the fused seed-embedding chain does not materialise this layer)
             _, hid = K.bias_act(K.linear_forward(t, ce0.weight), ce0.bias, 2)
@@ -236,7 +261,8 @@ class NMRF(nn.Module):
         feat = FfnFn.apply(cost, ce0.weight, ce0.bias, ce2.weight, ce2.bias, encoder)
         cat = torch.cat((feat, tape["enc"][:, : prop.proj.in_features - feat.shape[1]]), 1)
         x = LinearFn.apply(cat, prop.proj.weight, None, lambda t, v=tape["x"][0]: v)
-        ctx_tok = tape["ctx"].repeat_interleave(n, 0).contiguous()    # the context row of a pixel, once per label (NMP.py:548)
+        ctx_rows = tape["ctx"] if context is None else context.permute(0, 2, 3, 1).reshape(tape["ctx"].shape)
+        ctx_tok = ctx_rows.repeat_interleave(n, 0).contiguous()       # the context row of a pixel, once per label (NMP.py:548)
         for i, layer in enumerate(prop.layers):
             m = layer.nmp
             qkv_i = K.from_kv16(tape["qkv"][i]) if tape["kv16"] else tape["qkv"][i]
@@ -247,9 +273,10 @@ class NMRF(nn.Module):
                               m.mlp.fc2.weight, m.mlp.fc2.bias, m.norm2.eps, lambda v=tape["x"][i + 1]: v)
         return x
 
-    def _tail_with_grad(self, labels_curr, dims8, heads4, tok4, out_hw, prob, label_seeds, cv_rows):
-        """The tail of hot_path in training mode with grad_slice: norms + heads of every layer under autograd."""
-        from .autograd_ops import DpnFilterFn, LayerNormFn, LinearFn, MlpHeadFn, refine_epilogue_torch
+    def _tail_with_grad(self, labels_curr, dims8, heads4, tok4, out_hw, prob, label_seeds, cv_rows, graph=None):
+        """The tail of hot_path in training mode with grad_slice: norms + heads of every layer under autograd.  graph (full mode): the
+        encoder's 1/8 maps, the DPN context and the matching heads' maps at 1/8 and 1/4 WITH their autograd graphs (stock convolutions)."""
+        from .autograd_ops import CostVolumeFn, DpnFilterFn, LayerNormFn, LinearFn, MlpHeadFn, refine_epilogue_torch
         from .nmp import _ChainLauncher
         b, h8, w8, n = dims8
         if not hasattr(self, "_score"):
@@ -274,12 +301,19 @@ class NMRF(nn.Module):
         with torch.enable_grad():
             # the matching distribution as a function of the seed filter's parameters (the `init` loss of the Criterion, NMRF.py:300-330)
             fm = self.dpn.mlp
-            prob = DpnFilterFn.apply(cv_rows.contiguous(), fm[0].weight, fm[0].bias, fm[2].weight, fm[2].bias, fm[4].weight, fm[4].bias,
+            cv_rows = cv_rows.contiguous()
+            cv_g = None
+            if graph is not None:
+                cv_g = cv_rows = CostVolumeFn.apply(*graph["f8"], cv_rows.shape[2], cv_rows.shape[1], lambda v=cv_rows: v)
+            prob = DpnFilterFn.apply(cv_rows, fm[0].weight, fm[0].bias, fm[2].weight, fm[2].bias, fm[4].weight, fm[4].bias,
                                      lambda v=prob: v)
             # disparity proposals (DPN.py:131-132): labels = relu(prop_head(norm(last propagation block)) + seeds) as a function of the
             # propagation stage's last block, its final norm and the head -- the loss_prop branch of the Criterion
             prop = self.dpn.propagation
-            mem = self._propagation_rows_with_grad(prop)
+            if graph is None:
+                mem = self._propagation_rows_with_grad(prop)
+            else:
+                mem = self._propagation_rows_with_grad(prop, cv_g, label_seeds.reshape(-1, n).long().contiguous(), graph["context"])
             if mem is None:
                 mem = last_rows(prop)
             if prop.norm is not None:
@@ -287,7 +321,7 @@ class NMRF(nn.Module):
             proposal = torch.relu(head(self.dpn.prop_head, mem).view(-1, n) + label_seeds.reshape(-1, n)).reshape(b, -1, n)
             nm = self.inference.norm
             aux, delta, score = [], None, None
-            pres = self._stage_rows_with_grad(self.inference)
+            pres = self._stage_rows_with_grad(self.inference, graph and graph["heads8"], labels_curr)
             if pres is None:
                 pres = list(self.inference._pre_norm)
                 pres[-1] = last_rows(self.inference)
@@ -302,7 +336,7 @@ class NMRF(nn.Module):
                 self.refinement(disp_curr, fmap1, fmap2, fmap1_gw, fmap2_gw, token_major=tok4)
             nm4 = self.refinement.norm
             preds = []
-            pres = self._stage_rows_with_grad(self.refinement)
+            pres = self._stage_rows_with_grad(self.refinement, graph and graph["heads4"], disp_curr)
             if pres is None:
                 pres = list(self.refinement._pre_norm)
                 pres[-1] = last_rows(self.refinement)
@@ -377,15 +411,36 @@ class NMRF(nn.Module):
             side = self._side_stream
             side.wait_stream(main)
         context, ctx_ready = None, None
+        full = self._grad_full() and stages is None
+        graph = None
+        if full:
+            # N4, the whole model: the convolutional heads on stock PyTorch-ROCm autograd (both views as one batch: conv - InstanceNorm -
+            # ReLU - conv are per-sample, NMRF.py:211-214,233-236; DPN.py:127); the HIP stages below read the detached NCHW maps
+            overlap, side = False, main
+            with torch.enable_grad():
+                cat8, cat4 = torch.cat((fmap1_list[0], fmap2_list[0]), 0), torch.cat((fmap1_list[1], fmap2_list[1]), 0)
+                bq = fmap1_list[0].shape[0]
+                ctx_g = self.dpn.proj(fmap1_list[0])
+                split2 = lambda t: (t[:bq], t[bq:])
+                heads8_g = split2(self.concatconv(cat8)) + split2(self.gw(cat8))
+                heads4_g = split2(self.concatconv(cat4)) + split2(self.gw(cat4))
+            graph = {"f8": (fmap1_list[0], fmap2_list[0]), "context": ctx_g, "heads8": heads8_g, "heads4": heads4_g}
+            context = ctx_g.detach().permute(0, 2, 3, 1).contiguous()
+            heads8, tok8 = tuple(t.detach().contiguous() for t in heads8_g), False
+            heads4, tok4 = tuple(t.detach().contiguous() for t in heads4_g), False
+            fmap1_list, fmap2_list = [f.detach() for f in fmap1_list], [f.detach() for f in fmap2_list]
         with torch.cuda.stream(side):
-            if overlap:
+            if full:
+                pass
+            elif overlap:
                 # the DPN context convs first: the seed stage (cost volume, conv1d + softmax, NMS: latency-bound) runs beside them
                 context = self.dpn.context(fmap1_list[0], token_major=True)
                 ctx_ready = torch.cuda.Event()
                 ctx_ready.record(side)
                 context.record_stream(main)
-            heads8, tok8 = self._match_heads(fmap1_list[0], fmap2_list[0], self._head_cache8)
-            heads4, tok4 = self._match_heads(fmap1_list[1], fmap2_list[1], self._head_cache4)
+            if not full:
+                heads8, tok8 = self._match_heads(fmap1_list[0], fmap2_list[0], self._head_cache8)
+                heads4, tok4 = self._match_heads(fmap1_list[1], fmap2_list[1], self._head_cache4)
             if overlap:
                 for t in heads8 + heads4:
                     t.record_stream(main)
@@ -404,7 +459,7 @@ class NMRF(nn.Module):
         if self.training and getattr(self, "grad_slice", False) and stages is None:
             if not (self.inference.return_intermediate and self.refinement.return_intermediate):
                 raise NotImplementedError("grad_slice: the training-mode forward with NMP.RETURN_INTERMEDIATE (the reference's default)")
-            return self._tail_with_grad(labels_curr, (b, h8, w8, n), heads4, tok4, (h0, w0), prob, label_seeds, cv_rows)
+            return self._tail_with_grad(labels_curr, (b, h8, w8, n), heads4, tok4, (h0, w0), prob, label_seeds, cv_rows, graph)
         from .nmp import _ChainLauncher, _FusedCache, _split
         hl = self.infer_head.layers
         if (stages is None and not self.training and _split() and n == 4 and len(hl) == 3

@@ -1,14 +1,17 @@
-"""N4, first slice: one optimisation step over the part of the model whose gradients this build can produce on the MI355X
-(nmrf_amd.models.NMRF.enable_grad_slice: the WHOLE inference and refinement stages with their three heads, and -- behind the proposal
-loss -- the WHOLE propagation stage with its head, and the seed filter: 315 of the model's 351 tensors; the rest is the encoder, the
-matching heads and the DPN context convolutions), shaped like the reference's training loop (main.py:403-430):
+"""N4: one optimisation step on the MI355X, shaped like the reference's training loop (main.py:403-430).  Two extents
+(nmrf_amd.models.NMRF.enable_grad_slice):
+  * the SLICE (default): the WHOLE inference and refinement stages with their three heads, and -- behind the proposal loss -- the WHOLE
+    propagation stage with its head, and the seed filter: 315 of the model's 351 tensors, the convolutional modules frozen on their fused
+    forward-only kernels;
+  * full=True: every parameter -- encoder, matching heads and DPN context convolutions on stock PyTorch-ROCm autograd, joined to the HIP
+    stages by the backward of the cost volume, the cost taps and the warp + correlation rows.
 
     model.train(); loss_dict = criterion(model(sample), sample); losses = sum_k weight_dict[k] * loss_dict[k]
     param.grad = None; losses.backward(); clip_grad_norm_(GRAD_CLIP); optimizer.step()
 
 and, with more than one rank, the gradient average DistributedDataParallel performs for the reference (main.py:334-339) as ONE
 bucketed all-reduce over RCCL (`allreduce_gradients`: the slice's gradients are 0.27 M floats -- a single 1 MB bucket; one process per
-GPU, weights replicated, batch sharded as in nmrf_amd.parallel).  Everything else of the model stays frozen: its kernels are forward-only."""
+GPU, weights replicated, batch sharded as in nmrf_amd.parallel)."""
 import torch
 import torch.distributed as dist
 
@@ -18,22 +21,43 @@ SLICE_PREFIXES = ("infer_head.", "infer_score_head.", "refine_head.", "inference
 
 
 def slice_parameters(model):
-    """[(name, parameter)] the gradient slice reaches, in named_parameters() order."""
+    """[(name, parameter)] the gradient graph reaches, in named_parameters() order: the slice, or with enable_grad_slice(full=True)
+    every parameter."""
+    if getattr(model, "grad_full", False):
+        return list(model.named_parameters())
     return [(name, p) for name, p in model.named_parameters() if name.startswith(SLICE_PREFIXES)]
 
 
 def build_slice_optimizer(model, cfg):
-    """AdamW over the slice with the reference's grouping (main.py:186-245): plain parameters at BASE_LR / WEIGHT_DECAY, the LayerNorm
-    parameters at WEIGHT_DECAY_NORM.  Every other parameter is frozen (requires_grad False): no kernel could fill its .grad."""
+    """AdamW with the reference's parameter groups (build_optimizer, main.py:186-245) over the parameters the gradient graph reaches:
+    plain parameters at BASE_LR / WEIGHT_DECAY; normalisation layers at WEIGHT_DECAY_NORM; the relative-position tables of the window
+    attention without weight decay; a Swin trunk (`image_encoder.backbone.*`) at BASE_LR x BACKBONE_LR_DECAY / BACKBONE_WEIGHT_DECAY,
+    its bias tables without decay.  Every other parameter is frozen (requires_grad False): no kernel could fill its .grad."""
     keep = {id(p) for _, p in slice_parameters(model)}
     for p in model.parameters():
         p.requires_grad_(id(p) in keep)
-    norm_ids = {id(p) for m in model.modules() if isinstance(m, torch.nn.LayerNorm) for p in m.parameters()}
-    plain = [p for _, p in slice_parameters(model) if id(p) not in norm_ids]
-    norms = [p for _, p in slice_parameters(model) if id(p) in norm_ids]
-    groups = [{"params": plain, "lr": cfg.SOLVER.BASE_LR},
-              {"params": norms, "lr": cfg.SOLVER.BASE_LR, "weight_decay": cfg.SOLVER.WEIGHT_DECAY_NORM}]
-    return torch.optim.AdamW(groups, lr=cfg.SOLVER.BASE_LR, weight_decay=cfg.SOLVER.WEIGHT_DECAY)
+    s = cfg.SOLVER
+    norm_types = (torch.nn.BatchNorm2d, torch.nn.InstanceNorm2d, torch.nn.LayerNorm)
+    plain, norms, trunk, trunk_tab, enc_tab, seen = [], [], [], [], [], set()
+    for mname, module in model.named_modules():
+        for pname, p in module.named_parameters(recurse=False):
+            if id(p) not in keep or id(p) in seen:
+                continue
+            seen.add(id(p))
+            if ("%s.%s" % (mname, pname)).startswith("image_encoder.backbone"):
+                (trunk_tab if "relative_position_bias_table" in pname else trunk).append(p)
+            elif "relative_position_enc_table" in pname:
+                enc_tab.append(p)
+            elif isinstance(module, norm_types) and s.WEIGHT_DECAY_NORM is not None:
+                norms.append(p)
+            else:
+                plain.append(p)
+    groups = [{"params": plain, "lr": s.BASE_LR},
+              {"params": norms, "lr": s.BASE_LR, "weight_decay": s.WEIGHT_DECAY_NORM},
+              {"params": trunk, "lr": s.BASE_LR * s.BACKBONE_LR_DECAY, "weight_decay": s.BACKBONE_WEIGHT_DECAY},
+              {"params": trunk_tab, "lr": s.BASE_LR * s.BACKBONE_LR_DECAY, "weight_decay": 0.0},
+              {"params": enc_tab, "lr": s.BASE_LR, "weight_decay": 0.0}]
+    return torch.optim.AdamW([g for g in groups if g["params"]], lr=s.BASE_LR, weight_decay=s.WEIGHT_DECAY)
 
 
 def allreduce_gradients(params, group=None):
@@ -55,7 +79,7 @@ def allreduce_gradients(params, group=None):
 
 
 def train_step(model, criterion, optimizer, sample, grad_clip=1.0, group=None):
-    """One step of main.py:413-430 on the gradient slice.  sample: {'img1', 'img2', 'disp', 'valid'} (H, W multiples of
+    """One step of main.py:413-430 on the parameters of `optimizer` (build_slice_optimizer).  sample: {'img1', 'img2', 'disp', 'valid'} (H, W multiples of
     DATASETS.DIVIS_BY: the training-mode forward does not pad).  Returns (total loss as a float, the loss dict)."""
     if not getattr(model, "grad_slice", False):
         raise RuntimeError("call model.train().enable_grad_slice() first: without it the training-mode forward carries no autograd graph")

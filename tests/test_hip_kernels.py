@@ -1367,3 +1367,70 @@ def test_seed_filter_backward_vs_oracle_autograd(p, d):
     lhs = float((kk.unfold5(a, p, 8, d).double() * c.double()).sum())
     rhs = float((a.double() * kk.fold5(c, p, 8, d).double()).sum())
     assert abs(lhs - rhs) <= 1e-6 * max(1.0, abs(lhs)), (lhs, rhs)             # (fold5 adds its five taps in fp32)
+
+
+@pytest.mark.parametrize("b,c,h,w,d,g", [(1, 8, 3, 20, 6, 4), (2, 256, 5, 41, 24, 4), (1, 16, 2, 5, 9, 2)])
+def test_cost_volume_backward_vs_oracle_autograd(b, c, h, w, d, g):
+    """nmrf_cost_volume_bwd_f32 (CostVolumeFn) against fp64 autograd of the oracle's cost_volume, including D > W (bins no pixel reaches)."""
+    from nmrf_amd.models.autograd_ops import CostVolumeFn
+    kk = K()
+    f1, f2, gout = rnd(b, c, h, w, seed=1), rnd(b, c, h, w, seed=2), rnd(b * h * w, g, d, seed=3)
+    a, bb = f1.double().requires_grad_(True), f2.double().requires_grad_(True)
+    ref = O.cost_volume(a, bb, d, g)
+    g1, g2 = torch.autograd.grad(ref, [a, bb], gout.double())
+    x1, x2 = f1.to(DEV).requires_grad_(True), f2.to(DEV).requires_grad_(True)
+    cv = CostVolumeFn.apply(x1, x2, d, g, lambda: kk.cost_volume(x1.detach(), x2.detach(), d, g))
+    report("cost volume forward", cv.detach().cpu(), ref.detach(), 1e-5, 1e-6)
+    d1, d2 = torch.autograd.grad(cv, [x1, x2], gout.to(DEV))
+    report("cost volume df1", d1.cpu(), g1, 1e-5 * float(g1.abs().max()) + 1e-7)
+    report("cost volume df2", d2.cpu(), g2, 1e-5 * float(g2.abs().max()) + 1e-7)
+
+
+@pytest.mark.parametrize("p,n,g,d", [(9, 4, 4, 24), (130, 4, 4, 40), (5, 2, 3, 6)])
+def test_seed_taps_backward_vs_oracle_autograd(p, n, g, d):
+    """nmrf_seed_taps_bwd_f32 (SeedTapsFn) against autograd of the oracle's sample_cost: seeds at both ends of the disparity range, where
+    the clamped taps alias one bin and their gradients add up."""
+    from nmrf_amd.models.autograd_ops import SeedTapsFn
+    kk = K()
+    cv = rnd(p, g, d, seed=4)
+    seeds = torch.randint(0, d, (p, n), generator=torch.Generator().manual_seed(p))
+    seeds[0, 0], seeds[0, 1], seeds[1, 0] = 0, d - 1, 2
+    gout = rnd(p * n, 9 * g, seed=5)
+    cd = cv.double().requires_grad_(True)
+    ref = O.sample_cost(cd, seeds).reshape(p * n, 9 * g)
+    (gref,) = torch.autograd.grad(ref, [cd], gout.double())
+    cg = cv.to(DEV).requires_grad_(True)
+    sd = seeds.to(DEV)
+    cost = SeedTapsFn.apply(cg, sd, lambda: kk.seed_features(cg.detach(), sd, 3.14 / 64)[0])
+    assert torch.equal(cost.detach().cpu(), ref.detach().float())
+    (got,) = torch.autograd.grad(cost, [cg], gout.to(DEV))
+    report("seed taps dcv", got.cpu(), gref, 1e-6 * float(gref.abs().max()) + 1e-7)
+    # a wider row (the 48-column operand of the fused seed embedding): the padding columns are ignored
+    wide = torch.cat((gout, rnd(p * n, 12, seed=6)), 1).contiguous().to(DEV)
+    assert torch.equal(kk.seed_taps_backward(wide, sd, g, d), got)
+
+
+@pytest.mark.parametrize("b,h,w,n,lab", [(1, 3, 20, 4, 6.0), (2, 4, 70, 4, 30.0), (1, 5, 33, 1, 12.0)])
+def test_warp_corr_concat_backward_vs_oracle_autograd(b, h, w, n, lab):
+    """nmrf_warp_corr_concat_bwd_f32 (WarpCorrFn) against fp64 autograd of the oracle's warp_corr_concat in all four maps: labels that
+    sample left of the image (zero weight), on integer positions and in between; one label per pixel (the refinement stage) and four."""
+    from nmrf_amd.models.autograd_ops import WarpCorrFn
+    kk = K()
+    cf, cg, gr = 64, 256, 32
+    maps = [rnd(b, cc, h, w, seed=10 + i) for i, cc in enumerate((cf, cf, cg, cg))]
+    labels = (rnd(b * h * w, n, seed=3) + 1) * 0.5 * lab
+    labels[0, 0], labels[1, 0] = 0.0, 3.0
+    gout = rnd(b * h * w * n, 2 * cf + gr, seed=4)
+    md = [m.double().requires_grad_(True) for m in maps]
+    ref = O.warp_corr_concat(labels.double(), *md, groups=gr)
+    gref = torch.autograd.grad(ref, md, gout.double())
+    mg = [m.to(DEV).requires_grad_(True) for m in maps]
+    ld = labels.to(DEV).reshape(-1).contiguous()
+    rows = WarpCorrFn.apply(*mg, ld, n, gr, lambda: kk.warp_corr_concat(ld, *[m.detach() for m in mg], n, gr))
+    report("warp rows forward", rows.detach().cpu(), ref.detach(), 2e-5, 1e-5)
+    got = torch.autograd.grad(rows, mg, gout.to(DEV))
+    for name, a, r in zip(("df1", "df2", "dg1", "dg2"), got, gref):
+        # (the fp32 sampling position carries ~1e-6 of rounding in its bilinear weights, H6; fp64 autograd does not)
+        report("warp rows " + name, a.cpu(), r, 2e-5 * float(r.abs().max()) + 1e-6)
+    again = torch.autograd.grad(WarpCorrFn.apply(*mg, ld, n, gr, lambda: rows.detach()), mg, gout.to(DEV))
+    assert all(torch.equal(x, y) for x, y in zip(got, again))

@@ -740,6 +740,9 @@ def test_driver_two_forwards_in_flight():
     assert model.range_check is True
 
 
+CONV_SIDE = ("backbone.", "concatconv.", "gw.", "dpn.proj.")
+
+
 def test_training_backward_slice_matches_reference_gradients():
     """N4, first slice: model.train() + enable_grad_slice(): the loss of one training step (main.py:413-420: sum_k weight_dict[k] *
     loss_dict[k] of the reference's Criterion, restated in nmrf_amd.models.criterion) is differentiated through the prediction heads and
@@ -776,6 +779,8 @@ def test_training_backward_slice_matches_reference_gradients():
         worst = {}
         for key in [k for k in g if k.startswith(prefix)]:
             name = key[len(prefix):]
+            if name.startswith(CONV_SIDE):                                # (the slice leaves the convolutional modules forward-only:
+                continue                                                  #  test_training_backward_full_model_... covers them)
             want, got = t(g[key]), named[name].grad
             assert got is not None, name + ": no gradient"
             scale = float(want.abs().max())
@@ -797,7 +802,7 @@ def test_training_backward_slice_matches_reference_gradients():
     assert not missing, missing                                        # EVERY parameter of the two NMP stages and the heads has a gradient
     # The proposal loss is NOT part of the reference's trained loss (Criterion returns 'loss_prop', weight_dict names 'proposal_disp':
     # main.py:416 drops it), so after the step's backward the propagation slice has no gradient -- here as in the reference ...
-    prop = [k[len("grad_prop/"):] for k in g if k.startswith("grad_prop/")]
+    prop = [k[len("grad_prop/"):] for k in g if k.startswith("grad_prop/") and not k[len("grad_prop/"):].startswith(CONV_SIDE)]
     assert len(prop) == 49 and all(named[n].grad is None for n in prop)
     no_grad = [n for n, p in named.items() if p.grad is None]
     # forward-only kernels behind these: an earlier layer's block, the last layer's attention projections, the seed stage
@@ -815,6 +820,77 @@ def test_training_backward_slice_matches_reference_gradients():
     # eval mode is untouched by the switch
     ev = model.eval()({"img1": img1, "img2": img2})
     assert not ev["disp"].requires_grad and "aux_outputs" not in ev
+
+
+def test_training_backward_full_model_matches_reference_gradients():
+    """N4, the whole model: model.train().enable_grad_slice(full=True) -- encoder, matching heads and DPN context convolutions on stock
+    PyTorch-ROCm autograd, joined to the HIP stages by CostVolumeFn / SeedTapsFn / WarpCorrFn (csrc/backward.hip) and by the cost-volume /
+    context gradients of the seed filter and the propagation's q | k.  `model(sample)` end to end (images in, no oracle features), the
+    reference Criterion's weighted loss, backward: EVERY parameter the reference's loss reaches carries the reference's gradient -- the
+    stored tensors (`grad/*`: 143 of the stages + 10 of the convolutional side) entry by entry, every other convolutional tensor by its
+    norm and its projection on a fixed noise vector (`grad_stat/*`); `dpn.proj` stays None there as here (`grad_none/*`).  Then the
+    proposal loss alone (`grad_prop*`): propagation stage, `dpn.proj` and -- through the cost taps and the context -- the encoder."""
+    from nmrf_amd.models.criterion import build_criterion
+    from nmrf_amd.utils.hashinit import unit_noise
+    from tests.conftest import record_note
+    from tests.util import golden_images, make_cfg
+    g = golden("e2e_train")
+    md = int(g["max_disp"])
+    img1, img2 = golden_images(g)
+    model = build_product(md, DEV).train().enable_grad_slice(full=True)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = model({"img1": img1, "img2": img2})
+    assert torch.equal(out["initial_proposal"].cpu().long(), t(g["seeds"]).long())
+    report("disp_pred", out["disp_pred"].detach().cpu(), t(g["disp_pred"]), 4e-4)
+    crit = build_criterion(make_cfg(md))
+    losses = crit(out, {"disp": t(g["gt"]).to(DEV), "valid": t(g["valid"]).to(DEV)})
+    total = sum(losses[k] * crit.weight_dict[k] for k in losses if k in crit.weight_dict)
+    assert abs(float(total.detach()) - float(g["loss_total"])) <= 2e-4 * abs(float(g["loss_total"]))
+    named = dict(model.named_parameters())
+
+    def compare(tag):
+        worst, stats = {}, {}
+        for key in g:
+            if key.startswith(tag + "/"):
+                name = key[len(tag) + 1:]
+                want, got = t(g[key]), named[name].grad
+                assert got is not None, name + ": no gradient"
+                scale = float(want.abs().max())
+                err = float((got.cpu().double() - want.double()).abs().max())
+                worst[name] = err / max(scale, 1e-6)
+                assert err <= 1e-2 * scale + 2e-6, (tag, name, err, scale)       # (L1 loss: sign flips, see the slice test)
+            elif key.startswith(tag + "_stat/"):
+                name = key[len(tag) + 6:]
+                got = named[name].grad
+                assert got is not None, name + ": no gradient"
+                gd = got.detach().cpu().double().reshape(-1)
+                norm, proj = float(gd.norm()), float((gd * torch.from_numpy(unit_noise("gproj/" + name, gd.numel())).double()).sum())
+                wn, wp = [float(v) for v in g[key]]
+                # (floor: the bias of a convolution that feeds an InstanceNorm -- the two downsample branches -- has gradient 0 in exact
+                #  arithmetic; both sides hold ~1e-7 of rounding there)
+                stats[name] = max(abs(norm - wn), abs(proj - wp)) / max(wn, 1e-4)
+                assert abs(norm - wn) <= 1e-2 * wn + 2e-6 and abs(proj - wp) <= 1e-2 * wn + 2e-6, (tag, name, norm, wn, proj, wp)
+            elif key.startswith(tag + "_none/"):
+                assert named[key[len(tag) + 6:]].grad is None, key
+        return worst, stats
+    model.zero_grad(set_to_none=True)
+    total.backward(retain_graph=True)
+    worst, stats = compare("grad")
+    assert len(worst) == 143 + 9 and len(stats) == 23, (len(worst), len(stats))
+    record_note("training backward, whole model: %d parameter gradients entry by entry, worst max|d| / max|ref| = %.1e (%s); %d convolutional "
+                "tensors by norm + projection, worst %.1e of the norm (%s)" % (len(worst), max(worst.values()), max(worst, key=worst.get),
+                                                                               len(stats), max(stats.values()), max(stats, key=stats.get)))
+    reached = {n for n, p in named.items() if p.grad is not None}
+    model.zero_grad(set_to_none=True)
+    losses["loss_prop"].backward()
+    worst, stats = compare("grad_prop")
+    assert len(worst) == 49 + 8 and len(stats) == 21, (len(worst), len(stats))
+    record_note("training backward, whole model, proposal loss alone: %d entry by entry, worst %.1e (%s); %d by norm + projection, worst %.1e (%s)"
+                % (len(worst), max(worst.values()), max(worst, key=worst.get), len(stats), max(stats.values()), max(stats, key=stats.get)))
+    reached |= {n for n, p in named.items() if p.grad is not None}
+    assert reached == set(named), sorted(set(named) - reached)          # every parameter of the model is trainable on this build
 
 
 def test_train_steps_on_the_gradient_slice_reduce_the_loss():
@@ -850,3 +926,43 @@ def test_train_steps_on_the_gradient_slice_reduce_the_loss():
         train_step(model, crit, opt, sample, grad_clip=cfg.SOLVER.GRAD_CLIP)
     moved = {k for k, v in model.named_parameters() if not torch.equal(v.detach(), before[k])}
     assert moved == {k for k, _ in slice_parameters(model)}, moved ^ {k for k, _ in slice_parameters(model)}
+
+
+def test_train_steps_on_the_whole_model_reduce_the_loss():
+    """nmrf_amd.train.train_step with enable_grad_slice(full=True): the optimizer holds every parameter in the reference's groups
+    (main.py:186-245: the relative-position tables without weight decay), eight steps lower the loss, and every tensor the reference's
+    loss reaches moves -- encoder and matching heads included; `dpn.proj` and the propagation stage follow once 'loss_prop' has a weight."""
+    from nmrf_amd.models.criterion import build_criterion
+    from nmrf_amd.train import build_slice_optimizer, slice_parameters, train_step
+    from tests.conftest import record_note
+    from tests.util import golden_images, make_cfg
+    g = golden("e2e_train")
+    md = int(g["max_disp"])
+    cfg = make_cfg(md)
+    model = build_product(md, DEV).train().enable_grad_slice(full=True)
+    crit = build_criterion(cfg)
+    names = [k for k, _ in model.named_parameters()]
+    assert [k for k, _ in slice_parameters(model)] == names
+    opt = build_slice_optimizer(model, cfg)
+    held = {id(p): grp for grp in opt.param_groups for p in grp["params"]}
+    assert len(held) == len(names) and all(p.requires_grad for p in model.parameters())
+    tables = [p for k, p in model.named_parameters() if "relative_position_enc_table" in k]
+    assert len(tables) == 10 and all(held[id(p)]["weight_decay"] == 0.0 for p in tables)
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    img1, img2 = golden_images(g)
+    sample = {"img1": img1, "img2": img2, "disp": t(g["gt"]).clone(), "valid": t(g["valid"])}
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        curve = [train_step(model, crit, opt, sample, grad_clip=cfg.SOLVER.GRAD_CLIP)[0] for _ in range(8)]
+    record_note("train_step on the whole model, 8 AdamW steps: weighted loss %.2f -> %.2f" % (curve[0], curve[-1]))
+    assert curve[-1] < curve[0] - 0.5 and all(c == c for c in curve), curve
+    moved = {k for k, v in model.named_parameters() if not torch.equal(v.detach(), before[k])}
+    behind_prop = {k for k in names if k.startswith(("dpn.propagation.", "dpn.prop_head.", "dpn.proj."))}
+    assert moved == set(names) - behind_prop, moved ^ (set(names) - behind_prop)
+    crit.weight_dict["loss_prop"] = 1.0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        train_step(model, crit, opt, sample, grad_clip=cfg.SOLVER.GRAD_CLIP)
+    moved = {k for k, v in model.named_parameters() if not torch.equal(v.detach(), before[k])}
+    assert moved == set(names), set(names) - moved
