@@ -255,8 +255,9 @@ extern "C" int nmrf_layernorm_bwd_f32(const float *x, const float *g, const floa
 //     dq_i = s sum_j ds_ij (k_j + ek_r)      dk_j = s sum_i ds_ij (q_i + eq_r)      dv_j = sum_i p_ij dout_i
 //     dek_r += s ds_ij q_i                   deq_r += s ds_ij k_j                    dev_r += p_ij dout_i
 // One workgroup per (window, head, image); P and ds of the window live in a global scratch (2 x Tw^2 floats per workgroup), the table
-// gradient leaves as one part per (image, window) -- summed in fixed order by nmrf_sum_partials_f32: deterministic.  Correctness first:
-// one thread per query row / key column / table entry, fp32 VALU arithmetic (this is 5 x Tw^2 x 32 MACs per window and head).
+// gradient leaves as one part per (image, window) -- summed in fixed order by nmrf_sum_partials_f32: deterministic.  fp32 VALU arithmetic
+// (5 x Tw^2 x 32 MACs per window and head) spread over the whole workgroup: one thread per (query, key) pair for the logits and dp, one wave
+// per row for the softmax statistics, one thread per (token, channel) for dq | dk | dv and per (table row, channel) for the table.
 struct WinBwdArgs {
     const float *qkv, *table, *dout;
     float *dqkv, *dtab_parts, *scratch;
@@ -264,22 +265,40 @@ struct WinBwdArgs {
     float scale;
 };
 
-#define WB_LD 33          // LDS row stride of the [Tw][32] tiles (one thread per row: conflict-free)
+#define WB_LD 33          // LDS row stride of the [Tw][32] tiles
+#define WB_NMAX 4         // labels per pixel (register-blocked: the kernel is instantiated for N = 1 .. 4)
+#define WB_NT 512         // threads per workgroup: two waves per SIMD (the LDS image allows one workgroup per CU)
 
-__global__ __launch_bounds__(256) void window_attn_bwd_kernel(WinBwdArgs a) {
+// LDS: Q | K | dO [Tw][33], Eq | Ek [R][33], four int arrays [Tw], then a POOL that is, in turn,
+//   phase 0-1a: V [Tw][33] | Ev [R][33]                      phase 1b-3: A | Ap | Bq [Tw][W2 + 1] + one (ds, p) row buffer per wave
+//   phase 2:    a [16 N][Tw] row tile of ds, then [Tw][33] column tiles of ds and p
+__host__ __device__ inline size_t wb_pool_floats(int Tw, int W2, int R, int N) {
+    size_t a = (size_t)(Tw + R) * WB_LD, b = (size_t)Tw * (3 * W2 + 1) + (WB_NT / 64) * 2 * (size_t)Tw, c = (size_t)16 * N * Tw, d = (size_t)2 * Tw * WB_LD;
+    size_t m = a > b ? a : b;
+    m = m > c ? m : c;
+    return m > d ? m : d;
+}
+
+template <int N>
+__global__ __launch_bounds__(WB_NT) void window_attn_bwd_kernel(WinBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float wb_smem[];
-    const int win = a.win, N = a.N, W2 = win * win, Tw = W2 * N, span = 2 * win - 1, R = span * span;
-    float *Q = wb_smem, *Kt = Q + Tw * WB_LD, *V = Kt + Tw * WB_LD, *dO = V + Tw * WB_LD;
-    float *Eq = dO + Tw * WB_LD, *Ek = Eq + R * WB_LD, *Ev = Ek + R * WB_LD;
-    int *rowoff = reinterpret_cast<int *>(Ev + R * WB_LD);                    // [Tw] token index on the (un-rolled) grid
+    const int win = a.win, W2 = win * win, Tw = W2 * N, span = 2 * win - 1, R = span * span, LA = W2, LB = W2 + 1;
+    float *Q = wb_smem, *Kt = Q + Tw * WB_LD, *dO = Kt + Tw * WB_LD;
+    float *Eq = dO + Tw * WB_LD, *Ek = Eq + R * WB_LD;
+    int *rowoff = reinterpret_cast<int *>(Ek + R * WB_LD);                    // [Tw] token index on the (un-rolled) grid
     int *reg = rowoff + Tw;                                                    // [Tw] Swin region of the token's pixel
-    const int tid = threadIdx.x;
+    int *lin = reg + Tw;                                                       // [Tw] row * span + column of the token's pixel in the window
+    float *pool = reinterpret_cast<float *>(lin + Tw);
+    float *V = pool, *Ev = V + Tw * WB_LD;
+    float *A = pool, *Ap = A + Tw * LA, *Bq = Ap + Tw * LA, *rowbuf = Bq + Tw * LB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nwx = a.Wp / win, nwin = nwx * (a.Hp / win);
     const int w = blockIdx.x, head = blockIdx.y, bimg = blockIdx.z;
     const int wi = w / nwx, wj = w % nwx;
     const int ld = 3 * a.C;
     const float s = a.scale;
-    for (int i = tid; i < Tw; i += 256) {
+    const int roff = (win - 1) * (span + 1);                                   // rel(i, j) = lin[i] - lin[j] + roff
+    for (int i = tid; i < Tw; i += WB_NT) {
         const int pt = i / N, n = i - pt * N, pa = pt / win, pb = pt - pa * win;
         const int Yr = wi * win + pa, Xr = wj * win + pb;                      // rolled grid
         int Y = Yr + a.shift, X = Xr + a.shift;
@@ -288,9 +307,10 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(WinBwdArgs a) {
         rowoff[i] = ((bimg * a.Hp + Y) * a.Wp + X) * N + n;
         const int fy = Yr < a.Hp - win ? 0 : (Yr < a.Hp - a.shift ? 1 : 2), fx = Xr < a.Wp - win ? 0 : (Xr < a.Wp - a.shift ? 1 : 2);
         reg[i] = a.shift ? fy * 3 + fx : 0;
+        lin[i] = pa * span + pb;
     }
     __syncthreads();
-    for (int e = tid; e < Tw * 32; e += 256) {
+    for (int e = tid; e < Tw * 32; e += WB_NT) {
         const int i = e >> 5, c = e & 31;
         const float *row = a.qkv + (size_t)rowoff[i] * ld + head * 32 + c;
         Q[i * WB_LD + c] = row[0];
@@ -298,7 +318,7 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(WinBwdArgs a) {
         V[i * WB_LD + c] = row[2 * a.C];
         dO[i * WB_LD + c] = a.dout[(size_t)rowoff[i] * a.C + head * 32 + c];
     }
-    for (int e = tid; e < R * 32; e += 256) {
+    for (int e = tid; e < R * 32; e += WB_NT) {
         const int r = e >> 5, c = e & 31;
         const float *row = a.table + (size_t)r * ld + head * 96 + c;
         Eq[r * WB_LD + c] = row[0];
@@ -307,88 +327,119 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(WinBwdArgs a) {
     }
     __syncthreads();
     float *P = a.scratch + ((size_t)(bimg * a.heads + head) * nwin + w) * 2 * Tw * Tw, *dS = P + (size_t)Tw * Tw;
-    auto rel = [&](int i, int j) {
-        const int pi = i / N, pj = j / N;
-        return (pi / win - pj / win + win - 1) * span + (pi % win - pj % win + win - 1);
-    };
-    auto masked = [&](int i, int j) {
-        if (a.sibling && N > 1 && i / N == j / N && i != j) return true;
-        return reg[i] != reg[j];
-    };
-    // ---- phase 1: one thread per query row ----------------------------------------------------------------------------------------------
-    for (int i = tid; i < Tw; i += 256) {
-        const float *q = Q + i * WB_LD, *go = dO + i * WB_LD;
-        float m = -INFINITY;
-        for (int j = 0; j < Tw; ++j) {
-            float l = -INFINITY;
-            if (!masked(i, j)) {
-                const float *k = Kt + j * WB_LD;
-                const int r = rel(i, j);
-                const float *ek = Ek + r * WB_LD, *eq = Eq + r * WB_LD;
-                float acc = 0.f;
-                for (int c = 0; c < 32; ++c) acc = fmaf(q[c], k[c] + ek[c], fmaf(k[c], eq[c], acc));
-                l = acc * s;
-            }
-            P[(size_t)i * Tw + j] = l;
-            m = fmaxf(m, l);
-        }
-        float Z = 0.f;
-        for (int j = 0; j < Tw; ++j) {
-            const float l = P[(size_t)i * Tw + j];
-            const float e = l == -INFINITY ? 0.f : expf(l - m);
-            P[(size_t)i * Tw + j] = e;
-            Z += e;
-        }
-        const float rz = 1.0f / Z;
-        float D = 0.f;
-        for (int j = 0; j < Tw; ++j) {
-            const float p = P[(size_t)i * Tw + j] * rz;
-            P[(size_t)i * Tw + j] = p;
-            float dp = 0.f;
-            if (p != 0.f) {
-                const float *v = V + j * WB_LD, *ev = Ev + rel(i, j) * WB_LD;
-                for (int c = 0; c < 32; ++c) dp = fmaf(go[c], v[c] + ev[c], dp);
-            }
-            dS[(size_t)i * Tw + j] = dp;
-            D = fmaf(p, dp, D);
-        }
-        float dq[32];
-        for (int c = 0; c < 32; ++c) dq[c] = 0.f;
-        for (int j = 0; j < Tw; ++j) {
-            const float ds = P[(size_t)i * Tw + j] * (dS[(size_t)i * Tw + j] - D);
-            dS[(size_t)i * Tw + j] = ds;
-            if (ds != 0.f) {
-                const float *k = Kt + j * WB_LD, *ek = Ek + rel(i, j) * WB_LD;
-                for (int c = 0; c < 32; ++c) dq[c] = fmaf(ds, k[c] + ek[c], dq[c]);
+#ifdef WB_STOP                                                   // (tools/build_ab_winbwd.sh: where does the time go)
+#define WB_PHASE_END(k) if (WB_STOP <= (k)) return;
+#else
+#define WB_PHASE_END(k)
+#endif
+    WB_PHASE_END(0)
+    // ---- phase 1a: one thread per (query PIXEL, key): the N logits and dp = dout_i . (v_j + ev_r) of the pixel's labels share k, v and the
+    // three table rows (lanes = consecutive keys: conflict-free rows, coalesced stores) ---------------------------------------------------
+    for (int e = tid; e < W2 * Tw; e += WB_NT) {
+        const int pi = e / Tw, j = e - pi * Tw, i0 = pi * N;
+        const bool region = reg[i0] != reg[j];
+        const bool sib = a.sibling && N > 1 && j / N == pi;
+        const int r = lin[i0] - lin[j] + roff;
+        const float *k = Kt + j * WB_LD, *v = V + j * WB_LD, *ek = Ek + r * WB_LD, *eq = Eq + r * WB_LD, *ev = Ev + r * WB_LD;
+        float acc[N], dp[N];
+#pragma unroll
+        for (int n = 0; n < N; ++n) acc[n] = dp[n] = 0.f;
+        if (!region) {
+#pragma unroll 8
+            for (int c = 0; c < 32; ++c) {
+                const float kc = k[c], ke = kc + ek[c], ve = v[c] + ev[c], keq = kc * eq[c];
+#pragma unroll
+                for (int n = 0; n < N; ++n) {
+                    acc[n] = fmaf(Q[(i0 + n) * WB_LD + c], ke, acc[n] + keq);
+                    dp[n] = fmaf(dO[(i0 + n) * WB_LD + c], ve, dp[n]);
+                }
             }
         }
-        float *o = a.dqkv + (size_t)rowoff[i] * ld + head * 32;
-        for (int c = 0; c < 32; ++c) o[c] = dq[c] * s;
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            const bool off = region || (sib && i0 + n != j);
+            P[(size_t)(i0 + n) * Tw + j] = off ? -INFINITY : acc[n] * s;
+            dS[(size_t)(i0 + n) * Tw + j] = off ? 0.f : dp[n];
+        }
+    }
+    __threadfence_block();
+    __syncthreads();                                             // (V and Ev are dead from here: the pool holds A | Ap | Bq)
+    WB_PHASE_END(1)
+    // ---- phase 1b: one wave per query pixel, its N rows in turn: softmax, D = sum_j p dp, ds = p (dp - D) (fixed butterfly order:
+    // deterministic); and the label sums the table gradient needs: A[i][pj] = sum_n2 ds[i][(pj, n2)], Ap likewise of p,
+    // Bq[j][pi] = sum_n ds[(pi, n)][j] ---------------------------------------------------------------------------------------------------
+    {
+        float *rb = rowbuf + wave * 2 * Tw;
+        for (int pi = wave; pi < W2; pi += WB_NT / 64) {
+            float bq[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int n = 0; n < N; ++n) {
+                const int i = pi * N + n;
+                float lv[4], dv4[4];
+                float m = -INFINITY;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = lane + 64 * u;
+                    lv[u] = j < Tw ? P[(size_t)i * Tw + j] : -INFINITY;
+                    dv4[u] = j < Tw ? dS[(size_t)i * Tw + j] : 0.f;
+                    m = fmaxf(m, lv[u]);
+                }
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+                float Z = 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    lv[u] = lv[u] == -INFINITY ? 0.f : expf(lv[u] - m);
+                    Z += lv[u];
+                }
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) Z += __shfl_xor(Z, o, 64);
+                const float rz = 1.0f / Z;
+                float D = 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    lv[u] *= rz;
+                    D = fmaf(lv[u], dv4[u], D);
+                }
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) D += __shfl_xor(D, o, 64);
+                __builtin_amdgcn_wave_barrier();                 // (the previous row's label sums have read the row buffer)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = lane + 64 * u;
+                    if (j < Tw) {
+                        const float ds = lv[u] * (dv4[u] - D);
+                        P[(size_t)i * Tw + j] = lv[u];
+                        dS[(size_t)i * Tw + j] = ds;
+                        rb[j] = ds;
+                        rb[Tw + j] = lv[u];
+                        bq[u] += ds;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();                 // (LDS operations of one wave complete in order)
+                for (int pj = lane; pj < W2; pj += 64) {
+                    float sa = 0.f, sp = 0.f;
+                    for (int n2 = 0; n2 < N; ++n2) {
+                        sa += rb[pj * N + n2];
+                        sp += rb[Tw + pj * N + n2];
+                    }
+                    A[i * LA + pj] = sa;
+                    Ap[i * LA + pj] = sp;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = lane + 64 * u;
+                if (j < Tw) Bq[j * LB + pi] = bq[u];
+            }
+        }
     }
     __threadfence_block();
     __syncthreads();
-    // ---- phase 2: one thread per key column ---------------------------------------------------------------------------------------------
-    for (int j = tid; j < Tw; j += 256) {
-        float dk[32], dv[32];
-        for (int c = 0; c < 32; ++c) dk[c] = dv[c] = 0.f;
-        for (int i = 0; i < Tw; ++i) {
-            const float ds = dS[(size_t)i * Tw + j], p = P[(size_t)i * Tw + j];
-            if (p == 0.f && ds == 0.f) continue;
-            const float *q = Q + i * WB_LD, *go = dO + i * WB_LD, *eq = Eq + rel(i, j) * WB_LD;
-            for (int c = 0; c < 32; ++c) {
-                dk[c] = fmaf(ds, q[c] + eq[c], dk[c]);
-                dv[c] = fmaf(p, go[c], dv[c]);
-            }
-        }
-        float *o = a.dqkv + (size_t)rowoff[j] * ld + head * 32;
-        for (int c = 0; c < 32; ++c) {
-            o[a.C + c] = dk[c] * s;
-            o[2 * a.C + c] = dv[c];
-        }
-    }
-    // ---- phase 3: one thread per (table row, channel): every (query pixel, key pixel) pair with that offset, every label pair ------------
+    WB_PHASE_END(2)
+    // ---- phase 3: one thread per (table row, channel): every (query pixel, key pixel) pair with that offset ------------------------------
+    //     dek_r = s sum_i q_i A[i][pj]      deq_r = s sum_j k_j Bq[j][pi]      dev_r = sum_i dout_i Ap[i][pj]
     float *part = a.dtab_parts + ((size_t)bimg * nwin + w) * R * ld + head * 96;
-    for (int e = tid; e < R * 32; e += 256) {
+    for (int e = tid; e < R * 32; e += WB_NT) {
         const int r = e >> 5, c = e & 31;
         const int da = r / span - (win - 1), db = r % span - (win - 1);        // query pixel - key pixel
         float geq = 0.f, gek = 0.f, gev = 0.f;
@@ -398,44 +449,112 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(WinBwdArgs a) {
             for (int pb = 0; pb < win; ++pb) {
                 const int kb = pb - db;
                 if (kb < 0 || kb >= win) continue;
-                const int i0 = (pa * win + pb) * N, j0 = (ka * win + kb) * N;
-                for (int n = 0; n < N; ++n)
-                    for (int n2 = 0; n2 < N; ++n2) {
-                        const int i = i0 + n, j = j0 + n2;
-                        const float ds = dS[(size_t)i * Tw + j], p = P[(size_t)i * Tw + j];
-                        gek = fmaf(ds, Q[i * WB_LD + c], gek);
-                        geq = fmaf(ds, Kt[j * WB_LD + c], geq);
-                        gev = fmaf(p, dO[i * WB_LD + c], gev);
-                    }
+                const int pi = pa * win + pb, pj = ka * win + kb;
+                for (int n = 0; n < N; ++n) {
+                    const int i = pi * N + n, j = pj * N + n;
+                    gek = fmaf(A[i * LA + pj], Q[i * WB_LD + c], gek);
+                    gev = fmaf(Ap[i * LA + pj], dO[i * WB_LD + c], gev);
+                    geq = fmaf(Bq[j * LB + pi], Kt[j * WB_LD + c], geq);
+                }
             }
         }
         part[(size_t)r * ld + c] = geq * s;
         part[(size_t)r * ld + 32 + c] = gek * s;
         part[(size_t)r * ld + 64 + c] = gev;
     }
+    WB_PHASE_END(3)
+    // ---- phase 2: tiles of ds / p through the pool; one thread per (pixel of the tile, channel), its N labels in registers ---------------
+    const int pp = tid >> 5, c = tid & 31;
+    for (int pb0 = 0; pb0 < W2; pb0 += 16) {                      // dq: 16 query pixels (16 N rows of ds, contiguous in the scratch) at a time
+        const int npx = W2 - pb0 < 16 ? W2 - pb0 : 16;
+        __syncthreads();
+        for (int e = tid; e < npx * N * Tw; e += WB_NT) pool[e] = dS[(size_t)pb0 * N * Tw + e];
+        __syncthreads();
+        if (pp < npx) {
+            const int i0 = (pb0 + pp) * N, li = lin[i0] + roff;
+            const float *t = pool + pp * N * Tw;
+            float acc[N];
+#pragma unroll
+            for (int n = 0; n < N; ++n) acc[n] = 0.f;
+#pragma unroll 4
+            for (int j = 0; j < Tw; ++j) {                        // (a masked pair has ds = p = 0: it adds exactly 0)
+                const float ke = Kt[j * WB_LD + c] + Ek[(li - lin[j]) * WB_LD + c];
+#pragma unroll
+                for (int n = 0; n < N; ++n) acc[n] = fmaf(t[n * Tw + j], ke, acc[n]);
+            }
+#pragma unroll
+            for (int n = 0; n < N; ++n) a.dqkv[(size_t)rowoff[i0 + n] * ld + head * 32 + c] = acc[n] * s;
+        }
+    }
+    WB_PHASE_END(4)
+    float *tC = pool, *tP = pool + Tw * WB_LD;
+    for (int pb0 = 0; pb0 < W2; pb0 += 8) {                       // dk | dv: 8 key pixels (8 N columns of ds and p) at a time
+        const int npx = W2 - pb0 < 8 ? W2 - pb0 : 8, ncol = npx * N, j0 = pb0 * N;
+        __syncthreads();
+        for (int e = tid; e < Tw * 32; e += WB_NT) {
+            const int i = e >> 5, jj = e & 31;
+            tC[i * WB_LD + jj] = jj < ncol ? dS[(size_t)i * Tw + j0 + jj] : 0.f;
+            tP[i * WB_LD + jj] = jj < ncol ? P[(size_t)i * Tw + j0 + jj] : 0.f;
+        }
+        __syncthreads();
+        const int pq = pp & 7;                                    // (waves 0-3: dk of the 8 key pixels, waves 4-7: their dv)
+        if (pq < npx) {
+            const int jb = (pb0 + pq) * N, lj = roff - lin[jb];
+            float g[N];
+#pragma unroll
+            for (int n = 0; n < N; ++n) g[n] = 0.f;
+            if (pp < 8) {
+#pragma unroll 4
+                for (int i = 0; i < Tw; ++i) {
+                    const float qe = Q[i * WB_LD + c] + Eq[(lin[i] + lj) * WB_LD + c];
+#pragma unroll
+                    for (int n = 0; n < N; ++n) g[n] = fmaf(tC[i * WB_LD + pq * N + n], qe, g[n]);
+                }
+#pragma unroll
+                for (int n = 0; n < N; ++n) a.dqkv[(size_t)rowoff[jb + n] * ld + head * 32 + c + a.C] = g[n] * s;
+            } else {
+#pragma unroll 4
+                for (int i = 0; i < Tw; ++i) {
+                    const float go = dO[i * WB_LD + c];
+#pragma unroll
+                    for (int n = 0; n < N; ++n) g[n] = fmaf(tP[i * WB_LD + pq * N + n], go, g[n]);
+                }
+#pragma unroll
+                for (int n = 0; n < N; ++n) a.dqkv[(size_t)rowoff[jb + n] * ld + head * 32 + c + 2 * a.C] = g[n];
+            }
+        }
+    }
 }
 
 // qkv [B,Hp,Wp,N,3C] fp32 rows, table [(2 win - 1)^2, 3C], dout [B,Hp,Wp,N,C] -> dqkv (every element written), dtab_parts
-// [B * windows][(2 win - 1)^2][3C] (sum them with nmrf_sum_partials_f32), scratch: 2 * B * heads * windows * Tw^2 floats.
+// [B * windows][(2 win - 1)^2][3C] (sum them with nmrf_sum_partials_f32), scratch: 2 * B * heads * windows * Tw^2 floats.  N <= 4.
 extern "C" int nmrf_window_attn_bwd_f32(const float *qkv, const float *table, const float *dout, int B, int Hp, int Wp, int N, int C, int heads,
                                         int win, int shift, int sibling_mask, float *dqkv, float *dtab_parts, float *scratch, void *stream) {
     if (!qkv || !table || !dout || !dqkv || !dtab_parts || !scratch) return NMRF_ENULL;
-    if (B < 1 || N < 1 || win < 1 || Hp % win || Wp % win || shift < 0 || shift >= win || heads * 32 != C) return NMRF_EINVAL;
-    const int Tw = win * win * N, R = (2 * win - 1) * (2 * win - 1);
+    if (B < 1 || N < 1 || N > WB_NMAX || win < 1 || Hp % win || Wp % win || shift < 0 || shift >= win || heads * 32 != C) return NMRF_EINVAL;
+    const int W2 = win * win, Tw = W2 * N, R = (2 * win - 1) * (2 * win - 1);
     if (Tw > 256) return NMRF_EINVAL;
-    const size_t lds = ((size_t)(4 * Tw + 3 * R) * WB_LD + 2 * Tw) * sizeof(float);
+    const size_t lds = ((size_t)(3 * Tw + 2 * R) * WB_LD + 3 * Tw + wb_pool_floats(Tw, W2, R, N)) * sizeof(float);
     if (lds > 160 * 1024) return NMRF_EINVAL;
     static bool attr_set_dev[NMRF_MAX_DEV] = {};
     const int dev = nmrf_cur_device();
     if (dev < 0) return NMRF_ELAUNCH;
     if (!attr_set_dev[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(window_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
-            hipSuccess)
-            return NMRF_ELAUNCH;
+        const void *fns[4] = {reinterpret_cast<const void *>(window_attn_bwd_kernel<1>), reinterpret_cast<const void *>(window_attn_bwd_kernel<2>),
+                              reinterpret_cast<const void *>(window_attn_bwd_kernel<3>), reinterpret_cast<const void *>(window_attn_bwd_kernel<4>)};
+        for (const void *f : fns)
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return NMRF_ELAUNCH;
         attr_set_dev[dev] = true;
     }
     WinBwdArgs a{qkv, table, dout, dqkv, dtab_parts, scratch, Hp, Wp, N, C, heads, win, shift, sibling_mask ? 1 : 0, 1.0f / sqrtf(32.0f)};
-    hipLaunchKernelGGL(window_attn_bwd_kernel, dim3((Hp / win) * (Wp / win), heads, B), dim3(256), lds, (hipStream_t)stream, a);
+    const dim3 grid((Hp / win) * (Wp / win), heads, B);
+    hipStream_t st = (hipStream_t)stream;
+    switch (N) {
+        case 1: hipLaunchKernelGGL(window_attn_bwd_kernel<1>, grid, dim3(WB_NT), lds, st, a); break;
+        case 2: hipLaunchKernelGGL(window_attn_bwd_kernel<2>, grid, dim3(WB_NT), lds, st, a); break;
+        case 3: hipLaunchKernelGGL(window_attn_bwd_kernel<3>, grid, dim3(WB_NT), lds, st, a); break;
+        default: hipLaunchKernelGGL(window_attn_bwd_kernel<4>, grid, dim3(WB_NT), lds, st, a); break;
+    }
     return nmrf_launch_status();
 }
 

@@ -97,3 +97,65 @@ def train_step(model, criterion, optimizer, sample, grad_clip=1.0, group=None):
     torch.nn.utils.clip_grad_norm_(params, grad_clip)
     optimizer.step()
     return float(losses.detach()), {k: float(v.detach()) for k, v in loss_dict.items()}
+
+
+def build_lr_scheduler(optimizer, cfg, last_step=-1):
+    """The reference's schedule (main.py:380-388): OneCycleLR to BASE_LR over MAX_ITER + 100 steps, 5 % warm-up, cosine anneal, no momentum
+    cycling; `last_step` = the resumed step count (a resumed optimizer state carries `initial_lr`, which OneCycleLR needs then)."""
+    return torch.optim.lr_scheduler.OneCycleLR(optimizer, cfg.SOLVER.BASE_LR, cfg.SOLVER.MAX_ITER + 100, pct_start=0.05, cycle_momentum=False,
+                                               anneal_strategy="cos", last_epoch=last_step if last_step > 0 else -1)
+
+
+def save_checkpoint(path, model, optimizer=None, step=0, epoch=0):
+    """The reference's two checkpoint layouts (main.py:441-458): {'model'} for `step_%06d.pth`, + {'optimizer', 'step', 'epoch'} for
+    `checkpoint_latest.pth`.  State-dict keys are the reference's (strict-load contract of the model), so either side resumes the other's."""
+    ckpt = {"model": model.state_dict()}
+    if optimizer is not None:
+        ckpt.update(optimizer=optimizer.state_dict(), step=int(step), epoch=int(epoch))
+    torch.save(ckpt, path)
+
+
+def load_checkpoint(path, model, optimizer=None, strict=True, map_location="cuda"):
+    """Resume as main.py:352-372 does: weights from ckpt['model'] (or a bare state dict); optimizer, step and epoch when the file has all
+    three and an optimizer is given (SOLVER.NO_RESUME_OPTIMIZER = pass optimizer=None).  Returns (epoch, step)."""
+    ckpt = torch.load(path, map_location=map_location)
+    model.load_state_dict(ckpt["model"] if "model" in ckpt else ckpt, strict=strict)
+    if optimizer is not None and all(k in ckpt for k in ("optimizer", "step", "epoch")):
+        optimizer.load_state_dict(ckpt["optimizer"])
+        return int(ckpt["epoch"]), int(ckpt["step"])
+    return 0, 0
+
+
+def fit(model, criterion, optimizer, loader, cfg, checkpoint_dir=None, start_step=0, start_epoch=0, group=None, on_step=None,
+        set_epoch=None):
+    """The training loop of main.py:403-483 around train_step: model.train() + freeze_bn() per epoch, the OneCycle schedule stepped after
+    every optimizer step, `step_%06d.pth` every SOLVER.CHECKPOINT_PERIOD steps and at the end, `checkpoint_latest.pth` (with optimizer,
+    step, epoch) every SOLVER.LATEST_CHECKPOINT_PERIOD, both written by rank 0 only; stops at SOLVER.MAX_ITER.  `loader`: any iterable of
+    samples {'img1', 'img2', 'disp', 'valid'}, re-iterated per epoch; set_epoch(epoch): the DistributedSampler hook of main.py:409-410;
+    on_step(step, lr, total, loss_dict): the caller's logging (the reference writes TensorBoard scalars there).  Evaluation
+    (TEST.EVAL_PERIOD) is the caller's: nmrf_amd.driver runs the inference path.  Returns (step, epoch)."""
+    import os
+    rank0 = not (dist.is_available() and dist.is_initialized()) or dist.get_rank(group) == 0
+    sched = build_lr_scheduler(optimizer, cfg, start_step)
+    step, epoch, s = int(start_step), int(start_epoch), cfg.SOLVER
+    while step < s.MAX_ITER:
+        model.train()
+        model.freeze_bn()
+        if set_epoch is not None:
+            set_epoch(epoch)
+        for sample in loader:
+            total, loss_dict = train_step(model, criterion, optimizer, sample, s.GRAD_CLIP, group)
+            lr = sched.get_last_lr()[0]
+            sched.step()
+            step += 1
+            if on_step is not None:
+                on_step(step, lr, total, loss_dict)
+            if checkpoint_dir is not None and rank0:
+                if step % s.CHECKPOINT_PERIOD == 0 or step == s.MAX_ITER:
+                    save_checkpoint(os.path.join(checkpoint_dir, "step_%06d.pth" % step), model)
+                if step % s.LATEST_CHECKPOINT_PERIOD == 0:
+                    save_checkpoint(os.path.join(checkpoint_dir, "checkpoint_latest.pth"), model, optimizer, step, epoch)
+            if step >= s.MAX_ITER:
+                return step, epoch
+        epoch += 1
+    return step, epoch

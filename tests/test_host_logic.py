@@ -254,3 +254,56 @@ def test_kv16_format_restatement_against_a_scalar_reading_of_the_header():
             word = raw[t, (256 + c) * 4: (256 + c) * 4 + 4]
             assert word[:2].view(np.float16)[0] == hv and word[2:].view(np.float16)[0] == lv
             assert abs(float(np.float32(hv) + np.float32(lv)) - float(x[t, 256 + c])) <= 2.0 ** -21 * abs(float(x[t, 256 + c])) + 2.0 ** -25     # (lo goes subnormal below |x| ~ 2^-3: absolute 2^-25, split_mfma.h)
+
+
+def test_training_host_side_optimizer_groups_schedule_and_checkpoints(tmp_path):
+    """nmrf_amd.train, host side (no GPU): the optimizer groups of main.py:186-245 on the whole model (relative-position tables without
+    weight decay, LayerNorm parameters at WEIGHT_DECAY_NORM), the OneCycle schedule of main.py:380-388, and the two checkpoint layouts of
+    main.py:441-458 -- saved and resumed (weights, AdamW moments, step, epoch), loadable by the reference (same state-dict keys)."""
+    import json
+    from nmrf_amd.config import get_cfg
+    from nmrf_amd.models import build_model
+    from nmrf_amd.train import build_lr_scheduler, build_slice_optimizer, load_checkpoint, save_checkpoint, slice_parameters
+    cfg = get_cfg()
+    cfg.merge_from_list(["SOLVER.MAX_ITER", 50, "SOLVER.WEIGHT_DECAY_NORM", 0.002])
+    cfg.freeze()
+    model = build_model(cfg)[0].train().enable_grad_slice(full=True)
+    opt = build_slice_optimizer(model, cfg)
+    names = {id(p): k for k, p in model.named_parameters()}
+    assert sorted(names[id(p)] for g in opt.param_groups for p in g["params"]) == sorted(names.values())
+    by = {names[id(p)]: g for g in opt.param_groups for p in g["params"]}
+    assert by["inference.layers.0.nmp.attn.relative_position_enc_table"]["weight_decay"] == 0.0
+    assert by["refinement.norm.weight"]["weight_decay"] == 0.002 and by["inference.layers.1.nmp.norm2.bias"]["weight_decay"] == 0.002
+    assert by["backbone.conv1.weight"]["weight_decay"] == cfg.SOLVER.WEIGHT_DECAY and by["backbone.conv1.weight"]["lr"] == cfg.SOLVER.BASE_LR
+    # the slice: the convolutional side frozen
+    sl = build_model(cfg)[0].train().enable_grad_slice()
+    build_slice_optimizer(sl, cfg)
+    frozen = [k for k, p in sl.named_parameters() if not p.requires_grad]
+    assert len(slice_parameters(sl)) == 315 and frozen and all(k.startswith(("backbone.", "concatconv.", "gw.", "dpn.proj.")) for k in frozen)
+    # schedule: warm-up over 5 % of MAX_ITER + 100 steps to BASE_LR, cosine down
+    sched = build_lr_scheduler(opt, cfg)
+    lrs = []
+    for _ in range(cfg.SOLVER.MAX_ITER):
+        lrs.append(sched.get_last_lr()[0])
+        opt.step()
+        sched.step()
+    peak = max(range(len(lrs)), key=lrs.__getitem__)
+    assert lrs[peak] > 0.99 * cfg.SOLVER.BASE_LR and 6 <= peak <= 8 and lrs[0] < 0.05 * cfg.SOLVER.BASE_LR and all(a > b for a, b in zip(lrs[peak:], lrs[peak + 1:]))
+    # checkpoints
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.01)
+    save_checkpoint(str(tmp_path / "step.pth"), model)
+    save_checkpoint(str(tmp_path / "latest.pth"), model, opt, step=37, epoch=3)
+    assert set(torch.load(str(tmp_path / "step.pth"))) == {"model"}
+    other = build_model(cfg)[0].train().enable_grad_slice(full=True)
+    opt2 = build_slice_optimizer(other, cfg)
+    assert load_checkpoint(str(tmp_path / "step.pth"), other, opt2, map_location="cpu") == (0, 0)
+    assert load_checkpoint(str(tmp_path / "latest.pth"), other, opt2, map_location="cpu") == (3, 37)
+    assert all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), other.state_dict().values()))
+    s1, s2 = opt.state_dict()["state"], opt2.state_dict()["state"]
+    assert s1.keys() == s2.keys() and all(torch.equal(s1[k]["exp_avg_sq"], s2[k]["exp_avg_sq"]) for k in s1)
+    resumed = build_lr_scheduler(opt2, cfg, last_step=37)
+    assert abs(resumed.get_last_lr()[0] - lrs[38]) < 1e-12          # (last_epoch = start_step as main.py:378-388: the constructor's own step makes it 38)
+    with open(os.path.join(os.path.dirname(__file__), "golden", "state_dict_keys.json")) as f:
+        assert list(json.load(f)["default"]) == list(torch.load(str(tmp_path / "step.pth"))["model"])

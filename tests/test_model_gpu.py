@@ -1,6 +1,8 @@
 """GPU parity of the assembled hot path (nmrf_amd.models.NMRF on libnmrf_hip.so) against the golden
 vectors of the reference and against the CPU oracle; plus size-independent properties at the full
 BASELINE sizes where the oracle would take too long."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -966,3 +968,73 @@ def test_train_steps_on_the_whole_model_reduce_the_loss():
         train_step(model, crit, opt, sample, grad_clip=cfg.SOLVER.GRAD_CLIP)
     moved = {k for k, v in model.named_parameters() if not torch.equal(v.detach(), before[k])}
     assert moved == set(names), set(names) - moved
+
+
+def test_fit_loop_checkpoints_and_resumes_bit_exactly(tmp_path):
+    """nmrf_amd.train.fit (the loop of main.py:403-483): a run killed after two steps, `checkpoint_latest.pth`, a fresh process-like
+    resume (new model, new optimizer, load_checkpoint, schedule restarted at the saved step) and two more steps: the first resumed loss is the
+    continuous run's third, two resumes agree bit for bit on every parameter
+    of the gradient slice (its kernels and reductions are deterministic; with the stock MIOpen convolutions of the full mode only
+    the first resumed loss is compared).  `step_%06d.pth` files hold {'model'} only."""
+    from nmrf_amd.models.criterion import build_criterion
+    from nmrf_amd.train import build_slice_optimizer, fit, load_checkpoint
+    from tests.util import golden_images, make_cfg
+    import warnings
+    g = golden("e2e_train")
+    md = int(g["max_disp"])
+    img1, img2 = golden_images(g)
+    sample = {"img1": img1, "img2": img2, "disp": t(g["gt"]).clone(), "valid": t(g["valid"])}
+    for full in (False, True):
+        class OneSamplePerEpoch:                                     # an epoch of one batch; the process "dies" when `die_at` batches went out
+            def __init__(self, die_at):
+                self.left = die_at
+
+            def __iter__(self):
+                if self.left == 0:
+                    raise KeyboardInterrupt("killed")
+                self.left -= 1
+                return iter([sample])
+
+        def run(die_at, ckpt_dir, resume=None):
+            cfg = make_cfg(md, ["SOLVER.MAX_ITER", 4, "SOLVER.LATEST_CHECKPOINT_PERIOD", 2, "SOLVER.CHECKPOINT_PERIOD", 2])
+            model = build_product(md, DEV).train().enable_grad_slice(full=full)
+            crit, opt = build_criterion(cfg), build_slice_optimizer(model, cfg)
+            epoch, step = load_checkpoint(resume, model, opt) if resume else (0, 0)
+            log = []
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                try:
+                    out = fit(model, crit, opt, OneSamplePerEpoch(die_at), cfg, checkpoint_dir=ckpt_dir, start_step=step, start_epoch=epoch,
+                              on_step=lambda s, lr, total, ld: log.append((s, lr, total)))
+                except KeyboardInterrupt:
+                    out = None
+            return model, out, log
+        d1, d2 = tmp_path / ("a%d" % full), tmp_path / ("b%d" % full)
+        d1.mkdir(), d2.mkdir()
+        m4, (step4, epoch4), log4 = run(-1, str(d1))
+        assert (step4, epoch4) == (4, 3) and [s for s, _, _ in log4] == [1, 2, 3, 4]
+        assert sorted(os.listdir(str(d1))) == ["checkpoint_latest.pth", "step_000002.pth", "step_000004.pth"]
+        assert set(torch.load(str(d1 / "step_000004.pth"))) == {"model"}
+        m2, died, log2 = run(2, str(d2))                             # killed after two steps: checkpoint_latest.pth holds step 2
+        assert died is None and [s for s, _, _ in log2] == [1, 2] and (full or log2 == log4[:2])
+        import shutil
+        shutil.copy(str(d2 / "checkpoint_latest.pth"), str(d2 / "killed_at_2.pth"))      # (the resumed run writes its own latest at step 4)
+        mr, (stepr, epochr), logr = run(-1, str(d2), resume=str(d2 / "killed_at_2.pth"))
+        # the resumed run re-enters the saved epoch, and its schedule is main.py:378-388's: OneCycleLR(last_epoch = start_step), whose
+        # constructor takes one step of its own -- the learning rates of steps 3, 4 are the continuous run's of steps 4, 5 (a reference quirk,
+        # kept); so it is compared with a second resume from the same file, not with the continuous run
+        assert (stepr, epochr) == (4, 2) and [s for s, _, _ in logr] == [3, 4]
+        assert abs(logr[0][1] - log4[3][1]) < 1e-12 and logr[0][1] != log4[2][1]
+        mr2, _, logr2 = run(-1, str(d2), resume=str(d2 / "killed_at_2.pth"))
+        if not full:
+            for (k, a), (_, b) in zip(mr.state_dict().items(), mr2.state_dict().items()):
+                assert torch.equal(a, b), k
+            assert logr == logr2
+            # and the loss of the first resumed step is the loss the killed run would have seen next (same weights, same moments)
+            assert logr[0][2] == log4[2][2], (logr[0][2], log4[2][2])
+        else:
+            # the stock MIOpen convolutions of the full mode are not run-to-run deterministic (forward: 331.79806 / 331.79809 on the same
+            # weights; the discrete decisions of the path then amplify it step by step -- the continuous and the killed run have already
+            # parted at step 2), so: two resumes see the same loss on the restored weights to 1e-4
+            assert abs(logr[0][2] - logr2[0][2]) <= 1e-4 * abs(logr2[0][2]), (logr[0][2], logr2[0][2])
+            assert all(x == x for _, _, x in logr + logr2)

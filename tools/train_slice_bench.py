@@ -20,11 +20,12 @@ ap.add_argument("--height", type=int, default=256)
 ap.add_argument("--width", type=int, default=512)
 ap.add_argument("--batch", type=int, default=2)
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--full", action="store_true", help="enable_grad_slice(full=True): every parameter (convolutions on stock autograd)")
 a = ap.parse_args()
 cfg = get_cfg()
 cfg.freeze()
 model, crit = build_model(cfg)
-model = apply_hash_weights(model).to("cuda").train().enable_grad_slice()
+model = apply_hash_weights(model).to("cuda").train().enable_grad_slice(full=a.full)
 opt = build_slice_optimizer(model, cfg)
 prs = [synthetic_pair(a.height, a.width, seed=100 + i) for i in range(a.batch)]
 gt = torch.stack([p[2] for p in prs]).float()
@@ -47,6 +48,6 @@ with torch.no_grad():
     torch.cuda.synchronize()
     de = (time.perf_counter() - t1) / a.steps
 n = sum(p.numel() for _, p in slice_parameters(model))
-print("train_step at %dx%d, batch %d: %.1f ms per step (eval-mode forward of the same batch: %.1f ms); %d tensors / %.2f M parameters "
-      "trained; loss %.2f -> %.2f over %d steps" % (a.width, a.height, a.batch, dt * 1e3, de * 1e3, len(slice_parameters(model)), n / 1e6,
+print("train_step (%s) at %dx%d, batch %d: %.1f ms per step (eval-mode forward of the same batch: %.1f ms); %d tensors / %.2f M parameters "
+      "trained; loss %.2f -> %.2f over %d steps" % ("whole model" if a.full else "slice", a.width, a.height, a.batch, dt * 1e3, de * 1e3, len(slice_parameters(model)), n / 1e6,
                                                      losses[0], losses[-1], a.steps))
