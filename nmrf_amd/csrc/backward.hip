@@ -21,6 +21,9 @@ struct GemmArgs {
     int *range_flag;
 };
 
+// AK1 / BK1: the operand's k axis is contiguous, K % 8 == 0, rows 16-byte aligned: a lane's 8-run is two dwordx4 loads (with scalar loads
+// every lane of such an operand touches its own cache line 8 times per chunk and the address path, not the matrix pipe, sets the pace).
+template <bool AK1, bool BK1>
 __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs a) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int tile = blockIdx.x * 4 + wv;
@@ -36,20 +39,39 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     float guard = 0.f;
-    for (int c = c0; c < c1; ++c) {
-        const int k0 = c * 16 + 8 * kh;
-        float av[8], bv[8];
+    // register double buffer: the operands of chunk c + 1 are requested before chunk c is split and multiplied (a lone wave per tile
+    // otherwise sits out a full memory round trip per 16-deep chunk)
+    auto fetch8 = [&](auto vec_tag, const float *p, int64_t sk, bool ok, int k0, float *v) {
+        if constexpr (decltype(vec_tag)::value) {
+            float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+            if (ok && k0 < a.K) {
+                lo = *reinterpret_cast<const float4 *>(p + k0);
+                hi = *reinterpret_cast<const float4 *>(p + k0 + 4);
+            }
+            v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+        } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = k0 + e;
-            const bool kok = k < a.K;
-            av[e] = (iok && kok) ? pa[(int64_t)k * a.sa_k] : 0.f;
-            bv[e] = (jok && kok) ? pb[(int64_t)k * a.sb_k] : 0.f;
+            for (int e = 0; e < 8; ++e) v[e] = (ok && k0 + e < a.K) ? p[(int64_t)(k0 + e) * sk] : 0.f;
         }
+    };
+    auto fetch = [&](int c, float *av, float *bv) {
+        const int k0 = c * 16 + 8 * kh;
+        fetch8(std::integral_constant<bool, AK1>{}, pa, a.sa_k, iok, k0, av);
+        fetch8(std::integral_constant<bool, BK1>{}, pb, a.sb_k, jok, k0, bv);
+    };
+    float av[8], bv[8], an[8], bn[8];
+    if (c0 < c1) fetch(c0, av, bv);
+    for (int c = c0; c < c1; ++c) {
+        if (c + 1 < c1) fetch(c + 1, an, bn);
         h16x8 ah, al, bh, bl;
         split8u_g(av, ah, al, guard);
         split8u_g(bv, bh, bl, guard);
         split_mma1(ah, al, bh, bl, acc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            av[e] = an[e];
+            bv[e] = bn[e];
+        }
     }
     float *cp = a.C + (int64_t)blockIdx.y * a.split_stride;
 #pragma unroll
@@ -67,7 +89,15 @@ extern "C" int nmrf_gemm_split_f32(const float *A, int64_t sa_i, int64_t sa_k, c
     const int tiles_m = (M + 31) / 32, tiles_n = (N + 31) / 32, nchunks = (K + 15) / 16;
     const int cps = (nchunks + splits - 1) / splits;
     GemmArgs a{A, B, C, M, N, K, sa_i, sa_k, sb_k, sb_j, ldc, tiles_n, tiles_m * tiles_n, cps, split_stride, range_flag};
-    hipLaunchKernelGGL(gemm_split_kernel, dim3((unsigned)((a.n_tiles + 3) / 4), (unsigned)splits), dim3(256), 0, (hipStream_t)stream, a);
+    const dim3 grid((unsigned)((a.n_tiles + 3) / 4), (unsigned)splits);
+    hipStream_t st = (hipStream_t)stream;
+    const bool k8 = K % 8 == 0;
+    const bool ak1 = k8 && sa_k == 1 && sa_i % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
+    const bool bk1 = k8 && sb_k == 1 && sb_j % 4 == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0;
+    if (ak1 && bk1) hipLaunchKernelGGL((gemm_split_kernel<true, true>), grid, dim3(256), 0, st, a);
+    else if (ak1) hipLaunchKernelGGL((gemm_split_kernel<true, false>), grid, dim3(256), 0, st, a);
+    else if (bk1) hipLaunchKernelGGL((gemm_split_kernel<false, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_split_kernel<false, false>), grid, dim3(256), 0, st, a);
     return nmrf_launch_status();
 }
 
