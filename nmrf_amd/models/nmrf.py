@@ -106,20 +106,21 @@ class NMRF(nn.Module):
 
     @torch.no_grad()
     def forward(self, sample):
-        """model(sample) of NMRF.py:189-262.  Always runs under no_grad (the HIP kernels are forward-only): the returned tensors
-        never carry a grad_fn.  In training mode (model.train()) the forward is the reference's training-mode forward -- no input
-        padding (NMRF.py:203-205: H and W must be multiples of divis_by), no un-padding, per-layer intermediates when
-        return_intermediate, `aux_outputs` when aux_loss (NMRF.py:259-273) -- so that losses can be EVALUATED on it; a
-        loss.backward() on them fails loudly (no grad_fn), fine-tuning needs the reference's training path."""
+        """model(sample) of NMRF.py:189-262.  The fused HIP kernels are forward-only, so the body runs under no_grad; in training mode
+        (model.train()) it is the reference's training-mode forward -- no input padding (NMRF.py:203-205: H and W must be multiples of
+        divis_by), no un-padding, per-layer intermediates when return_intermediate, `aux_outputs` when aux_loss (NMRF.py:259-273).
+        Without enable_grad_slice() the returned tensors carry no grad_fn (losses can be EVALUATED; a loss.backward() fails loudly); with
+        it the outputs hang on an autograd graph of torch.autograd.Functions whose backward is csrc/backward.hip (models/autograd_ops.py)
+        -- the message-passing stages and heads, or with full=True every parameter (nmrf_amd/train.py)."""
         enc = self.backbone if self.compat else self.image_encoder
         from .backbone import Backbone
         if self.training and not isinstance(enc, Backbone):
             raise NotImplementedError("training-mode forward: CNN backbone only (the Swin-T trunk has stochastic depth in training mode)")
-        if self.training and not getattr(self, "_warned_train", False):
+        if self.training and not getattr(self, "grad_slice", False) and not getattr(self, "_warned_train", False):
             import warnings
             warnings.warn("nmrf_amd: the model is in TRAINING mode (nn.Module's default after build_model -- call model.eval() for "
                           "inference): this runs the training-mode FORWARD only -- no padding / un-padding, aux_outputs returned, forward-only "
-                          "HIP kernels, no autograd graph")
+                          "HIP kernels, no autograd graph (enable_grad_slice() builds one)")
             self._warned_train = True
         if self.device.type != "cuda":
             raise RuntimeError("the NMRF hot path runs on an MI355X through libnmrf_hip.so; there is no CPU "
@@ -177,7 +178,7 @@ class NMRF(nn.Module):
         """N4 (round 5): in training mode, build an autograd graph over the three message-passing stages and their heads -- the WHOLE
         propagation, inference and refinement stages (seed embedding / ffn, every layer's norm1 / q | k | v / stripe, sibling or window
         attention with its LePE kernels or relative-position table / proj / norm2 / MLP, the stage-final norms) and `prop_head`,
-        `infer_head`, `infer_score_head`, `refine_head`: 315 of 351 tensors (models/autograd_ops.py: every Function's forward value is the
+        `infer_head`, `infer_score_head`, `refine_head`: 315 of the 340 parameter tensors (models/autograd_ops.py: every Function's forward value is the
         fused HIP launch's, backward = csrc/backward.hip).  The reference detaches `labels_curr` and `disp_curr` (NMRF.py:215,231), so
         `Criterion(model(sample)).backward()` leaves the REFERENCE's own gradients in `.grad` of the 206 tensors behind the hand-over; the
         propagation stage is reached by the proposal loss only, which carries no weight in the reference's weight_dict (add
@@ -403,7 +404,8 @@ class NMRF(nn.Module):
         # the proposal stage -- latency-bound attention kernels that leave most of the chip idle at batch 1 --
         # runs on the main one; joined before their first consumer.  Captured as parallel branches by hipGraph.
         main = torch.cuda.current_stream()
-        overlap = os.environ.get("NMRF_OVERLAP", "1") != "0"
+        full = self._grad_full() and stages is None                # (N4, whole model: the convolutional heads run under autograd below)
+        overlap = os.environ.get("NMRF_OVERLAP", "1") != "0" and not full
         side = main
         if overlap:
             if self._side_stream is None:
@@ -411,12 +413,10 @@ class NMRF(nn.Module):
             side = self._side_stream
             side.wait_stream(main)
         context, ctx_ready = None, None
-        full = self._grad_full() and stages is None
         graph = None
         if full:
             # N4, the whole model: the convolutional heads on stock PyTorch-ROCm autograd (both views as one batch: conv - InstanceNorm -
             # ReLU - conv are per-sample, NMRF.py:211-214,233-236; DPN.py:127); the HIP stages below read the detached NCHW maps
-            overlap, side = False, main
             with torch.enable_grad():
                 cat8, cat4 = torch.cat((fmap1_list[0], fmap2_list[0]), 0), torch.cat((fmap1_list[1], fmap2_list[1]), 0)
                 bq = fmap1_list[0].shape[0]
@@ -430,9 +430,7 @@ class NMRF(nn.Module):
             heads4, tok4 = tuple(t.detach().contiguous() for t in heads4_g), False
             fmap1_list, fmap2_list = [f.detach() for f in fmap1_list], [f.detach() for f in fmap2_list]
         with torch.cuda.stream(side):
-            if full:
-                pass
-            elif overlap:
+            if overlap:
                 # the DPN context convs first: the seed stage (cost volume, conv1d + softmax, NMS: latency-bound) runs beside them
                 context = self.dpn.context(fmap1_list[0], token_major=True)
                 ctx_ready = torch.cuda.Event()

@@ -1,7 +1,7 @@
 """N4: one optimisation step on the MI355X, shaped like the reference's training loop (main.py:403-430).  Two extents
 (nmrf_amd.models.NMRF.enable_grad_slice):
   * the SLICE (default): the WHOLE inference and refinement stages with their three heads, and -- behind the proposal loss -- the WHOLE
-    propagation stage with its head, and the seed filter: 315 of the model's 351 tensors, the convolutional modules frozen on their fused
+    propagation stage with its head, and the seed filter: 315 of the model's 340 parameter tensors, the convolutional modules frozen on their fused
     forward-only kernels;
   * full=True: every parameter -- encoder, matching heads and DPN context convolutions on stock PyTorch-ROCm autograd, joined to the HIP
     stages by the backward of the cost volume, the cost taps and the warp + correlation rows.
