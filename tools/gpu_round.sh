@@ -10,7 +10,7 @@ rm -f gpurun_out/e2e_stats.jsonl
 ( timeout 2400 python -m pytest tests -m gpu -q --tb=short -rf -p no:cacheprovider ${PYTEST_ARGS} 2>&1 | tail -200 ) > gpurun_out/pytest_gpu.log
 echo "pytest exit: ${PIPESTATUS[0]}" >> gpurun_out/pytest_gpu.log
 ( timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -20 ) > gpurun_out/smoke.log
-( timeout 900 python bench.py --steps 20 --warmup 5 2>&1 | tail -5 ) > gpurun_out/bench.log
+( timeout 900 python bench.py 2>&1 | tail -5 ) > gpurun_out/bench.log      # the driver's command: defaults (100 timed steps)
 if [ -z "$LEAN" ]; then      # LEAN=1: tests, smoke, bench and the kernel trace only
 ( NMRF_LINEAR=fp32 timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | tail -2 ) > gpurun_out/bench_fp32_linears.log
 ( timeout 600 python tools/kernel_bench.py --iters 20 --which window,stripe,refine,block 2>&1 | grep -v stamp | tail -60 ) > gpurun_out/kernel_bench_block.log
