@@ -307,3 +307,21 @@ def test_training_host_side_optimizer_groups_schedule_and_checkpoints(tmp_path):
     assert abs(resumed.get_last_lr()[0] - lrs[38]) < 1e-12          # (last_epoch = start_step as main.py:378-388: the constructor's own step makes it 38)
     with open(os.path.join(os.path.dirname(__file__), "golden", "state_dict_keys.json")) as f:
         assert list(json.load(f)["default"]) == list(torch.load(str(tmp_path / "step.pth"))["model"])
+
+
+def test_integration_appendix_lists_every_entry_point():
+    """INTEGRATION.md's appendix (tools/gen_abi_index.py) is generated from include/nmrf_hip.h: in step with the header, one row per
+    exported symbol of the binding, and every A-row / N-row entry point cites reference lines."""
+    import subprocess
+    import sys
+    from nmrf_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert subprocess.call([sys.executable, os.path.join(root, "tools", "gen_abi_index.py"), "--check"]) == 0
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    body = doc[doc.index("<!-- abi-index:begin -->"):doc.index("<!-- abi-index:end -->")]
+    rows = {l.split("`")[1]: l for l in body.splitlines() if l.startswith("| `nmrf_")}
+    assert set(rows) == set(_lib.PROTOTYPES) | {"nmrf_strerror"} or set(rows) == set(_lib.PROTOTYPES)
+    uncited = [n for n, l in rows.items() if l.rstrip().endswith("| – |")]
+    helpers = ("nmrf_selftest_", "nmrf_strerror", "nmrf_abi_version", "nmrf_pack_", "nmrf_host_", "nmrf_sum_partials", "nmrf_colsum_",
+               "nmrf_act_bwd", "nmrf_layernorm", "nmrf_instance_stats", "nmrf_prep_images_s2d_f32")
+    assert all(n.startswith(helpers) for n in uncited), [n for n in uncited if not n.startswith(helpers)]
