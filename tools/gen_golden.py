@@ -206,6 +206,64 @@ def run_train():
     print("e2e_train", {k: v.shape for k, v in d.items() if hasattr(v, "shape")}, os.path.getsize(path) // 1024, "KiB")
 
 
+def run_train_b2():
+    """e2e_train_b2.npz: the training step of run_train on a BATCH of two different pairs (64x128: 1/8 grid 8x16 -> window padding 4 / 2,
+    1/4 grid 16x32): the reference's loss and, for EVERY parameter, the norm of its gradient and its projection on a fixed noise vector
+    (nmrf_amd.utils.hashinit.unit_noise("gproj/<name>")) -- the batch dimension of every backward kernel against the reference's autograd."""
+    model, cfg = refshim.build_reference_model(["DPN.MAX_DISP", 128, "SOLVER.LOSS_TYPE", "SMOOTH_L1"])
+    apply_hash_weights(model)
+    model.train()
+    from nmrf.models import build_model
+    crit = build_model(cfg)[1]                                  # (SMOOTH_L1, the Criterion's other loss type: its derivative is continuous, so
+    #                                                             the comparison is free of the L1 sign flips that blur run_train's)
+    shapes_seeds = [(64, 128, 1020), (64, 128, 1021)]
+    ls, rs, gts = zip(*[synthetic_pair(h, w, seed=sd) for (h, w, sd) in shapes_seeds])
+    img1, img2 = torch.stack(ls), torch.stack(rs)
+    gt = torch.stack([torch.as_tensor(g) for g in gts]).float()
+    valid = (gt > 0) & (gt < cfg.SOLVER.MAX_DISP)
+    d = {"pair_hws": np.asarray(shapes_seeds, np.int64), "max_disp": np.int64(cfg.DPN.MAX_DISP),
+         "img1": _np(img1).astype(np.uint8), "img2": _np(img2).astype(np.uint8), "gt": _np(gt), "valid": _np(valid)}
+
+    def stats(tag):
+        for name, p in model.named_parameters():
+            if p.grad is None:
+                d[tag + "_none/" + name] = np.int8(1)
+                continue
+            g = _np(p.grad).astype(np.float64)
+            d[tag + "_stat/" + name] = np.asarray([np.sqrt((g * g).sum()), (g.reshape(-1) * unit_noise("gproj/" + name, g.size)).sum(),
+                                                   np.abs(g).max()])
+    model.zero_grad(set_to_none=True)
+    gw_outs, cc_outs = [], []
+    if os.environ.get("NMRF_B2_FULL"):
+        def keep(lst):
+            def f(m, i, o):
+                o.retain_grad()
+                lst.append(o)
+            return f
+        model.gw.register_forward_hook(keep(gw_outs))
+        model.concatconv.register_forward_hook(keep(cc_outs))
+    out = model({"img1": img1.clone().float(), "img2": img2.clone().float()})
+    losses = crit(out, {"disp": gt, "valid": valid})
+    total = sum(losses[k] * crit.weight_dict[k] for k in losses if k in crit.weight_dict)
+    total.backward()
+    for i, o in enumerate(gw_outs[:4]):
+        d["dgw%d" % i] = _np(o.grad)
+    for i, o in enumerate(cc_outs[:4]):
+        d["dcc%d" % i] = _np(o.grad)
+    d.update(loss_total=_np(total), seeds=_np(out["initial_proposal"]).astype(np.int16), disp_pred=_np(out["disp_pred"]))
+    stats("grad")
+    if os.environ.get("NMRF_B2_FULL"):                          # (diagnostic fixture: whole tensors of the matching heads)
+        for name in ("gw.0.weight", "gw.3.weight", "concatconv.0.weight", "concatconv.3.weight"):
+            d["grad/" + name] = _np(dict(model.named_parameters())[name].grad)
+    model.zero_grad(set_to_none=True)
+    out = model({"img1": img1.clone().float(), "img2": img2.clone().float()})
+    crit(out, {"disp": gt, "valid": valid})["loss_prop"].backward()
+    stats("grad_prop")
+    path = os.path.join(OUT, "e2e_train_b2.npz")
+    np.savez_compressed(path, **d)
+    print("e2e_train_b2", len(d), "entries", os.path.getsize(path) // 1024, "KiB")
+
+
 def run_swin():
     """Swin-T + deformable neck config (configs/sceneflow_swint.yaml + MAX_DISP 256): encoder features, outputs,
     and the state-dict key/shape listing of both configs (for the strict-load contract tests)."""
@@ -339,6 +397,9 @@ def run_msda():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if "--train-b2-only" in sys.argv:
+        run_train_b2()
+        sys.exit(0)
     if "--train-only" in sys.argv:
         run_train()
         sys.exit(0)
@@ -352,3 +413,4 @@ if __name__ == "__main__":
     run_msda()
     run_swin()
     run_train()
+    run_train_b2()
