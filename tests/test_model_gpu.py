@@ -1100,3 +1100,49 @@ def test_training_backward_full_model_batch_of_two_matches_reference():
     record_note("  proposal loss alone: %d gradients, worst %.1e (%s)" % (len(worst2), max(worst2.values()), max(worst2, key=worst2.get)))
     assert len(worst) + len(worst2) >= len(named)
     assert not bad, bad
+
+
+def test_training_backward_at_the_trained_checkpoint_matches_reference():
+    """The regime a real run is in: the TRAINED reference checkpoint (tests/golden/trained_sd.npz, load_state_dict strict), the first batch of
+    the training stream (two 96x192 crops, 40 disparity bins, L1), whole model: loss and, per parameter, gradient norm + projection against
+    the reference's own autograd at those weights (tests/golden/e2e_train_t.npz, tools/gen_golden.py:run_train_trained)."""
+    from nmrf_amd.models.criterion import build_criterion
+    from nmrf_amd.utils.hashinit import unit_noise
+    from tests.conftest import record_note
+    from tests.util import make_cfg
+    import warnings
+    g = golden("e2e_train_t")
+    md = int(g["max_disp"])
+    img1, img2 = t(g["img1"]).float(), t(g["img2"]).float()
+    model = build_product(md, DEV, weights="trained").train().enable_grad_slice(full=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = model({"img1": img1, "img2": img2})
+    seeds_equal = float((out["initial_proposal"].cpu().long() == t(g["seeds"]).long()).float().mean())
+    crit = build_criterion(make_cfg(md))
+    losses = crit(out, {"disp": t(g["gt"]).to(DEV), "valid": t(g["valid"]).to(DEV)})
+    total = sum(losses[k] * crit.weight_dict[k] for k in losses if k in crit.weight_dict)
+    model.zero_grad(set_to_none=True)
+    total.backward()
+    named = dict(model.named_parameters())
+    worst, bad = {}, []
+    for key in g:
+        if key.startswith("grad_stat/"):
+            name = key[len("grad_stat/"):]
+            got = named[name].grad
+            assert got is not None, name + ": no gradient"
+            gd = got.detach().cpu().double().reshape(-1)
+            norm, proj = float(gd.norm()), float((gd * torch.from_numpy(unit_noise("gproj/" + name, gd.numel())).double()).sum())
+            wn, wp, wmax = [float(v) for v in g[key]]
+            worst[name] = max(abs(norm - wn), abs(proj - wp)) / max(wn, 1e-6)
+            if not (abs(norm - wn) <= 5e-2 * wn + 1e-4 and abs(proj - wp) <= 5e-2 * wn + 1e-4):
+                bad.append((name, norm, wn, proj, wp))
+        elif key.startswith("grad_none/"):
+            assert named[key[len("grad_none/"):]].grad is None, key
+    top = sorted(worst, key=worst.get, reverse=True)[:8]
+    record_note("training backward at the trained checkpoint (2 x 96x192, D 40): loss %.5f vs the reference's %.5f, seeds equal on %.2f %% of "
+                "the entries; %d gradients by norm + projection, median %.1e / worst %.1e of the norm (%s)" % (
+                    float(total.detach()), float(g["loss_total"]), 100 * seeds_equal, len(worst), sorted(worst.values())[len(worst) // 2],
+                    worst[top[0]], "; ".join("%s %.1e" % (k, worst[k]) for k in top)))
+    assert seeds_equal >= 0.999 and abs(float(total.detach()) - float(g["loss_total"])) <= 2e-3 * abs(float(g["loss_total"]))
+    assert not bad, bad

@@ -264,6 +264,42 @@ def run_train_b2():
     print("e2e_train_b2", len(d), "entries", os.path.getsize(path) // 1024, "KiB")
 
 
+def run_train_trained():
+    """e2e_train_t.npz: the training step at the TRAINED weights (tests/golden/trained_sd.npz) on the first batch of the training stream
+    (tools/synthetic_crops.py: two 96x192 crops, default MAX_DISP 320 -> 40 disparity bins, L1 loss) -- the regime a real training run is
+    in: structured weights, small losses, the sizes of tools/train_synthetic.py.  Per parameter: norm of the reference's gradient, its
+    projection on a fixed noise vector, its largest entry."""
+    from synthetic_crops import Crops
+    model, cfg = refshim.build_reference_model([])
+    with np.load(os.path.join(OUT, "trained_sd.npz")) as z:
+        sd = {k: torch.from_numpy(np.ascontiguousarray(z[k])) for k in z.files}
+    missing = model.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys and all("relative_position_index" in k or "indicator" in k for k in missing.missing_keys), missing
+    model.train()
+    from nmrf.models import build_model
+    crit = build_model(cfg)[1]
+    l, r, gt = Crops().batch(2)
+    valid = (gt > 0) & (gt < cfg.SOLVER.MAX_DISP)
+    d = {"max_disp": np.int64(cfg.DPN.MAX_DISP), "img1": _np(l).astype(np.uint8), "img2": _np(r).astype(np.uint8), "gt": _np(gt),
+         "valid": _np(valid)}
+    assert np.array_equal(d["img1"].astype(np.float32), _np(l))
+    model.zero_grad(set_to_none=True)
+    out = model({"img1": l.clone(), "img2": r.clone()})
+    losses = crit(out, {"disp": gt, "valid": valid})
+    total = sum(losses[k] * crit.weight_dict[k] for k in losses if k in crit.weight_dict)
+    total.backward()
+    d.update(loss_total=_np(total), seeds=_np(out["initial_proposal"]).astype(np.int16), disp_pred=_np(out["disp_pred"]))
+    for name, p in model.named_parameters():
+        if p.grad is None:
+            d["grad_none/" + name] = np.int8(1)
+            continue
+        g = _np(p.grad).astype(np.float64)
+        d["grad_stat/" + name] = np.asarray([np.sqrt((g * g).sum()), (g.reshape(-1) * unit_noise("gproj/" + name, g.size)).sum(), np.abs(g).max()])
+    path = os.path.join(OUT, "e2e_train_t.npz")
+    np.savez_compressed(path, **d)
+    print("e2e_train_t", len(d), "entries", os.path.getsize(path) // 1024, "KiB; loss", float(total))
+
+
 def run_swin():
     """Swin-T + deformable neck config (configs/sceneflow_swint.yaml + MAX_DISP 256): encoder features, outputs,
     and the state-dict key/shape listing of both configs (for the strict-load contract tests)."""
@@ -400,6 +436,9 @@ if __name__ == "__main__":
     if "--train-b2-only" in sys.argv:
         run_train_b2()
         sys.exit(0)
+    if "--train-trained-only" in sys.argv:
+        run_train_trained()
+        sys.exit(0)
     if "--train-only" in sys.argv:
         run_train()
         sys.exit(0)
@@ -414,3 +453,4 @@ if __name__ == "__main__":
     run_swin()
     run_train()
     run_train_b2()
+    run_train_trained()            # (needs tests/golden/trained_sd.npz: tools/gen_trained_golden.py)
