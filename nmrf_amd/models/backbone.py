@@ -191,8 +191,7 @@ def create_backbone(cfg):
         return Backbone(cfg.BACKBONE.OUT_CHANNELS, cfg.BACKBONE.NORM_FN)
     if kind == "swin":
         from .swin_neck import SwinAdaptor
-        # both shipped Swin-T configs set DROP_PATH 0.4 (configs/sceneflow_swint.yaml): stochastic depth is the identity under
-        # model.eval(), the only mode this build runs (NMRF.forward raises in training mode), so the rate is accepted and unused
+        # both shipped Swin-T configs set DROP_PATH 0.4 (configs/sceneflow_swint.yaml): stochastic depth, the identity under model.eval()
         backbone = SwinAdaptor(cfg.BACKBONE.OUT_CHANNELS, cfg.BACKBONE.DROP_PATH)
         if cfg.BACKBONE.WEIGHT_URL:                   # pretrained Swin-T trunk (nmrf/models/backbone.py:188-196)
             weight = checkpoint_filter_fn(torch.load(cfg.BACKBONE.WEIGHT_URL, map_location="cpu"))

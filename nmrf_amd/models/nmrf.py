@@ -114,8 +114,6 @@ class NMRF(nn.Module):
         -- the message-passing stages and heads, or with full=True every parameter (nmrf_amd/train.py)."""
         enc = self.backbone if self.compat else self.image_encoder
         from .backbone import Backbone
-        if self.training and not isinstance(enc, Backbone):
-            raise NotImplementedError("training-mode forward: CNN backbone only (the Swin-T trunk has stochastic depth in training mode)")
         if self.training and not getattr(self, "grad_slice", False) and not getattr(self, "_warned_train", False):
             import warnings
             warnings.warn("nmrf_amd: the model is in TRAINING mode (nn.Module's default after build_model -- call model.eval() for "
@@ -162,7 +160,11 @@ class NMRF(nn.Module):
             if not self.training:
                 padder = InputPadder(image1.shape, mode="proposal", divis_by=self.divis_by)
                 image1, image2 = padder.pad(image1, image2)
-            fmap1_list, fmap2_list = self.extract_feature(image1, image2)
+            if self._grad_full():                                   # (the Swin-T trunk + neck: stock autograd, MSDA through its Function)
+                with torch.enable_grad():
+                    fmap1_list, fmap2_list = self.extract_feature(image1, image2)
+            else:
+                fmap1_list, fmap2_list = self.extract_feature(image1, image2)
         try:
             out = self.hot_path(fmap1_list, fmap2_list, (h0, w0))
         finally:

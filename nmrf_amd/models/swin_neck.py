@@ -64,10 +64,20 @@ class WindowAttention(nn.Module):
         return self.proj(out)
 
 
+def _drop_path(x, rate, training):
+    """Stochastic depth per sample (timm DropPath as swin.py:228-233,300-301 uses it): in training mode a residual branch is dropped for a
+    whole sample with probability `rate` and the kept ones are scaled by 1 / (1 - rate); the identity in eval mode."""
+    if rate == 0.0 or not training:
+        return x
+    keep = 1.0 - rate
+    mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
+    return x * (mask / keep)
+
+
 class SwinTransformerBlock(nn.Module):
-    def __init__(self, dim, num_heads, window_size, shift_size, mlp_ratio):
+    def __init__(self, dim, num_heads, window_size, shift_size, mlp_ratio, drop_path=0.0):
         super().__init__()
-        self.ws, self.shift = window_size, shift_size
+        self.ws, self.shift, self.drop_path = window_size, shift_size, float(drop_path)
         self.norm1 = nn.LayerNorm(dim)
         self.attn = WindowAttention(dim, window_size, num_heads)
         self.norm2 = nn.LayerNorm(dim)
@@ -84,8 +94,8 @@ class SwinTransformerBlock(nn.Module):
         y = _unwindows(self.attn(_windows(y, ws), mask if self.shift else None), ws, b, hp, wp)
         if self.shift:
             y = torch.roll(y, (self.shift, self.shift), (1, 2))
-        x = x + y[:, :h, :w]
-        return x + self.mlp(self.norm2(x))
+        x = x + _drop_path(y[:, :h, :w], self.drop_path, self.training)
+        return x + _drop_path(self.mlp(self.norm2(x)), self.drop_path, self.training)
 
 
 class PatchMerging(nn.Module):
@@ -102,11 +112,12 @@ class PatchMerging(nn.Module):
 
 
 class BasicLayer(nn.Module):
-    def __init__(self, dim, depth, num_heads, window_size, mlp_ratio, downsample):
+    def __init__(self, dim, depth, num_heads, window_size, mlp_ratio, downsample, drop_path=None):
         super().__init__()
         self.ws, self.shift = window_size, window_size // 2
         self.blocks = nn.ModuleList(
-            SwinTransformerBlock(dim, num_heads, window_size, 0 if i % 2 == 0 else window_size // 2, mlp_ratio)
+            SwinTransformerBlock(dim, num_heads, window_size, 0 if i % 2 == 0 else window_size // 2, mlp_ratio,
+                                 drop_path[i] if drop_path else 0.0)
             for i in range(depth))
         self.downsample = PatchMerging(dim) if downsample else None
 
@@ -144,11 +155,13 @@ class PatchEmbed(nn.Module):
 
 
 class SwinTransformer(nn.Module):
-    def __init__(self, embed_dim=96, depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24), window_size=7, mlp_ratio=4.0):
+    def __init__(self, embed_dim=96, depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24), window_size=7, mlp_ratio=4.0, drop_path_rate=0.0):
         super().__init__()
         self.patch_embed = PatchEmbed(4, 3, embed_dim)
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(depths))]      # stochastic depth decay rule (swin.py:592-609)
         self.layers = nn.ModuleList(
-            BasicLayer(embed_dim * 2 ** i, depths[i], num_heads[i], window_size, mlp_ratio, i < len(depths) - 1)
+            BasicLayer(embed_dim * 2 ** i, depths[i], num_heads[i], window_size, mlp_ratio, i < len(depths) - 1,
+                       dpr[sum(depths[:i]):sum(depths[:i + 1])])
             for i in range(len(depths)))
         for m in self.modules():
             if isinstance(m, nn.Linear):
@@ -254,7 +267,7 @@ class DeformNeck(nn.Module):
 class SwinAdaptor(nn.Module):
     def __init__(self, out_channels, drop_path_rate=0.0):
         super().__init__()
-        self.backbone = SwinTransformer()
+        self.backbone = SwinTransformer(drop_path_rate=drop_path_rate)         # (the neck's own drop_path is 0: backbone.py:111-117)
         self.neck = DeformNeck(out_channels, [96, 192, 384, 768], deform_ratio=0.5)
         self.output_dim = out_channels
         self.register_buffer("mean", torch.tensor([123.675, 116.28, 103.53]).view(1, 3, 1, 1))

@@ -1146,3 +1146,73 @@ def test_training_backward_at_the_trained_checkpoint_matches_reference():
                     worst[top[0]], "; ".join("%s %.1e" % (k, worst[k]) for k in top)))
     assert seeds_equal >= 0.999 and abs(float(total.detach()) - float(g["loss_total"])) <= 2e-3 * abs(float(g["loss_total"]))
     assert not bad, bad
+
+
+def test_training_backward_swin_configuration_matches_reference():
+    """N4 for the Swin-T + deformable-neck configuration (configs/sceneflow_swint.yaml keys; BACKBONE.DROP_PATH 0 -- stochastic depth is random,
+    so only the rate-0 step has a reference to compare with): the trunk and the neck run on stock PyTorch-ROCm autograd, the multi-scale
+    deformable attention through its Function (nmrf_msda_backward_f32), the rest as in the CNN configuration.  `model(sample)` on a 64x128
+    pair: loss, seeds, and for EVERY parameter the norm of its gradient + its projection on a fixed noise vector against the reference's own
+    autograd (tests/golden/e2e_train_swin.npz, tools/gen_golden.py:run_train_swin).  With the shipped DROP_PATH 0.4 the same step runs with
+    per-sample stochastic depth (timm DropPath semantics) and the eval-mode output is untouched by it."""
+    from nmrf_amd.models.criterion import build_criterion
+    from nmrf_amd.utils.hashinit import unit_noise
+    from tests.conftest import record_note
+    from tests.test_swin_config import SWIN_OPTS
+    from tests.util import make_cfg
+    import warnings
+    g = golden("e2e_train_swin")
+    md = int(g["max_disp"])
+    opts = tuple(o for o in SWIN_OPTS if o not in ("DPN.MAX_DISP", 256)) + ("BACKBONE.DROP_PATH", 0.0)
+    img1, img2 = t(g["img1"]).float(), t(g["img2"]).float()
+    model = build_product(md, DEV, opts=opts).train().enable_grad_slice(full=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = model({"img1": img1, "img2": img2})
+    assert torch.equal(out["initial_proposal"].cpu().long(), t(g["seeds"]).long())
+    report("disp_pred", out["disp_pred"].detach().cpu(), t(g["disp_pred"]), 1e-3)
+    crit = build_criterion(make_cfg(md, opts))
+    losses = crit(out, {"disp": t(g["gt"]).to(DEV), "valid": t(g["valid"]).to(DEV)})
+    total = sum(losses[k] * crit.weight_dict[k] for k in losses if k in crit.weight_dict)
+    assert abs(float(total.detach()) - float(g["loss_total"])) <= 5e-4 * abs(float(g["loss_total"])), (float(total.detach()), float(g["loss_total"]))
+    model.zero_grad(set_to_none=True)
+    total.backward()
+    named = dict(model.named_parameters())
+    worst, bad = {}, []
+    for key in g:
+        if key.startswith("grad_stat/"):
+            name = key[len("grad_stat/"):]
+            got = named[name].grad
+            assert got is not None, name + ": no gradient"
+            gd = got.detach().cpu().double().reshape(-1)
+            norm, proj = float(gd.norm()), float((gd * torch.from_numpy(unit_noise("gproj/" + name, gd.numel())).double()).sum())
+            wn, wp, wmax = [float(v) for v in g[key]]
+            worst[name] = max(abs(norm - wn), abs(proj - wp)) / max(wn, 1e-6)
+            if not (abs(norm - wn) <= 2.5e-2 * wn + 1e-4 and abs(proj - wp) <= 2.5e-2 * wn + 1e-4):
+                bad.append((name, norm, wn, proj, wp))
+        elif key.startswith("grad_none/"):
+            assert named[key[len("grad_none/"):]].grad is None, key
+    top = sorted(worst, key=worst.get, reverse=True)[:6]
+    enc = [k for k in worst if k.startswith("image_encoder.")]
+    record_note("training backward, Swin-T configuration: %d parameter gradients (%d of the trunk + neck) by norm + projection vs the reference's "
+                "autograd, median %.1e / worst %.1e of the norm (%s)" % (len(worst), len(enc), sorted(worst.values())[len(worst) // 2],
+                                                                       worst[top[0]], "; ".join("%s %.1e" % (k, worst[k]) for k in top)))
+    assert not bad, bad
+    assert len(enc) > 150
+    # the shipped rate: stochastic depth in training mode, none in eval mode
+    m4 = build_product(md, DEV, opts=tuple(o for o in SWIN_OPTS if o not in ("DPN.MAX_DISP", 256)) + ("BACKBONE.DROP_PATH", 0.4))
+    rates = [blk.drop_path for layer in m4.image_encoder.backbone.layers for blk in layer.blocks]
+    assert rates[0] == 0.0 and abs(rates[-1] - 0.4) < 1e-6 and all(a <= b for a, b in zip(rates, rates[1:])) and len(rates) == 12
+    with torch.no_grad():
+        e1 = m4.eval()({"img1": img1, "img2": img2})["disp"]
+        e0 = model.eval()({"img1": img1, "img2": img2})["disp"]
+    assert torch.equal(e0, e1)
+    torch.manual_seed(1)
+    m4.train().enable_grad_slice(full=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        o4 = m4({"img1": img1.repeat(2, 1, 1, 1), "img2": img2.repeat(2, 1, 1, 1)})
+    l4 = crit(o4, {"disp": t(g["gt"]).repeat(2, 1, 1).to(DEV), "valid": t(g["valid"]).repeat(2, 1, 1).to(DEV)})
+    sum(l4[k] * crit.weight_dict[k] for k in l4 if k in crit.weight_dict).backward()
+    assert all(torch.isfinite(p.grad).all() for p in m4.image_encoder.parameters() if p.grad is not None)
+    assert not torch.equal(o4["disp_pred"][0], o4["disp_pred"][1])              # the two copies of the pair drew different depth masks

@@ -80,7 +80,7 @@ def test_swin_model_on_gpu():
 
 def test_shipped_swint_yaml_keys_build_verbatim():
     """configs/sceneflow_swint.yaml and kitti_mix_train_swint.yaml of the reference set BACKBONE.DROP_PATH 0.4; stochastic depth is
-    the identity in eval mode, so build_model must accept the keys exactly as shipped (it used to raise)."""
+    the identity in eval mode and per-sample branch dropping in training mode."""
     from nmrf_amd.config import get_cfg
     from nmrf_amd.models import build_model
     cfg = get_cfg()
@@ -89,6 +89,16 @@ def test_shipped_swint_yaml_keys_build_verbatim():
     cfg.freeze()
     model, criterion = build_model(cfg)
     assert criterion.weight_dict["loss_disp"] == cfg.SOLVER.LOSS_WEIGHTS[-1] and hasattr(model, "image_encoder") and model.divis_by == 32
-    model.eval()
-    with pytest.raises(NotImplementedError):
+    rates = [blk.drop_path for layer in model.image_encoder.backbone.layers for blk in layer.blocks]
+    assert len(rates) == 12 and rates[0] == 0.0 and abs(rates[-1] - 0.4) < 1e-6        # the decay rule of swin.py:592-609
+    # stochastic depth: per-sample masks in training mode (timm DropPath), the identity in eval mode
+    blk = model.image_encoder.backbone.layers[3].blocks[1]
+    x = torch.randn(6, 2, 2, 768, generator=torch.Generator().manual_seed(0))
+    torch.manual_seed(3)
+    with torch.no_grad():
+        y_eval = blk.eval()(x, None)
+        y_train = blk.train()(x, None)
+        same = [bool(torch.equal(a, b)) for a, b in zip(y_eval, y_train)]
+    assert not all(same)                                         # (rate 0.4, two branches, six samples)
+    with pytest.raises(RuntimeError, match="no CPU"):            # the training-mode forward runs (round 5) -- on the MI355X only
         model.train()({"img1": torch.zeros(1, 3, 32, 32), "img2": torch.zeros(1, 3, 32, 32)})

@@ -300,6 +300,39 @@ def run_train_trained():
     print("e2e_train_t", len(d), "entries", os.path.getsize(path) // 1024, "KiB; loss", float(total))
 
 
+def run_train_swin():
+    """e2e_train_swin.npz: the training step of the Swin-T + deformable-neck configuration (configs/sceneflow_swint.yaml keys) with
+    BACKBONE.DROP_PATH 0 -- stochastic depth is random, so only the rate-0 step can be compared -- on one 64x128 pair: loss, seeds and per
+    parameter the norm / noise projection / largest entry of the reference's gradient (trunk, neck incl. the MSDA offsets, heads, stages)."""
+    opts = ["BACKBONE.MODEL_TYPE", "swin", "BACKBONE.OUT_CHANNELS", 128, "DATASETS.DIVIS_BY", 32, "BACKBONE.COMPAT", False,
+            "DPN.MAX_DISP", 128, "BACKBONE.DROP_PATH", 0.0]
+    model, cfg = refshim.build_reference_model(opts)
+    apply_hash_weights(model)
+    model.train()
+    from nmrf.models import build_model
+    crit = build_model(cfg)[1]
+    l, r, gt = synthetic_pair(64, 128, seed=2010)
+    img1, img2, gt = l[None].float(), r[None].float(), torch.as_tensor(gt)[None].float()
+    valid = (gt > 0) & (gt < cfg.SOLVER.MAX_DISP)
+    d = {"max_disp": np.int64(cfg.DPN.MAX_DISP), "img1": _np(img1).astype(np.uint8), "img2": _np(img2).astype(np.uint8), "gt": _np(gt),
+         "valid": _np(valid)}
+    model.zero_grad(set_to_none=True)
+    out = model({"img1": img1.clone(), "img2": img2.clone()})
+    losses = crit(out, {"disp": gt, "valid": valid})
+    total = sum(losses[k] * crit.weight_dict[k] for k in losses if k in crit.weight_dict)
+    total.backward()
+    d.update(loss_total=_np(total), seeds=_np(out["initial_proposal"]).astype(np.int16), disp_pred=_np(out["disp_pred"]))
+    for name, p in model.named_parameters():
+        if p.grad is None:
+            d["grad_none/" + name] = np.int8(1)
+            continue
+        g = _np(p.grad).astype(np.float64)
+        d["grad_stat/" + name] = np.asarray([np.sqrt((g * g).sum()), (g.reshape(-1) * unit_noise("gproj/" + name, g.size)).sum(), np.abs(g).max()])
+    path = os.path.join(OUT, "e2e_train_swin.npz")
+    np.savez_compressed(path, **d)
+    print("e2e_train_swin", len(d), "entries", os.path.getsize(path) // 1024, "KiB; loss", float(total))
+
+
 def run_swin():
     """Swin-T + deformable neck config (configs/sceneflow_swint.yaml + MAX_DISP 256): encoder features, outputs,
     and the state-dict key/shape listing of both configs (for the strict-load contract tests)."""
@@ -436,6 +469,9 @@ if __name__ == "__main__":
     if "--train-b2-only" in sys.argv:
         run_train_b2()
         sys.exit(0)
+    if "--train-swin-only" in sys.argv:
+        run_train_swin()
+        sys.exit(0)
     if "--train-trained-only" in sys.argv:
         run_train_trained()
         sys.exit(0)
@@ -453,4 +489,5 @@ if __name__ == "__main__":
     run_swin()
     run_train()
     run_train_b2()
+    run_train_swin()
     run_train_trained()            # (needs tests/golden/trained_sd.npz: tools/gen_trained_golden.py)

@@ -185,7 +185,18 @@ def install(third_party_only=False):
         return ms_deform_attn_core_pytorch(value, shapes.tolist(), loc, w)
 
     msda.ms_deform_attn_forward = _fwd
-    msda.ms_deform_attn_backward = None
+
+    def _bwd(value, shapes, start, loc, w, grad_output, im2col_step):
+        # the compiled extension's backward, restated as autograd of the reference's own pure-PyTorch formulation (fixtures of the
+        # Swin configuration's training step: tools/gen_golden.py:run_train_swin)
+        import torch
+        from ops.functions.ms_deform_attn_func import ms_deform_attn_core_pytorch
+        with torch.enable_grad():
+            v, l, ww = (t.detach().clone().requires_grad_(True) for t in (value, loc, w))
+            out = ms_deform_attn_core_pytorch(v, shapes.tolist(), l, ww)
+            return torch.autograd.grad(out, (v, l, ww), grad_output)
+
+    msda.ms_deform_attn_backward = _bwd
 
     if REF not in sys.path:
         sys.path.insert(0, REF)
