@@ -1097,7 +1097,7 @@ def msda_backward(value, shapes, lvl_start, loc, w, grad_out):
     return gv, gl, gw
 
 
-# ---- N4, first slice: the pieces of a backward pass through the token-linear chains (csrc/backward.hip, include/nmrf_hip.h) -------------
+# ---- N4: the pieces of a backward pass through the token-linear chains (csrc/backward.hip, include/nmrf_hip.h) -------------
 def _sum_parts(parts, n, out=None):
     """parts [S, n] (contiguous) -> [n]: rounds of 32 parts per group (nmrf_sum_partials_grouped_f32), a fixed reduction tree."""
     s_ = parts.shape[0]

@@ -2,9 +2,10 @@
 `NMRF.forward`, restated in this build's own formulation.  Plain PyTorch (the losses are a few elementwise passes over the
 outputs, nothing for a hand-written kernel); works on CPU and on the MI355X, differentiable through torch autograd.
 
-Inference build: `NMRF.forward` produces the eval-mode dictionary only (no `aux_outputs`: the HIP kernels are forward-only), so
-what this module gives a caller of the reference's drivers is the loss / EPE logging of an evaluation pass and the criterion object
-`build_model(cfg)` is expected to return (nmrf/models/__init__.py:9-10); `aux_outputs`, when a caller supplies them, are honoured.
+In eval mode `NMRF.forward` produces the eval-mode dictionary (no `aux_outputs`) and this module gives a caller of the reference's drivers
+the loss / EPE logging of an evaluation pass; in training mode the dictionary carries `aux_outputs` (NMRF.py:259-273) and, with
+`model.enable_grad_slice()`, an autograd graph: `sum_k weight_dict[k] * loss_dict[k]` is then the loss `nmrf_amd.train.train_step`
+back-propagates (main.py:413-420).  It is also the criterion object `build_model(cfg)` returns (nmrf/models/__init__.py:9-10).
 
 Terms (names and reductions as the reference's training loop reads them, main.py:413-420):
   loss_prop   smooth-L1 between every valid ground-truth pixel of an 8x8 cell and the NEAREST of the cell's N proposals (x8 px),

@@ -1,8 +1,9 @@
 """NMRF top module: same constructor arguments, forward API and state-dict names as
-nmrf/models/NMRF.py:21-262, with the hot path on libnmrf_hip.so.  The kernels are forward-only: model.eval() is the product path;
+nmrf/models/NMRF.py:21-262, with the hot path on libnmrf_hip.so.  model.eval() is the product path: fused forward-only kernels.
 model.train() runs the reference's TRAINING-mode forward (no input padding, per-layer intermediates, `aux_outputs`,
-NMRF.py:203-205, 216-223, 259-273) under no_grad, so that the `Criterion` (models/criterion.py) can be evaluated on it -- there is
-no autograd graph to back-propagate through (backward kernels are not built).
+NMRF.py:203-205, 216-223, 259-273) on the same kernels, so that the `Criterion` (models/criterion.py) can be evaluated on it; with
+enable_grad_slice() its outputs hang on an autograd graph whose backward is csrc/backward.hip (models/autograd_ops.py,
+nmrf_amd/train.py) -- the message-passing stages and heads, or with full=True every parameter of either configuration.
 """
 import os
 
@@ -538,8 +539,9 @@ class NMRF(nn.Module):
 
 
 def build(cfg):
-    """(model, criterion) like nmrf/models/NMRF.py:432-447.  The model is the inference build (forward-only HIP kernels); the
-    criterion (models/criterion.py, plain PyTorch) evaluates the reference's loss terms on its output dictionary."""
+    """(model, criterion) like nmrf/models/NMRF.py:432-447: the model in nn.Module's default training state, as the reference returns it
+    (callers of the inference path call .eval(), inference.py:150); the criterion (models/criterion.py, plain PyTorch) evaluates the
+    reference's loss terms on its output dictionary -- differentiable once model.enable_grad_slice() is on (nmrf_amd/train.py)."""
     from .criterion import build_criterion
     kwargs = NMRF.from_config(cfg)
     return NMRF(**kwargs), build_criterion(cfg)
