@@ -197,6 +197,11 @@ class NMRF(nn.Module):
         self.inference.keep_pre_norm = self.refinement.keep_pre_norm = self.dpn.propagation.keep_pre_norm = bool(on)
         return self
 
+    def enable_training(self, convolutions=True):
+        """model.train() + the autograd graph of enable_grad_slice: every parameter (convolutions=True, the reference's training), or the
+        message-passing stages, heads and seed filter with the convolutional side frozen on its fused kernels (convolutions=False)."""
+        return self.train().enable_grad_slice(True, full=convolutions)
+
     @staticmethod
     def _stage_rows_with_grad(stage, maps=None, labels=None):
         """The residual stream of EVERY layer of an NMP stage (inference: self-edge + window sites, four labels per pixel; refinement:

@@ -267,7 +267,8 @@ def test_training_host_side_optimizer_groups_schedule_and_checkpoints(tmp_path):
     cfg = get_cfg()
     cfg.merge_from_list(["SOLVER.MAX_ITER", 50, "SOLVER.WEIGHT_DECAY_NORM", 0.002])
     cfg.freeze()
-    model = build_model(cfg)[0].train().enable_grad_slice(full=True)
+    model = build_model(cfg)[0].enable_training()
+    assert model.training and model.grad_slice and model.grad_full and not build_model(cfg)[0].enable_training(convolutions=False).grad_full
     opt = build_slice_optimizer(model, cfg)
     names = {id(p): k for k, p in model.named_parameters()}
     assert sorted(names[id(p)] for g in opt.param_groups for p in g["params"]) == sorted(names.values())
