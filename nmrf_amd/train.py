@@ -60,6 +60,9 @@ def build_slice_optimizer(model, cfg):
     return torch.optim.AdamW([g for g in groups if g["params"]], lr=s.BASE_LR, weight_decay=s.WEIGHT_DECAY)
 
 
+build_optimizer = build_slice_optimizer          # the reference's name (main.py:186): build_optimizer(model, cfg)
+
+
 def allreduce_gradients(params, group=None):
     """Average the gradients of `params` over the ranks of `group` with ONE all-reduce of a flat bucket (what DDP's reducer does
     bucket by bucket, main.py:334-339); identity without a process group.  A parameter without a gradient on this rank contributes
