@@ -278,13 +278,34 @@ def _add_ln(x, y, norm, extra=None, extra_div=1, ld=None):
 
 
 # --------------------------------------------------------------------------------------------------
+# NMP.NORMALIZE_BEFORE False: the forward_post form of the three block types (NMP.py:110-135, 366-382, 576-591).  No shipped config
+# sets it, so it is not fused: every linear is one launch of the split-fp16 GEMM (nmrf_gemm_split_f32) + its bias / GELU pass, every
+# LayerNorm one nmrf_layernorm_f32, around the same attention kernels on fp32 q | k | v rows.
+# --------------------------------------------------------------------------------------------------
+def _rows_linear(x, lin, act=0):
+    """act(x W^T + b) of an nn.Linear on token rows [T,K]; act 0 identity, 2 GELU(erf)."""
+    y = K.linear_forward(x if x.is_contiguous() else x.contiguous(), lin.weight)
+    if lin.bias is None and not act:
+        return y
+    return K.bias_act(y, lin.bias, act, want_pre=not act)[1]
+
+
+def _post_norm_tail(m, x, msg):
+    """x = norm1(x + proj(msg)) and, for a block with an MLP, x = norm2(x + mlp(x))  (NMP.py:124-126, 374-380, 586-590)."""
+    x = K.layer_norm(x + _rows_linear(msg, m.proj), m.norm1.weight, m.norm1.bias, m.norm1.eps)
+    if hasattr(m, "mlp"):
+        h = _rows_linear(x, m.mlp.fc1, act=2)
+        x = K.layer_norm(x + _rows_linear(h, m.mlp.fc2), m.norm2.weight, m.norm2.bias, m.norm2.eps)
+    return x
+
+
+# --------------------------------------------------------------------------------------------------
 # self edges (BasicAttention, NMP.py:70-139)
 # --------------------------------------------------------------------------------------------------
 class BasicAttention(nn.Module):
     def __init__(self, dim, qk_dim, num_heads=8, normalize_before=True):
         super().__init__()
-        if not normalize_before:
-            raise NotImplementedError("only NORMALIZE_BEFORE=True (every shipped config) has a HIP path")
+        self.normalize_before = bool(normalize_before)
         self.num_heads = num_heads
         self.norm1 = nn.LayerNorm(dim)
         self.q, self.k, self.v = nn.Linear(qk_dim, dim), nn.Linear(qk_dim, dim), nn.Linear(dim, dim)
@@ -302,8 +323,16 @@ class BasicAttention(nn.Module):
         x, qkv = r if y is not None else (x, r)
         return x, self._proj(K.self_attn(qkv, n, self.num_heads))
 
+    def forward_post(self, x, abs_encoding, n):
+        """BasicAttention.forward_post (NMP.py:110-128): q, k on [x | enc], v on x -- no norm in front --, x = norm1(x + proj(attn))."""
+        cat = torch.cat((x, abs_encoding[:, : self.q.in_features - x.shape[1]]), 1)
+        qkv = torch.cat((_rows_linear(cat, self.q), _rows_linear(cat, self.k), _rows_linear(x, self.v)), 1)
+        return _post_norm_tail(self, x, K.self_attn(qkv, n, self.num_heads))
+
     def forward(self, label_rep, abs_encoding, n):
         """label_rep [T,C], abs_encoding [T,31] -> [T,C]; n = labels per pixel."""
+        if not self.normalize_before:
+            return self.forward_post(label_rep, abs_encoding, n)
         x, y = self.forward_pair(label_rep, None, abs_encoding, n)
         return x + y
 
@@ -339,8 +368,7 @@ class WindowAttention(nn.Module):
 class SwinNMP(nn.Module):
     def __init__(self, dim, qkv_dim, num_heads, window_size=7, shift_size=0, mlp_ratio=4., normalize_before=True):
         super().__init__()
-        if not normalize_before:
-            raise NotImplementedError("only NORMALIZE_BEFORE=True (every shipped config) has a HIP path")
+        self.normalize_before = bool(normalize_before)
         assert 0 <= shift_size < window_size
         self.dim, self.window_size, self.shift_size = dim, window_size, shift_size
         self.qkv = nn.Linear(qkv_dim, 3 * dim)
@@ -357,7 +385,14 @@ class SwinNMP(nn.Module):
         x, qkv = r if y is not None else (x, r)
         return self.mlp.forward_ln(x, self._proj(self.attn(qkv, dims, sibling_mask)), self.norm2)
 
+    def forward_post(self, x, abs_encoding, dims, sibling_mask):
+        """SwinNMP.forward_post (NMP.py:366-382) on the padded token grid dims = (B, Hp, Wp, N)."""
+        qkv = _rows_linear(torch.cat((x, abs_encoding[:, : self.qkv.in_features - self.dim]), 1), self.qkv)
+        return _post_norm_tail(self, x, self.attn(qkv, dims, sibling_mask))
+
     def forward(self, label_rep, abs_encoding, dims, sibling_mask):
+        if not self.normalize_before:
+            return self.forward_post(label_rep, abs_encoding, dims, sibling_mask)
         x, y = self.forward_pair(label_rep, None, abs_encoding, dims, sibling_mask)
         return x + y
 
@@ -379,8 +414,7 @@ class CSWinAttention(nn.Module):
 class CSWinNMP(nn.Module):
     def __init__(self, dim, qk_dim, v_dim, num_heads, split_size=1, mlp_ratio=4., normalize_before=True):
         super().__init__()
-        if not normalize_before:
-            raise NotImplementedError("only NORMALIZE_BEFORE=True (every shipped config) has a HIP path")
+        self.normalize_before = bool(normalize_before)
         if v_dim != dim:
             raise NotImplementedError("v_dim > dim (fourier_grid_embed branch, NMP.py:552-555) is dead in every config")
         self.dim = dim
@@ -393,8 +427,17 @@ class CSWinNMP(nn.Module):
         self._packed_qkv = _FusedCache()
         self._proj = _Lin(self.proj)
 
+    def forward_post(self, x, context_tok, dims):
+        """CSWinNMP.forward_post (NMP.py:576-591); context_tok [T, Cctx]: the context row of a token's pixel."""
+        b, h, wd, n = dims
+        cat = torch.cat((x, context_tok), 1)
+        qkv = torch.cat((_rows_linear(cat, self.q), _rows_linear(cat, self.k), _rows_linear(x, self.v)), 1)
+        return _post_norm_tail(self, x, K.stripe_attn(qkv, self.attns[0].get_v.weight, self.attns[1].get_v.weight, b, h, wd, n))
+
     def forward(self, seed_rep, context, dims):
         """seed_rep [T,C]; context [B*H*W, Cctx] (per pixel, shared by its N labels); dims=(B,H,W,N)."""
+        if not self.normalize_before:
+            return self.forward_post(seed_rep, context.repeat_interleave(dims[3], 0), dims)
         x, y = self.forward_pair(seed_rep, None, context, dims)
         return x + y
 
@@ -514,6 +557,8 @@ class Propagation(nn.Module):
         b, h, wd, cc = context.shape
         n = label_seed.shape[-1]
         dims = (b, h, wd, n)
+        if not self.layers[0].nmp.normalize_before:
+            return self._forward_post(cost_volume, label_seed, context.reshape(b * h * wd, cc), dims)
         split = self._split_ok(cc)
         ctx = context.reshape(b * h * wd, cc)
         seeds_f = None
@@ -544,6 +589,24 @@ class Propagation(nn.Module):
         elif y is not None:
             x = x + y
         return x.unsqueeze(0), seeds_f
+
+
+def _propagation_forward_post(self, cost_volume, label_seed, ctx, dims):
+    """Propagation.forward with NMP.NORMALIZE_BEFORE False (NMP.py:636-667 around CSWinNMP.forward_post): seed embedding = cost_encoder on
+    the 9 x G cost taps, proj on [features | Fourier]; five post-norm layers; the stage's final norm."""
+    cost, enc = K.seed_features(cost_volume, label_seed, 3.14 / 64)
+    ce = self.cost_encoder
+    feat = _rows_linear(_rows_linear(cost, ce[0], act=2), ce[2])
+    x = _rows_linear(torch.cat((feat, enc[:, : self.proj.in_features - feat.shape[1]]), 1), self.proj)
+    ctx_tok = ctx.repeat_interleave(dims[3], 0).contiguous()
+    for layer in self.layers:
+        x = layer.nmp.forward_post(x, ctx_tok, dims)
+    if self.norm is not None:
+        x = K.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+    return x.unsqueeze(0), label_seed.float()
+
+
+Propagation._forward_post = _propagation_forward_post
 
 
 def _qkv_of(nmp):
@@ -622,6 +685,10 @@ class Inference(nn.Module):
                 enc = K.fourier_embed(labels_flat, self.normalizer, 32, out=ebuf, out_map=to_p)
             x = self._ffn(wcc, 160) if to_p is None else self._ffn(wcc, 160, out=xbuf, out_map=to_p)
             t_dense = dims[0] * dims[1] * dims[2] * dims[3]
+            if not self.layers[0].nmp.normalize_before:
+                if collect is not None:
+                    raise NotImplementedError("return_intermediate (training mode) with NMP.NORMALIZE_BEFORE False")
+                return self._run_blocks_post(x, enc, pdims, to_d)
             if collect is not None and getattr(self, "keep_pre_norm", False):
                 # the tape of the training-mode forward (NMRF.enable_grad_slice): every tensor a backward through the WHOLE stage needs --
                 # the ffn operand, the Fourier rows and, appended by _run_blocks, each layer's residual stream, q | k | v and message
@@ -760,6 +827,20 @@ class Inference(nn.Module):
             keep = (to_dense >= 0).nonzero().squeeze(1)
             return (ln if self.norm is not None else x).index_select(0, keep)
         return ln if self.norm is not None else x
+
+    def _run_blocks_post(self, x, enc, pdims, to_dense):
+        """The layers of the stage in their forward_post form (NMP.NORMALIZE_BEFORE False) on the padded token grid, then the crop to the
+        dense grid and the stage's final norm (NMP.py:764-790, 866-892)."""
+        n = pdims[3]
+        for l in self.layers:
+            if hasattr(l, "self_nmp"):
+                x = l.self_nmp.forward_post(x, enc, n)
+            x = l.nmp.forward_post(x, enc, pdims, hasattr(l, "self_nmp"))
+        if to_dense is not None:
+            x = x.index_select(0, (to_dense >= 0).nonzero().squeeze(1))
+        if self.norm is not None:
+            x = K.layer_norm(x.contiguous(), self.norm.weight, self.norm.bias, self.norm.eps)
+        return x
 
     def forward(self, labels, fmap1, fmap2, fmap1_gw, fmap2_gw, token_major=False):
         """labels [B*H*W, N] -> [1, B*H*W, N, C]   (token_major: the four maps are [B,H,W,C] instead of [B,C,H,W]);

@@ -44,6 +44,7 @@ class OracleCfg:
     divis_by: int = 8
     eps: float = 1e-3          # DPN.py:39
     backbone_prefix: str = "backbone"   # "image_encoder" when COMPAT=False (NMRF.py:108-113)
+    normalize_before: bool = True       # NMP.NORMALIZE_BEFORE: False = the forward_post form of every block (NMP.py:110-135, 366-382, 576-591)
 
 
 # --------------------------------------------------------------------------- #
@@ -357,12 +358,12 @@ def stripe_attention(q, k, v, lepe_w, axis, scale):
     return out.permute(0, 1, 3, 4, 2, 5)
 
 
-def cswin_layer(x, ctx, w, pre, dims):
-    """One PropagationLayer = CSWinNMP.forward_pre (NMP.py:561-574).
+def cswin_layer(x, ctx, w, pre, dims, post=False):
+    """One PropagationLayer = CSWinNMP.forward_pre (NMP.py:561-574); post: forward_post (NMP.py:576-591).
     x [T,128]; ctx [B,H,W,64]; dims=(B,H,W,N)."""
     b, h, wd, n = dims
     c = x.shape[-1]
-    xn = _ln(x, w, pre + ".norm1")
+    xn = x if post else _ln(x, w, pre + ".norm1")
     qk_in = torch.cat((xn.view(b, h, wd, n, c), ctx[:, :, :, None, :].expand(b, h, wd, n, ctx.shape[-1])), -1)
     q = _lin(qk_in, w, pre + ".q")
     k = _lin(qk_in, w, pre + ".k")
@@ -378,6 +379,9 @@ def cswin_layer(x, ctx, w, pre, dims):
         outs.append(o.reshape(b, h, wd, n, half))
     msg = torch.cat(outs, -1).reshape(-1, c)
     x = x + _lin(msg, w, pre + ".proj")
+    if post:
+        x = _ln(x, w, pre + ".norm1")
+        return _ln(x + _gelu_mlp(x, w, pre + ".mlp"), w, pre + ".norm2")
     return x + _gelu_mlp(_ln(x, w, pre + ".norm2"), w, pre + ".mlp")
 
 
@@ -386,7 +390,7 @@ def propagation(cv, seeds, ctx, w, cfg, dims, stages=None):
     if stages is not None:
         stages["seed_embed"] = x
     for i in range(cfg.num_prop_layers):
-        x = cswin_layer(x, ctx, w, f"dpn.propagation.layers.{i}.nmp", dims)
+        x = cswin_layer(x, ctx, w, f"dpn.propagation.layers.{i}.nmp", dims, post=not cfg.normalize_before)
         if stages is not None:
             stages[f"prop_layer{i}"] = x
     return _ln(x, w, "dpn.propagation.norm")
@@ -443,9 +447,10 @@ def warp_corr_concat(labels, f1, f2, g1, g2, groups=32):
 # --------------------------------------------------------------------------- #
 # A10  per-pixel self-edge attention (NMP.py:90-108)
 # --------------------------------------------------------------------------- #
-def self_attention_layer(x, enc, w, pre, n, heads):
+def self_attention_layer(x, enc, w, pre, n, heads, post=False):
+    """BasicAttention.forward_pre (NMP.py:90-108); post: forward_post (NMP.py:110-128)."""
     t, c = x.shape
-    xn = _ln(x, w, pre + ".norm1")
+    xn = x if post else _ln(x, w, pre + ".norm1")
     qk_in = torch.cat((xn, enc), -1)
     hd = c // heads
     q = _lin(qk_in, w, pre + ".q").view(t // n, n, heads, hd).transpose(1, 2)
@@ -453,7 +458,8 @@ def self_attention_layer(x, enc, w, pre, n, heads):
     v = _lin(xn, w, pre + ".v").view(t // n, n, heads, hd).transpose(1, 2)
     attn = torch.softmax((q @ k.transpose(-1, -2)) * (hd ** -0.5), -1)
     out = (attn @ v).transpose(1, 2).reshape(t, c)
-    return x + _lin(out, w, pre + ".proj")
+    x = x + _lin(out, w, pre + ".proj")
+    return _ln(x, w, pre + ".norm1") if post else x
 
 
 # --------------------------------------------------------------------------- #
@@ -511,14 +517,17 @@ def window_attention(qkv, table, dims, win, shift, heads, sibling_mask):
     return out
 
 
-def swin_layer(x, enc, w, pre, dims, win, shift, heads, sibling_mask):
-    """SwinNMP.forward_pre (NMP.py:350-364)."""
+def swin_layer(x, enc, w, pre, dims, win, shift, heads, sibling_mask, post=False):
+    """SwinNMP.forward_pre (NMP.py:350-364); post: forward_post (NMP.py:366-382)."""
     b, hp, wp, n = dims
     c = x.shape[-1]
-    qkv = _lin(torch.cat((_ln(x, w, pre + ".norm1"), enc), -1), w, pre + ".qkv")
+    qkv = _lin(torch.cat((x if post else _ln(x, w, pre + ".norm1"), enc), -1), w, pre + ".qkv")
     msg = window_attention(qkv.view(b, hp, wp, n, 3 * c), w[pre + ".attn.relative_position_enc_table"],
                            dims, win, shift, heads, sibling_mask)
     x = x + _lin(msg.reshape(-1, c), w, pre + ".proj")
+    if post:
+        x = _ln(x, w, pre + ".norm1")
+        return _ln(x + _gelu_mlp(x, w, pre + ".mlp"), w, pre + ".norm2")
     return x + _gelu_mlp(_ln(x, w, pre + ".norm2"), w, pre + ".mlp")
 
 
@@ -553,9 +562,9 @@ def inference(labels, f1, f2, g1, g2, w, cfg, stages=None, intermediate=None):
     enc, _, _ = _pad_tokens(enc, dims, cfg.window_size)
     for i in range(cfg.num_infer_layers):
         pre = f"inference.layers.{i}"
-        x = self_attention_layer(x, enc, w, pre + ".self_nmp", n, cfg.infer_heads)
+        x = self_attention_layer(x, enc, w, pre + ".self_nmp", n, cfg.infer_heads, post=not cfg.normalize_before)
         shift = 0 if i % 2 == 0 else cfg.window_size // 2
-        x = swin_layer(x, enc, w, pre + ".nmp", pdims, cfg.window_size, shift, cfg.infer_heads, True)
+        x = swin_layer(x, enc, w, pre + ".nmp", pdims, cfg.window_size, shift, cfg.infer_heads, True, post=not cfg.normalize_before)
         if stages is not None:
             stages[f"infer_layer{i}"] = x
         if intermediate is not None:
@@ -577,7 +586,7 @@ def refinement(disp_q, f1, f2, g1, g2, w, cfg, stages=None, intermediate=None):
     enc, _, _ = _pad_tokens(enc, dims, win)
     for i in range(cfg.num_refine_layers):
         shift = 0 if i % 2 == 0 else win // 2
-        x = swin_layer(x, enc, w, f"refinement.layers.{i}.nmp", pdims, win, shift, cfg.infer_heads, False)
+        x = swin_layer(x, enc, w, f"refinement.layers.{i}.nmp", pdims, win, shift, cfg.infer_heads, False, post=not cfg.normalize_before)
         if stages is not None:
             stages[f"refine_layer{i}"] = x
         if intermediate is not None:

@@ -31,10 +31,10 @@ def _oracle_chain_side(oout):
     return dict(score=st["score"], coarse=st["coarse"], disp_curr=st["disp_curr"], disp=oout["disp"])
 
 
-def _oracle_features(g):
+def _oracle_features(g, **cfg_kw):
     """Backbone features computed by the oracle on CPU (stock convs): the GPU hot path is then fed the
     exact same activations the reference saw, so seeds can be required bit-exact."""
-    w, cfg = oracle_weights(int(g["max_disp"]), weights=_weights_of(g)), oracle_cfg(int(g["max_disp"]))
+    w, cfg = oracle_weights(int(g["max_disp"]), weights=_weights_of(g)), oracle_cfg(int(g["max_disp"]), **cfg_kw)
     from tests.util import golden_images, operand_range
     with torch.no_grad(), operand_range() as rng:
         out = O.forward(w, cfg, *golden_images(g), return_stages=True)
@@ -48,13 +48,16 @@ def _weights_of(g):
     return "trained" if "train_steps" in g else "hash"
 
 
-@pytest.mark.parametrize("name", ["e2e_a", "e2e_b", "e2e_c", "e2e_d", "e2e_t"])
+@pytest.mark.parametrize("name", ["e2e_a", "e2e_b", "e2e_c", "e2e_d", "e2e_t", "e2e_post"])
 def test_hot_path_from_reference_features(name):
     """e2e_t: the same chain on the TRAINED reference checkpoint (tests/golden/trained_sd.npz through load_state_dict), with the
-    largest |activation| each split-fp16 stage saw printed beside the 65 520 limit of csrc/split_mfma.h."""
+    largest |activation| each split-fp16 stage saw printed beside the 65 520 limit of csrc/split_mfma.h.
+    e2e_post: NMP.NORMALIZE_BEFORE False -- the forward_post form of every message-passing block (NMP.py:110-135, 366-382, 576-591; no shipped
+    config sets it), un-fused on the HIP split GEMM / LayerNorm / attention kernels."""
     g = golden(name)
-    w, cfg, oout, (fl, fr) = _oracle_features(g)
-    model = build_product(int(g["max_disp"]), DEV, weights=_weights_of(g))
+    post = name == "e2e_post"
+    w, cfg, oout, (fl, fr) = _oracle_features(g, **({"normalize_before": False} if post else {}))
+    model = build_product(int(g["max_disp"]), DEV, weights=_weights_of(g), opts=("NMP.NORMALIZE_BEFORE", False) if post else ())
     with torch.no_grad():
         out, cand = _gpu_chain_side(model, [f.to(DEV) for f in fl], [f.to(DEV) for f in fr], g["disp"].shape[-2:])
     assert model.check_range()

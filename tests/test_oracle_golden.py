@@ -278,3 +278,36 @@ def test_training_mode_outputs_match_the_reference():
     assert set(got) == set(want), (sorted(got), sorted(want))
     for k, v in want.items():
         assert abs(float(got[k]) - v) <= 2e-4 * max(1.0, abs(v)), (k, float(got[k]), v)
+
+
+def test_post_norm_configuration_vs_reference():
+    """NMP.NORMALIZE_BEFORE False -- no shipped config sets it, the reference implements it (forward_post of BasicAttention / SwinNMP /
+    CSWinNMP, NMP.py:110-135, 366-382, 576-591): the oracle's post-norm blocks against the reference run of tests/golden/e2e_post.npz,
+    stage by stage and end to end."""
+    g = golden("e2e_post")
+    md = int(g["max_disp"])
+    w, cfg = oracle_weights(md), oracle_cfg(md, normalize_before=False)
+    with torch.no_grad():
+        out = O.forward(w, cfg, *_imgs(g), return_stages=True)
+        pre = O.forward(w, oracle_cfg(md), *_imgs(g))
+    st = out["stages"]
+    report("prob", out["prob"], t(g["prob"]), 2e-6)
+    assert torch.equal(out["initial_proposal"].long(), t(g["seeds"]).long())
+    report("prop_layer0", st["prop_layer0"][::2], t(g["prop_layer0_sub2"]), 5e-5)
+    report("proposal", out["proposal"], t(g["proposal"]), 5e-5)
+    report("infer_self0", st["infer_self0"][::2], t(g["infer_self0_sub2"]), 5e-5) if "infer_self0" in st else None
+    report("infer_layer1", st["infer_layer1"][::2], t(g["infer_layer1_sub2"]), 1e-4)
+    # (the refinement stage from the REFERENCE's coarse disparity, as test_refinement_stage_from_reference_disparity does: a winner-take-all
+    #  near-tie would otherwise feed it another input)
+    fm, heads = _feature_maps(g, w, cfg)
+    (f1, g1), (f2, g2) = heads(fm["fmap4_l"]), heads(fm["fmap4_r"])
+    rs = {}
+    with torch.no_grad():
+        tgt = O.refinement(t(g["disp_curr"]), f1, f2, g1, g2, w, cfg, rs)
+    report("refine_layer1", rs["refine_layer1"][::2], t(g["refine_layer1_sub2"]), 1e-4)
+    report("refine_tgt", tgt, t(g["refine_tgt"]), 1e-4)
+    s = disp_stats(out["disp"], t(g["disp"]))
+    from tests.conftest import record_disp_stats
+    record_disp_stats("oracle vs reference e2e_post (NORMALIZE_BEFORE False)", s)
+    assert s["epe"] < 1e-3 and s["median"] < 2e-4 and s["frac_gt_0p5"] < 2e-3, s
+    assert float((pre["disp"] - out["disp"]).abs().mean()) > 1e-2        # (it IS another function than the pre-norm one)

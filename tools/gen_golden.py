@@ -469,6 +469,9 @@ if __name__ == "__main__":
     if "--train-b2-only" in sys.argv:
         run_train_b2()
         sys.exit(0)
+    if "--post-only" in sys.argv:
+        run_e2e("e2e_post", [(52, 100, 1006)], ["DPN.MAX_DISP", 128, "NMP.NORMALIZE_BEFORE", False], full=True)
+        sys.exit(0)
     if "--train-swin-only" in sys.argv:
         run_train_swin()
         sys.exit(0)
@@ -484,6 +487,8 @@ if __name__ == "__main__":
     # mid-size: 17 key tiles per horizontal stripe (129 pixels x 4 labels), both window paddings live; the images are the
     # closed-form synthetic pairs of these seeds and are regenerated where the fixture is consumed
     run_e2e("e2e_d", [(136, 1032, 1004), (136, 1032, 1005)], [], full=False, store_images=False)
+    # NMP.NORMALIZE_BEFORE False (no shipped config sets it): the forward_post form of every message-passing block
+    run_e2e("e2e_post", [(52, 100, 1006)], ["DPN.MAX_DISP", 128, "NMP.NORMALIZE_BEFORE", False], full=True)
     run_nms()
     run_msda()
     run_swin()
