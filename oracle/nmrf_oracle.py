@@ -12,7 +12,11 @@ vectors captured from the real reference (imported in the build container by
 ``tools/gen_golden.py``) in ``tests/test_oracle_golden.py``.  The arithmetic of
 third-party ATen ops the reference calls (``topk`` tie order, ``grid_sample``,
 ``median``) is restated explicitly here (see ``topk_ties``, ``warp_row``) and
-in ``oracle/topk_ref.c``, and pinned by the same goldens.
+in ``oracle/topk_ref.c``, and pinned by the same goldens.  Pinned configurations: the
+default one (hash weights: e2e_a ... e2e_d; the TRAINED reference checkpoint: e2e_t), the Swin-T encoder (e2e_swin), the training-mode
+forward (e2e_train) and NMP.NORMALIZE_BEFORE False -- the forward_post blocks (e2e_post).  The functions are differentiable torch code: the
+backward kernels are compared with torch autograd of these restatements in fp64 (tests/test_hip_kernels.py), the model-level gradients
+with the reference's own autograd (tests/golden/e2e_train*.npz).
 
 All citations are ``file:line`` relative to the reference repo root.
 Functional style: ``w`` is a flat dict of tensors keyed by the reference's
