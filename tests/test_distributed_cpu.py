@@ -154,3 +154,73 @@ def test_gradient_bucket_allreduce_world2():
     assert all(ok for _, ok in res), res
     from nmrf_amd.train import allreduce_gradients
     assert allreduce_gradients([torch.nn.Parameter(torch.zeros(2))]) == 0           # no process group: identity
+
+
+class _TinyStereo(torch.nn.Module):
+    """A stand-in with the surface nmrf_amd.train.fit / train_step touch (grad_slice, freeze_bn, model(sample) -> {'disp'}): the loop, the
+    gradient average and the rank-0 checkpoints are host logic -- the real model's forward needs the MI355X."""
+
+    def __init__(self):
+        super().__init__()
+        self.grad_slice = True
+        self.lin = torch.nn.Linear(3, 1)
+        self.frozen_bn_calls = 0
+
+    def freeze_bn(self):
+        self.frozen_bn_calls += 1
+
+    def forward(self, sample):
+        return {"disp": self.lin(sample["img1"]).squeeze(-1)}
+
+
+class _TinyCriterion:
+    weight_dict = {"loss_disp": 2.0}
+
+    def __call__(self, out, sample):
+        return {"loss_disp": (out["disp"] - sample["disp"]).abs().mean(), "epe_train": (out["disp"] - sample["disp"]).abs().mean().detach()}
+
+
+def _fit_worker(rank, world, port, q, ckpt_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nmrf_amd.config import get_cfg
+        from nmrf_amd.train import fit
+        cfg = get_cfg()
+        cfg.merge_from_list(["SOLVER.MAX_ITER", 5, "SOLVER.CHECKPOINT_PERIOD", 2, "SOLVER.LATEST_CHECKPOINT_PERIOD", 4])
+        cfg.freeze()
+        torch.manual_seed(0)
+        model = _TinyStereo()                                          # same initial weights on both ranks (as DDP broadcasts them)
+        opt = torch.optim.AdamW(model.parameters(), lr=cfg.SOLVER.BASE_LR)
+        g = torch.Generator().manual_seed(100 + rank)                  # each rank its own shard of the data
+        batches = [{"img1": torch.randn(8, 3, generator=g), "img2": None, "disp": torch.randn(8, generator=g), "valid": torch.ones(8, dtype=torch.bool)}
+                   for _ in range(2)]
+        epochs, lrs = [], []
+        step, epoch = fit(model, _TinyCriterion(), opt, batches, cfg, checkpoint_dir=ckpt_dir, set_epoch=epochs.append,
+                          on_step=lambda s, lr, total, ld: lrs.append(lr))
+        w = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+        q.put((rank, step, epoch, epochs, model.frozen_bn_calls, w.tolist(), len(lrs)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fit_loop_world2_rank0_checkpoints_and_gradient_average(tmp_path):
+    """nmrf_amd.train.fit on two gloo ranks with a stand-in model: five steps over two-batch epochs (set_epoch 0, 1, 2; freeze_bn per epoch),
+    the ranks see different data and end with IDENTICAL weights (the gradient average of main.py:334-339), rank 0 alone writes
+    step_000002 / step_000004 / step_000005 (MAX_ITER) and checkpoint_latest (step 4)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fit_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=90) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, r1) = res
+    assert r0[1:5] == (5, 2, [0, 1, 2], 3) and r1[1:5] == r0[1:5] and r0[6] == 5
+    assert r0[5] == r1[5], (r0[5], r1[5])                             # bit-identical parameters on both ranks
+    assert sorted(os.listdir(str(tmp_path))) == ["checkpoint_latest.pth", "step_000002.pth", "step_000004.pth", "step_000005.pth"]
+    latest = torch.load(str(tmp_path / "checkpoint_latest.pth"))
+    assert latest["step"] == 4 and latest["epoch"] == 1 and set(latest) == {"model", "optimizer", "step", "epoch"}
