@@ -691,9 +691,11 @@ def hot_path(w, cfg, feats8, feats4, pad_hw, out_hw, stages=None, seeds=None, au
     f1, f2 = conv_head(l8, w, "concatconv"), conv_head(r8, w, "concatconv")
     g1, g2 = conv_head(l8, w, "gw"), conv_head(r8, w, "gw")
     inter8 = [] if aux else None
+    proposal = labels                       # the returned proposals keep their graph (the proposal loss); the stages below see constants:
+    labels = labels.detach()                # `labels_curr = labels[-1].detach()` (NMRF.py:215)
     tgt = inference(labels, f1, f2, g1, g2, w, cfg, stages, inter8)
     coarse, score = coarse_heads(tgt, labels, w, dims8)
-    disp_q = wta_median(coarse, score)
+    disp_q = wta_median(coarse, score).detach()                        # `disp_curr = disp_curr.detach()` (NMRF.py:232)
 
     f1, f2 = conv_head(l4, w, "concatconv"), conv_head(r4, w, "concatconv")
     g1, g2 = conv_head(l4, w, "gw"), conv_head(r4, w, "gw")
@@ -710,7 +712,7 @@ def hot_path(w, cfg, feats8, feats4, pad_hw, out_hw, stages=None, seeds=None, au
             aux_outputs.append({"disp_pred": refine_epilogue(t, disp_q, w, pad_hw, out_hw)[1]})
 
     out = {
-        "proposal": labels.view(b, -1, n),
+        "proposal": proposal.view(b, -1, n),
         "prob": prob,
         "initial_proposal": seeds.to(mem.dtype).view(b, -1, n),
         "disp": disp,

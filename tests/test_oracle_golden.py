@@ -311,3 +311,62 @@ def test_post_norm_configuration_vs_reference():
     record_disp_stats("oracle vs reference e2e_post (NORMALIZE_BEFORE False)", s)
     assert s["epe"] < 1e-3 and s["median"] < 2e-4 and s["frac_gt_0p5"] < 2e-3, s
     assert float((pre["disp"] - out["disp"]).abs().mean()) > 1e-2        # (it IS another function than the pre-norm one)
+
+
+@pytest.mark.parametrize("name", ["e2e_train", "e2e_train_b2", "e2e_train_t"])
+def test_oracle_autograd_matches_reference_gradients(name):
+    """The oracle is differentiable torch code with the reference's two detach points (NMRF.py:215,232), so its autograd is the checker of
+    every backward kernel (tests/test_hip_kernels.py).  Pinned here against the REFERENCE's own autograd: the training-mode forward, the
+    reference Criterion's weighted loss (restated in nmrf_amd.models.criterion -- plain PyTorch, no HIP), backward -- entry by entry where the
+    fixture stores tensors (e2e_train: 152), by gradient norm + projection on a fixed noise vector for every parameter otherwise (e2e_train_b2:
+    a batch of two, SMOOTH_L1; e2e_train_t: the trained checkpoint on a training batch); then the proposal loss alone where stored."""
+    from nmrf_amd.models.criterion import build_criterion
+    from nmrf_amd.utils.hashinit import unit_noise
+    from tests.util import make_cfg
+    g = golden(name)
+    md = int(g["max_disp"])
+    w0 = oracle_weights(md, weights="trained" if name == "e2e_train_t" else "hash")
+    w = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in w0.items()}
+    cfg = oracle_cfg(md)
+    img1, img2 = (t(g["img1"]).float(), t(g["img2"]).float())
+    out = O.forward(w, cfg, img1, img2, training=True)
+    assert torch.equal(out["initial_proposal"].long(), t(g["seeds"]).long())
+    crit = build_criterion(make_cfg(md, ["SOLVER.LOSS_TYPE", "SMOOTH_L1"] if name == "e2e_train_b2" else []))
+    losses = crit(out, {"disp": t(g["gt"]), "valid": t(g["valid"])})
+    total = sum(losses[k] * crit.weight_dict[k] for k in losses if k in crit.weight_dict)
+    assert abs(float(total.detach()) - float(g["loss_total"])) <= 1e-5 * abs(float(g["loss_total"]))
+
+    def compare(tag):
+        n_full = n_stat = 0
+        for key in g:
+            if key.startswith(tag + "/"):
+                nm = key[len(tag) + 1:]
+                want, got = t(g[key]), w[nm].grad
+                assert got is not None, nm
+                scale = float(want.abs().max())
+                # (L1: a pixel whose prediction sits within rounding of its target flips the sign of its term; measured <= 8e-3 of the
+                #  largest entry.  Floor: gradients that are 0 in exact arithmetic)
+                assert float((got - want).abs().max()) <= 2e-2 * scale + 2e-6, (tag, nm)
+                n_full += 1
+            elif key.startswith(tag + "_stat/"):
+                nm = key[len(tag) + 6:]
+                got = w[nm].grad
+                assert got is not None, nm
+                gd = got.double().reshape(-1)
+                norm, proj = float(gd.norm()), float((gd * torch.from_numpy(unit_noise("gproj/" + nm, gd.numel())).double()).sum())
+                wn, wp = float(g[key][0]), float(g[key][1])
+                assert abs(norm - wn) <= 2e-2 * wn + 1e-5 and abs(proj - wp) <= 2e-2 * wn + 1e-5, (tag, nm, norm, wn, proj, wp)
+                n_stat += 1
+            elif key.startswith(tag + "_none/"):
+                assert w[key[len(tag) + 6:]].grad is None, key
+        return n_full, n_stat
+    total.backward(retain_graph=True)
+    n_full, n_stat = compare("grad")
+    assert n_full + n_stat >= 150
+    if any(k.startswith("grad_prop") for k in g):
+        for v in w.values():
+            if v.is_floating_point():
+                v.grad = None
+        losses["loss_prop"].backward()
+        n_full, n_stat = compare("grad_prop")
+        assert n_full + n_stat >= 50
