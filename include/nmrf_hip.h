@@ -40,7 +40,7 @@ const char *nmrf_strerror(int code);
  * in a separate pass when range_flag != NULL; pass NULL when qkv was produced by nmrf_nmp_block16_f32, which range-checks its q_out. */
 int nmrf_range_scan_f32(const float *x, int64_t n, int *range_flag, void *stream);   /* n % 4 == 0, x 16-byte aligned */
 /* ABI version of this header; bumps on any signature change. */
-int nmrf_abi_version(void);   /* currently 25 */
+int nmrf_abi_version(void);   /* currently 26 */
 
 /* A2  group-wise correlation volume.
  * replaces build_correlation_volume + the permute of DPN.forward
@@ -151,6 +151,17 @@ int nmrf_window_attn_f32(const float *qkv, const float *table, int B, int Hp, in
  *  kv16 == 2: the same rows, the same kernel, but those relative-position terms on the VALU in fp32 -- no bound on the table; the
  *  form a caller selects for a checkpoint whose table exceeds 32 (nmrf_amd.kernels.window_attn does, once per parameter version).
  *  Rows in a configuration the pre-split kernel does not cover return NMRF_EINVAL instead of being read as floats.) */
+
+/* A10(ii), the shipped inference configuration as a persistent kernel (csrc/window_attn6.hip): 6 x 6 windows, four labels per pixel,
+ * C == 128 (four heads), kv16 rows (see nmrf_nmp_block16_f32).  Same result as nmrf_window_attn_f32(win 6, N 4, kv16 1) up to
+ * summation order (WindowAttention.forward, nmrf/models/NMP.py:185-289, 803-826).  The relative-position table arrives PACKED:
+ *   nmrf_window_table_pack_f32(table [121, 3C], C, heads) -> packed, heads x 49152 bytes: per head ek and eq as split fp16 pairs
+ *   x 2^10 (eq also x s log2 e) in [hi | lo][8 channel chunks][121 rows][4 halves] order, then ev in fp32 [8][121][4], zero-padded;
+ *   the layout a block copies into LDS as is.  Pack once per parameter version; |table| < 32 is the CALLER's check as above.
+ * B * Hp * Wp * 4 * 384 must stay below 2^30 (32-bit byte offsets), else NMRF_EINVAL: use nmrf_window_attn_f32. */
+int nmrf_window_table_pack_f32(const float *table, int C, int heads, void *packed, void *stream);
+int nmrf_window_attn6_f32(const float *qkv, const void *packed, int B, int Hp, int Wp, int C, int heads, int shift,
+                          int sibling_mask, float *out, void *stream);
 
 /* A8/A11/A14  narrow prediction-head layers: out[T,N] = act(x[T,K] w[N,K]^T + bias), N <= 64, K % 4 == 0, K <= 512
  * (LDS: 32*(K+4) + 8*npt*K floats <= 64 KiB), act 0 = identity, 1 = ReLU; bias may be NULL.

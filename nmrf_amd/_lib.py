@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnmrf_hip.so")      # (tools may point this at another build BEFORE the first load(): bench.py --lib)
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -36,6 +36,8 @@ PROTOTYPES = {
     "nmrf_warp_corr_concat_fourier_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _F, _P, _I, _P, _P],
     "nmrf_self_attn_f32": [_P, _L, _I, _I, _I, _P, _P],
     "nmrf_window_attn_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "nmrf_window_table_pack_f32": [_P, _I, _I, _P, _P],
+    "nmrf_window_attn6_f32": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "nmrf_linear_smalln_f32": [_P, _P, _P, _L, _I, _I, _I, _P, _P],
     "nmrf_superpixel_downsample_f32": [_P, _P, _I, _I, _I, _I, _P, _P],
     "nmrf_wta_median_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _P],

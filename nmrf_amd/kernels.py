@@ -363,6 +363,30 @@ def _table_fits_fp16(table):
     return ok
 
 
+_TABLE_PACK = {}
+W6_HEAD_BYTES = 49152          # csrc/window_attn6.hip
+
+
+def window_table_packed(table, heads):
+    """The relative-position table of a window-attention layer in the layout the persistent 6 x 6 x 4 kernel copies into LDS
+    (nmrf_window_table_pack_f32), made once per (tensor object, version) like the range verdict above."""
+    import weakref
+    ent = _TABLE_PACK.get(id(table))
+    key = (table._version, table.data_ptr())
+    if ent is not None and ent[0]() is table and ent[1] == key:
+        return ent[2]
+    if len(_TABLE_PACK) > 256:
+        for k in [k for k, e in _TABLE_PACK.items() if e[0]() is None]:
+            del _TABLE_PACK[k]
+    packed = torch.zeros(heads * W6_HEAD_BYTES, dtype=torch.uint8, device=table.device)
+    _lib.check(_lib.load().nmrf_window_table_pack_f32(_p(table), heads * 32, heads, _p(packed), _stream()), "window_table_pack")
+    _TABLE_PACK[id(table)] = (weakref.ref(table), key, packed)
+    return packed
+
+
+WINDOW6 = os.environ.get("NMRF_WINDOW6", "1") != "0"     # A/B: 0 = the two-windows-per-block kernel of rounds 2-5
+
+
 @_on_device
 def window_attn(qkv, table, b, hp, wp, n, heads, win, shift, sibling_mask, checked=False, kv16=False):
     """checked: the producer of qkv range-checked it (no scan pass).  kv16: the k | v thirds of qkv are split fp16 operand pairs
@@ -378,6 +402,16 @@ def window_attn(qkv, table, b, hp, wp, n, heads, win, shift, sibling_mask, check
     assert t == b * hp * wp * n
     out = torch.empty(t, c, device=qkv.device, dtype=torch.float32)
     tw = win * win * n                                 # reference form: 5 contractions of tw^2 x 32 MACs per (window, head)
+    if kv16 == 1 and WINDOW6 and c == 128 and heads == 4 and qkv.numel() < (1 << 30):
+        # the persistent kernel: one block per (CU, head) keeps the packed table in LDS, one wave per query tile
+        packed = window_table_packed(table, heads)
+        _hb("window_attn_w6_n4", row="A10", bound="mfma", split=True,
+            flops=b * (hp // win) * (wp // win) * heads * 5 * 2.0 * tw * tw * 32, bytes=4.0 * (qkv.numel() + t * c),
+            label="window_attn6_kernel (6 x 6 x 4 inference windows, persistent, A10)", pmc=["window_attn6_kernel<"])
+        _lib.check(_lib.load().nmrf_window_attn6_f32(_p(qkv), _p(packed), b, hp, wp, c, heads, shift, int(bool(sibling_mask)), _p(out),
+                                                     _stream()), "window_attn6")
+        _he("window_attn_w6_n4")
+        return out
     fast = {(6, 4): ("window_attn_fast_kernel<5, 6, 4, 2, 3, false, 1, true, true, false>" if kv16 == 1 else
                      "window_attn_fast_kernel<5, 6, 4, 2, 3, false, 1, true, false, false>" if kv16 else
                      "window_attn_fast_kernel<5, 6, 4, 2, 3, false, 1, false, false, false>"),

@@ -662,6 +662,46 @@ def test_window_attention_on_kv16_rows(shift):
     report("window attention on kv16 rows", c.cpu(), a.cpu().double(), 3e-6, 1e-6)
 
 
+@pytest.mark.parametrize("b,hp,wp,shift,sib", [
+    (1, 6, 6, 0, True), (1, 6, 6, 3, True), (2, 12, 18, 3, True), (1, 12, 12, 3, False), (3, 18, 6, 5, True), (1, 6, 30, 1, False),
+    (1, 12, 12, 0, False),
+    # padded token grids of the BASELINE configs (KITTI 208 windows, SceneFlow 240), regular and shifted, batch > 1 (several items per wave)
+    (1, 48, 156, 0, True), (1, 48, 156, 3, True), (2, 48, 156, 3, True), (1, 72, 120, 3, True), (9, 48, 156, 0, True)])
+def test_window_attention_persistent_kernel(b, hp, wp, shift, sib):
+    """csrc/window_attn6.hip (the product's 6 x 6 x 4 inference-window kernel: persistent head-fixed blocks, packed table in LDS, one
+    wave per query tile, relative-position logit terms formed per key tile on the 4x4x4 MFMA and contracted with one-hot partners)
+    on kv16 rows: against the oracle's restatement of WindowAttention.forward (NMP.py:185-289) on the fp32 rows the operands were
+    split from, and against the two-windows-per-block kernel of rounds 2-5 on the same kv16 rows (summation order only)."""
+    kk = K()
+    tkn = b * hp * wp * 4
+    qkv = rnd(tkn, 384, seed=hp * wp + shift + 7, scale=1.5)
+    table = rnd(121, 384, seed=61, scale=0.5)
+    rows, tab = kk.to_kv16(qkv.to(DEV)), table.to(DEV)
+    assert kk.WINDOW6
+    got = kk.window_attn(rows, tab, b, hp, wp, 4, 4, 6, shift, sib, kv16=True)
+    assert torch.isfinite(got).all()
+    if b * hp * wp <= 2 * 48 * 156:
+        ref = O.window_attention(qkv.view(b, hp, wp, 4, 384), table, (b, hp, wp, 4), 6, shift, 4, sib)
+        report("window_attn6 vs oracle", got.cpu(), ref.reshape(tkn, 128), 2e-5, 1e-5)
+    kk.WINDOW6 = False
+    try:
+        old = kk.window_attn(rows, tab, b, hp, wp, 4, 4, 6, shift, sib, kv16=True)
+    finally:
+        kk.WINDOW6 = True
+    report("window_attn6 vs the two-window kernel", got.cpu(), old.cpu().double(), 5e-6, 2e-6)
+    # a second call on the same table object reuses the packed table; an in-place update of the table repacks it
+    again = kk.window_attn(rows, tab, b, hp, wp, 4, 4, 6, shift, sib, kv16=True)
+    assert torch.equal(again, got)
+    if b == 1 and hp == 12 and shift == 3:
+        tab2 = tab.clone()
+        first = kk.window_attn(rows, tab2, b, hp, wp, 4, 4, 6, shift, sib, kv16=True)
+        tab2.mul_(0.5)
+        half = kk.window_attn(rows, tab2, b, hp, wp, 4, 4, 6, shift, sib, kv16=True)
+        ref2 = O.window_attention(qkv.view(b, hp, wp, 4, 384), table * 0.5, (b, hp, wp, 4), 6, shift, 4, sib)
+        report("window_attn6 after an in-place table update", half.cpu(), ref2.reshape(tkn, 128), 2e-5, 1e-5)
+        assert not torch.equal(first, half)
+
+
 @pytest.mark.parametrize("scale,form", [(0.3, 1), (12.0, 1), (12.0, 2), (45.0, 2)])
 def test_window_attention_kv16_table_magnitude_and_valu_fallback(scale, form):
     """the kv16 window kernel stages its relative-position table x 2^10 as split fp16 for the matrix-pipe form of the

@@ -308,6 +308,82 @@ if "window" in which:
                 if not rep:
                     print("   one vs two windows per block: max |diff| %.3e" % float((o_new - o_two).abs().max()))
             print("   MFMA vs VALU phase 0: max |diff| %.3e (output scale %.3e)" % (float((o_new - o_old).abs().max()), float(o_old.abs().max())))
+if "window6" in which:
+    # round 6: the persistent 6 x 6 x 4 kernel (csrc/window_attn6.hip) against the two-windows-per-block kernel, interleaved, min of 3 rounds
+    hp, wp = 48, 156
+    qkv, table = mk("q", b * hp * wp * n, 384), mk("t", 121, 384)
+    q16 = K.to_kv16(qkv)
+    def t_us6(fn, nrep):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(nrep):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / nrep
+    for shift in (0, 3):
+        best = {}
+        outs = {}
+        for rnd_ in range(3):
+            for tag, flag in (("two windows per block (rounds 2-5)", False), ("persistent, one wave per query tile (round 6)", True)):
+                K.WINDOW6 = flag
+                outs[tag] = K.window_attn(q16, table, b, hp, wp, n, 4, 6, shift, True, kv16=True)
+                best[tag] = min(best.get(tag, 1e9), t_us6(lambda: K.window_attn(q16, table, b, hp, wp, n, 4, 6, shift, True, kv16=True), args.iters))
+        K.WINDOW6 = True
+        a_, b_ = list(outs.values())
+        print("window_attn 6x6x4 kv16 batch %d shift %d: %s; max |diff| %.2e" % (b, shift, ", ".join("%s %.1f us" % kv for kv in best.items()),
+                                                                                  float((a_ - b_).abs().max())), flush=True)
+if "window6_census" in which:
+    # timing ablations / variants of the persistent window kernel (debug build: nmrf_debug_window6_variant), interleaved, min of 3
+    _l.nmrf_debug_window6_variant.restype = ctypes.c_int
+    hp, wp = 48, 156
+    qkv, table = mk("q", b * hp * wp * n, 384), mk("t", 121, 384)
+    q16 = K.to_kv16(qkv)
+    names = {0: "product (12 waves, Q parked in LDS)", 1: "8 waves, Q in registers", 2: "8 waves, Q parked", 3: "4 waves, Q in registers",
+             4: "12 waves, loads one tile ahead", 5: "8 waves, loads one tile ahead", 101: "- value-embedding term",
+             102: "- 4x4x4 pass (1 chunk of 8)", 104: "- P V MFMAs", 108: "- K Q^T MFMAs", 116: "- exponentials", 132: "- per-tile K / V loads",
+             131: "- all of the arithmetic above", 163: "- everything (loads + arithmetic)"}
+    best = {}
+    for rnd_ in range(3):
+        for v in names:
+            _l.nmrf_debug_window6_variant(v)
+            f = lambda: K.window_attn(q16, table, b, hp, wp, n, 4, 6, 3, True, kv16=True)
+            f(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                f()
+            e1.record(); torch.cuda.synchronize()
+            best[v] = min(best.get(v, 1e9), e0.elapsed_time(e1) * 1e3 / args.iters)
+    _l.nmrf_debug_window6_variant(0)
+    for v, nm in names.items():
+        print("window_attn6 batch %d  %-44s %8.1f us" % (b, nm, best[v]), flush=True)
+if "window6_stamps" in which:
+    # per-phase s_memtime timeline of a wave's first item in the persistent window kernel (timed instantiations of the debug build)
+    _l.nmrf_debug_window6_variant.restype = ctypes.c_int
+    _l.nmrf_debug_window6_stamps.restype = ctypes.c_int
+    hp, wp = 48, 156
+    qkv, table = mk("q", b * hp * wp * n, 384), mk("t", 121, 384)
+    q16 = K.to_kv16(qkv)
+    for v, nw, nm in ((10, 12, "12 waves per block"), (11, 8, "8 waves per block"), (12, 4, "4 waves per block")):
+        st = torch.zeros(256 * nw * 64, dtype=torch.int64, device=dev)
+        _l.nmrf_debug_window6_stamps(ctypes.c_void_p(st.data_ptr()))
+        _l.nmrf_debug_window6_variant(v)
+        for _ in range(3):
+            K.window_attn(q16, table, b, hp, wp, n, 4, 6, 3, True, kv16=True)
+        torch.cuda.synchronize()
+        _l.nmrf_debug_window6_variant(0)
+        t_ = st.view(256 * nw, 64).cpu().double()
+        t_ = t_[t_[:, 33] > 0]
+        d = lambda a, c: float((t_[:, a] - t_[:, c]).mean())
+        tiles = []
+        for kt in range(5):
+            prev = 1 if kt == 0 else 7 + 6 * (kt - 1)
+            tiles.append("[4x4x4 %5.0f | KQ %5.0f | softmax %5.0f | PV %5.0f | ev %5.0f]" % (d(2 + 6 * kt, prev), d(3 + 6 * kt, 2 + 6 * kt), d(4 + 6 * kt, 3 + 6 * kt),
+                                                                                           d(5 + 6 * kt, 4 + 6 * kt), d(7 + 6 * kt, 5 + 6 * kt)))
+        print("window_attn6 batch %d, %s: first item of %d waves: prologue %.0f cycles, item %.0f, store %.0f; tiles:" % (b, nm, len(t_), d(1, 0), d(33, 0), d(33, 32)))
+        for x in tiles:
+            print("    " + x)
 if "stripe" in which:
     qkv = mk("q2", b * h * w * n, 384)
     lv, lh = mk("lv", 64, 1, 3, 3), mk("lh", 64, 1, 3, 3)
