@@ -384,7 +384,7 @@ def window_table_packed(table, heads):
     return packed
 
 
-WINDOW6 = os.environ.get("NMRF_WINDOW6", "1") != "0"     # A/B: 0 = the two-windows-per-block kernel of rounds 2-5
+WINDOW6 = True      # tests / tools set False for the A/B against the two-windows-per-block kernel of rounds 2-5 (never read from the environment)
 
 
 @_on_device

@@ -339,9 +339,8 @@ if "window6_census" in which:
     hp, wp = 48, 156
     qkv, table = mk("q", b * hp * wp * n, 384), mk("t", 121, 384)
     q16 = K.to_kv16(qkv)
-    names = {0: "product (12 waves, Q parked in LDS)", 1: "8 waves, Q in registers", 2: "8 waves, Q parked", 3: "4 waves, Q in registers",
-             4: "12 waves, loads one tile ahead", 5: "8 waves, loads one tile ahead", 101: "- value-embedding term",
-             102: "- 4x4x4 pass (1 chunk of 8)", 104: "- P V MFMAs", 108: "- K Q^T MFMAs", 116: "- exponentials", 132: "- per-tile K / V loads",
+    names = {0: "product (8 waves per block)", 1: "12 waves per block", 3: "4 waves per block", 101: "- value-embedding term",
+             102: "- 4x4x4 passes (1 chunk of 8)", 104: "- P V MFMAs", 108: "- K Q^T MFMAs", 116: "- exponentials", 132: "- per-tile K / V loads",
              131: "- all of the arithmetic above", 163: "- everything (loads + arithmetic)"}
     best = {}
     for rnd_ in range(3):
@@ -365,7 +364,7 @@ if "window6_stamps" in which:
     hp, wp = 48, 156
     qkv, table = mk("q", b * hp * wp * n, 384), mk("t", 121, 384)
     q16 = K.to_kv16(qkv)
-    for v, nw, nm in ((10, 12, "12 waves per block"), (11, 8, "8 waves per block"), (12, 4, "4 waves per block")):
+    for v, nw, nm in ((10, 8, "8 waves per block"), (11, 12, "12 waves per block"), (12, 4, "4 waves per block")):
         st = torch.zeros(256 * nw * 64, dtype=torch.int64, device=dev)
         _l.nmrf_debug_window6_stamps(ctypes.c_void_p(st.data_ptr()))
         _l.nmrf_debug_window6_variant(v)
