@@ -423,9 +423,12 @@ int nmrf_selftest_lds_dma(const float *src, float *dst, int n_float4, void *stre
  *   wgrad   dW = dy^T . x     : A = dy (sa_i = 1, sa_k = N), B = x [T,K] (sb_k = K, sb_j = 1), reduction over the T tokens
  *   forward y  = x . W^T      : A = x [T,K] (sa_i = K, sa_k = 1), B = W (sb_k = 1, sb_j = K)                   (recomputation of saved-for-backward values)
  * splits > 1: the K range is cut into `splits` parts, part s writes its product to C + s*split_stride (>= M*ldc); the caller sums them.
+ * a_amax: NULL, or a DEVICE float holding max |A|: A is then multiplied by the power of two that puts that maximum at [2^13, 2^14) before
+ *   its fp16 split and the product scaled back -- for a GRADIENT operand (dy of a mean loss is ~1 / (B H W): unscaled, entries of 1e-6 ...
+ *   1e-7 would lose most of their bits in the split); B (weights, activations) is used as it is.
  * range_flag: the fp16 range guard of the split operands (see the top of this header), may be NULL. */
 int nmrf_gemm_split_f32(const float *A, int64_t sa_i, int64_t sa_k, const float *B, int64_t sb_k, int64_t sb_j, int M, int N, int K,
-                        float *C, int ldc, int splits, int64_t split_stride, int *range_flag, void *stream);
+                        float *C, int ldc, int splits, int64_t split_stride, const float *a_amax, int *range_flag, void *stream);
 /* out[i] = sum_{s < S} parts[s*stride + i], s ascending (i < n). */
 int nmrf_sum_partials_f32(const float *parts, int S, int64_t n, int64_t stride, float *out, void *stream);
 /* The same in groups: out[g*n + i] = sum over the parts s in [g*group, min(S, (g+1)*group)) -- a caller with many parts reduces in rounds

@@ -68,7 +68,7 @@ PROTOTYPES = {
     "nmrf_selftest_mfma_f32": [_P, _P, _I, _P, _P],
     "nmrf_selftest_mfma_f16split": [_P, _P, _I, _I, _P, _P],
     "nmrf_selftest_lds_dma": [_P, _P, _I, _P],
-    "nmrf_gemm_split_f32": [_P, _L, _L, _P, _L, _L, _I, _I, _I, _P, _I, _I, _L, _P, _P],
+    "nmrf_gemm_split_f32": [_P, _L, _L, _P, _L, _L, _I, _I, _I, _P, _I, _I, _L, _P, _P, _P],
     "nmrf_sum_partials_f32": [_P, _I, _L, _L, _P, _P],
     "nmrf_sum_partials_grouped_f32": [_P, _I, _L, _L, _I, _P, _P],
     "nmrf_colsum_partials_f32": [_P, _L, _I, _I, _P, _P],

@@ -19,6 +19,7 @@ struct GemmArgs {
     int ldc, tiles_n, n_tiles, cps;
     int64_t split_stride;
     int *range_flag;
+    const float *a_amax;      // device: max |A| (or NULL): A is multiplied by a power of two that puts this at [2^13, 2^14) before its split
 };
 
 // AK1 / BK1: the operand's k axis is contiguous, K % 8 == 0, rows 16-byte aligned: a lane's 8-run is two dwordx4 loads (with scalar loads
@@ -39,6 +40,20 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     float guard = 0.f;
+    // The unscaled split (split_mfma.h) keeps 22 bits down to |v| = 2^-3 and an ABSOLUTE error of 2^-25 below: fine for O(1) activations,
+    // not for a GRADIENT operand -- dy of a mean loss is ~1 / (B H W), 1e-6 ... 1e-7 at training sizes, where entries would lose most of
+    // their bits or flush to zero.  With a_amax the A operand is rescaled by an exact power of two first (as packed weights
+    // are) and the product is scaled back in the epilogue: errors relative to the tensor's largest entry, ~2^-38.
+    float a_mul = 1.f, c_mul = 1.f;
+    if (a.a_amax) {
+        const float m = *a.a_amax;
+        if (m > 0.f && m < INFINITY) {
+            const int e = (int)((__float_as_uint(m) >> 23) & 0xffu) - 127;         // floor(log2 m) (a subnormal maximum: e = -127, clamped below)
+            const int sh = 13 - (e < -100 ? -100 : e);
+            a_mul = ldexpf(1.0f, sh < 126 ? sh : 126);
+            c_mul = ldexpf(1.0f, -(sh < 126 ? sh : 126));
+        }
+    }
     // register double buffer: the operands of chunk c + 1 are requested before chunk c is split and multiplied (a lone wave per tile
     // otherwise sits out a full memory round trip per 16-deep chunk)
     auto fetch8 = [&](auto vec_tag, const float *p, int64_t sk, bool ok, int k0, float *v) {
@@ -64,6 +79,8 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs a) {
     for (int c = c0; c < c1; ++c) {
         if (c + 1 < c1) fetch(c + 1, an, bn);
         h16x8 ah, al, bh, bl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) av[e] *= a_mul;
         split8u_g(av, ah, al, guard);
         split8u_g(bv, bh, bl, guard);
         split_mma1(ah, al, bh, bl, acc);
@@ -77,18 +94,19 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = tm * 32 + mfma_row(r, kh);
-        if (row < a.M && jok) cp[(int64_t)row * a.ldc + j] = acc[r];
+        if (row < a.M && jok) cp[(int64_t)row * a.ldc + j] = acc[r] * c_mul;
     }
     split_guard_commit(guard, a.range_flag);
 }
 
 extern "C" int nmrf_gemm_split_f32(const float *A, int64_t sa_i, int64_t sa_k, const float *B, int64_t sb_k, int64_t sb_j, int M, int N,
-                                   int K, float *C, int ldc, int splits, int64_t split_stride, int *range_flag, void *stream) {
+                                   int K, float *C, int ldc, int splits, int64_t split_stride, const float *a_amax, int *range_flag,
+                                   void *stream) {
     if (!A || !B || !C) return NMRF_ENULL;
     if (M < 1 || N < 1 || K < 1 || ldc < N || splits < 1 || splits > 65535 || (splits > 1 && split_stride < (int64_t)M * ldc)) return NMRF_EINVAL;
     const int tiles_m = (M + 31) / 32, tiles_n = (N + 31) / 32, nchunks = (K + 15) / 16;
     const int cps = (nchunks + splits - 1) / splits;
-    GemmArgs a{A, B, C, M, N, K, sa_i, sa_k, sb_k, sb_j, ldc, tiles_n, tiles_m * tiles_n, cps, split_stride, range_flag};
+    GemmArgs a{A, B, C, M, N, K, sa_i, sa_k, sb_k, sb_j, ldc, tiles_n, tiles_m * tiles_n, cps, split_stride, range_flag, a_amax};
     const dim3 grid((unsigned)((a.n_tiles + 3) / 4), (unsigned)splits);
     hipStream_t st = (hipStream_t)stream;
     const bool k8 = K % 8 == 0;

@@ -1149,16 +1149,38 @@ def _sum_parts(parts, n, out=None):
     return out
 
 
-def _gemm(a, sa_i, sa_k, b, sb_k, sb_j, m, n, k, splits=1):
-    """C[m,n] = op(A) . op(B) on the split-fp16 MFMA with explicit element strides; splits > 1: K split + fixed-order sum."""
+_AMAX = {}
+
+
+def grad_amax(dy):
+    """max |dy| as a device scalar (no read-back), shared by the dgrad and the wgrad of one gradient tensor: nmrf_gemm_split_f32 rescales
+    its A operand from it by a power of two before the fp16 split (gradients of a mean loss are ~1 / (B H W), far below the range in
+    which the unscaled split keeps 22 bits).  One torch reduction per (tensor object, version) -- plumbing."""
+    import weakref
+    ent = _AMAX.get(id(dy))
+    key = (dy._version, dy.data_ptr())
+    if ent is not None and ent[0]() is dy and ent[1] == key:
+        return ent[2]
+    if len(_AMAX) > 64:
+        _AMAX.clear()
+    with torch.no_grad():
+        m = torch.linalg.vector_norm(dy.detach().reshape(-1), ord=float("inf")).reshape(1)
+    _AMAX[id(dy)] = (weakref.ref(dy), key, m)
+    return m
+
+
+def _gemm(a, sa_i, sa_k, b, sb_k, sb_j, m, n, k, splits=1, a_amax=None):
+    """C[m,n] = op(A) . op(B) on the split-fp16 MFMA with explicit element strides; splits > 1: K split + fixed-order sum.
+    a_amax: device scalar max |A| (grad_amax) when A is a gradient."""
     _chk(a, b)
     out = torch.empty(m, n, device=a.device, dtype=torch.float32)
     if splits <= 1:
-        _lib.check(_lib.load().nmrf_gemm_split_f32(_p(a), sa_i, sa_k, _p(b), sb_k, sb_j, m, n, k, _p(out), n, 1, 0, _rf(a), _stream()), "gemm_split")
+        _lib.check(_lib.load().nmrf_gemm_split_f32(_p(a), sa_i, sa_k, _p(b), sb_k, sb_j, m, n, k, _p(out), n, 1, 0, _p(a_amax), _rf(a),
+                                                   _stream()), "gemm_split")
         return out
     parts = torch.empty(splits, m, n, device=a.device, dtype=torch.float32)
-    _lib.check(_lib.load().nmrf_gemm_split_f32(_p(a), sa_i, sa_k, _p(b), sb_k, sb_j, m, n, k, _p(parts), n, splits, m * n, _rf(a), _stream()),
-               "gemm_split")
+    _lib.check(_lib.load().nmrf_gemm_split_f32(_p(a), sa_i, sa_k, _p(b), sb_k, sb_j, m, n, k, _p(parts), n, splits, m * n, _p(a_amax),
+                                               _rf(a), _stream()), "gemm_split")
     _sum_parts(parts.view(splits, m * n), m * n, out=out.view(-1))
     return out
 
@@ -1174,7 +1196,7 @@ def linear_forward(x, w):
 def linear_dgrad(dy, w):
     """dy [T,N], w [N,K] -> dx [T,K] = dy . w."""
     t, n = dy.shape
-    return _gemm(dy, n, 1, w, w.shape[1], 1, t, w.shape[1], n)
+    return _gemm(dy, n, 1, w, w.shape[1], 1, t, w.shape[1], n, a_amax=grad_amax(dy))
 
 
 @_on_device
@@ -1184,7 +1206,7 @@ def linear_wgrad(dy, x):
     k = x.shape[1]
     tiles = ((n + 31) // 32) * ((k + 31) // 32)
     splits = max(1, min(256, (t + 511) // 512, max(1, 2048 // tiles)))
-    return _gemm(dy, 1, n, x, k, 1, n, k, t, splits=splits)
+    return _gemm(dy, 1, n, x, k, 1, n, k, t, splits=splits, a_amax=grad_amax(dy))
 
 
 @_on_device

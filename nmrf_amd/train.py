@@ -29,23 +29,30 @@ def slice_parameters(model):
 
 
 def build_slice_optimizer(model, cfg):
-    """AdamW with the reference's parameter groups (build_optimizer, main.py:186-245) over the parameters the gradient graph reaches:
-    plain parameters at BASE_LR / WEIGHT_DECAY; normalisation layers at WEIGHT_DECAY_NORM; the relative-position tables of the window
-    attention without weight decay; a Swin trunk (`image_encoder.backbone.*`) at BASE_LR x BACKBONE_LR_DECAY / BACKBONE_WEIGHT_DECAY,
-    its bias tables without decay.  Every other parameter is frozen (requires_grad False): no kernel could fill its .grad."""
+    """AdamW with the reference's parameter groups, in the reference's ORDER (build_optimizer, main.py:186-245; an optimizer state dict
+    stores its groups by position, so `checkpoint_latest.pth` of either side loads into the other's optimizer) over the parameters the
+    gradient graph reaches: plain parameters at BASE_LR / WEIGHT_DECAY; modules named `*sampling_offsets*` (the MSDeformAttn offsets of
+    the Swin-T neck) at BASE_LR x 0.1 (main.py:217-218, 227-228); normalisation layers at WEIGHT_DECAY_NORM; a Swin trunk
+    (`image_encoder.backbone.*`) at BASE_LR x BACKBONE_LR_DECAY / BACKBONE_WEIGHT_DECAY, its bias tables without decay; the
+    relative-position tables of the window attention without weight decay.  Parameters outside the gradient graph are frozen
+    (requires_grad False: no kernel could fill their .grad); a parameter the caller froze beforehand STAYS frozen and joins no group,
+    as in the reference (main.py:206-207)."""
     keep = {id(p) for _, p in slice_parameters(model)}
     for p in model.parameters():
-        p.requires_grad_(id(p) in keep)
+        if id(p) not in keep:
+            p.requires_grad_(False)
     s = cfg.SOLVER
     norm_types = (torch.nn.BatchNorm2d, torch.nn.InstanceNorm2d, torch.nn.LayerNorm)
-    plain, norms, trunk, trunk_tab, enc_tab, seen = [], [], [], [], [], set()
+    plain, offsets, norms, trunk, trunk_tab, enc_tab, seen = [], [], [], [], [], [], set()
     for mname, module in model.named_modules():
         for pname, p in module.named_parameters(recurse=False):
-            if id(p) not in keep or id(p) in seen:
+            if id(p) not in keep or not p.requires_grad or id(p) in seen:
                 continue
             seen.add(id(p))
             if ("%s.%s" % (mname, pname)).startswith("image_encoder.backbone"):
                 (trunk_tab if "relative_position_bias_table" in pname else trunk).append(p)
+            elif "sampling_offsets" in mname:
+                offsets.append(p)
             elif "relative_position_enc_table" in pname:
                 enc_tab.append(p)
             elif isinstance(module, norm_types) and s.WEIGHT_DECAY_NORM is not None:
@@ -53,11 +60,12 @@ def build_slice_optimizer(model, cfg):
             else:
                 plain.append(p)
     groups = [{"params": plain, "lr": s.BASE_LR},
+              {"params": offsets, "lr": s.BASE_LR * 0.1},
               {"params": norms, "lr": s.BASE_LR, "weight_decay": s.WEIGHT_DECAY_NORM},
               {"params": trunk, "lr": s.BASE_LR * s.BACKBONE_LR_DECAY, "weight_decay": s.BACKBONE_WEIGHT_DECAY},
               {"params": trunk_tab, "lr": s.BASE_LR * s.BACKBONE_LR_DECAY, "weight_decay": 0.0},
               {"params": enc_tab, "lr": s.BASE_LR, "weight_decay": 0.0}]
-    return torch.optim.AdamW([g for g in groups if g["params"]], lr=s.BASE_LR, weight_decay=s.WEIGHT_DECAY)
+    return torch.optim.AdamW([g for g in groups if g["params"]], weight_decay=s.WEIGHT_DECAY)
 
 
 build_optimizer = build_slice_optimizer          # the reference's name (main.py:186): build_optimizer(model, cfg)
@@ -65,16 +73,24 @@ build_optimizer = build_slice_optimizer          # the reference's name (main.py
 
 def allreduce_gradients(params, group=None):
     """Average the gradients of `params` over the ranks of `group` with ONE all-reduce of a flat bucket (what DDP's reducer does
-    bucket by bucket, main.py:334-339); identity without a process group.  A parameter without a gradient on this rank contributes
-    zeros (DDP's find_unused_parameters semantics are not needed: the slice is the same on every rank)."""
+    bucket by bucket, main.py:334-339); identity without a process group.  A parameter whose .grad is None on EVERY rank keeps None
+    (AdamW then skips it, as with one rank: e.g. the propagation stage under the reference's weight_dict, which drops loss_prop) --
+    decided by a second, tiny all-reduce of a has-gradient mask, so that the result does not depend on the world size; a parameter
+    some rank has a gradient for takes zeros from the others."""
     params = [p for p in params if p.requires_grad]
     if not params or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return 0
-    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+    ref = next((p.grad for p in params if p.grad is not None), params[0])
+    has = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], device=ref.device, dtype=torch.float32)
+    dist.all_reduce(has, op=dist.ReduceOp.SUM, group=group)
+    live = [p for p, h in zip(params, has.tolist()) if h > 0]
+    if not live:
+        return 0
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in live])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     flat /= dist.get_world_size(group)
     off = 0
-    for p in params:
+    for p in live:
         n = p.numel()
         p.grad = flat[off:off + n].view_as(p).clone()
         off += n
@@ -86,7 +102,9 @@ def train_step(model, criterion, optimizer, sample, grad_clip=1.0, group=None):
     DATASETS.DIVIS_BY: the training-mode forward does not pad).  Returns (total loss as a float, the loss dict)."""
     if not getattr(model, "grad_slice", False):
         raise RuntimeError("call model.train().enable_grad_slice() first: without it the training-mode forward carries no autograd graph")
-    model.train()
+    if not model.training:
+        # (not model.train() here: it would put the BatchNorm layers fit() froze with freeze_bn() back into training mode, main.py:405-406)
+        raise RuntimeError("train_step needs the model in training mode: model.train(); model.freeze_bn() -- as fit() does per epoch")
     out = model(sample)
     dev = out["disp"].device
     loss_dict = criterion(out, {"disp": sample["disp"].to(dev).clone(), "valid": sample["valid"].to(dev)})

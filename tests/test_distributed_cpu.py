@@ -126,14 +126,16 @@ def _grad_worker(rank, world, port, q):
     try:
         from nmrf_amd.train import allreduce_gradients
         torch.manual_seed(0)
-        ps = [torch.nn.Parameter(torch.zeros(3, 5)), torch.nn.Parameter(torch.zeros(7)), torch.nn.Parameter(torch.zeros(2, 2))]
+        ps = [torch.nn.Parameter(torch.zeros(3, 5)), torch.nn.Parameter(torch.zeros(7)), torch.nn.Parameter(torch.zeros(2, 2)),
+              torch.nn.Parameter(torch.zeros(4))]
         ps[2].requires_grad_(False)                                   # frozen: not part of the bucket
         ps[0].grad = torch.full((3, 5), float(rank + 1))
         if rank == 0:
             ps[1].grad = torch.arange(7.0)                             # rank 1 has no gradient for this one: zeros
+        # ps[3]: trainable, but NO rank has a gradient (a loss term without weight): must stay None -- AdamW skips it as with one rank
         n = allreduce_gradients(ps)
         ok = (n == 22 and torch.allclose(ps[0].grad, torch.full((3, 5), 1.5)) and torch.allclose(ps[1].grad, torch.arange(7.0) / 2)
-              and ps[2].grad is None)
+              and ps[2].grad is None and ps[3].grad is None)
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

@@ -1207,6 +1207,34 @@ def test_backward_gemm_pieces_vs_fp64(t_, n, k):
     assert torch.equal(db, kk.bias_grad(dy.to(DEV)))
 
 
+@pytest.mark.parametrize("mag", [1e-4, 1e-6, 1e-7, 3e-9])
+def test_backward_gemm_small_gradients_keep_their_bits(mag):
+    """dy of a mean loss is ~1 / (B H W) -- 1e-6 ... 1e-7 at training sizes -- where the UNSCALED fp16 split of an operand
+    (absolute error 2^-25, flush below 3e-8) would lose most of a gradient's bits (17 % rms error at 1e-7 in a CPU emulation).  The
+    GEMM rescales its gradient operand by a power of two from the tensor's device-side maximum: dgrad / wgrad of entries of this size,
+    with a 1000x spread inside the tensor, against fp64 RELATIVE to the result's size."""
+    kk = K()
+    t_, n, k = 3000, 128, 128
+    x, w = rnd(t_, k, seed=1, scale=1.5), rnd(n, k, seed=2, scale=0.2)
+    dy = rnd(t_, n, seed=3) * mag
+    dy[::7] *= 1e-3                                                  # rows three orders of magnitude below the largest
+    xd, wd, dyd = x.double(), w.double(), dy.double()
+    dx = kk.linear_dgrad(dy.to(DEV), w.to(DEV)).cpu().double()
+    ref = dyd @ wd
+    err = float((dx - ref).abs().max() / ref.abs().max())
+    assert err < 2e-6, f"dgrad relative error {err:.2e} at |dy| ~ {mag:g}"
+    small = float(((dx - ref)[::7].abs().max()) / ref[::7].abs().max())    # the small rows on their own scale
+    assert small < 2e-3, f"dgrad of the 1000x smaller rows: relative error {small:.2e}"
+    dw = kk.linear_wgrad(dy.to(DEV), x.to(DEV)).cpu().double()
+    refw = dyd.T @ xd
+    errw = float((dw - refw).abs().max() / refw.abs().max())
+    assert errw < 5e-6, f"wgrad relative error {errw:.2e} at |dy| ~ {mag:g}"
+    assert torch.isfinite(dx).all() and torch.isfinite(dw).all()
+    # an all-zero gradient (amax = 0): no scaling, zeros out
+    z = torch.zeros(64, n, device=DEV)
+    assert float(kk.linear_dgrad(z, w.to(DEV)).abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("t_,c", [(64, 128), (1000, 128), (333, 64), (50, 512)])
 def test_backward_elementwise_pieces_vs_fp64(t_, c):
     kk = K()

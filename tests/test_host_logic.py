@@ -256,6 +256,62 @@ def test_kv16_format_restatement_against_a_scalar_reading_of_the_header():
             assert abs(float(np.float32(hv) + np.float32(lv)) - float(x[t, 256 + c])) <= 2.0 ** -21 * abs(float(x[t, 256 + c])) + 2.0 ** -25     # (lo goes subnormal below |x| ~ 2^-3: absolute 2^-25, split_mfma.h)
 
 
+def test_optimizer_groups_follow_the_reference_order_incl_sampling_offsets():
+    """build_optimizer of main.py:186-245 gives modules named `*sampling_offsets*` (MSDeformAttn, Swin-T neck) BASE_LR x 0.1
+    and lists its groups in a fixed order (plain, offsets, norms, trunk, trunk bias tables, enc tables): an optimizer state dict stores
+    groups by position, so the layout must match for `checkpoint_latest.pth` to resume on either side.  Also: a parameter frozen by the
+    caller stays frozen (main.py:206-207), and train_step does not flip BatchNorm back into training mode."""
+    from nmrf_amd.config import get_cfg
+    from nmrf_amd.models import build_model
+    from nmrf_amd.train import build_slice_optimizer
+    cfg = get_cfg()
+    cfg.merge_from_list(["BACKBONE.MODEL_TYPE", "swin", "BACKBONE.OUT_CHANNELS", 128, "DATASETS.DIVIS_BY", 32, "SOLVER.WEIGHT_DECAY_NORM", 0.002,
+                         "SOLVER.BACKBONE_LR_DECAY", 0.5])
+    cfg.freeze()
+    model = build_model(cfg)[0].train().enable_grad_slice(full=True)
+    names = {id(p): k for k, p in model.named_parameters()}
+    pinned = next(p for k, p in model.named_parameters() if k.endswith("infer_head.layers.0.weight"))
+    pinned.requires_grad_(False)
+    opt = build_slice_optimizer(model, cfg)
+    assert not pinned.requires_grad and all(id(pinned) != id(p) for g in opt.param_groups for p in g["params"])
+    kinds = []
+    for g in opt.param_groups:
+        ks = [names[id(p)] for p in g["params"]]
+        if all("sampling_offsets" in k for k in ks):
+            kinds.append("offsets")
+            assert abs(g["lr"] - cfg.SOLVER.BASE_LR * 0.1) < 1e-15 and g["weight_decay"] == cfg.SOLVER.WEIGHT_DECAY and len(ks) >= 2
+        elif all(k.startswith("image_encoder.backbone") for k in ks):
+            kinds.append("trunk_tab" if all("relative_position_bias_table" in k for k in ks) else "trunk")
+            assert abs(g["lr"] - cfg.SOLVER.BASE_LR * 0.5) < 1e-15
+        elif all("relative_position_enc_table" in k for k in ks):
+            kinds.append("enc_tab")
+            assert g["weight_decay"] == 0.0
+        elif g["weight_decay"] == 0.002:
+            kinds.append("norms")
+        else:
+            kinds.append("plain")
+            assert not any("sampling_offsets" in k for k in ks) and g["lr"] == cfg.SOLVER.BASE_LR
+    # (the trunk groups key on the prefix `image_encoder.backbone`, main.py:213, which no module of NMRF carries -- the Swin trunk lives
+    #  under `backbone.` -- so they are empty on both sides; the order of the others is the reference's)
+    order = ["plain", "offsets", "norms", "trunk", "trunk_tab", "enc_tab"]
+    assert kinds == [k for k in order if k in kinds] and {"plain", "offsets", "norms", "enc_tab"} <= set(kinds), kinds
+    # the reference's own function on the same module tree (parameter names are the strict-load contract): identical group layout
+    ref_main = os.path.join("/root/reference", "main.py")
+    if os.path.exists(ref_main):
+        import ast
+        src = open(ref_main).read()
+        fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "build_optimizer")
+        scope = {"torch": torch}
+        exec(compile(ast.Module(body=[fn], type_ignores=[]), ref_main, "exec"), scope)
+        pinned.requires_grad_(False)
+        ref_opt = scope["build_optimizer"](model, cfg)
+        assert len(ref_opt.param_groups) == len(opt.param_groups)
+        for a, b in zip(ref_opt.param_groups, opt.param_groups):
+            assert [id(p) for p in a["params"]] == [id(p) for p in b["params"]]
+            assert abs(a["lr"] - b["lr"]) < 1e-15 and a["weight_decay"] == b["weight_decay"]
+        opt.load_state_dict(ref_opt.state_dict())                     # a reference `checkpoint_latest.pth` resumes here
+
+
 def test_training_host_side_optimizer_groups_schedule_and_checkpoints(tmp_path):
     """nmrf_amd.train, host side (no GPU): the optimizer groups of main.py:186-245 on the whole model (relative-position tables without
     weight decay, LayerNorm parameters at WEIGHT_DECAY_NORM), the OneCycle schedule of main.py:380-388, and the two checkpoint layouts of

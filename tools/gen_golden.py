@@ -15,6 +15,8 @@ Fixtures
   e2e_c.npz   40x72,  MAX_DISP 128, B=2 (two different pairs): small outputs
   e2e_d.npz   136x1032, MAX_DISP 320 (D=40), B=2: small outputs; 1/8 grid 17x129 = 17 key tiles per horizontal stripe
               (the long-loop stripe kernel of the KITTI bench), images regenerated from (h, w, seed)
+  e2e_k384.npz  48x392, MAX_DISP 384 (D=48: configs/kitti_mix_train.yaml:7, kitti_mix_2015_train.yaml:7), B=1: outputs + stage tensors
+  e2e_z312.npz  40x320, MAX_DISP 312 (D=39, odd: configs/zero_shot_evaluation.yaml:11), B=1: outputs + stage tensors
   nms_cases.npz   crafted logits rows (ties, plateaus, NaN, ...) pushed through
               the reference's DPN.forward NMS+topk (DPN.py:119-125), D in {16,24,32,40,48}
   e2e_swin.npz / state_dict_keys.json   Swin-T + DeformNeck config: encoder features + outputs; key/shape listings
@@ -113,6 +115,13 @@ def run_e2e(name, shapes_seeds, opts, full, store_images=True):
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **d)
     print(name, {k: v.shape for k, v in d.items() if hasattr(v, "shape")}, os.path.getsize(path) // 1024, "KiB")
+
+
+def run_shipped_disp():
+    """The disparity ranges of the reference's other shipped configs: MAX_DISP 384 -> D = 48 (the KITTI training
+    configs) and MAX_DISP 312 -> D = 39, an odd number of hypotheses (zero-shot evaluation)."""
+    run_e2e("e2e_k384", [(48, 392, 1020)], ["DPN.MAX_DISP", 384], full="stages")
+    run_e2e("e2e_z312", [(40, 320, 1021)], ["DPN.MAX_DISP", 312], full="stages")
 
 
 def run_train():
@@ -469,6 +478,9 @@ if __name__ == "__main__":
     if "--train-b2-only" in sys.argv:
         run_train_b2()
         sys.exit(0)
+    if "--shipped-disp-only" in sys.argv:
+        run_shipped_disp()
+        sys.exit(0)
     if "--post-only" in sys.argv:
         run_e2e("e2e_post", [(52, 100, 1006)], ["DPN.MAX_DISP", 128, "NMP.NORMALIZE_BEFORE", False], full=True)
         sys.exit(0)
@@ -489,6 +501,7 @@ if __name__ == "__main__":
     run_e2e("e2e_d", [(136, 1032, 1004), (136, 1032, 1005)], [], full=False, store_images=False)
     # NMP.NORMALIZE_BEFORE False (no shipped config sets it): the forward_post form of every message-passing block
     run_e2e("e2e_post", [(52, 100, 1006)], ["DPN.MAX_DISP", 128, "NMP.NORMALIZE_BEFORE", False], full=True)
+    run_shipped_disp()
     run_nms()
     run_msda()
     run_swin()
