@@ -137,7 +137,7 @@ def test_dpn_filter_softmax_and_golden_prob():
         report(f"prob P={pp} G={gg} D={d}", got, want, 3e-6)
 
 
-@pytest.mark.parametrize("d", [16, 24, 32, 40, 48])
+@pytest.mark.parametrize("d", [16, 24, 32, 39, 40, 48])
 def test_nms_topk_crafted_cases_bit_exact(d):
     g = golden("nms_cases")
     prob = t(g[f"prob_{d}"])
@@ -173,7 +173,7 @@ def test_nms_topk_every_rows_per_wave_variant(rows):
 
 
 def test_nms_topk_on_reference_prob_gives_reference_seeds():
-    for name in ("e2e_a", "e2e_b", "e2e_c"):
+    for name in ("e2e_a", "e2e_b", "e2e_c", "e2e_k384", "e2e_z312"):
         g = golden(name)
         got = K().nms_topk(t(g["prob"]).to(DEV), 4, 1e-3).cpu()
         assert torch.equal(got, t(g["seeds"]).long().reshape(-1, 4)), name
@@ -185,7 +185,7 @@ def _select_seeds(prob, k=4, eps=1e-3, do_nms=True):
     return K().seed_select(prob.to(DEV), vol, k, eps, 3.14 / 64, 31, do_nms=do_nms)[0].cpu()
 
 
-@pytest.mark.parametrize("d", [24, 32, 40])
+@pytest.mark.parametrize("d", [16, 24, 32, 39, 40, 48])
 def test_seed_select_crafted_cases_bit_exact(d):
     """The register / scalar-unit form of NMS + top-k (csrc/seed.hip seed_select_kernel) on every crafted row of the reference
     fixture: plateaus, all-tied rows, values at eps, NaN, signed zeros -- same indices in the same order as ATen's CPU top-k."""
@@ -227,7 +227,7 @@ def test_seed_select_features_equal_the_two_kernel_path():
         wc, we = K().seed_features(vol.to(DEV), want, 3.14 / 64, ld)
         assert torch.equal(seeds, want.cpu()) and torch.equal(seeds_f, want.cpu().float())
         assert torch.equal(cost, wc.cpu()) and torch.equal(enc, we.cpu())
-    for name in ("e2e_a", "e2e_b", "e2e_c"):
+    for name in ("e2e_a", "e2e_b", "e2e_c", "e2e_k384", "e2e_z312"):
         g = golden(name)
         assert torch.equal(_select_seeds(t(g["prob"])), t(g["seeds"]).long().reshape(-1, 4)), name
 

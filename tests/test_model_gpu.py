@@ -48,10 +48,12 @@ def _weights_of(g):
     return "trained" if "train_steps" in g else "hash"
 
 
-@pytest.mark.parametrize("name", ["e2e_a", "e2e_b", "e2e_c", "e2e_d", "e2e_t", "e2e_post"])
+@pytest.mark.parametrize("name", ["e2e_a", "e2e_b", "e2e_c", "e2e_d", "e2e_t", "e2e_post", "e2e_k384", "e2e_z312"])
 def test_hot_path_from_reference_features(name):
     """e2e_t: the same chain on the TRAINED reference checkpoint (tests/golden/trained_sd.npz through load_state_dict), with the
     largest |activation| each split-fp16 stage saw printed beside the 65 520 limit of csrc/split_mfma.h.
+    e2e_k384 / e2e_z312: the disparity ranges of the reference's other shipped configs -- MAX_DISP 384 (D = 48, configs/kitti_mix_train.yaml:7) and
+    MAX_DISP 312 (D = 39, an odd number of hypotheses, configs/zero_shot_evaluation.yaml:11).
     e2e_post: NMP.NORMALIZE_BEFORE False -- the forward_post form of every message-passing block (NMP.py:110-135, 366-382, 576-591; no shipped
     config sets it), un-fused on the HIP split GEMM / LayerNorm / attention kernels."""
     g = golden(name)
@@ -85,7 +87,7 @@ def test_hot_path_from_reference_features(name):
         check_chain(name, cand, base, refine_from)
 
 
-@pytest.mark.parametrize("name", ["e2e_a", "e2e_b"])
+@pytest.mark.parametrize("name", ["e2e_a", "e2e_b", "e2e_k384", "e2e_z312"])
 def test_stages_from_reference_inputs(name):
     """Each stage of the GPU path fed with the reference's own stage inputs (goldens e2e_a: D=16, e2e_b: D=40, the default
     MAX_DISP), so the ~1e3x Fourier amplification of upstream fp32 noise cannot mask or fake an error."""

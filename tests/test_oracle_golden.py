@@ -110,7 +110,9 @@ def _weights_of(g):
     return "trained" if "train_steps" in g else "hash"
 
 
-@pytest.mark.parametrize("name", ["e2e_a", "e2e_b", "e2e_c", "e2e_d", "e2e_t"])
+# e2e_k384 / e2e_z312: the disparity ranges of the reference's other shipped configs (MAX_DISP 384 -> D = 48: configs/kitti_mix_train.yaml:7;
+# MAX_DISP 312 -> D = 39, odd: configs/zero_shot_evaluation.yaml:11)
+@pytest.mark.parametrize("name", ["e2e_a", "e2e_b", "e2e_c", "e2e_d", "e2e_t", "e2e_k384", "e2e_z312"])
 def test_end_to_end_outputs(name):
     """Whole forward vs the reference.  Seeds are bit-exact, probabilities 2e-6, proposals 5e-5; the final disparity is held to
     the contract of BASELINE.json (EPE within 1e-3 px; measured 3e-5 ... 1.2e-4) plus a median and an outlier bound, because
@@ -129,7 +131,7 @@ def test_end_to_end_outputs(name):
     assert st["epe"] < 1e-3 and st["median"] < 2e-4 and st["frac_gt_0p5"] < 2e-3, st       # the CPU oracle meets the raw contract
 
 
-@pytest.mark.parametrize("name", ["e2e_a", "e2e_b", "e2e_t"])
+@pytest.mark.parametrize("name", ["e2e_a", "e2e_b", "e2e_t", "e2e_k384", "e2e_z312"])
 def test_wta_inputs_vs_reference_captures(name):
     """The tensors entering the winner-take-all (NMRF.py:218-228): the oracle's candidates / scores against forward-hook captures
     of the reference's infer_head / infer_score_head outputs, and the decision itself: same winner except at near-ties
@@ -203,7 +205,7 @@ def c_nms_topk(lib, prob, k, eps, do_nms=1):
     return out
 
 
-@pytest.mark.parametrize("d", [16, 24, 32, 40, 48])
+@pytest.mark.parametrize("d", [16, 24, 32, 39, 40, 48])
 def test_nms_topk_crafted_cases(d, liboracle):
     g = golden("nms_cases")
     logits, prob_ref, seeds_ref = t(g[f"logits_{d}"]), t(g[f"prob_{d}"]), g[f"seeds_{d}"].astype(np.int64)

@@ -18,7 +18,7 @@ Fixtures
   e2e_k384.npz  48x392, MAX_DISP 384 (D=48: configs/kitti_mix_train.yaml:7, kitti_mix_2015_train.yaml:7), B=1: outputs + stage tensors
   e2e_z312.npz  40x320, MAX_DISP 312 (D=39, odd: configs/zero_shot_evaluation.yaml:11), B=1: outputs + stage tensors
   nms_cases.npz   crafted logits rows (ties, plateaus, NaN, ...) pushed through
-              the reference's DPN.forward NMS+topk (DPN.py:119-125), D in {16,24,32,40,48}
+              the reference's DPN.forward NMS+topk (DPN.py:119-125), D in {16,24,32,39,40,48}
   e2e_swin.npz / state_dict_keys.json   Swin-T + DeformNeck config: encoder features + outputs; key/shape listings
   e2e_train.npz   the reference in TRAINING mode (forward only): aux_outputs of every inference / refinement layer + its Criterion's
               losses on them (see run_train)
@@ -401,7 +401,7 @@ def crafted_logits(d, rows_per_kind=24):
 
 def run_nms():
     out = {}
-    for dmax in (128, 192, 256, 320, 384):
+    for dmax in (128, 192, 256, 312, 320, 384):                       # D = 16, 24, 32, 39 (zero_shot_evaluation.yaml), 40, 48
         d = dmax // 8
         model, cfg = refshim.build_reference_model(["DPN.MAX_DISP", dmax])
         apply_hash_weights(model)
@@ -477,6 +477,9 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if "--train-b2-only" in sys.argv:
         run_train_b2()
+        sys.exit(0)
+    if "--nms-only" in sys.argv:
+        run_nms()
         sys.exit(0)
     if "--shipped-disp-only" in sys.argv:
         run_shipped_disp()
