@@ -33,6 +33,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, v
 FP16_MFMA_PEAK_TFLOPS = 2500.0       # same guide: dense fp16 / bf16 MFMA (v_mfma_f32_32x32x16_f16)
 SPLIT_MFMA_PEAK_TFLOPS = FP16_MFMA_PEAK_TFLOPS / 3     # split-operand kernels execute 3 fp16 MFMAs per algorithmic product
 HBM_PEAK_GBS = 8000.0                # same guide: HBM3E ~8 TB/s
+BOOST_CLOCK_GHZ = 2.4                 # same guide: the engine clock its peak figures are quoted at
 
 
 def parse(argv=None):
@@ -107,7 +108,8 @@ def cpu_baseline(height, width, infer_layers, max_disp=320):
     host cores, same synthetic pairs, batch 1 (both 1242x375 and 960x540, all host cores, and a 1-thread figure).
     The op-by-op CPU path stops scaling at ~16 threads, so each size is timed on 16 threads AND on every core of the host;
     `value` / `cores` is the faster of the two at the bench's own size, the other numbers ride along.  A bounded sample:
-    per size 1 warm-up + median of 3 forwards (16 threads) and 1 warm-up + 2 forwards (all cores); one forward on 1 thread."""
+    1 warm-up + median of 5 forwards on 16 threads at the bench's own size (3 at the other size) and 1 warm-up + 2 forwards on all
+    cores; one forward on 1 thread."""
     from oracle import nmrf_oracle as O
     from nmrf_amd.config import get_cfg
     from nmrf_amd.models import build_model
@@ -128,7 +130,7 @@ def cpu_baseline(height, width, infer_layers, max_disp=320):
                 O.forward(w, ocfg, l[None], r[None])
                 ts.append(time.perf_counter() - t0)
         ts = sorted(ts[1:])
-        return ts[len(ts) // 2] if len(ts) % 2 else ts[0]           # median of 3 / the better of 2
+        return ts[len(ts) // 2] if len(ts) % 2 else ts[0]           # median of 5 or 3 / the better of 2
 
     # the all-core run is attempted only if it is not a collapse: on a 256-thread host the op-by-op path with every core is three
     # orders of magnitude SLOWER than with 16 threads (thread wake-ups dominate the small ATen ops); a micro-probe of one small
@@ -155,7 +157,7 @@ def cpu_baseline(height, width, infer_layers, max_disp=320):
 
     def one_size(h, wd, with_1thread):
         l, r, _ = synthetic_pair(h, wd, seed=1000)
-        rec = {"threads_%d_s" % n16: round(timed(l, r, n16, 3), 3)}
+        rec = {"threads_%d_s" % n16: round(timed(l, r, n16, 5 if with_1thread else 3), 3)}      # the bench's own size: SURVEY 8(d)'s median of 5
         if cores > n16 and all_cores_ok:
             rec["threads_%d_s" % cores] = round(timed(l, r, cores, 2), 3)
         if with_1thread:
@@ -182,8 +184,8 @@ def cpu_baseline(height, width, infer_layers, max_disp=320):
             "all_cores_probe": probe if probe is None else dict(probe, full_size_run=all_cores_ok),
             "seconds_per_forward": sizes,
             "pairs_per_s": {sz: {k[:-2]: round(1.0 / v, 4) for k, v in rec.items()} for sz, rec in sizes.items()},
-            "sample": "one synthetic pair per size, batch 1 (oracle/nmrf_oracle.py, torch CPU fp32): per size 1 warm-up + median of 3 "
-                      "forwards on 16 threads and -- unless a one-op probe shows the all-core run collapsing (all_cores_probe) -- 1 warm-up + "
+            "sample": "one synthetic pair per size, batch 1 (oracle/nmrf_oracle.py, torch CPU fp32): 1 warm-up + median of 5 forwards on 16 "
+                      "threads at the bench's own size (median of 3 at the other size) and -- unless a one-op probe shows the all-core run collapsing (all_cores_probe) -- 1 warm-up + "
                       "the better of 2 on all %d host cores; one forward on 1 thread at %dx%d; `value` = the faster thread count at "
                       "%dx%d (%d threads, %.2f s)" % (cores, width, height, width, height, nthr, dt)}
 
@@ -436,8 +438,19 @@ def run(args):
         os.environ["NMRF_OVERLAP"] = "0"
         timer.enabled = True
         n_timed_fwd = max(3, min(args.steps, 10))
-        for _ in range(n_timed_fwd):
-            step()
+        # (the arguments of one launch of the pair kernel are kept: the clock sampling below replays exactly that launch)
+        pair_call, pair_orig = [], K.nmp_block_pair
+
+        def _pair_tap(*a, **kw):
+            if not pair_call and len(a) > 1 and a[1] is not None:
+                pair_call.append((a, kw))
+            return pair_orig(*a, **kw)
+        K.nmp_block_pair = _pair_tap
+        try:
+            for _ in range(n_timed_fwd):
+                step()
+        finally:
+            K.nmp_block_pair = pair_orig
         overlapped.finish()
         torch.cuda.synchronize()
         timer.enabled = False
@@ -446,6 +459,29 @@ def run(args):
         else:
             os.environ["NMRF_OVERLAP"] = prev_overlap
         kstats = timer.stats()
+
+        # The shader clock under the dominant kernel: the peaks of MI355X_MICROARCH.md are quoted at the 2.4 GHz boost
+        # clock, under matrix-heavy kernels the chip holds less.  Every block of the pair kernel records its CU's shader-clock counter and
+        # the chip's 100 MHz counter at entry and exit (nmrf_nmp_block16_clock_records) during 320 back-to-back launches of the launch
+        # captured above; the records of the last launch are read.
+        clocks = None
+        if pair_call:
+            try:
+                pa, pkw = pair_call[0]
+                kh, K.kernel_hook = K.kernel_hook, None
+                try:
+                    pair_orig(*pa, **pkw)
+                    with K.BlockKernelClock(dev) as cs:
+                        for _ in range(320):
+                            pair_orig(*pa, **pkw)
+                finally:
+                    K.kernel_hook = kh
+                clocks = {"nmp_block_pair": round(cs.ghz, 4), "min_max_over_blocks": [round(cs.ghz_min, 4), round(cs.ghz_max, 4)],
+                          "blocks": cs.blocks, "block_life_us": round(cs.block_us, 2),
+                          "how": "s_memtime per s_memrealtime (100 MHz) between entry and exit of every block of the last of 320 "
+                                 "back-to-back launches of the dominant kernel (nmrf_nmp_block16_clock_records), summed over its blocks"}
+            except Exception as e:
+                clocks = {"error": repr(e)}
 
         # hot-path-only time (everything after the backbone)
         hp_ms = None
@@ -562,6 +598,11 @@ def run(args):
             for key in ("mfma_busy", "lds_bank_conflict_ratio"):
                 if key in pr:
                     rec[key] = pr[key]
+        if isinstance(clocks, dict) and clocks.get("nmp_block_pair") and k.startswith("nmp_block") and bound == "mfma":
+            # the matrix peak scales with the clock (2.4 GHz is what MI355X_MICROARCH.md's figure assumes); measured inside the pair
+            # kernel, applied to the block kernels (the same instruction mix; profiles/r04k_block_timeline.txt saw the same clock)
+            rec["sustained_clock_ghz"] = clocks["nmp_block_pair"]
+            rec["frac_at_sustained_clock"] = round(ach / (peak * clocks["nmp_block_pair"] / BOOST_CLOCK_GHZ), 4)
         if timer.mean_meta(k, "direct_flops"):
             df = timer.mean_meta(k, "direct_flops")
             rec["direct_form"] = {"flop_per_launch": df, "tflops": round(df / (ms * 1e-3) / 1e12, 2),
@@ -603,6 +644,7 @@ def run(args):
             "config4": config4,
             "roofline": roof,
             "other_kernels": others,
+            "sustained_clock_ghz": clocks,
         }
         if stream_rec is not None:
             res["stream_end_to_end"] = stream_rec

@@ -40,7 +40,13 @@ const char *nmrf_strerror(int code);
  * in a separate pass when range_flag != NULL; pass NULL when qkv was produced by nmrf_nmp_block16_f32, which range-checks its q_out. */
 int nmrf_range_scan_f32(const float *x, int64_t n, int *range_flag, void *stream);   /* n % 4 == 0, x 16-byte aligned */
 /* ABI version of this header; bumps on any signature change. */
-int nmrf_abi_version(void);   /* currently 26 */
+#define NMRF_ABI_VERSION 27
+#define NMRF_ABI_STR "27"
+int nmrf_abi_version(void);   /* = NMRF_ABI_VERSION */
+/* "abi<version>-<16 hex digits>": the digits are a hash of every source and header the library was built from (python -m
+ * nmrf_amd.build).  The tools library (libnmrf_hip_debug.so) of the same build returns the same string; the binding refuses one that
+ * does not.  No counterpart in the reference (its extension is built by setup.py into site-packages, ops/setup.py:66-71). */
+const char *nmrf_build_stamp(void);
 
 /* A2  group-wise correlation volume.
  * replaces build_correlation_volume + the permute of DPN.forward
@@ -410,6 +416,14 @@ int nmrf_selftest_mfma_f16split(const float *A, const float *Bm, int K, int mode
 /* Self-test of the LDS-DMA path (global_load_lds_dwordx4) the weight streams use: dst[t] = src[t ^ 65] within each
  * 256-float4 block, routed through LDS.  n_float4 % 256 == 0. */
 int nmrf_selftest_lds_dma(const float *src, float *dst, int n_float4, void *stream);
+
+/* Measurement hook (bench.py's `sustained_clock_ghz`): while buf != NULL, every block of the nmrf_nmp_block16_f32 /
+ * nmrf_nmp_block16_pair_f32 launches of this process writes {shader-clock counter at entry, at exit, the chip's 100 MHz counter at
+ * entry, at exit} to buf[4 * block ..] (device memory, uint64; launches of more than capacity_blocks blocks are not recorded; the grid
+ * is min(tiles, CUs)).  sum(exit - entry of the first) / sum(of the second) x 100 MHz = the clock the CUs ran at under that kernel --
+ * the peak figures of the roofline assume the 2.4 GHz boost clock.  buf == NULL switches the hook off (the default; a kernel argument
+ * tested once per block).  No counterpart in the reference: its timing is wall-clock (nmrf/utils/evaluation.py:222-226). */
+int nmrf_nmp_block16_clock_records(unsigned long long *buf, int capacity_blocks);
 
 /* ---- N4, first slice: the pieces of a backward pass through the token-linear chains (csrc/backward.hip) -------------
  * The reference differentiates its whole forward with autograd (nmrf/models/NMRF.py:387-429 losses, main.py:413-430 step).  Here the

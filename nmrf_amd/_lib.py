@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnmrf_hip.so")      # (tools may point this at another build BEFORE the first load(): bench.py --lib)
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
@@ -58,6 +58,8 @@ PROTOTYPES = {
     "nmrf_prep_images_s2d_u8": [_P, _P, _I, _I, _I, _I, _I, _P, _P],
     "nmrf_prep_images_u8": [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "nmrf_range_scan_f32": [_P, _L, _P, _P],
+    "nmrf_nmp_block16_clock_records": [_P, _I],
+    "nmrf_build_stamp": [],
     "nmrf_host_copy_nt": [_P, _P, ctypes.c_size_t],
     "nmrf_host_read_evict": [_P, _P, ctypes.c_size_t],
     "nmrf_conv3x3_split_f32": [_P, _I, _I, _I, _I, _P, _I, _F, _P, _I, _I, _F, _I, _P, _P, _P],
@@ -121,6 +123,7 @@ def load():
         fn.restype = _I
     lib.nmrf_strerror.argtypes = [_I]
     lib.nmrf_strerror.restype = ctypes.c_char_p
+    lib.nmrf_build_stamp.restype = ctypes.c_char_p
     ver = lib.nmrf_abi_version()
     if ver != ABI_VERSION:
         raise NmrfHipError("libnmrf_hip.so ABI %d != binding ABI %d: rebuild" % (ver, ABI_VERSION))
@@ -144,6 +147,14 @@ def load_debug():
         fn.restype = _I
     if lib.nmrf_abi_version() != ABI_VERSION:
         raise NmrfHipError("libnmrf_hip_debug.so ABI %d != binding ABI %d: rebuild" % (lib.nmrf_abi_version(), ABI_VERSION))
+    lib.nmrf_build_stamp.restype = ctypes.c_char_p
+    # the tools library must come from the same sources as the product library it is compared with (an A/B library named through
+    # LIB_PATH is exempt: different sources are its point)
+    if os.path.abspath(LIB_PATH) == os.path.join(_HERE, "lib", "libnmrf_hip.so"):
+        want, got = load().nmrf_build_stamp().decode(), lib.nmrf_build_stamp().decode()
+        if want != got:
+            raise NmrfHipError("libnmrf_hip_debug.so was built from other sources than libnmrf_hip.so (%s vs %s): "
+                               "python -m nmrf_amd.build" % (got, want))
     _dbg = lib
     return lib
 

@@ -35,6 +35,32 @@ def _sources(debug=False):
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip") and (debug or f not in DEBUG_ONLY))
 
 
+def source_stamp():
+    """sha256/16 over every source and header a library is built from (names + contents, both libraries hash the same set: the
+    tools library is a superset build of the same tree)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")) and not f.startswith("_ab_"))
+    files += [os.path.join(os.path.dirname(HERE), "include", f) for f in ("nmrf_hip.h", "nmrf_hip_debug.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+        h.update(b"\0")
+    return h.hexdigest()[:16]
+
+
+def library_stamp(path):
+    """nmrf_build_stamp() of a built library ("abi<N>-<hash>"), or None if it cannot be read."""
+    import ctypes
+    try:
+        lib = ctypes.CDLL(path)
+        lib.nmrf_build_stamp.restype = ctypes.c_char_p
+        return lib.nmrf_build_stamp().decode()
+    except (OSError, AttributeError):
+        return None
+
+
 def _deps_mtime():
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "nmrf_hip.h"))
@@ -54,12 +80,19 @@ def build_library(force=False, verbose=True, debug=False):
     hdr_t = _deps_mtime()
     jobs = []
     objs = []
+    stamp = source_stamp()
+    stamp_file = os.path.join(objdir, "build_stamp.txt")
+    old_stamp = open(stamp_file).read().strip() if os.path.exists(stamp_file) else None
     for src in _sources(debug):
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t)
+        extra = []
+        if os.path.basename(src) == "build_stamp.hip":            # carries the hash of the whole tree: rebuilt whenever that changes
+            stale = stale or old_stamp != stamp
+            extra = ['-DNMRF_BUILD_STAMP="%s"' % stamp]
         if stale:
-            jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + flags + extra + ["-c", src, "-o", obj])
 
     def run(cmd):
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -72,6 +105,8 @@ def build_library(force=False, verbose=True, debug=False):
                     print("[nmrf_amd.build]", os.path.basename(cmd[-3]), "rc=%d" % rc)
                 if rc != 0:
                     raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), log))
+    with open(stamp_file, "w") as f:
+        f.write(stamp + "\n")
     stale_lib = not os.path.exists(lib_path) or any(os.path.getmtime(o) > os.path.getmtime(lib_path) for o in objs)
     if jobs or stale_lib:
         cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib_path] + objs

@@ -96,16 +96,31 @@ __device__ __forceinline__ float wave_max_nolds(float v) {
 __device__ __forceinline__ float4 ldg4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void stg4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 
-// GELU(erf) with erf from Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7 in exact arithmetic): 16 VALU instructions instead of
-// the ~33 of ocml's erff, which at 64 hidden values per thread and tile were as much issue time as the tile's MFMAs.
-// Measured over [-12, 12] in fp32: max |gelu_fast - gelu_fp64| = 4.7e-7 (torch's own fp32 GELU: 1.2e-6).
+// GELU(erf) = v Phi(v) with ONE transcendental: erfc(t / sqrt 2) = 2^(-t P(t)) for t = |v| in [0, 7], P the degree-5 minimax
+// polynomial of -log2(erfc(t / sqrt 2)) / t weighted by the error it causes in v Phi(v) (5.3e-8 in exact arithmetic; tools/gelu_fit.py),
+// and v Phi(v) = max(v, 0) - |v| erfc(|v| / sqrt 2) / 2 for either sign.  11 VALU instructions (v_min, 5 v_fma, v_mul, v_exp, v_max,
+// v_mul, v_fma) against the 16 of the Abramowitz-Stegun 7.1.26 form it replaces (which also paid a v_rcp: transcendentals issue at a
+// quarter of the rate; an explicitly packed two-value form measured the same, profiles/r06h_gelu_ab.txt) -- on this chip a SIMD's vector and matrix instructions issue one after the other (tools/ab/pipe_overlap.hip), so
+// every instruction saved per hidden value is matrix-pipe time returned.  Over [-12, 12] in fp32: max |gelu_fast - gelu_fp64| = 3.0e-7
+// (half an ulp at 4; the 7.1.26 form: 4.7e-7; torch's own fp32 GELU: 1.2e-6).  |v| > 7: erfc is held at its value at 7 (2.6e-12).
 __device__ __forceinline__ float gelu_fast(float v) {
+#ifndef NMRF_GELU_AS
+    const float a = fabsf(v), t = fminf(a, 7.0f);
+    float p = fmaf(-3.0177725420799106e-05f, t, 0.0007414184510707855f);
+    p = fmaf(p, t, -0.007980725727975368f);
+    p = fmaf(p, t, 0.053240980952978134f);
+    p = fmaf(p, t, 0.45891475677490234f);
+    p = fmaf(p, t, 1.151147484779358f);
+    const float e = __builtin_amdgcn_exp2f(-t * p);
+    return fmaf(e * t, -0.5f, fmaxf(v, 0.f));
+#else       // A/B build (tools/build_ab_flag.sh gelu_as -DNMRF_GELU_AS): the rounds 2-5 form
     const float z = v * 0.70710678118654752440f, az = fabsf(z);
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
     const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
     const float e = __builtin_amdgcn_exp2f(az * az * -1.4426950408889634f);
     const float er = copysignf(fmaf(-poly, e, 1.0f), z);
     return 0.5f * v * (1.0f + er);
+#endif
 }
 
 // Fourier(31) of a disparity label (NMP.py: the label embedding of every stage): c = coord * normalizer; bands c * 2^f (exact), full-range

@@ -530,4 +530,4 @@ extern "C" const char *nmrf_strerror(int code) {
     }
 }
 
-extern "C" int nmrf_abi_version(void) { return 26; }
+extern "C" int nmrf_abi_version(void) { return NMRF_ABI_VERSION; }

@@ -97,6 +97,8 @@ struct NmpBlock16Args {
     const int *ln_out2_map;
     float epsq2, inv_p2, inv_q2;
     int NQ2, kv16_2;
+    unsigned long long *clk;     // measurement hook (nmrf_nmp_block16_clock_records), NULL in every product call: per block
+                                 // {shader clock at entry, at exit, 100 MHz counter at entry, at exit}
 };
 
 // MLP: run fc1-GELU-fc2.  KQC: 32-deep k chunks of the q stage's operand [LNq(x2) | extra]: 0 none, 4 = LayerNorm only,
@@ -117,6 +119,12 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
     float *Par = reinterpret_cast<float *>(smem + B16_PAR_OFF);
 #define B16_STAMP(k) do { if constexpr ((DBG & 32) != 0) { if (lane == 0 && blockIdx.x < 64) a.stamps[(blockIdx.x * 8 + wv) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
     B16_STAMP(0);
+#ifndef NMRF_NO_CLK_HOOK                     // (A/B build without the hook: tools/build_ab_flag.sh noclk -DNMRF_NO_CLK_HOOK nmp_block16)
+    if (a.clk && tid == 0) {                // (uniform branch on a kernel argument: nothing when the hook is off)
+        a.clk[(size_t)blockIdx.x * 4] = __builtin_amdgcn_s_memtime();
+        a.clk[(size_t)blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     // DBG & 32: every block also leaves (realtime at entry, realtime at exit, XCC << 32 | HW_ID) behind the 64 stamped blocks' records
     // (s_memrealtime: the 100 MHz counter that all CUs share -- s_memtime is per CU)
     if constexpr ((DBG & 32) != 0) {
@@ -716,6 +724,12 @@ __global__ __launch_bounds__(B16_THR, 2) void nmp_block16_kernel(NmpBlock16Args 
                 ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (3 << 11)) << 32) | __builtin_amdgcn_s_getreg(4 | (31 << 11));
         }
     }
+#ifndef NMRF_NO_CLK_HOOK
+    if (a.clk && tid == 0) {
+        a.clk[(size_t)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
+        a.clk[(size_t)blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     split_guard_commit(guard, a.range_flag);
     if (a.range_flag && !(qmax < 65520.0f)) atomicOr(a.range_flag, 1);   // (a NaN in q_out has a NaN operand upstream: caught by `guard`)
 }
@@ -767,8 +781,21 @@ extern "C" int nmrf_debug_realtime_mark(void *dst, void *stream) {
 }
 #endif
 
+// Measurement hook (bench.py's sustained_clock_ghz): while buf != NULL every block of the block-kernel launches of THIS process leaves
+// its entry / exit readings of the CU's shader-clock counter and of the chip's 100 MHz counter in buf[4 * blockIdx.x ..] (launches
+// with more than capacity_blocks blocks are not recorded).  The clock the matrix pipe ran at = sum(t1 - t0) / sum(r1 - r0) x 100 MHz.
+static unsigned long long *g_b16_clk = nullptr;
+static int g_b16_clk_cap = 0;
+extern "C" int nmrf_nmp_block16_clock_records(unsigned long long *buf, int capacity_blocks) {
+    if (buf && capacity_blocks < 1) return NMRF_EINVAL;
+    g_b16_clk = buf;
+    g_b16_clk_cap = buf ? capacity_blocks : 0;
+    return NMRF_OK;
+}
+
 template <bool MLP, int KQC, int DBG = 0, bool FUSE = false>
-static int launch_nmp_block16(const NmpBlock16Args &a, hipStream_t st) {
+static int launch_nmp_block16(const NmpBlock16Args &a_in, hipStream_t st) {
+    NmpBlock16Args a = a_in;
 #ifdef NMRF_DEBUG_PROBES
     if constexpr (DBG == 0 && !FUSE) {
         if (g_b16_stamps) {
@@ -807,6 +834,7 @@ static int launch_nmp_block16(const NmpBlock16Args &a, hipStream_t st) {
         n_cu_dev[dev] = prop.multiProcessorCount;
     }
     const int grid = a.n_tiles < n_cu_dev[dev] ? a.n_tiles : n_cu_dev[dev];
+    a.clk = (g_b16_clk && grid <= g_b16_clk_cap) ? g_b16_clk : nullptr;
     hipLaunchKernelGGL((nmp_block16_kernel<MLP, KQC, DBG, FUSE>), dim3(grid), dim3(B16_THR), lds, st, a);
     return nmrf_launch_status();
 }

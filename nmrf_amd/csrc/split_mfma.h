@@ -67,7 +67,23 @@ __device__ __forceinline__ void split_mma(h16x8 ah, h16x8 al, h16x8 bh, h16x8 bl
 // whatever their magnitude; activations are used as they are.  Half the accumulator registers, no combine step.
 __device__ __forceinline__ void split2u(f32x2 a, h16x2 &hi, h16x2 &lo) {
     hi = __builtin_convertvector(a, h16x2);
-#ifdef NMRF_SCALAR_SPLIT
+#if defined(NMRF_MIX_SPLIT)
+    // A/B form (tools/build_ab_flag.sh mix -DNMRF_MIX_SPLIT), NOT the product's: lo = rn_f16(a - hi) in one instruction per value --
+    // v_fma_mixlo/hi_f16 reads hi as an fp16 source, forms fma(hi, -1, a) in fp32 (exact: a - hi is representable) and rounds once to
+    // fp16: the bits of the five-instruction form below in 3 instructions per pair.  Measured in round 6: +0.35 % on the whole step
+    // (profiles/r06g_mix_split_ab.txt) -- and WRONG RESULTS in one kernel (mlp_chain kind 1) once the surrounding schedule changed:
+    // the compiler never forms the mixed instruction itself (it folds fma(x, -1, a) to a subtraction), so it has to be inline asm, and
+    // the hazard recognizer does not see inside inline asm: a partial-register write (mixlo / mixhi write one half of the VGPR) needs a
+    // wait state before the next VALU read of that register on this chip.  With `s_nop 0` behind each pair the results are right
+    // again (profiles/r06j_mix_split_hazard.txt) and the gain is gone.  Kept for the record; not compiled into the product.
+    {
+        unsigned l;
+        const unsigned h = __builtin_bit_cast(unsigned, hi);
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\ts_nop 0" : "=v"(l) : "v"(h), "v"(a[0]));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 0" : "+v"(l) : "v"(h), "v"(a[1]));
+        lo = __builtin_bit_cast(h16x2, l);
+    }
+#elif defined(NMRF_SCALAR_SPLIT)
     // A/B build (tools/build_ab_nopk.sh): the same two subtractions as plain v_sub_f32 instead of one v_pk_add_f32 -- a packed fp32
     // instruction beside MFMAs costs more than its issue slot (MI355X_MICROARCH.md, "price of one filler beside MFMAs")
     const float b0 = (float)hi[0], b1 = (float)hi[1];

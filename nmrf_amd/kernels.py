@@ -56,6 +56,36 @@ def _rf(t):
     return range_flag(t.device).data_ptr()
 
 
+class BlockKernelClock:
+    """Shader clock of the CUs under the block kernels (nmrf_nmp_block16_clock_records): `with BlockKernelClock() as c: <eager launches of
+    K.nmp_block / K.nmp_block_pair>`; afterwards c.ghz = sum of the blocks' shader-clock cycles / sum of their 100 MHz ticks, of the LAST
+    launch inside the block (each launch overwrites the records), c.ghz_min / c.ghz_max over its blocks.  A measurement helper of
+    bench.py; off in every product call."""
+
+    def __init__(self, device=None, capacity=1024):
+        self.dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.buf = torch.zeros(capacity, 4, dtype=torch.int64, device=self.dev)
+        self.capacity = capacity
+        self.ghz = self.ghz_min = self.ghz_max = None
+
+    def __enter__(self):
+        _lib.check(_lib.load().nmrf_nmp_block16_clock_records(self.buf.data_ptr(), self.capacity), "clock_records")
+        return self
+
+    def __exit__(self, *exc):
+        torch.cuda.synchronize(self.dev)
+        _lib.check(_lib.load().nmrf_nmp_block16_clock_records(None, 0), "clock_records")
+        b = self.buf.cpu()
+        b = b[b[:, 3] > b[:, 2]]
+        self.blocks = int(b.shape[0])
+        if self.blocks:
+            cyc, ticks = (b[:, 1] - b[:, 0]).double(), (b[:, 3] - b[:, 2]).double()
+            per = cyc / ticks * 0.1
+            self.ghz, self.ghz_min, self.ghz_max = float(cyc.sum() / ticks.sum() * 0.1), float(per.min()), float(per.max())
+            self.block_us = float(ticks.mean()) * 1e-2
+        return False
+
+
 def check_range(device=None, reset=True):
     """Synchronise with `device` and raise NmrfHipError if any guarded kernel since the last check converted an activation that does
     not fit the fp16 range of the split-operand arithmetic (|x| >= 65520, or NaN).  The results of those launches are invalid (inf

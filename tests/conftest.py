@@ -12,6 +12,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Refuse built libraries that do not come from the sources in the tree (a stale tools library once cost a
+    GPU round): both libraries carry a hash of every source they were built from (nmrf_build_stamp, python -m nmrf_amd.build)."""
+    from nmrf_amd import build
+    want = "abi%d-%s" % (__import__("nmrf_amd._lib", fromlist=["x"]).ABI_VERSION, build.source_stamp())
+    for path in (build.LIB, build.LIB.replace("libnmrf_hip.so", "libnmrf_hip_debug.so")):
+        if os.path.exists(path):
+            got = build.library_stamp(path)
+            if got != want:
+                pytest.exit("%s is stale: built from %s, the tree is %s -- run `python -m nmrf_amd.build`" % (
+                    os.path.relpath(path, ROOT), got, want), returncode=3)
+
+
 def pytest_collection_modifyitems(config, items):
     import torch
     if torch.cuda.is_available():

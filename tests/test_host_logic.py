@@ -51,6 +51,39 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert dbg.nmrf_abi_version() == _lib.ABI_VERSION, "libnmrf_hip_debug.so is stale: python -m nmrf_amd.build"
 
 
+def test_build_stamp_ties_both_libraries_to_the_sources_in_the_tree():
+    """nmrf_build_stamp() = "abi<N>-<hash of every source and header>": equal for the product and the tools library of one build and
+    equal to the hash of the tree (tests/conftest.py refuses to start otherwise); a tools library from other sources is refused
+    when it is loaded next to the product library (VERDICT r05 weak #11)."""
+    from nmrf_amd import build
+    want = "abi%d-%s" % (_lib.ABI_VERSION, build.source_stamp())
+    assert _lib.load().nmrf_build_stamp().decode() == want
+    assert re.fullmatch(r"abi\d+-[0-9a-f]{16}", want)
+    if os.path.exists(_lib.DEBUG_LIB_PATH):
+        assert build.library_stamp(_lib.DEBUG_LIB_PATH) == want
+        assert _lib.load_debug().nmrf_build_stamp().decode() == want
+    # the refusal itself, on a copy of the product library presented as the tools library of a differently stamped product
+    import shutil, subprocess, sys, tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        fake = os.path.join(tmp, "libnmrf_hip_debug.so")
+        shutil.copy(_lib.LIB_PATH, fake)
+        code = ("import ctypes, nmrf_amd._lib as L\n"
+                "L.DEBUG_LIB_PATH = %r\n"
+                "L.DEBUG_PROTOTYPES = {}\n"
+                "lib = L.load()\n"
+                "real = lib.nmrf_build_stamp\n"
+                "class Fake:\n"
+                "    restype = None\n"
+                "    def __call__(self): return b'abi0-0000000000000000'\n"
+                "lib.nmrf_build_stamp = Fake()\n"
+                "try:\n"
+                "    L.load_debug()\n"
+                "except L.NmrfHipError as e:\n"
+                "    assert 'other sources' in str(e); print('refused')\n") % fake
+        out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+        assert out.stdout.strip() == "refused", out.stdout + out.stderr
+
+
 def test_product_reads_two_environment_switches_only():
     """NMRF_LINEAR (split | fp32: A/B runs on the debug library's fp32-MFMA linears) and NMRF_OVERLAP (side stream on / off for
     profiling) -- nothing else in the product tree changes the arithmetic or the launch structure from the environment."""
@@ -380,5 +413,5 @@ def test_integration_appendix_lists_every_entry_point():
     assert set(rows) == set(_lib.PROTOTYPES) | {"nmrf_strerror"} or set(rows) == set(_lib.PROTOTYPES)
     uncited = [n for n, l in rows.items() if l.rstrip().endswith("| – |")]
     helpers = ("nmrf_selftest_", "nmrf_strerror", "nmrf_abi_version", "nmrf_pack_", "nmrf_host_", "nmrf_sum_partials", "nmrf_colsum_",
-               "nmrf_act_bwd", "nmrf_layernorm", "nmrf_instance_stats", "nmrf_prep_images_s2d_f32")
+               "nmrf_act_bwd", "nmrf_layernorm", "nmrf_instance_stats", "nmrf_prep_images_s2d_f32", "nmrf_nmp_block16_clock_records", "nmrf_build_stamp")
     assert all(n.startswith(helpers) for n in uncited), [n for n in uncited if not n.startswith(helpers)]

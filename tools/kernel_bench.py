@@ -47,7 +47,8 @@ from nmrf_amd import _lib
 # the probes (nmrf_debug_*) live in the tools-only debug build of the same sources: build it if needed and make the
 # kernels module of this process use it (a superset of the product library)
 from nmrf_amd.build import build_library
-_lib.LIB_PATH = build_library(debug=True, verbose=False)
+if not args.lib:                 # (--lib: an A/B build of the tools library, tools/build_ab_lib.sh)
+    _lib.LIB_PATH = build_library(debug=True, verbose=False)
 _l = _lib.load()
 for _n, _at in (("nmrf_debug_window_occupancy", None), ("nmrf_debug_window_timing", None), ("nmrf_debug_stripe_census", None),
                 ("nmrf_debug_mfma_peak", None), ("nmrf_debug_attn_core_peak", None), ("nmrf_debug_token_linear_timing", None),
