@@ -51,13 +51,15 @@ def source_stamp():
 
 
 def library_stamp(path):
-    """nmrf_build_stamp() of a built library ("abi<N>-<hash>"), or None if it cannot be read."""
-    import ctypes
+    """nmrf_build_stamp() of a built library ("abi<N>-<hash>") read from the file's bytes, or None.  Deliberately NOT through dlopen: a
+    HIP library loaded before `import torch` binds to the system's libamdhip64 while torch brings its own -- every later launch from
+    that library then fails (found the hard way: a conftest hook that dlopen-ed the libraries first, round 6)."""
+    import re
     try:
-        lib = ctypes.CDLL(path)
-        lib.nmrf_build_stamp.restype = ctypes.c_char_p
-        return lib.nmrf_build_stamp().decode()
-    except (OSError, AttributeError):
+        with open(path, "rb") as f:
+            m = re.search(rb"abi\d+-[0-9a-f]{16}(?=\x00)", f.read())
+        return m.group(0).decode() if m else None
+    except OSError:
         return None
 
 

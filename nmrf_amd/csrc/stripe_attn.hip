@@ -58,10 +58,18 @@ __device__ __forceinline__ int64_t stripe_row(const StripeGeom &g, int64_t base_
 // nmrf_nmp_block16_f32, include/nmrf_hip.h) -- the K fragment is four 16-byte loads that ARE the MFMA operands, the V fragment
 // 16 words and 16 v_perm_b32; without it each key tile pays 2 x 48 VALU instructions to split them (of ~250 in a tile).
 // The body of one block: work item `item` of the logical grid g.gx x g.gy x g.gz (the kernels below map blockIdx to items).
+// LDS pool of the SHARED form (four-label stripes with pre-split k | v, one key range), declared by the KERNEL and handed to the body:
+// the merged kernel runs either body in a block, never both, and two private pools cost it its fourth block per CU.
+#define SA_SROW 36
+#define SA_LP_ROWS 144                                         // LePE window: 4 query tiles + 4 tokens before + 12 after (4 used, 8 pad a chunk)
+#define SA_POOL_FLOATS (SA_LP_ROWS * SA_SROW + 96)             // >= the K and V tile rings of the key loop (4 x 32 x SA_SROW)
+template <int NSHIFT, int KSPLIT, bool KV16>
+constexpr int stripe_pool_floats() { return (KV16 && KSPLIT == 1 && NSHIFT == 2) ? SA_POOL_FLOATS : 4; }
+
 template <int AXIS, int NSHIFT, int KSPLIT, bool CENSUS = false, bool KV16 = false>
 __device__ __forceinline__ void stripe_attn_body(const float *__restrict__ qkv, const float *__restrict__ lepe, const StripeGeom &g,
                                                  float scale, float *__restrict__ out, unsigned long long *__restrict__ census,
-                                                 const int item) {
+                                                 const int item, float *s_pool) {
     constexpr int QPB = 4 / KSPLIT;                           // query tiles per block
     float guard = 0.f;                                        // fp16 range guard of the q / k / v splits (split_mfma.h)
     const int total = g.gx * g.gy * g.gz;
@@ -90,9 +98,13 @@ __device__ __forceinline__ void stripe_attn_body(const float *__restrict__ qkv, 
     // instruction, four such per tile and wave, and the L1 address path (not the matrix pipe, not the VALU: cutting a third of a
     // tile's VALU work bought 8 %) set the pace.  Rows are padded to 36 floats: the b128 fragment reads are conflict-free.
     constexpr bool SHARED = KV16 && KSPLIT == 1 && NSHIFT == 2;
-    constexpr int SROW = 36;
-    __shared__ __attribute__((aligned(16))) float s_k[SHARED ? 2 : 1][SHARED ? 32 * SROW : 4];
-    __shared__ __attribute__((aligned(16))) float s_v[SHARED ? 2 : 1][SHARED ? 32 * SROW : 4];
+    constexpr int SROW = SA_SROW;
+    // one pool (s_pool, the kernel's): the K and V tile rings of the key loop ([2][32 * SROW] each), then -- every wave past the loop's
+    // last barrier -- the LePE window of the block (LP_ROWS token rows of v, SROW floats apart) and the three tap vectors of the head
+    constexpr int LP_ROWS = SA_LP_ROWS;
+    static_assert(SA_POOL_FLOATS >= 4 * 32 * SA_SROW, "the pool holds the two tile rings");
+    float (*s_k)[SHARED ? 32 * SROW : 1] = reinterpret_cast<float (*)[SHARED ? 32 * SROW : 1]>(s_pool);
+    float (*s_v)[SHARED ? 32 * SROW : 1] = reinterpret_cast<float (*)[SHARED ? 32 * SROW : 1]>(s_pool + (SHARED ? 2 * 32 * SROW : 0));
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: key loop + addresses on the SALU
     const int qi = lane & 31, hi = lane >> 5;
@@ -408,7 +420,81 @@ __device__ __forceinline__ void stripe_attn_body(const float *__restrict__ qkv, 
     // before the loop keeps 20-36 more VGPRs live and costs the 4th wave per SIMD; the leading wave collects the other
     // blocks from LDS after the merge barrier (it used to do all 36 float4 + 48 weight loads alone while 3 waves idled).
     float rpe[4 * RB_PER];
-    {
+    if constexpr (SHARED) {
+        // The same three sums as products on the matrix pipe (round 6; the VALU form below took 8-11k of a block's ~55k cycles: 36
+        // row-per-lane 16-byte loads and 48 tap loads per lane behind the key loop, profiles/r06m_stripe_census.txt):
+        //   R_tap^T[d][q] = sum_key V[key][d] * pat_tap[q][key],   pat_c = [key == q], pat_-/+ = [pixel(key) == pixel(q) -/+ 1]
+        // over the 40 tokens around the wave's query tile -- V^T is the A operand exactly as in P V, the 0 / 1 patterns are exact in
+        // fp16 (two MFMAs per 16-key chunk: V's hi and lo halves), and rpe = w_c R_c + w_- R_- + w_+ R_+ per channel afterwards.
+        // The block stages the v rows of its 128 queries + 4 before + 12 after ONCE, coalesced (every thread 16-byte pieces of whole
+        // rows), into the pool the key loop has left; rows outside the stripe shadow its end tokens and meet a zero pattern.
+        const int tap_m = (AXIS == 0) ? 1 : 3, tap_c = 4, tap_p = (AXIS == 0) ? 7 : 5;
+        float *s_lp = s_pool, *s_w = s_pool + LP_ROWS * SROW;
+        const int Q0 = bx * QPB * SA_TILE;
+        for (int i = threadIdx.x; i < LP_ROWS * 8; i += 256) {
+            const int row = i >> 3, pc = i & 7;
+            int sk = Q0 - 4 + row;
+            sk = sk < 0 ? 0 : (sk < g.Ts ? sk : g.Ts - 1);
+            stg4(&s_lp[row * SROW + 4 * pc], ldg4(qkv + stripe_row<NSHIFT>(g, base_pix, sk) * ld + 2 * g.C + coff + 4 * pc));
+        }
+        if (threadIdx.x < 96) {
+            const int tp = threadIdx.x >> 5, d = threadIdx.x & 31;
+            s_w[threadIdx.x] = lepe[(size_t)(head * 32 + d) * 9 + (tp == 0 ? tap_c : (tp == 1 ? tap_m : tap_p))];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rpe[r] = 0.f;
+        if (wave_on) {
+            // k slot (chunk c, jj, half hi) <-> token Q0 - 4 + 32 qslot + 16 c + 8 hi + jj of the stripe, on both operands
+            h16x8 lvh[3], lvl[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float *vr = s_lp + (32 * qslot + 16 * c + 8 * hi) * SROW + qi;
+                unsigned h[4], l[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned e0 = __builtin_bit_cast(unsigned, vr[(2 * k) * SROW]), e1 = __builtin_bit_cast(unsigned, vr[(2 * k + 1) * SROW]);
+                    h[k] = __builtin_amdgcn_perm(e1, e0, 0x05040100u);
+                    l[k] = __builtin_amdgcn_perm(e1, e0, 0x07060302u);
+                }
+                lvh[c] = __builtin_bit_cast(h16x8, make_uint4(h[0], h[1], h[2], h[3]));
+                lvl[c] = __builtin_bit_cast(h16x8, make_uint4(l[0], l[1], l[2], l[3]));
+            }
+            const int qb = (qi >> 2) + 8;                       // pixel of the query, in pixels from the one before the tile's first, + 7
+#pragma unroll
+            for (int tp = 0; tp < 3; ++tp) {
+                f32x16 R;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) R[r] = 0.f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    unsigned pw[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        unsigned wd = 0;
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int kk = 16 * c + 8 * hi + 2 * k + e;            // window slot of this key; its token: q0 - 4 + kk
+                            const int sk = q0 - 4 + kk;
+                            const int ka = (kk + 28) >> 2;                         // its pixel on the scale of qb
+                            const bool on = sk >= 0 && sk < g.Ts && (tp == 0 ? kk - 4 == qi : (tp == 1 ? ka == qb - 1 : ka == qb + 1));
+                            wd |= on ? (e ? 0x3c000000u : 0x00003c00u) : 0u;       // fp16 1.0
+                        }
+                        pw[k] = wd;
+                    }
+                    const h16x8 pat = __builtin_bit_cast(h16x8, make_uint4(pw[0], pw[1], pw[2], pw[3]));
+                    R = mfma16h(lvl[c], pat, R);
+                    R = mfma16h(lvh[c], pat, R);
+                }
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4 *>(s_w + 32 * tp + 8 * rb + 4 * hi);    // channels mfma_row(4 rb, hi) ..
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rpe[4 * rb + e] = fmaf(wv[e], R[4 * rb + e], rpe[4 * rb + e]);
+                }
+            }
+        }
+    } else {
         const int tap_m = (AXIS == 0) ? 1 : 3, tap_c = 4, tap_p = (AXIS == 0) ? 7 : 5;
         const bool has_prev = q_pix > 0, has_next = q_pix < g.L - 1;
         const int64_t prev_row = stripe_row<NSHIFT>(g, base_pix, (has_prev ? q_pix - 1 : q_pix) * nlab);
@@ -508,7 +594,8 @@ __global__ __launch_bounds__(256, 2) void stripe_attn_kernel(const float *__rest
     const int chunk = gridDim.x >> 3;                          // the launch pads the grid to a multiple of 8
     const int item = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
     if (item >= total) return;
-    stripe_attn_body<AXIS, NSHIFT, KSPLIT, CENSUS, KV16>(qkv, lepe, g, scale, out, census, item);
+    __shared__ __attribute__((aligned(16))) float s_pool[stripe_pool_floats<NSHIFT, KSPLIT, KV16>()];
+    stripe_attn_body<AXIS, NSHIFT, KSPLIT, CENSUS, KV16>(qkv, lepe, g, scale, out, census, item, s_pool);
 }
 
 // Both axes of a propagation layer in ONE launch (four labels per pixel, pre-split k | v rows): the two kernels are independent --
@@ -519,13 +606,14 @@ template <int NSHIFT, bool KV16>
 __global__ __launch_bounds__(256, 2) void stripe_attn_both_kernel(const float *__restrict__ qkv, const float *__restrict__ lepe_v,
                                                               const float *__restrict__ lepe_h, StripeGeom gv, StripeGeom gh,
                                                               float scale, float *__restrict__ out, int chunk_h, int chunk_v) {
+    __shared__ __attribute__((aligned(16))) float s_pool[stripe_pool_floats<NSHIFT, 1, KV16>()];
     const int xcd = (int)(blockIdx.x & 7), k = (int)(blockIdx.x >> 3);
     if (k < chunk_h) {
         const int item = xcd * chunk_h + k;
-        if (item < gh.gx * gh.gy * gh.gz) stripe_attn_body<1, NSHIFT, 1, false, KV16>(qkv, lepe_h, gh, scale, out, nullptr, item);
+        if (item < gh.gx * gh.gy * gh.gz) stripe_attn_body<1, NSHIFT, 1, false, KV16>(qkv, lepe_h, gh, scale, out, nullptr, item, s_pool);
     } else {
         const int item = xcd * chunk_v + (k - chunk_h);
-        if (item < gv.gx * gv.gy * gv.gz) stripe_attn_body<0, NSHIFT, 1, false, KV16>(qkv, lepe_v, gv, scale, out, nullptr, item);
+        if (item < gv.gx * gv.gy * gv.gz) stripe_attn_body<0, NSHIFT, 1, false, KV16>(qkv, lepe_v, gv, scale, out, nullptr, item, s_pool);
     }
 }
 
