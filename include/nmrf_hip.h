@@ -448,6 +448,9 @@ int nmrf_sum_partials_f32(const float *parts, int S, int64_t n, int64_t stride, 
 /* The same in groups: out[g*n + i] = sum over the parts s in [g*group, min(S, (g+1)*group)) -- a caller with many parts reduces in rounds
  * (a fixed tree: deterministic) instead of one long serial chain per element. */
 int nmrf_sum_partials_grouped_f32(const float *parts, int S, int64_t n, int64_t stride, int group, float *out, void *stream);
+/* The same sum for MANY parts of a NARROW row in one launch: per column, 32 lanes add the parts p, p + 32, ... in ascending order and
+ * the 32 lane sums are added in ascending order -- a fixed tree for a given S (deterministic; not the bits of the serial sum above). */
+int nmrf_sum_partials_tree_f32(const float *parts, int S, int64_t n, int64_t stride, float *out, void *stream);
 /* parts[b][n] = sum of x[t][n] over the rows_per_block rows of block b (b < ceil(T / rows_per_block)): the bias gradient's first pass. */
 int nmrf_colsum_partials_f32(const float *x, int64_t T, int N, int rows_per_block, float *parts, void *stream);
 /* pre_out = pre_in + bias (bias, pre_out may be NULL; pre_out may alias pre_in); act_out (may be NULL) = act(pre_in + bias):

@@ -140,6 +140,32 @@ extern "C" int nmrf_sum_partials_grouped_f32(const float *parts, int S, int64_t 
     hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)blocks, (unsigned)groups), dim3(256), 0, (hipStream_t)stream, parts, S, n, stride, group, out);
     return nmrf_launch_status();
 }
+// The whole reduction of MANY parts of a NARROW row in one launch (round 6: the training step spent 504 launches / 4 ms per step in
+// rounds of the grouped kernel above): a block owns 8 columns; its 32 part-lanes each add the parts p, p + 32, p + 64, ... in ascending
+// order, then lane 0 adds the 32 lane sums in ascending order through LDS -- a fixed tree for a given S: the same bits every run.
+__global__ __launch_bounds__(256) void sum_partials_tree_kernel(const float *__restrict__ parts, int S, int64_t n, int64_t stride,
+                                                                float *__restrict__ out) {
+    __shared__ float sh[32][9];
+    const int c8 = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int64_t col = (int64_t)blockIdx.x * 8 + c8;
+    float s = 0.f;
+    if (col < n)
+        for (int k = pl; k < S; k += 32) s += parts[(int64_t)k * stride + col];
+    sh[pl][c8] = s;
+    __syncthreads();
+    if (pl == 0 && col < n) {
+        float t = sh[0][c8];
+#pragma unroll
+        for (int p = 1; p < 32; ++p) t += sh[p][c8];
+        out[col] = t;
+    }
+}
+extern "C" int nmrf_sum_partials_tree_f32(const float *parts, int S, int64_t n, int64_t stride, float *out, void *stream) {
+    if (!parts || !out) return NMRF_ENULL;
+    if (S < 1 || n < 1 || stride < n || ceil_div64(n, 8) > 0x7fffffff) return NMRF_EINVAL;
+    hipLaunchKernelGGL(sum_partials_tree_kernel, dim3((unsigned)ceil_div64(n, 8)), dim3(256), 0, (hipStream_t)stream, parts, S, n, stride, out);
+    return nmrf_launch_status();
+}
 extern "C" int nmrf_sum_partials_f32(const float *parts, int S, int64_t n, int64_t stride, float *out, void *stream) {
     return nmrf_sum_partials_grouped_f32(parts, S, n, stride, S < 1 ? 1 : S, out, stream);
 }

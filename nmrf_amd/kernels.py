@@ -1166,6 +1166,12 @@ def _sum_parts(parts, n, out=None):
     """parts [S, n] (contiguous) -> [n]: rounds of 32 parts per group (nmrf_sum_partials_grouped_f32), a fixed reduction tree."""
     s_ = parts.shape[0]
     cur = parts
+    if s_ > 32 and n < 8192:
+        # many parts of a narrow row (bias / LayerNorm / table sums): the whole tree in one launch (nmrf_sum_partials_tree_f32)
+        if out is None:
+            out = torch.empty(n, device=parts.device, dtype=torch.float32)
+        _lib.check(_lib.load().nmrf_sum_partials_tree_f32(_p(cur), s_, n, n, _p(out), _stream()), "sum_partials_tree")
+        return out
     # (wide rows -- a weight gradient's K-split parts -- have a thread per element to keep the chip busy: one pass over all parts; narrow
     #  rows -- bias and LayerNorm sums, 64 ... 512 elements -- would be one long serial chain per thread: rounds of 32)
     while s_ > 32 and not (n >= 8192 and s_ <= 256):

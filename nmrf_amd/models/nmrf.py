@@ -34,8 +34,12 @@ class NMRF(nn.Module):
             backbone = kwargs.pop("backbone")
             return self.__init__(backbone, **kwargs)
         super().__init__()
-        if activation != "gelu" or any(r != 0 for r in (attn_drop, proj_drop, drop_path, dropout)):
-            raise NotImplementedError("inference build: GELU, no dropout (all shipped configs)")
+        if activation != "gelu":
+            raise NotImplementedError("the fused kernels implement GELU (every shipped config; relu / glu: NMP.py:984-992)")
+        # Dropout / stochastic depth (default.py:56-59, NMP.py:198, 343-349): identities in eval mode, so a model configured with
+        # them evaluates exactly like the reference; only a TRAINING-mode forward would have to draw masks, and raises.
+        self.drop_rates = {"attn_drop": float(attn_drop), "proj_drop": float(proj_drop), "drop_path": float(drop_path),
+                           "dropout": float(dropout)}
         if not with_refinement:
             raise NotImplementedError("refinement is always on in the reference (NMRF.py:131-152)")
         self.num_proposals, self.max_disp, self.divis_by = num_proposals, max_disp, divis_by
@@ -115,6 +119,9 @@ class NMRF(nn.Module):
         -- the message-passing stages and heads, or with full=True every parameter (nmrf_amd/train.py)."""
         enc = self.backbone if self.compat else self.image_encoder
         from .backbone import Backbone
+        if self.training and any(self.drop_rates.values()):
+            raise NotImplementedError("training-mode forward with non-zero dropout / drop-path rates %r: the fused kernels draw no "
+                                      "masks (eval mode is exact: the rates are identities there)" % (self.drop_rates,))
         if self.training and not getattr(self, "grad_slice", False) and not getattr(self, "_warned_train", False):
             import warnings
             warnings.warn("nmrf_amd: the model is in TRAINING mode (nn.Module's default after build_model -- call model.eval() for "

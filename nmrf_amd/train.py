@@ -9,9 +9,10 @@
     model.train(); loss_dict = criterion(model(sample), sample); losses = sum_k weight_dict[k] * loss_dict[k]
     param.grad = None; losses.backward(); clip_grad_norm_(GRAD_CLIP); optimizer.step()
 
-and, with more than one rank, the gradient average DistributedDataParallel performs for the reference (main.py:334-339) as ONE
-bucketed all-reduce over RCCL (`allreduce_gradients`: the slice's gradients are 0.27 M floats -- a single 1 MB bucket; one process per
-GPU, weights replicated, batch sharded as in nmrf_amd.parallel)."""
+and, with more than one rank, the gradient average DistributedDataParallel performs for the reference (main.py:334-339): bucket by bucket
+under the backward pass (`OverlappedGradientReducer`: ~8 MB buckets in reverse parameter order, asynchronous all-reduces over RCCL,
+identical collective order on every rank), or as ONE flat all-reduce behind it (`allreduce_gradients`: the first step, and callers
+without a reducer); one process per GPU, weights replicated, batch sharded as in nmrf_amd.parallel."""
 import torch
 import torch.distributed as dist
 
@@ -97,9 +98,97 @@ def allreduce_gradients(params, group=None):
     return flat.numel()
 
 
-def train_step(model, criterion, optimizer, sample, grad_clip=1.0, group=None):
+class OverlappedGradientReducer:
+    """The gradient average of DistributedDataParallel's reducer (main.py:334-339) overlapped with the backward pass: the parameters
+    that carry gradients are cut into buckets of ~`bucket_bytes` in REVERSE registration order (the order their gradients become
+    ready), every parameter's post-accumulate hook counts its bucket down, and a complete bucket is all-reduced asynchronously (RCCL
+    works on its own stream) while autograd keeps producing the next one; `finish()` launches what is left, waits, averages and
+    writes the gradients back.
+
+    Every rank issues the SAME collectives in the SAME order whatever its data did:
+      * the first step is the flat path (`allreduce_gradients`), whose has-gradient mask -- summed over the ranks -- defines the live
+        parameter set once, identically everywhere (a loss term without weight leaves whole stages without gradients);
+      * buckets are launched strictly in bucket order (b only after b - 1), early when complete, otherwise in finish();
+      * a live parameter that got no gradient on this rank in this step contributes zeros.
+    A gradient on a parameter outside the live set (the loss structure changed) raises: rebuild the reducer.
+    One rank / no process group: everything is the identity."""
+
+    def __init__(self, params, group=None, bucket_bytes=8 << 20):
+        self.params = [p for p in params if p.requires_grad]
+        self.group, self.bucket_bytes = group, int(bucket_bytes)
+        self.active = bool(self.params) and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.buckets = None                  # list of lists of parameters, set by the first (flat) step
+        self._hooks, self._inflight, self._next, self._pending, self._bucket_of = [], [], 0, [], {}
+
+    def _build(self, live):
+        self.buckets, cur, size = [], [], 0
+        for p in reversed(live):
+            cur.append(p)
+            size += p.numel() * p.element_size()
+            if size >= self.bucket_bytes:
+                self.buckets.append(cur)
+                cur, size = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self._bucket_of = {id(p): b for b, ps in enumerate(self.buckets) for p in ps}
+        live_ids = set(self._bucket_of)
+        for p in self.params:
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._ready if id(p) in live_ids else self._stray))
+
+    def _stray(self, p):
+        raise RuntimeError("a parameter outside the reducer's live set received a gradient: the loss structure changed -- build a "
+                           "new OverlappedGradientReducer")
+
+    def prepare(self):
+        """Before backward: arm the bucket counters."""
+        if self.active and self.buckets is not None:
+            self._pending = [len(ps) for ps in self.buckets]
+            self._inflight, self._next = [], 0
+
+    def _launch_ready(self, force=False):
+        while self._next < len(self.buckets) and (force or self._pending[self._next] == 0):
+            ps = self.buckets[self._next]
+            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in ps])
+            self._inflight.append((ps, flat, dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+            self._next += 1
+
+    def _ready(self, p):
+        self._pending[self._bucket_of[id(p)]] -= 1
+        self._launch_ready()
+
+    def finish(self):
+        """After backward: the averaged gradients are in .grad when this returns.  Returns the number of floats reduced."""
+        if not self.active:
+            return 0
+        if self.buckets is None:                                         # first step: the flat path defines the live set
+            n = allreduce_gradients(self.params, self.group)
+            self._build([p for p in self.params if p.grad is not None])
+            return n
+        self._launch_ready(force=True)
+        world, n = dist.get_world_size(self.group), 0
+        for ps, flat, work in self._inflight:
+            work.wait()
+            flat /= world
+            off = 0
+            for p in ps:
+                k = p.numel()
+                p.grad = flat[off:off + k].view_as(p).clone()
+                off += k
+            n += off
+        self._inflight = []
+        return n
+
+    def close(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
+def train_step(model, criterion, optimizer, sample, grad_clip=1.0, group=None, reducer=None):
     """One step of main.py:413-430 on the parameters of `optimizer` (build_slice_optimizer).  sample: {'img1', 'img2', 'disp', 'valid'} (H, W multiples of
-    DATASETS.DIVIS_BY: the training-mode forward does not pad).  Returns (total loss as a float, the loss dict)."""
+    DATASETS.DIVIS_BY: the training-mode forward does not pad).  reducer: an OverlappedGradientReducer over the optimizer's parameters
+    (fit() builds one when there is more than one rank) -- the gradient average then runs bucket by bucket under the backward pass
+    instead of as one flat all-reduce behind it.  Returns (total loss as a float, the loss dict)."""
     if not getattr(model, "grad_slice", False):
         raise RuntimeError("call model.train().enable_grad_slice() first: without it the training-mode forward carries no autograd graph")
     if not model.training:
@@ -112,9 +201,14 @@ def train_step(model, criterion, optimizer, sample, grad_clip=1.0, group=None):
     losses = sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)
     for p in model.parameters():
         p.grad = None                                              # (main.py:419-421: "more efficient zero_grad")
+    if reducer is not None:
+        reducer.prepare()
     losses.backward()
     params = [p for g in optimizer.param_groups for p in g["params"]]
-    allreduce_gradients(params, group)
+    if reducer is not None:
+        reducer.finish()                                           # buckets reduced while backward ran (OverlappedGradientReducer)
+    else:
+        allreduce_gradients(params, group)
     torch.nn.utils.clip_grad_norm_(params, grad_clip)
     optimizer.step()
     return float(losses.detach()), {k: float(v.detach()) for k, v in loss_dict.items()}
@@ -159,24 +253,31 @@ def fit(model, criterion, optimizer, loader, cfg, checkpoint_dir=None, start_ste
     rank0 = not (dist.is_available() and dist.is_initialized()) or dist.get_rank(group) == 0
     sched = build_lr_scheduler(optimizer, cfg, start_step)
     step, epoch, s = int(start_step), int(start_epoch), cfg.SOLVER
-    while step < s.MAX_ITER:
-        model.train()
-        model.freeze_bn()
-        if set_epoch is not None:
-            set_epoch(epoch)
-        for sample in loader:
-            total, loss_dict = train_step(model, criterion, optimizer, sample, s.GRAD_CLIP, group)
-            lr = sched.get_last_lr()[0]
-            sched.step()
-            step += 1
-            if on_step is not None:
-                on_step(step, lr, total, loss_dict)
-            if checkpoint_dir is not None and rank0:
-                if step % s.CHECKPOINT_PERIOD == 0 or step == s.MAX_ITER:
-                    save_checkpoint(os.path.join(checkpoint_dir, "step_%06d.pth" % step), model)
-                if step % s.LATEST_CHECKPOINT_PERIOD == 0:
-                    save_checkpoint(os.path.join(checkpoint_dir, "checkpoint_latest.pth"), model, optimizer, step, epoch)
-            if step >= s.MAX_ITER:
-                return step, epoch
-        epoch += 1
-    return step, epoch
+    reducer = OverlappedGradientReducer([p for g in optimizer.param_groups for p in g["params"]], group)
+    if not reducer.active:
+        reducer = None
+    try:
+        while step < s.MAX_ITER:
+            model.train()
+            model.freeze_bn()
+            if set_epoch is not None:
+                set_epoch(epoch)
+            for sample in loader:
+                total, loss_dict = train_step(model, criterion, optimizer, sample, s.GRAD_CLIP, group, reducer)
+                lr = sched.get_last_lr()[0]
+                sched.step()
+                step += 1
+                if on_step is not None:
+                    on_step(step, lr, total, loss_dict)
+                if checkpoint_dir is not None and rank0:
+                    if step % s.CHECKPOINT_PERIOD == 0 or step == s.MAX_ITER:
+                        save_checkpoint(os.path.join(checkpoint_dir, "step_%06d.pth" % step), model)
+                    if step % s.LATEST_CHECKPOINT_PERIOD == 0:
+                        save_checkpoint(os.path.join(checkpoint_dir, "checkpoint_latest.pth"), model, optimizer, step, epoch)
+                if step >= s.MAX_ITER:
+                    return step, epoch
+            epoch += 1
+        return step, epoch
+    finally:
+        if reducer is not None:
+            reducer.close()

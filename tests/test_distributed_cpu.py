@@ -141,6 +141,75 @@ def _grad_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _reducer_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nmrf_amd.train import OverlappedGradientReducer, allreduce_gradients
+
+        def make():
+            torch.manual_seed(0)
+            return torch.nn.ModuleDict(dict(l1=torch.nn.Linear(4, 8), l2=torch.nn.Linear(8, 3), side=torch.nn.Linear(4, 3),
+                                            unused=torch.nn.Linear(3, 2)))         # `unused`: no loss term reaches it on any rank
+
+        def loss_of(m, x, with_side):
+            y = m["l2"](torch.relu(m["l1"](x))).sum()
+            return y + m["side"](x).pow(2).sum() if with_side else y
+        a, b = make(), make()
+        red = OverlappedGradientReducer(list(a.parameters()), bucket_bytes=64)      # tiny buckets: several all-reduces per step
+        ok, launches = True, []
+        for step in range(4):
+            g = torch.Generator().manual_seed(100 * step + rank)
+            x = torch.randn(5, 4, generator=g)
+            with_side = not (rank == 1 and step == 2)                 # one rank, one step: a live parameter without a gradient -> zeros
+            for m in (a, b):
+                for p in m.parameters():
+                    p.grad = None
+            red.prepare()
+            loss_of(a, x, with_side).backward()
+            early = len(red._inflight)                                # buckets already in flight when backward returns
+            n = red.finish()
+            loss_of(b, x, with_side).backward()
+            allreduce_gradients(list(b.parameters()))
+            launches.append((early, n))
+            for (k, pa), pb in zip(a.named_parameters(), b.parameters()):
+                if k.startswith("unused"):
+                    ok = ok and pa.grad is None and pb.grad is None
+                else:
+                    ok = ok and pa.grad is not None and torch.equal(pa.grad, pb.grad)
+        nb = len(red.buckets)
+        red.close()
+        q.put((rank, bool(ok), nb, launches))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_gradient_reducer_world2():
+    """nmrf_amd.train.OverlappedGradientReducer (the DDP step): buckets in reverse parameter order all-reduced
+    while backward still runs, the same collectives in the same order on both ranks -- gradients equal, bit for bit, to the flat
+    all-reduce behind the backward pass on every step, including the one where a rank has no gradient for a live parameter; a
+    parameter no rank has a gradient for keeps None."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reducer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _ in res), res
+    for _, _, nb, launches in res:
+        assert nb >= 3                                                # 64-byte buckets: l2, l1 and side end up in different buckets
+        assert launches[0][0] == 0                                    # the first step is the flat path
+        assert any(early > 0 for early, _ in launches[1:]), launches  # later steps: buckets left during the backward pass
+    # one rank: the reducer is inert
+    from nmrf_amd.train import OverlappedGradientReducer
+    r1 = OverlappedGradientReducer([torch.nn.Parameter(torch.zeros(2))])
+    assert not r1.active and r1.finish() == 0
+
+
 def test_gradient_bucket_allreduce_world2():
     """nmrf_amd.train.allreduce_gradients: the DDP gradient average of main.py:334-339 as one flat bucket (gloo here, RCCL on GPUs)."""
     ctx = mp.get_context("spawn")

@@ -294,6 +294,22 @@ def test_mixed_sizes_with_equal_padded_grid_through_one_model():
         assert float(d.median()) < 1e-5 and float((d > 0.1).float().mean()) < 1e-4, (float(d.median()), float(d.mean()), float(d.max()))
 
 
+def test_dropout_rates_are_identities_in_eval_mode_and_refused_in_training_mode():
+    """NMP.ATTN_DROP / PROJ_DROP / DROP_PATH / DROPOUT (default.py:56-59; nn.Dropout and timm's DropPath, NMP.py:198, 343-349) change
+    nothing in eval mode: a model built with non-zero rates has the same state dict and returns the same bits as one built with
+    zeros.  A training-mode forward would have to draw masks: it raises instead of silently skipping them."""
+    from nmrf_amd.utils.hashinit import synthetic_pair
+    opts = ("NMP.ATTN_DROP", 0.1, "NMP.PROJ_DROP", 0.1, "NMP.DROP_PATH", 0.2, "NMP.DROPOUT", 0.1)
+    plain, dropped = build_product(320, DEV), build_product(320, DEV, opts=opts)
+    assert list(plain.state_dict()) == list(dropped.state_dict()) and dropped.drop_rates["drop_path"] == 0.2
+    l, r, _ = synthetic_pair(120, 264, seed=5)
+    smp = {"img1": l[None].to(DEV), "img2": r[None].to(DEV)}
+    with torch.no_grad():
+        assert torch.equal(plain(smp)["disp"], dropped(smp)["disp"])
+    with pytest.raises(NotImplementedError, match="dropout"):
+        dropped.train()(smp)
+
+
 def test_middlebury_half_res_size_runs():
     """Largest BASELINE size (config 5 geometry: ~1500x1000, D_max 256 -> D=32, divisible-by-32 padding) on the
     CNN backbone: shapes, finiteness, seeds in range."""
