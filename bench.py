@@ -50,6 +50,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stream-figure", action="store_true", help="skip the end-to-end StereoStream figure")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per step")
+    ap.add_argument("--no-clock-sample", action="store_true", help="skip the 320 back-to-back launches of the dominant kernel behind "
+                    "sustained_clock_ghz (kernel traces / --pmc passes of this command: they would dominate the per-kernel totals)")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL result gather at N>1")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find mode)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the result gather even at N=1 (smoke)")
@@ -465,7 +467,7 @@ def run(args):
         # the chip's 100 MHz counter at entry and exit (nmrf_nmp_block16_clock_records) during 320 back-to-back launches of the launch
         # captured above; the records of the last launch are read.
         clocks = None
-        if pair_call:
+        if pair_call and not args.no_clock_sample:
             try:
                 pa, pkw = pair_call[0]
                 kh, K.kernel_hook = K.kernel_hook, None

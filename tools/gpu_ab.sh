@@ -8,7 +8,7 @@ mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for v in A B; do
   lib=$REPO/${!v}
-  ( NMRF_OVERLAP=0 timeout 600 rocprofv3 --kernel-trace --stats -d "$REPO/gpurun_out/prof" -o ${TAG}_$v -- python "$REPO/bench.py" --steps 8 --warmup 2 --no-cpu-baseline --no-stream-figure --no-graph --lib $lib ${BENCH_ARGS} 2>&1 | tail -3 ) > "$REPO/gpurun_out/rocprof_$v.log"
+  ( NMRF_OVERLAP=0 timeout 600 rocprofv3 --kernel-trace --stats -d "$REPO/gpurun_out/prof" -o ${TAG}_$v -- python "$REPO/bench.py" --steps 8 --warmup 2 --no-cpu-baseline --no-stream-figure --no-graph --no-clock-sample --lib $lib ${BENCH_ARGS} 2>&1 | tail -3 ) > "$REPO/gpurun_out/rocprof_$v.log"
 done
 cd "$REPO"
 da=$(find gpurun_out/prof -name "${TAG}_A_results.db" | head -1); db=$(find gpurun_out/prof -name "${TAG}_B_results.db" | head -1)

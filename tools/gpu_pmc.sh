@@ -13,7 +13,7 @@ run passC FETCH_SIZE GRBM_GUI_ACTIVE
 run passD WRITE_SIZE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM
 fi
 # the conv kernel runs 9-12 different layers per forward: its traffic is collected on the model itself (eager, 2 forwards)
-runm() { tag=$1; shift; ( NMRF_OVERLAP=0 timeout 600 rocprofv3 --kernel-trace --pmc "$@" -d "$REPO/gpurun_out/pmc" -o "$tag" --output-format csv -- python "$REPO/bench.py" --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-stream-figure 2>&1 | tail -2 ) > "$REPO/gpurun_out/pmc/$tag.log"; }
+runm() { tag=$1; shift; ( NMRF_OVERLAP=0 timeout 600 rocprofv3 --kernel-trace --pmc "$@" -d "$REPO/gpurun_out/pmc" -o "$tag" --output-format csv -- python "$REPO/bench.py" --steps 2 --warmup 1 --no-graph --no-clock-sample --no-cpu-baseline --no-stream-figure 2>&1 | tail -2 ) > "$REPO/gpurun_out/pmc/$tag.log"; }
 if [ -z "$PMC_SKIP_MODEL" ]; then
 runm passM1 FETCH_SIZE GRBM_GUI_ACTIVE
 runm passM2 WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES

@@ -25,9 +25,9 @@ if [ "$1" != "quick" ]; then
   ( timeout 900 python bench.py --steps 5 --warmup 2 --backbone swin --height 1000 --width 1500 --max-disp 256 --no-cpu-baseline 2>&1 | tail -2 ) > gpurun_out/bench_swin_middlebury.log
 fi
 cd /tmp && export TMPDIR=/tmp
-( NMRF_OVERLAP=0 timeout 600 rocprofv3 --kernel-trace --stats -d "$REPO/gpurun_out/prof" -o ${TAG} -- python "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-stream-figure --no-graph 2>&1 | tail -5 ) > "$REPO/gpurun_out/rocprof.log"
+( NMRF_OVERLAP=0 timeout 600 rocprofv3 --kernel-trace --stats -d "$REPO/gpurun_out/prof" -o ${TAG} -- python "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-stream-figure --no-graph --no-clock-sample 2>&1 | tail -5 ) > "$REPO/gpurun_out/rocprof.log"
 if [ "$1" != "quick" ]; then
-  ( NMRF_OVERLAP=0 timeout 600 rocprofv3 --kernel-trace --stats -d "$REPO/gpurun_out/prof" -o ${TAG}_swin -- python "$REPO/bench.py" --steps 2 --warmup 1 --backbone swin --height 1000 --width 1500 --max-disp 256 --no-cpu-baseline --no-stream-figure --no-graph 2>&1 | tail -5 ) > "$REPO/gpurun_out/rocprof_swin.log"
+  ( NMRF_OVERLAP=0 timeout 600 rocprofv3 --kernel-trace --stats -d "$REPO/gpurun_out/prof" -o ${TAG}_swin -- python "$REPO/bench.py" --steps 2 --warmup 1 --backbone swin --height 1000 --width 1500 --max-disp 256 --no-cpu-baseline --no-stream-figure --no-graph --no-clock-sample 2>&1 | tail -5 ) > "$REPO/gpurun_out/rocprof_swin.log"
 fi
 cd "$REPO"
 for t in ${TAG} ${TAG}_swin; do
