@@ -175,6 +175,144 @@ __global__ __launch_bounds__(256, PB == 2 ? 4 : 3) void msda_fwd_d8_kernel(const
     }
 }
 
+// Tiled form of the fast path (round 6).  The kernel above runs at the rate of L2 -> L1 line fills, not of HBM: a tap is the 32-byte row of
+// one head of one pixel, a pixel's eight heads are two 128-byte lines, so the 64 lanes of a load touch 64 lines and use a quarter of each
+// (~2 KB of fills per (query, head); 68-101 us per call whether the level holds 49 MB or 0.8 MB).  Here a block owns an 8 x 8 tile of
+// the QUERY grid (all eight heads: 512 threads, lanes = consecutive heads as above, so loc / weights / out stay fully coalesced),
+// reduces the bounding box of its taps on the sampled level, stages that box ONCE with coalesced 256-byte pixel rows into LDS
+// (pixel pitch 72 floats: adjacent pixels start 8 banks apart) and takes every tap from there.  The query grid is not an argument of
+// the operator: the launcher GUESSES it (an integer multiple k of the level's H x W with k^2 H W = Lq -- the neck's queries are the
+// 1/4-resolution grid, its levels 1/4 ... 1/32); a wrong guess costs locality, never correctness: the box comes from the data, and a
+// block whose box exceeds the LDS budget (large learned offsets) takes its taps from global memory as before.
+// Arithmetic: the point / tap / accumulation order of msda_fwd_d8_kernel; points outside the map are skipped (what the generic
+// kernel does; the kernel above multiplies their clamped taps by a zero weight: the same value for finite data).
+#define MSDA_T_PITCH 68
+// TY: rows of the query tile (8 x TY queries x 8 heads = 64 TY threads).  The product form is TY = 8 (512 threads, up to 504 staged
+// pixels, one block per CU); TY = 4 (256 threads, 252 pixels, two blocks per CU) measured slower at three of the four levels.  The next
+// tile's three operand vectors are requested before the current tile's taps.
+template <int NPT, int TY>
+__global__ __launch_bounds__(64 * TY) void msda_fwd_d8_tiled_kernel(const float *__restrict__ value, const int64_t *__restrict__ shapes,
+        const int64_t *__restrict__ lvl_start, const float *__restrict__ loc, const float *__restrict__ wgt, int B, int S, int Lq, int kq,
+        int cap_px, float *__restrict__ out) {
+    static_assert(NPT == 4, "three 16-byte operand loads per thread");
+    constexpr int NTHR = 64 * TY;
+    extern __shared__ __attribute__((aligned(16))) float s_px[];                 // [cap_px][MSDA_T_PITCH]
+    __shared__ int s_box[TY][4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int m = tid & 7, ql = tid >> 3, ty = ql >> 3, tx = ql & 7;
+    const int Hh = (int)shapes[0], Ww = (int)shapes[1];
+    // the guessed query grid: kq x the level's (the launcher checked kq^2 S = Lq); a level whose H W is not S falls back to one row
+    const bool grid_ok = (int64_t)Hh * Ww == S;
+    const int qh = grid_ok ? Hh * kq : 1, qw = grid_ok ? Ww * kq : Lq;
+    const int tiles_x = (qw + 7) / 8, tiles_y = (qh + TY - 1) / TY;
+    // persistent, XCD-aware: the blocks of one XCD walk a contiguous run of tiles (neighbouring boxes share their margins in that L2)
+    const int per_img = tiles_x * tiles_y, total = per_img * B;
+    const int chunk = (total + 7) / 8;
+    const int jstep = (int)(gridDim.x >> 3), j0 = (int)(blockIdx.x >> 3), xcd = (int)(blockIdx.x & 7);
+    auto item_of = [&](int jj) { return (jj < chunk && xcd * chunk + jj < total) ? xcd * chunk + jj : -1; };
+    struct Q { int64_t bqm; bool valid; int b; };
+    auto query_of = [&](int item) {
+        const int b = item / per_img, tile = item - b * per_img;
+        const int qy = (tile / tiles_x) * TY + ty, qx = (tile % tiles_x) * 8 + tx;
+        const bool valid = qy < qh && qx < qw;
+        const int64_t q = (int64_t)(valid ? qy : qh - 1) * qw + (valid ? qx : qw - 1);
+        return Q{((int64_t)b * Lq + q) * 8 + m, valid, b};
+    };
+    int item = item_of(j0);
+    if (item < 0) return;                                                         // (whole block)
+    Q cur = query_of(item);
+    float4 l0 = ldg4(loc + cur.bqm * (NPT * 2)), l1 = ldg4(loc + cur.bqm * (NPT * 2) + 4), w4 = ldg4(wgt + cur.bqm * NPT);
+    for (int jj = j0;; jj += jstep) {
+    const int nitem = item_of(jj + jstep);
+    const Q nxt = nitem >= 0 ? query_of(nitem) : cur;
+    const bool valid = cur.valid;
+    const int64_t bqm = cur.bqm;
+    const int b = cur.b;
+    const float lx[NPT] = {l0.x, l0.z, l1.x, l1.z}, ly[NPT] = {l0.y, l0.w, l1.y, l1.w}, aw[NPT] = {w4.x, w4.y, w4.z, w4.w};
+    // geometry of the four points: clamped corner coordinates, bilinear weights (zero where an axis index leaves the map)
+    int x0[NPT], x1[NPT], y0[NPT], y1[NPT];
+    float tw[NPT][4];
+    bool in[NPT];
+    int bx0 = 0x7fffffff, by0 = 0x7fffffff, bx1 = -1, by1 = -1;
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt) {
+        const float w_im = lx[pt] * Ww - 0.5f, h_im = ly[pt] * Hh - 0.5f;
+        const bool inside = h_im > -1 && w_im > -1 && h_im < Hh && w_im < Ww;
+        const float hf = floorf(h_im), wf = floorf(w_im);
+        const int h0 = inside ? (int)hf : 0, w0 = inside ? (int)wf : 0;
+        y0[pt] = h0 < 0 ? 0 : h0; y1[pt] = h0 + 1 < Hh ? h0 + 1 : Hh - 1;
+        x0[pt] = w0 < 0 ? 0 : w0; x1[pt] = w0 + 1 < Ww ? w0 + 1 : Ww - 1;
+        const float lh = inside ? h_im - hf : 0.f, lw = inside ? w_im - wf : 0.f;
+        const float wy[2] = {inside && h0 >= 0 ? 1 - lh : 0.f, inside && h0 + 1 < Hh ? lh : 0.f};
+        const float wx[2] = {w0 >= 0 ? 1 - lw : 0.f, w0 + 1 < Ww ? lw : 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tw[pt][k] = wy[k >> 1] * wx[k & 1];
+        in[pt] = inside && valid;
+        if (in[pt]) {
+            bx0 = min(bx0, x0[pt]); bx1 = max(bx1, x1[pt]);
+            by0 = min(by0, y0[pt]); by1 = max(by1, y1[pt]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        bx0 = min(bx0, __shfl_xor(bx0, o)); by0 = min(by0, __shfl_xor(by0, o));
+        bx1 = max(bx1, __shfl_xor(bx1, o)); by1 = max(by1, __shfl_xor(by1, o));
+    }
+    if (lane == 0) { s_box[wv][0] = bx0; s_box[wv][1] = by0; s_box[wv][2] = bx1; s_box[wv][3] = by1; }
+    __syncthreads();                                                              // (also: the previous tile's taps are done -- s_px is free)
+#pragma unroll
+    for (int w = 0; w < TY; ++w) {
+        bx0 = min(bx0, s_box[w][0]); by0 = min(by0, s_box[w][1]);
+        bx1 = max(bx1, s_box[w][2]); by1 = max(by1, s_box[w][3]);
+    }
+    const int wb = bx1 - bx0 + 1, hb = by1 - by0 + 1;
+    const bool staged = bx1 >= bx0 && by1 >= by0 && (int64_t)wb * hb <= cap_px;      // (block-uniform)
+    const float *vimg = value + ((int64_t)b * S + lvl_start[0]) * 64;             // pixel 0, head 0 of this image's level
+    if (staged) {
+        const int pieces = wb * hb * 16;                                          // 16-byte pieces: 16 per 256-byte pixel
+        for (int i = tid; i < pieces; i += NTHR) {
+            const int pix = i >> 4, pc = i & 15, py = pix / wb, px = pix - py * wb;
+            stg4(s_px + pix * MSDA_T_PITCH + 4 * pc, ldg4(vimg + ((int64_t)(by0 + py) * Ww + bx0 + px) * 64 + 4 * pc));
+        }
+    }
+    // the next tile's operands: their round trip runs under this tile's taps
+    const float4 n0 = ldg4(loc + nxt.bqm * (NPT * 2)), n1 = ldg4(loc + nxt.bqm * (NPT * 2) + 4), nw = ldg4(wgt + nxt.bqm * NPT);
+    __syncthreads();                                                              // staged pixels visible; s_box read by every wave
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt) {
+        if (!in[pt]) continue;
+        const int yy[2] = {y0[pt], y1[pt]}, xx[2] = {x0[pt], x1[pt]};
+        f32x4 va[4], vb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float *src = staged ? s_px + ((yy[k >> 1] - by0) * wb + (xx[k & 1] - bx0)) * MSDA_T_PITCH + 8 * m
+                                      : vimg + ((int64_t)yy[k >> 1] * Ww + xx[k & 1]) * 64 + 8 * m;
+            va[k] = *reinterpret_cast<const f32x4 *>(src);
+            vb[k] = *reinterpret_cast<const f32x4 *>(src + 4);
+        }
+        float sx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float t = tw[pt][k];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                sx[c] += t * va[k][c];
+                sx[4 + c] += t * vb[k][c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] += sx[c] * aw[pt];
+    }
+    if (valid) {
+        stg4(out + bqm * 8, make_float4(acc[0], acc[1], acc[2], acc[3]));
+        stg4(out + bqm * 8 + 4, make_float4(acc[4], acc[5], acc[6], acc[7]));
+    }
+    if (nitem < 0) break;
+    item = nitem; cur = nxt; l0 = n0; l1 = n1; w4 = nw;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void msda_bwd_kernel(const T *__restrict__ value, const int64_t *__restrict__ shapes,
         const int64_t *__restrict__ lvl_start, const T *__restrict__ loc, const T *__restrict__ wgt,
@@ -224,7 +362,7 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(const T *__restrict__ val
 }
 
 #ifdef NMRF_DEBUG_PROBES
-static int g_msda_variant = 0;       // tools: 1 = generic kernel, 2 = four points per load batch, 3 = one item per thread without prefetch
+static int g_msda_variant = 0;       // tools: 1 = generic kernel, 2 = four points per load batch, 3 = one item per thread without prefetch, 4 = untiled d8 form, 5 = tiled with 8 x 4 tiles
 extern "C" int nmrf_debug_msda_variant(int v) { g_msda_variant = v; return NMRF_OK; }
 #endif
 
@@ -267,6 +405,42 @@ static int msda_forward(const T *value, const int64_t *shapes, const int64_t *lv
             if (g_msda_variant != 1)
 #endif
             {
+                // tiled form (see msda_fwd_d8_tiled_kernel): one level, eight heads, Lq = kq^2 S for an integer kq
+                int kq = 0;
+                if (L == 1 && M == 8 && Lq % S == 0) {
+                    const int64_t r = Lq / S;
+                    const int k = (int)(sqrt((double)r) + 0.5);
+                    if ((int64_t)k * k == r && k >= 1) kq = k;
+                }
+#ifdef NMRF_DEBUG_PROBES
+                if (g_msda_variant == 4) kq = 0;                               // tools: the untiled product form of rounds 4-5
+#endif
+                if (kq) {
+                    // 8 x 8 query tiles, 512 threads, one block per CU with up to 504 staged pixels (137 KB): measured against 8 x 4 tiles /
+                    // 256 threads / 252 pixels / two blocks per CU at the four levels of the neck (profiles/r06s_msda_tiled.txt)
+                    static bool attr_set_dev[NMRF_MAX_DEV] = {};
+                    bool small = false;
+#ifdef NMRF_DEBUG_PROBES
+                    small = g_msda_variant == 5;                                   // tools: the 8 x 4-tile form
+#endif
+                    const int cap_small = 252, cap_big = 504;
+                    if (!attr_set_dev[dev]) {
+                        // (the kernels also hold a few bytes of static LDS: the attribute is the dynamic part only)
+                        if (hipFuncSetAttribute(reinterpret_cast<const void *>(msda_fwd_d8_tiled_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                cap_small * MSDA_T_PITCH * 4) != hipSuccess ||
+                            hipFuncSetAttribute(reinterpret_cast<const void *>(msda_fwd_d8_tiled_kernel<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                cap_big * MSDA_T_PITCH * 4) != hipSuccess)
+                            return NMRF_ELAUNCH;
+                        attr_set_dev[dev] = true;
+                    }
+                    if (small)
+                        hipLaunchKernelGGL((msda_fwd_d8_tiled_kernel<4, 4>), dim3((unsigned)((2 * n_cu_dev[dev] + 7) / 8 * 8)), dim3(256),
+                                           (size_t)cap_small * MSDA_T_PITCH * 4, st, value, shapes, lvl_start, loc, w, B, S, Lq, kq, cap_small, out);
+                    else
+                        hipLaunchKernelGGL((msda_fwd_d8_tiled_kernel<4, 8>), dim3((unsigned)((n_cu_dev[dev] + 7) / 8 * 8)), dim3(512),
+                                           (size_t)cap_big * MSDA_T_PITCH * 4, st, value, shapes, lvl_start, loc, w, B, S, Lq, kq, cap_big, out);
+                    return nmrf_launch_status();
+                }
                 hipLaunchKernelGGL((msda_fwd_d8_kernel<4>), dim3(persistent), dim3(256), 0, st, value, shapes, lvl_start, loc, w, B, S, M, L, Lq,
                                    P, out);
                 return nmrf_launch_status();

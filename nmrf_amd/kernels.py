@@ -1137,8 +1137,9 @@ def msda_forward(value, shapes, lvl_start, loc, w):
     out = torch.empty(b, lq, m * d, device=value.device, dtype=dt)
     fn = _lib.load().nmrf_msda_forward_f32 if dt == torch.float32 else _lib.load().nmrf_msda_forward_f64
     _hb("msda_forward", row="A15", bound="hbm", bytes=float(value.element_size()) * (value.numel() + loc.numel() + w.numel() + out.numel()),
-        flops=2.0 * b * lq * m * d * l * p * 5, label="msda_fwd_kernel (multi-scale deformable attention forward, A15)",
-        pmc=["msda_fwd_kernel"])
+        flops=2.0 * b * lq * m * d * l * p * 5, label="msda_fwd_d8_tiled_kernel / msda_fwd_d8_kernel / msda_fwd_kernel (multi-scale deformable "
+        "attention forward, A15; the tiled form when the queries are a grid over one level of 8 x 8-channel heads)",
+        pmc=["msda_fwd_d8_tiled_kernel<", "msda_fwd_d8_kernel<", "msda_fwd_kernel"])
     _lib.check(fn(_p(value), _p(shapes), _p(lvl_start), _p(loc), _p(w), b, s, m, d, l, lq, p, _p(out), _stream()),
                "msda_forward")
     _he("msda_forward")

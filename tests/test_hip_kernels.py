@@ -3,6 +3,8 @@ nmrf_amd.kernels) against the CPU oracle on the same seeded inputs, and against 
 captured from the reference.  Integer outputs are bit-exact; fp32 tolerances are stated per test.
 Run on the MI355X box:  python -m pytest tests -m gpu -q
 """
+import os
+
 import numpy as np
 
 import pytest
@@ -476,6 +478,43 @@ def test_msda_forward_at_middlebury_swin_shapes(lvl):
     # grid_sample round trip ((2*loc - 1 + 1) * W - 1) / 2: one fp32 ulp of a coordinate up to 376 = 2e-5 px, times the unit
     # gradient of a random value map (measured max 2.3e-5 at the 256x376 level, < 3e-6 at the small golden shapes)
     report("msda config-5", got, O.msda_core(value, shapes, loc, wgt), 6e-5, 1e-5)
+
+
+@pytest.mark.parametrize("qh,qw,kq,spread", [(64, 96, 1, 4.0), (52, 76, 2, 4.0), (37, 51, 1, 3.0), (40, 72, 4, 6.0), (24, 40, 1, 60.0)])
+def test_msda_forward_tiled_form_with_neck_like_locations(qh, qw, kq, spread):
+    """A15, the tiled form (msda_fwd_d8_tiled_kernel, round 6): 8 heads x 8 channels, one level, 4 points, queries on a grid kq times
+    the level's (Lq = kq^2 H W -- what the launcher recognises), sampling locations = the query's own reference point + offsets of a
+    few level pixels, as the neck produces them (adaptor_modules.py:78-90): the block stages the bounding box of its taps in LDS.
+    Partial tiles (grids that are no multiple of 8), points outside the map, and offsets too large for the LDS budget (spread 60: the
+    taps come from global memory again) -- against the fp64 generic kernel, and to a few ulps against the untiled fast path where the
+    tools library is present (the same arithmetic in the same order)."""
+    from nmrf_amd import _lib
+    h, w = qh // kq, qw // kq
+    assert h * kq == qh and w * kq == qw
+    lq = qh * qw
+    value = rnd(2, h * w, 8, 8, seed=61)
+    ys, xs = torch.meshgrid((torch.arange(qh) + 0.5) / qh, (torch.arange(qw) + 0.5) / qw, indexing="ij")
+    ref = torch.stack((xs, ys), -1).reshape(1, lq, 1, 1, 1, 2)
+    loc = (ref + rnd(2, lq, 8, 1, 4, 2, seed=62) * spread / torch.tensor([w, h], dtype=torch.float32)).contiguous()
+    wgt = torch.softmax(rnd(2, lq, 8, 1, 4, seed=63) * 2, -1).contiguous()
+    shapes, start = torch.tensor([[h, w]]), torch.tensor([0])
+    dv, ds, dst, dl, dw = (x.to(DEV) for x in (value, shapes, start, loc, wgt))
+    got = K().msda_forward(dv, ds, dst, dl, dw)
+    want = K().msda_forward(dv.double(), ds, dst, dl.double(), dw.double()).cpu()
+    # (fp32 coordinates: a sample 1 ulp off at a coordinate of ~100 moves the bilinear weights by ~1e-5)
+    report("msda tiled vs fp64 generic", got.cpu(), want, 3e-5, 1e-5)
+    if os.path.exists(_lib.DEBUG_LIB_PATH):
+        dbg = _lib.load_debug()
+        out2 = torch.empty_like(got)
+        dbg.nmrf_debug_msda_variant(4)                                  # the untiled msda_fwd_d8_kernel
+        try:
+            _lib.check(dbg.nmrf_msda_forward_f32(dv.data_ptr(), ds.data_ptr(), dst.data_ptr(), dl.data_ptr(), dw.data_ptr(),
+                                                 2, h * w, 8, 8, 1, lq, 4, out2.data_ptr(), None), "msda untiled")
+            torch.cuda.synchronize()
+        finally:
+            dbg.nmrf_debug_msda_variant(0)
+        # (same operations in the same order; the compiler contracts the multiply-adds of the two kernels differently: a few ulps)
+        assert float((got - out2).abs().max()) <= 5e-7 * max(1.0, float(out2.abs().max())), float((got - out2).abs().max())
 
 
 @pytest.mark.parametrize("t_,k,n,relu", [(1000, 128, 64, False), (333, 128, 16, True), (4097, 128, 1, False), (70, 36, 5, True)])

@@ -265,11 +265,21 @@ if "msda" in which:
         shapes = torch.tensor([[hh, ww]], device=dev)
         start = torch.tensor([0], device=dev)
         out_new = K.msda_forward(value, shapes, start, loc, wgt)
-        for var, tag in ((0, "product: persistent, operands prefetched, 2 points per load batch"), (3, "one item per thread, no prefetch"),
-                         (2, "persistent, 4 points per load batch"), (1, "generic kernel"), (0, "product again")):
+        for var, tag in ((0, "product: tiled, taps from an LDS-staged bounding box (round 6)"),
+                         (4, "untiled: persistent, operands prefetched, 2 points per load batch (rounds 4-5)"), (3, "one item per thread, no prefetch"),
+                         (5, "tiled, 8 x 4 tiles, two 256-thread blocks per CU"), (1, "generic kernel"), (0, "product again"), (4, "untiled again"), (5, "8 x 4 tiles again")):
             _l.nmrf_debug_msda_variant(var)
             timeit("msda_forward level %dx%d (%s)" % (hh, ww, tag), lambda: K.msda_forward(value, shapes, start, loc, wgt))
+        # offsets too large for the staged box (+- 14 px): the tiled kernel's blocks take their taps from global memory
+        loc_far = (ref + noise * 14.0 / torch.tensor([ww, hh], device=dev, dtype=torch.float32)).contiguous()
+        for var, tag in ((0, "tiled kernel, +-14 px offsets: boxes do not fit, taps from global memory"), (4, "untiled, +-14 px offsets")) * 2:
+            _l.nmrf_debug_msda_variant(var)
+            timeit("msda_forward level %dx%d (%s)" % (hh, ww, tag), lambda: K.msda_forward(value, shapes, start, loc_far, wgt))
+        _l.nmrf_debug_msda_variant(4)
+        out_untiled = K.msda_forward(value, shapes, start, loc, wgt)
         _l.nmrf_debug_msda_variant(0)
+        print("   tiled vs untiled: max |diff| %.2e; algorithmic bytes %.1f MB" % (float((out_new - out_untiled).abs().max()),
+              (loc.numel() + wgt.numel() + out_new.numel() + value.numel()) * 4 / 1e6), flush=True)
         if old is not None:
             out_old = torch.empty_like(out_new)
             call_old = lambda: old.nmrf_msda_forward_f32(value.data_ptr(), shapes.data_ptr(), start.data_ptr(), loc.data_ptr(), wgt.data_ptr(),
