@@ -415,3 +415,34 @@ def test_integration_appendix_lists_every_entry_point():
     helpers = ("nmrf_selftest_", "nmrf_strerror", "nmrf_abi_version", "nmrf_pack_", "nmrf_host_", "nmrf_sum_partials", "nmrf_colsum_",
                "nmrf_act_bwd", "nmrf_layernorm", "nmrf_instance_stats", "nmrf_prep_images_s2d_f32", "nmrf_nmp_block16_clock_records", "nmrf_build_stamp")
     assert all(n.startswith(helpers) for n in uncited), [n for n in uncited if not n.startswith(helpers)]
+
+
+def test_gelu_fast_coefficients_meet_their_stated_error():
+    """csrc/common.h:gelu_fast (round 6): v Phi(v) = max(v, 0) - |v| 2^(-t P(t)) / 2 with t = min(|v|, 7) and the degree-5 polynomial whose
+    coefficients are in the header.  Emulated in fp32 (every operation rounded once, as the kernel's v_fma / v_mul / v_exp do) against
+    fp64 erf over [-12, 12]: the header states 3.0e-7 (half an ulp at 4), the form it replaced had 4.7e-7."""
+    import numpy as np
+    from scipy.special import erf
+    src = open(os.path.join(ROOT, "nmrf_amd", "csrc", "common.h")).read()
+    body = src[src.index("__device__ __forceinline__ float gelu_fast(float v) {"):]
+    body = body[:body.index("#else")]
+    co = [float(x) for x in re.findall(r"(-?\d\.\d+(?:e-?\d+)?)f", body)]
+    # fminf(a, 7.0f), then c5, c4 (first fma), c3, c2, c1, c0, then the -0.5f / 0.f of the last line
+    assert co[0] == 7.0 and len(co) >= 7, co
+    c5, c4, c3, c2, c1, c0 = co[1:7]
+    f32 = np.float32
+
+    def fma(a, b, c):
+        return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(f32)
+
+    v = np.concatenate([np.linspace(-12, 12, 1200001), np.random.default_rng(0).normal(size=400000) * 2]).astype(f32)
+    t = np.minimum(np.abs(v), f32(7.0))
+    p = fma(np.full_like(v, f32(c5)), t, np.full_like(v, f32(c4)))
+    for c in (c3, c2, c1, c0):
+        p = fma(p, t, np.full_like(v, f32(c)))
+    e = np.exp2((-t.astype(np.float64) * p.astype(np.float64)).astype(f32).astype(np.float64)).astype(f32)
+    got = fma((e.astype(np.float64) * t.astype(np.float64)).astype(f32), np.full_like(v, f32(-0.5)), np.maximum(v, f32(0)))
+    want = 0.5 * v.astype(np.float64) * (1 + erf(v.astype(np.float64) / np.sqrt(2)))
+    err = np.abs(got - want)
+    assert err.max() <= 3.2e-7, (float(err.max()), float(v[err.argmax()]))
+    assert np.all(got[v > 8] == v[v > 8]) and np.all(np.abs(got[v < -8]) < 1e-10)     # the tails: identity / zero
