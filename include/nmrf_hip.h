@@ -443,7 +443,11 @@ int nmrf_nmp_block16_clock_records(unsigned long long *buf, int capacity_blocks)
  * range_flag: the fp16 range guard of the split operands (see the top of this header), may be NULL. */
 int nmrf_gemm_split_f32(const float *A, int64_t sa_i, int64_t sa_k, const float *B, int64_t sb_k, int64_t sb_j, int M, int N, int K,
                         float *C, int ldc, int splits, int64_t split_stride, const float *a_amax, int *range_flag, void *stream);
-/* out[i] = sum_{s < S} parts[s*stride + i], s ascending (i < n). */
+/* *out = max(*out, max_i |x[i]|) for a caller-ZEROED device float (the a_amax operand of nmrf_gemm_split_f32): one pass, one atomic per
+ * block on the value's bit pattern -- order-independent, deterministic; NaNs are dropped (the consumer's range guard reports them).
+ * x 16-byte aligned. */
+int nmrf_absmax_f32(const float *x, int64_t n, float *out, void *stream);
+/* out[i] = sum_{s < S} parts[s*stride + i] (i < n), added in a fixed order (four interleaved partial sums): deterministic. */
 int nmrf_sum_partials_f32(const float *parts, int S, int64_t n, int64_t stride, float *out, void *stream);
 /* The same in groups: out[g*n + i] = sum over the parts s in [g*group, min(S, (g+1)*group)) -- a caller with many parts reduces in rounds
  * (a fixed tree: deterministic) instead of one long serial chain per element. */

@@ -119,15 +119,23 @@ extern "C" int nmrf_gemm_split_f32(const float *A, int64_t sa_i, int64_t sa_k, c
     return nmrf_launch_status();
 }
 
-// out[g*n + i] = sum of parts[s*stride + i] over the `group` parts s of group g, s ascending (the deterministic second pass of every
+// out[g*n + i] = sum of parts[s*stride + i] over the `group` parts s of group g, in a fixed order (the deterministic second pass of every
 // split reduction here; a caller with many parts reduces in rounds of `group`: a fixed tree, same bits every run)
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float *__restrict__ parts, int S, int64_t n, int64_t stride, int group,
                                                            float *__restrict__ out) {
     const int s0 = blockIdx.y * group, s1 = min(S, s0 + group);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        float s = 0.f;
-        for (int k = s0; k < s1; ++k) s += parts[(int64_t)k * stride + i];
-        out[(int64_t)blockIdx.y * n + i] = s;
+        // four interleaved accumulators (four loads in flight), combined in a fixed order: deterministic, not the serial sum's bits
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int k = s0;
+        for (; k + 3 < s1; k += 4) {
+            a0 += parts[(int64_t)k * stride + i];
+            a1 += parts[(int64_t)(k + 1) * stride + i];
+            a2 += parts[(int64_t)(k + 2) * stride + i];
+            a3 += parts[(int64_t)(k + 3) * stride + i];
+        }
+        for (; k < s1; ++k) a0 += parts[(int64_t)k * stride + i];
+        out[(int64_t)blockIdx.y * n + i] = (a0 + a1) + (a2 + a3);
     }
 }
 extern "C" int nmrf_sum_partials_grouped_f32(const float *parts, int S, int64_t n, int64_t stride, int group, float *out, void *stream) {
@@ -142,15 +150,27 @@ extern "C" int nmrf_sum_partials_grouped_f32(const float *parts, int S, int64_t 
 }
 // The whole reduction of MANY parts of a NARROW row in one launch (round 6: the training step spent 504 launches / 4 ms per step in
 // rounds of the grouped kernel above): a block owns 8 columns; its 32 part-lanes each add the parts p, p + 32, p + 64, ... in ascending
-// order, then lane 0 adds the 32 lane sums in ascending order through LDS -- a fixed tree for a given S: the same bits every run.
+// order (four interleaved accumulators), then lane 0 adds the 32 lane sums in ascending order through LDS -- a fixed tree for a given S:
+// the same bits every run.
 __global__ __launch_bounds__(256) void sum_partials_tree_kernel(const float *__restrict__ parts, int S, int64_t n, int64_t stride,
                                                                 float *__restrict__ out) {
     __shared__ float sh[32][9];
     const int c8 = threadIdx.x & 7, pl = threadIdx.x >> 3;
     const int64_t col = (int64_t)blockIdx.x * 8 + c8;
     float s = 0.f;
-    if (col < n)
-        for (int k = pl; k < S; k += 32) s += parts[(int64_t)k * stride + col];
+    if (col < n) {
+        // four independent accumulators: four loads in flight instead of a chain of dependent round trips (combined in a fixed order)
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int k = pl;
+        for (; k + 96 < S; k += 128) {
+            s0 += parts[(int64_t)k * stride + col];
+            s1 += parts[(int64_t)(k + 32) * stride + col];
+            s2 += parts[(int64_t)(k + 64) * stride + col];
+            s3 += parts[(int64_t)(k + 96) * stride + col];
+        }
+        for (; k < S; k += 32) s0 += parts[(int64_t)k * stride + col];
+        s = (s0 + s1) + (s2 + s3);
+    }
     sh[pl][c8] = s;
     __syncthreads();
     if (pl == 0 && col < n) {
@@ -170,15 +190,76 @@ extern "C" int nmrf_sum_partials_f32(const float *parts, int S, int64_t n, int64
     return nmrf_sum_partials_grouped_f32(parts, S, n, stride, S < 1 ? 1 : S, out, stream);
 }
 
+// max |x| into *out (which the caller has ZEROED): per-thread maxima over 16-byte loads, wave and block reduction, one atomicMax of the
+// value's bit pattern per block (non-negative floats order like their bits; the maximum does not depend on the order of the atomics:
+// deterministic).  NaNs are dropped by fmaxf -- the consumers' own range guard reports them.  (Round 6: torch's norm(inf) took 14.7 us
+// per gradient tensor, 92 per training step.)
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, int64_t n, float *__restrict__ out) {
+    __shared__ float sh[4];
+    float m = 0.f;
+    const int64_t n4 = n >> 2;
+    const float4 *v = reinterpret_cast<const float4 *>(x);
+    const int64_t step = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    auto m4 = [](float4 t) { return fmaxf(fmaxf(fabsf(t.x), fabsf(t.y)), fmaxf(fabsf(t.z), fabsf(t.w))); };
+    for (; i + 3 * step < n4; i += 4 * step) {                     // four loads in flight
+        const float4 t0 = v[i], t1 = v[i + step], t2 = v[i + 2 * step], t3 = v[i + 3 * step];
+        m = fmaxf(m, fmaxf(fmaxf(m4(t0), m4(t1)), fmaxf(m4(t2), m4(t3))));
+    }
+    for (; i < n4; i += step) m = fmaxf(m, m4(v[i]));
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+        atomicMax(reinterpret_cast<unsigned *>(out), __float_as_uint(m));
+    }
+}
+extern "C" int nmrf_absmax_f32(const float *x, int64_t n, float *out, void *stream) {
+    if (!x || !out) return NMRF_ENULL;
+    if (n < 1 || (reinterpret_cast<uintptr_t>(x) & 15)) return NMRF_EINVAL;
+    int64_t blocks = ceil_div64(n / 4 > 0 ? n / 4 : 1, 256 * 4);
+    if (blocks > 512) blocks = 512;                                // (more blocks: their atomics on one address serialise -- 4096: 21 us)
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n, out);
+    return nmrf_launch_status();
+}
+
 // bias gradient: parts[b][n] = sum over the rows of block b of x[t][n]   (then nmrf_sum_partials_f32 over b)
+// All 256 threads work whatever N is: a column is shared by RL = 256 / N' row lanes (N' = N rounded up to a power of two <= 256),
+// lane rl adds the rows rl, rl + RL, ... of the block with four independent accumulators (four loads in flight, combined in a fixed
+// order), and the RL lane sums are added in ascending order through LDS -- a fixed tree: the same bits every run.  (Round 6: the
+// one-thread-per-column walk before it took 21.8 us per call for 8 MB, 92 calls per training step.)
 __global__ __launch_bounds__(256) void colsum_partials_kernel(const float *__restrict__ x, int64_t T, int N, int rows_per_block,
                                                               float *__restrict__ parts) {
+    __shared__ float sh[256];
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < T ? r0 + rows_per_block : T;
-    for (int c = threadIdx.x; c < N; c += 256) {
-        float s = 0.f;
-        for (int64_t r = r0; r < r1; ++r) s += x[r * N + c];
-        parts[(int64_t)blockIdx.x * N + c] = s;
+    int np = 1;
+    while (np < N && np < 256) np <<= 1;                          // columns per pass (power of two <= 256)
+    const int RL = 256 / np, c0 = threadIdx.x & (np - 1), rl = threadIdx.x / np;
+    for (int cb = 0; cb < N; cb += np) {                          // (N > 256: several passes)
+        const int c = cb + c0;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (c < N) {
+            int64_t r = r0 + rl;
+            for (; r + 3 * RL < r1; r += 4 * RL) {
+                s0 += x[r * N + c];
+                s1 += x[(r + RL) * N + c];
+                s2 += x[(r + 2 * RL) * N + c];
+                s3 += x[(r + 3 * RL) * N + c];
+            }
+            for (; r < r1; r += RL) s0 += x[r * N + c];
+        }
+        sh[threadIdx.x] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (rl == 0 && c < N) {
+            float t = sh[c0];
+            for (int k = 1; k < RL; ++k) t += sh[k * np + c0];
+            parts[(int64_t)blockIdx.x * N + c] = t;
+        }
+        __syncthreads();
     }
 }
 extern "C" int nmrf_colsum_partials_f32(const float *x, int64_t T, int N, int rows_per_block, float *parts, void *stream) {

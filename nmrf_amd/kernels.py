@@ -519,6 +519,39 @@ def token_linear(x, packed_w, n, k, bias=None, ln=None, y=None, extra=None, extr
     return (x_out, out) if y is not None else out
 
 
+# max |w| of the weights about to be packed, fetched for MANY tensors with one read-back (nmrf_amd.train.train_step: the optimizer bumps
+# every parameter's version each step, so every launch site re-packs -- one `float(w.abs().max())` each was 89 device read-backs, 89
+# reductions and 107 abs kernels per training step).  Keyed on (data_ptr, version) of live parameters; the same value bit for bit.
+_AMAX_CACHE = {}
+
+
+def prefetch_amax(tensors):
+    ts = [t for t in tensors if t.is_cuda and t.dtype == torch.float32 and t.numel() > 0]
+    _AMAX_CACHE.clear()
+    if not ts:
+        return 0
+    with torch.no_grad():
+        try:
+            vals = torch._foreach_norm(ts, float("inf"))
+        except (RuntimeError, TypeError):
+            vals = [t.abs().max() for t in ts]
+        host = torch.stack([v.reshape(()) for v in vals]).tolist()             # ONE synchronising read
+    for t, v in zip(ts, host):
+        _AMAX_CACHE[(t.data_ptr(), t._version)] = float(v)
+    return len(ts)
+
+
+def cached_amax(t):
+    """The prefetched max |t| of a live parameter (this version), or None."""
+    return _AMAX_CACHE.get((t.data_ptr(), t._version))
+
+
+def _amax(weight, amax=None):
+    if amax is None:
+        amax = cached_amax(weight)
+    return float(weight.abs().max()) if amax is None else float(amax)
+
+
 @_on_device
 def pack_split_weight(weight, kp=None):
     """[N,K] nn.Linear weight -> (split-fp16 MFMA fragment pairs [N/32, Kp/16, 512] (int32 view of 2 KB pairs), 1/scale) for
@@ -527,18 +560,18 @@ def pack_split_weight(weight, kp=None):
     _chk(weight)
     n, k = weight.shape
     kp = kp or (k + 15) // 16 * 16
-    amax = float(weight.abs().max())
+    amax = _amax(weight)
     scale = 1.0 if not (amax > 0 and math.isfinite(amax)) else 2.0 ** min(40, max(-40, math.floor(math.log2(16383.0 / amax))))
     out = torch.empty(n // 32, kp // 16, 512, device=weight.device, dtype=torch.int32)
     _lib.check(_lib.load().nmrf_pack_split_weight_f32(_p(weight), n, k, kp, scale, _p(out), _stream()), "pack_split_weight")
     return out, 1.0 / scale
 
 
-def _pack_scaled(weight, kp, fn_name, rows, kchunk):
+def _pack_scaled(weight, kp, fn_name, rows, kchunk, amax=None):
     import math
     _chk(weight)
     n, k = weight.shape
-    amax = float(weight.abs().max())
+    amax = _amax(weight, amax)
     scale = 1.0 if not (amax > 0 and math.isfinite(amax)) else 2.0 ** min(40, max(-40, math.floor(math.log2(16383.0 / amax))))
     out = torch.empty(n // rows, kp // kchunk, 512, device=weight.device, dtype=torch.int32)
     _lib.check(getattr(_lib.load(), fn_name)(_p(weight), n, k, kp, scale, _p(out), _stream()), fn_name)
@@ -546,12 +579,13 @@ def _pack_scaled(weight, kp, fn_name, rows, kchunk):
 
 
 @_on_device
-def pack_split_weight16(weight, kp):
-    """[N,K] -> (pairs [N/16, Kp/32, 512] for nmp_block16 (16-row strips x 32-deep chunks), 1/scale)."""
-    return _pack_scaled(weight, kp, "nmrf_pack_split_weight16_f32", 16, 32)
+def pack_split_weight16(weight, kp, amax=None):
+    """[N,K] -> (pairs [N/16, Kp/32, 512] for nmp_block16 (16-row strips x 32-deep chunks), 1/scale).  amax: max |weight| if the caller
+    knows it (a concatenation of parameters whose maxima were prefetched)."""
+    return _pack_scaled(weight, kp, "nmrf_pack_split_weight16_f32", 16, 32, amax)
 
 
-def block_stream16(wp=None, w1=None, w2=None, wq=None, kq=0):
+def block_stream16(wp=None, w1=None, w2=None, wq=None, kq=0, wq_amax=None):
     """Weight stream of one nmp_block16 launch (include/nmrf_hip.h): proj | W1 strip pairs interleaved with W2 k chunks | q;
     within proj / W1 / q two adjacent 16-row strips are interleaved chunk by chunk (the kernel feeds them to two accumulators)."""
     import ctypes
@@ -573,7 +607,7 @@ def block_stream16(wp=None, w1=None, w2=None, wq=None, kq=0):
         seq.append(p2[15])
         parts.append(torch.stack(seq).view(-1, 512))
     if wq is not None:
-        pk, inv[3] = pack_split_weight16(wq, kq)
+        pk, inv[3] = pack_split_weight16(wq, kq, wq_amax)
         parts.append(ilv(pk).view(-1, 512))
     stream = torch.cat(parts).contiguous()
     assert stream.shape[0] % 8 == 0
@@ -1192,7 +1226,7 @@ _AMAX = {}
 def grad_amax(dy):
     """max |dy| as a device scalar (no read-back), shared by the dgrad and the wgrad of one gradient tensor: nmrf_gemm_split_f32 rescales
     its A operand from it by a power of two before the fp16 split (gradients of a mean loss are ~1 / (B H W), far below the range in
-    which the unscaled split keeps 22 bits).  One torch reduction per (tensor object, version) -- plumbing."""
+    which the unscaled split keeps 22 bits).  One nmrf_absmax_f32 launch per (tensor object, version)."""
     import weakref
     ent = _AMAX.get(id(dy))
     key = (dy._version, dy.data_ptr())
@@ -1201,9 +1235,29 @@ def grad_amax(dy):
     if len(_AMAX) > 64:
         _AMAX.clear()
     with torch.no_grad():
-        m = torch.linalg.vector_norm(dy.detach().reshape(-1), ord=float("inf")).reshape(1)
+        d = dy.detach()
+        if d.is_contiguous() and d.dtype == torch.float32 and d.data_ptr() % 16 == 0 and d.numel() > 0:
+            m = _zeroed_scalar(d.device)
+            _lib.check(_lib.load().nmrf_absmax_f32(_p(d), d.numel(), _p(m), _stream()), "absmax")
+        else:
+            m = torch.linalg.vector_norm(d.reshape(-1), ord=float("inf")).reshape(1)
     _AMAX[id(dy)] = (weakref.ref(dy), key, m)
     return m
+
+
+_ZPOOL = {}
+
+
+def _zeroed_scalar(device):
+    """A one-float device tensor holding 0: slices of a pool that is refilled (one torch.zeros) every 1024 requests -- a scalar per
+    gradient tensor without a fill kernel each."""
+    ent = _ZPOOL.get(device)
+    if ent is None or ent[1] >= ent[0].numel():
+        ent = [torch.zeros(1024, device=device, dtype=torch.float32), 0]
+        _ZPOOL[device] = ent
+    i = ent[1]
+    ent[1] = i + 4                                                 # 16-byte spacing
+    return ent[0][i:i + 1]
 
 
 def _gemm(a, sa_i, sa_k, b, sb_k, sb_j, m, n, k, splits=1, a_amax=None):

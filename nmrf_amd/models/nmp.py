@@ -161,14 +161,16 @@ class _BlockLauncher:
         return tuple(ps)
 
     def _build(self):
-        wq = bq = None
+        wq = bq = wq_amax = None
         if self.nxt_linears:
             k = max(l.in_features for l in self.nxt_linears)
             wq = torch.cat([_pad_cols(l.weight, k) for l in self.nxt_linears], 0).contiguous()
             bq = torch.cat([l.bias for l in self.nxt_linears]).contiguous()
+            am = [K.cached_amax(l.weight) for l in self.nxt_linears]           # (training: prefetched by train_step; zero padding adds nothing)
+            wq_amax = None if any(a is None for a in am) else max(am)
         stream, stages, inv = K.block_stream16(None if self.proj is None else self.proj.weight.contiguous(),
                                                None if self.mlp is None else self.mlp[1].fc1.weight.contiguous(),
-                                               None if self.mlp is None else self.mlp[1].fc2.weight.contiguous(), wq, self.kq)
+                                               None if self.mlp is None else self.mlp[1].fc2.weight.contiguous(), wq, self.kq, wq_amax)
         return stream, stages, inv, bq, (0 if wq is None else wq.shape[0])
 
     def __call__(self, x, msg=None, extra=None, extra_div=1, want_x=True, ln_out=None, ln_out_map=None, attn_qkv=None):

@@ -194,6 +194,8 @@ def train_step(model, criterion, optimizer, sample, grad_clip=1.0, group=None, r
     if not model.training:
         # (not model.train() here: it would put the BatchNorm layers fit() froze with freeze_bn() back into training mode, main.py:405-406)
         raise RuntimeError("train_step needs the model in training mode: model.train(); model.freeze_bn() -- as fit() does per epoch")
+    from . import kernels as K
+    K.prefetch_amax(p for p in model.parameters() if p.dim() == 2)     # the step re-packs every weight: their maxima in one read-back
     out = model(sample)
     dev = out["disp"].device
     loss_dict = criterion(out, {"disp": sample["disp"].to(dev).clone(), "valid": sample["valid"].to(dev)})

@@ -1541,3 +1541,51 @@ def test_warp_corr_concat_backward_vs_oracle_autograd(b, h, w, n, lab):
         report("warp rows " + name, a.cpu(), r, 2e-5 * float(r.abs().max()) + 1e-6)
     again = torch.autograd.grad(WarpCorrFn.apply(*mg, ld, n, gr, lambda: rows.detach()), mg, gout.to(DEV))
     assert all(torch.equal(x, y) for x, y in zip(got, again))
+
+
+def test_prefetched_weight_maxima_give_the_same_packed_streams():
+    """kernels.prefetch_amax (one read-back for many weights, used by train_step) feeds the pack-time scale of the split-fp16 weight
+    streams: the same value as the per-tensor `w.abs().max()`, hence the same stream bit for bit; an in-place update (new version)
+    invalidates the entry."""
+    kk = K()
+    ws = [rnd(128, 128, seed=1, scale=0.3).to(DEV), rnd(512, 128, seed=2, scale=0.05).to(DEV), rnd(384, 160, seed=3, scale=2.0).to(DEV)]
+    plain = [kk.pack_split_weight16(w, w.shape[1]) for w in ws]
+    assert kk.prefetch_amax(ws) == 3
+    for w in ws:
+        assert kk.cached_amax(w) == float(w.abs().max())
+    again = [kk.pack_split_weight16(w, w.shape[1]) for w in ws]
+    for (a, ia), (b, ib) in zip(plain, again):
+        assert ia == ib and torch.equal(a, b)
+    # a concatenation of parameters: the caller hands over the maximum of the parts
+    cat = torch.cat((ws[0], ws[0] * 0.5), 0).contiguous()
+    a, ia = kk.pack_split_weight16(cat, 128)
+    b, ib = kk.pack_split_weight16(cat, 128, amax=max(kk.cached_amax(ws[0]), 0.5 * kk.cached_amax(ws[0])))
+    assert ia == ib and torch.equal(a, b)
+    ws[0].mul_(3.0)
+    assert kk.cached_amax(ws[0]) is None
+    kk.prefetch_amax([])
+    assert kk.cached_amax(ws[1]) is None
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 1000, 16384 * 128, 16384 * 128 + 3])
+def test_absmax_matches_torch_and_is_order_independent(n):
+    """nmrf_absmax_f32 (the gradient operand's maximum for nmrf_gemm_split_f32): the exact value torch's norm(inf) returns, the same on
+    every run; a NaN is dropped (the consumers' range guard reports it), not propagated."""
+    from nmrf_amd import _lib
+    x = (rnd(n, seed=n % 97) * 3e-4).to(DEV)
+    x[n // 2] = -7.5e-3
+    out = torch.zeros(1, device=DEV)
+    _lib.check(_lib.load().nmrf_absmax_f32(x.data_ptr(), n, out.data_ptr(), None), "absmax")
+    assert float(out) == float(x.abs().max()) == 7.5e-3 or float(out) == float(x.abs().max())
+    out2 = torch.zeros(1, device=DEV)
+    _lib.check(_lib.load().nmrf_absmax_f32(x.data_ptr(), n, out2.data_ptr(), None), "absmax")
+    assert torch.equal(out, out2)
+    if n > 8:
+        x[3] = float("nan")
+        out3 = torch.zeros(1, device=DEV)
+        _lib.check(_lib.load().nmrf_absmax_f32(x.data_ptr(), n, out3.data_ptr(), None), "absmax")
+        assert float(out3) == float(out)
+    # through the wrapper: one launch per (tensor, version), cached
+    g = (rnd(300, 128, seed=5) * 1e-5).to(DEV)
+    m1 = K().grad_amax(g)
+    assert float(m1) == float(g.abs().max()) and K().grad_amax(g) is m1
