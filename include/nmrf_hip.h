@@ -443,6 +443,9 @@ int nmrf_nmp_block16_clock_records(unsigned long long *buf, int capacity_blocks)
  * range_flag: the fp16 range guard of the split operands (see the top of this header), may be NULL. */
 int nmrf_gemm_split_f32(const float *A, int64_t sa_i, int64_t sa_k, const float *B, int64_t sb_k, int64_t sb_j, int M, int N, int K,
                         float *C, int ldc, int splits, int64_t split_stride, const float *a_amax, int *range_flag, void *stream);
+/* qkv16 [T,384] rows whose k | v thirds are split fp16 pairs (kv16 of nmrf_nmp_block16_f32) -> qkv [T,384] fp32 rows with k = hi + lo,
+ * v = hi + lo (2^-22 relative of what the producer split): the operand of the attention backward kernels.  Both 16-byte aligned. */
+int nmrf_from_kv16_f32(const float *qkv16, int64_t T, float *qkv, void *stream);
 /* *out = max(*out, max_i |x[i]|) for a caller-ZEROED device float (the a_amax operand of nmrf_gemm_split_f32): one pass, one atomic per
  * block on the value's bit pattern -- order-independent, deterministic; NaNs are dropped (the consumer's range guard reports them).
  * x 16-byte aligned. */

@@ -75,6 +75,7 @@ PROTOTYPES = {
     "nmrf_sum_partials_grouped_f32": [_P, _I, _L, _L, _I, _P, _P],
     "nmrf_sum_partials_tree_f32": [_P, _I, _L, _L, _P, _P],
     "nmrf_absmax_f32": [_P, _L, _P, _P],
+    "nmrf_from_kv16_f32": [_P, _L, _P, _P],
     "nmrf_colsum_partials_f32": [_P, _L, _I, _I, _P, _P],
     "nmrf_bias_act_f32": [_P, _P, _L, _I, _I, _P, _P, _P],
     "nmrf_act_bwd_f32": [_P, _P, _L, _I, _P, _P],

@@ -99,6 +99,87 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs a) {
     split_guard_commit(guard, a.range_flag);
 }
 
+// Both operands contiguous along their OUTPUT index (sa_i == 1, sb_j == 1: the weight gradient dW = dy^T x, whose contraction runs over
+// the tokens): a lane of the kernel above reads its 8-run of k with eight 4-byte loads per operand and chunk -- sixteen load
+// instructions per three MFMAs (45.8 us per call, 95 calls per training step).  Here a wave reads each 16 x 32 operand tile as whole
+// 128-byte rows (k fixed, 32 outputs: one 16-byte load per lane for 8 k-rows, two per chunk and operand), parks it in a wave-private
+// LDS tile [16 k][32 + 1] and picks its MFMA 8-runs up from there.  Same products, same accumulation order: the same bits.
+__global__ __launch_bounds__(256) void gemm_split_ic_kernel(GemmArgs a) {
+    __shared__ float s_t[4][2][16][33];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tile = blockIdx.x * 4 + wv;
+    if (tile >= a.n_tiles) return;                         // (no block barrier in this kernel)
+    const int tm = tile / a.tiles_n, tn = tile % a.tiles_n;
+    const int kh = lane >> 5, jl = lane & 31;
+    const int i = tm * 32 + jl, j = tn * 32 + jl;
+    const bool jok = j < a.N;
+    const int nchunks = (a.K + 15) / 16;
+    const int c0 = blockIdx.y * a.cps, c1 = min(nchunks, c0 + a.cps);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float guard = 0.f;
+    float a_mul = 1.f, c_mul = 1.f;
+    if (a.a_amax) {
+        const float m = *a.a_amax;
+        if (m > 0.f && m < INFINITY) {
+            const int e = (int)((__float_as_uint(m) >> 23) & 0xffu) - 127;
+            const int sh = 13 - (e < -100 ? -100 : e);
+            a_mul = ldexpf(1.0f, sh < 126 ? sh : 126);
+            c_mul = ldexpf(1.0f, -(sh < 126 ? sh : 126));
+        }
+    }
+    // loading role of a lane: k-row lane >> 3 (of 8) of a half chunk, outputs 4 (lane & 7) .. + 3 of the tile
+    const int lk = lane >> 3, lo4 = 4 * (lane & 7);
+    const bool a_in = tm * 32 + lo4 < a.M, b_in = tn * 32 + lo4 < a.N;       // (M, N multiples of 4: checked by the launcher)
+    const float *pa = a.A + tm * 32 + lo4, *pb = a.B + tn * 32 + lo4;
+    auto fetch = [&](int c, float4 (&va)[2], float4 (&vb)[2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = c * 16 + 8 * h + lk;
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            va[h] = (a_in && k < a.K) ? ldg4(pa + (int64_t)k * a.sa_k) : z;
+            vb[h] = (b_in && k < a.K) ? ldg4(pb + (int64_t)k * a.sb_k) : z;
+        }
+    };
+    float4 va[2], vb[2], na[2], nb[2];
+    if (c0 < c1) fetch(c0, va, vb);
+    float (*ta)[33] = s_t[wv][0], (*tb)[33] = s_t[wv][1];
+    for (int c = c0; c < c1; ++c) {
+        if (c + 1 < c1) fetch(c + 1, na, nb);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float *ra = &ta[8 * h + lk][lo4], *rb = &tb[8 * h + lk][lo4];
+            ra[0] = va[h].x; ra[1] = va[h].y; ra[2] = va[h].z; ra[3] = va[h].w;
+            rb[0] = vb[h].x; rb[1] = vb[h].y; rb[2] = vb[h].z; rb[3] = vb[h].w;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float av[8], bv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            av[e] = ta[8 * kh + e][jl] * a_mul;
+            bv[e] = tb[8 * kh + e][jl];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        h16x8 ah, al, bh, bl;
+        split8u_g(av, ah, al, guard);
+        split8u_g(bv, bh, bl, guard);
+        split_mma1(ah, al, bh, bl, acc);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { va[h] = na[h]; vb[h] = nb[h]; }
+    }
+    float *cp = a.C + (int64_t)blockIdx.y * a.split_stride;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = tm * 32 + mfma_row(r, kh);
+        if (row < a.M && jok) cp[(int64_t)row * a.ldc + j] = acc[r] * c_mul;
+    }
+    (void)i;
+    split_guard_commit(guard, a.range_flag);
+}
+
 extern "C" int nmrf_gemm_split_f32(const float *A, int64_t sa_i, int64_t sa_k, const float *B, int64_t sb_k, int64_t sb_j, int M, int N,
                                    int K, float *C, int ldc, int splits, int64_t split_stride, const float *a_amax, int *range_flag,
                                    void *stream) {
@@ -112,7 +193,10 @@ extern "C" int nmrf_gemm_split_f32(const float *A, int64_t sa_i, int64_t sa_k, c
     const bool k8 = K % 8 == 0;
     const bool ak1 = k8 && sa_k == 1 && sa_i % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
     const bool bk1 = k8 && sb_k == 1 && sb_j % 4 == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0;
-    if (ak1 && bk1) hipLaunchKernelGGL((gemm_split_kernel<true, true>), grid, dim3(256), 0, st, a);
+    const bool ic = sa_i == 1 && sb_j == 1 && M % 4 == 0 && N % 4 == 0 && sa_k % 4 == 0 && sb_k % 4 == 0 &&
+                    ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
+    if (ic) hipLaunchKernelGGL(gemm_split_ic_kernel, grid, dim3(256), 0, st, a);
+    else if (ak1 && bk1) hipLaunchKernelGGL((gemm_split_kernel<true, true>), grid, dim3(256), 0, st, a);
     else if (ak1) hipLaunchKernelGGL((gemm_split_kernel<true, false>), grid, dim3(256), 0, st, a);
     else if (bk1) hipLaunchKernelGGL((gemm_split_kernel<false, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((gemm_split_kernel<false, false>), grid, dim3(256), 0, st, a);
@@ -188,6 +272,47 @@ extern "C" int nmrf_sum_partials_tree_f32(const float *parts, int S, int64_t n, 
 }
 extern "C" int nmrf_sum_partials_f32(const float *parts, int S, int64_t n, int64_t stride, float *out, void *stream) {
     return nmrf_sum_partials_grouped_f32(parts, S, n, stride, S < 1 ? 1 : S, out, stream);
+}
+
+// kv16 rows (q fp32 | k | v as split fp16 pairs, include/nmrf_hip.h: what the block kernels write for the attention kernels) -> fp32 rows
+// with k = hi + lo, v = hi + lo: the operand of the attention BACKWARD kernels, which take fp32 rows.  One launch instead of the ~15 torch
+// view / shift / mask / stack / add passes per layer of the training-mode tape (round 6).  k third, per head: 16 words of hi halves then
+// 16 words of lo halves, element 2 j in the low half of word j; v third: word c = hi | lo << 16 of channel c.
+__global__ __launch_bounds__(256) void from_kv16_kernel(const float *__restrict__ in, int64_t T, float *__restrict__ out) {
+    const int64_t total = T * 96;                                  // float4 groups per row: 32 q + 32 k + 32 v
+    auto h2f = [](unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); };
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t t = i / 96;
+        const int g = (int)(i - t * 96);
+        const float *row = in + t * 384;
+        float4 o;
+        if (g < 32) {
+            o = ldg4(row + 4 * g);
+        } else if (g < 64) {
+            const int hd = (g - 32) >> 3, e0 = ((g - 32) & 7) * 4;
+            const unsigned *w = reinterpret_cast<const unsigned *>(row) + 128 + 32 * hd + (e0 >> 1);
+            const unsigned h0 = w[0], h1 = w[1], l0 = w[16], l1 = w[17];
+            o.x = h2f((unsigned short)(h0 & 0xffffu)) + h2f((unsigned short)(l0 & 0xffffu));
+            o.y = h2f((unsigned short)(h0 >> 16)) + h2f((unsigned short)(l0 >> 16));
+            o.z = h2f((unsigned short)(h1 & 0xffffu)) + h2f((unsigned short)(l1 & 0xffffu));
+            o.w = h2f((unsigned short)(h1 >> 16)) + h2f((unsigned short)(l1 >> 16));
+        } else {
+            const unsigned *w = reinterpret_cast<const unsigned *>(row) + 256 + 4 * (g - 64);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = h2f((unsigned short)(w[e] & 0xffffu)) + h2f((unsigned short)(w[e] >> 16));
+            o = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        stg4(out + t * 384 + 4 * g, o);
+    }
+}
+extern "C" int nmrf_from_kv16_f32(const float *qkv16, int64_t T, float *qkv, void *stream) {
+    if (!qkv16 || !qkv) return NMRF_ENULL;
+    if (T < 1 || ((reinterpret_cast<uintptr_t>(qkv16) | reinterpret_cast<uintptr_t>(qkv)) & 15)) return NMRF_EINVAL;
+    int64_t blocks = ceil_div64(T * 96, 256 * 2);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(from_kv16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, qkv16, T, qkv);
+    return nmrf_launch_status();
 }
 
 // max |x| into *out (which the caller has ZEROED): per-thread maxima over 16-byte loads, wave and block reduction, one atomicMax of the

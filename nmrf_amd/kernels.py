@@ -1383,6 +1383,16 @@ def from_kv16(qkv):
     """The inverse of to_kv16 (torch views and bit operations -- plumbing): rows whose k | v thirds are split fp16 pairs -> fp32 rows with
     k = hi + lo, v = hi + lo (the value the attention kernels multiply: up to 2^-22 relative of what the producer split)."""
     t = qkv.shape[0]
+    if qkv.is_cuda and qkv.is_contiguous() and qkv.dtype == torch.float32 and qkv.shape[1] == 384 and qkv.data_ptr() % 16 == 0 and t > 0:
+        out = torch.empty_like(qkv)                                              # one launch (nmrf_from_kv16_f32): the training tape asks per layer
+        _lib.check(_lib.load().nmrf_from_kv16_f32(_p(qkv), t, _p(out), _stream()), "from_kv16")
+        return out
+    return _from_kv16_torch(qkv)
+
+
+def _from_kv16_torch(qkv):
+    """from_kv16 as torch views and bit operations (rows the kernel does not take; the restatement its test compares it with)."""
+    t = qkv.shape[0]
     out = qkv.clone()
     words = qkv.view(torch.int32)
     half = lambda w16: (w16 & 0xffff).to(torch.int16).view(torch.float16).float()

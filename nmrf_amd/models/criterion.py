@@ -46,7 +46,8 @@ class Criterion(nn.Module):
         nearest = (tgt.unsqueeze(-1) - disp_prop.unsqueeze(-2)).abs().argmin(-1)                # first minimum, like torch.min
         matched = disp_prop.gather(-1, nearest)
         valid = (tgt > 0) & (tgt < self.max_disp)
-        total = F.smooth_l1_loss(matched[valid], tgt[valid], reduction="sum")
+        # (masked sums instead of the reference's boolean indexing -- the same terms, no nonzero / index_put launches and no read-back)
+        total = (F.smooth_l1_loss(matched, tgt, reduction="none") * valid).sum()
         return {"loss_prop": total / (valid.sum() + 1e-6)}
 
     # ---- initial distribution ------------------------------------------------------------------------------------------------
@@ -66,26 +67,33 @@ class Criterion(nn.Module):
         label.scatter_add_(-1, lo.clamp(max=nd - 1), (1 - frac) * wgt)
         label.scatter_add_(-1, (lo + 1).clamp(max=nd - 1), frac * wgt)
         label = label / label.sum(-1, keepdim=True).clamp(min=1e-3)
-        hit = label > 0
-        nll = -(prob[hit].clamp(min=1e-6).log() * label[hit]).sum()
+        nll = -(prob.clamp(min=1e-6).log() * label).sum()                # (entries with label 0 add nothing: the reference indexes label > 0)
         cells = (wgt.sum(-1) > 0).sum()
         loss = nll / (cells + 1e-6)
         assert not torch.isnan(loss).any()
         return {"init": loss}
 
     # ---- disparities --------------------------------------------------------------------------------------------------------------
-    def loss_coarse(self, disp_pred, logits_pred, disp_gt):
-        valid = (disp_gt > 0) & (disp_gt < self.max_disp)
-        if not valid.any():                     # keeps the graph alive with a zero loss (NMRF.py:374-375)
+    def _valid(self, disp_gt, valid=None):
+        """(mask, number of valid pixels as a tensor, any valid pixel at all) -- forward() computes them once per target and hands them to
+        every term (the reference re-derives them, with one `valid.any()` read-back, per auxiliary output)."""
+        if valid is not None:
+            return valid
+        m = (disp_gt > 0) & (disp_gt < self.max_disp)
+        return m, m.sum(), bool(m.any())
+
+    def loss_coarse(self, disp_pred, logits_pred, disp_gt, valid=None):
+        m, cnt, has = self._valid(disp_gt, valid)
+        if not has:                             # keeps the graph alive with a zero loss (NMRF.py:374-375)
             return {"loss_coarse_disp": F.smooth_l1_loss(disp_pred, disp_pred.detach()) + F.smooth_l1_loss(logits_pred, logits_pred.detach())}
         err = self.loss_fn(disp_pred, disp_gt.unsqueeze(-1).expand_as(disp_pred), reduction="none")
-        return {"loss_coarse_disp": (F.softmax(logits_pred, -1) * err).sum(-1)[valid].mean()}
+        return {"loss_coarse_disp": ((F.softmax(logits_pred, -1) * err).sum(-1) * m).sum() / cnt}      # the mean over the valid pixels
 
-    def loss_disp(self, disp_pred, disp_gt):
-        valid = (disp_gt > 0) & (disp_gt < self.max_disp)
-        if not valid.any():
+    def loss_disp(self, disp_pred, disp_gt, valid=None):
+        m, cnt, has = self._valid(disp_gt, valid)
+        if not has:
             return {"loss_disp": F.smooth_l1_loss(disp_pred, disp_pred.detach())}
-        return {"loss_disp": self.loss_fn(disp_pred[valid], disp_gt[valid], reduction="mean")}
+        return {"loss_disp": (self.loss_fn(disp_pred, disp_gt, reduction="none") * m).sum() / cnt}
 
     def forward(self, outputs, targets, log=True):
         """outputs: the dictionary of NMRF.forward; targets: {'disp' [B,H,W], 'valid' bool [B,H,W]} -> dict of scalar losses."""
@@ -94,16 +102,16 @@ class Criterion(nn.Module):
         gt[~targets["valid"].to(disp.device)] = 0            # (in place, as the reference does: callers see the masked target)
         losses = self.loss_prop(outputs["proposal"] * 8, gt)
         losses.update(self.loss_init(outputs["prob"], gt))
+        vm = self._valid(gt)
         if "disp_pred" in outputs:
-            losses.update(self.loss_disp(outputs["disp_pred"] * 4, gt))
+            losses.update(self.loss_disp(outputs["disp_pred"] * 4, gt, vm))
         if log:
-            valid = (gt > 0) & (gt < self.max_disp)
-            losses["epe_train"] = (disp - gt).abs()[valid].mean()
+            losses["epe_train"] = ((disp - gt).abs() * vm[0]).sum() / vm[1]
         for i, aux in enumerate(outputs.get("aux_outputs", ())):
             if "logits_pred" in aux:
-                part = self.loss_coarse(aux["disp_pred"] * 8, aux["logits_pred"], gt)
+                part = self.loss_coarse(aux["disp_pred"] * 8, aux["logits_pred"], gt, vm)
             else:
-                part = self.loss_disp(aux["disp_pred"] * 4, gt)
+                part = self.loss_disp(aux["disp_pred"] * 4, gt, vm)
             losses.update({f"{k}_{i}": v for k, v in part.items()})
         return losses
 

@@ -1589,3 +1589,14 @@ def test_absmax_matches_torch_and_is_order_independent(n):
     g = (rnd(300, 128, seed=5) * 1e-5).to(DEV)
     m1 = K().grad_amax(g)
     assert float(m1) == float(g.abs().max()) and K().grad_amax(g) is m1
+
+
+def test_from_kv16_kernel_equals_its_torch_restatement():
+    """nmrf_from_kv16_f32 (one launch per layer of the training tape) = the torch view / shift / mask formulation, bit for bit, on rows
+    the block kernel's format restatement (kernels.to_kv16) produced; q passes through untouched."""
+    kk = K()
+    for t_ in (1, 7, 4 * 1000 + 3):
+        qkv = (rnd(t_, 384, seed=t_) * 3.0).to(DEV)
+        q16 = kk.to_kv16(qkv)
+        got, want = kk.from_kv16(q16), kk._from_kv16_torch(q16)
+        assert torch.equal(got, want) and torch.equal(got[:, :128], qkv[:, :128])

@@ -413,7 +413,7 @@ def test_integration_appendix_lists_every_entry_point():
     assert set(rows) == set(_lib.PROTOTYPES) | {"nmrf_strerror"} or set(rows) == set(_lib.PROTOTYPES)
     uncited = [n for n, l in rows.items() if l.rstrip().endswith("| – |")]
     helpers = ("nmrf_selftest_", "nmrf_strerror", "nmrf_abi_version", "nmrf_pack_", "nmrf_host_", "nmrf_sum_partials", "nmrf_colsum_",
-               "nmrf_act_bwd", "nmrf_absmax", "nmrf_layernorm", "nmrf_instance_stats", "nmrf_prep_images_s2d_f32", "nmrf_nmp_block16_clock_records", "nmrf_build_stamp")
+               "nmrf_act_bwd", "nmrf_absmax", "nmrf_from_kv16", "nmrf_layernorm", "nmrf_instance_stats", "nmrf_prep_images_s2d_f32", "nmrf_nmp_block16_clock_records", "nmrf_build_stamp")
     assert all(n.startswith(helpers) for n in uncited), [n for n in uncited if not n.startswith(helpers)]
 
 
