@@ -104,7 +104,9 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(GemmArgs a) {
 // instructions per three MFMAs (45.8 us per call, 95 calls per training step).  Here a wave reads each 16 x 32 operand tile as whole
 // 128-byte rows (k fixed, 32 outputs: one 16-byte load per lane for 8 k-rows, two per chunk and operand), parks it in a wave-private
 // LDS tile [16 k][32 + 1] and picks its MFMA 8-runs up from there.  Same products, same accumulation order: the same bits.
+template <bool AIC, bool BIC>       // operand contiguous along its output index (through the LDS tile) -- otherwise along k (two 16-byte loads per 8-run)
 __global__ __launch_bounds__(256) void gemm_split_ic_kernel(GemmArgs a) {
+    static_assert(AIC || BIC, "both operands k-contiguous: gemm_split_kernel<true, true>");
     __shared__ float s_t[4][2][16][33];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int tile = blockIdx.x * 4 + wv;
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(256) void gemm_split_ic_kernel(GemmArgs a) {
     const int tm = tile / a.tiles_n, tn = tile % a.tiles_n;
     const int kh = lane >> 5, jl = lane & 31;
     const int i = tm * 32 + jl, j = tn * 32 + jl;
-    const bool jok = j < a.N;
+    const bool iok = i < a.M, jok = j < a.N;
     const int nchunks = (a.K + 15) / 16;
     const int c0 = blockIdx.y * a.cps, c1 = min(nchunks, c0 + a.cps);
     f32x16 acc;
@@ -129,18 +131,30 @@ __global__ __launch_bounds__(256) void gemm_split_ic_kernel(GemmArgs a) {
             c_mul = ldexpf(1.0f, -(sh < 126 ? sh : 126));
         }
     }
-    // loading role of a lane: k-row lane >> 3 (of 8) of a half chunk, outputs 4 (lane & 7) .. + 3 of the tile
+    // IC operand, loading role of a lane: k-row lane >> 3 (of 8) of a half chunk, outputs 4 (lane & 7) .. + 3 of the tile
     const int lk = lane >> 3, lo4 = 4 * (lane & 7);
-    const bool a_in = tm * 32 + lo4 < a.M, b_in = tn * 32 + lo4 < a.N;       // (M, N multiples of 4: checked by the launcher)
-    const float *pa = a.A + tm * 32 + lo4, *pb = a.B + tn * 32 + lo4;
-    auto fetch = [&](int c, float4 (&va)[2], float4 (&vb)[2]) {
+    const bool a_in = tm * 32 + lo4 < a.M, b_in = tn * 32 + lo4 < a.N;       // (IC: M / N multiples of 4, checked by the launcher)
+    const float *pa = AIC ? a.A + tm * 32 + lo4 : a.A + (int64_t)(iok ? i : 0) * a.sa_i;
+    const float *pb = BIC ? a.B + tn * 32 + lo4 : a.B + (int64_t)(jok ? j : 0) * a.sb_j;
+    // per chunk and operand: IC -> two float4 (k rows lk and 8 + lk); K1 -> the lane's own 8-run as two float4
+    auto fetch1 = [&](auto ic, const float *p, int64_t sk, bool in_tile, bool ok, int c, float4 (&v)[2]) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (decltype(ic)::value) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int k = c * 16 + 8 * h + lk;
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            va[h] = (a_in && k < a.K) ? ldg4(pa + (int64_t)k * a.sa_k) : z;
-            vb[h] = (b_in && k < a.K) ? ldg4(pb + (int64_t)k * a.sb_k) : z;
+            for (int h = 0; h < 2; ++h) {
+                const int k = c * 16 + 8 * h + lk;
+                v[h] = (in_tile && k < a.K) ? ldg4(p + (int64_t)k * sk) : z;
+            }
+        } else {
+            const int k0 = c * 16 + 8 * kh;
+            const bool on = ok && k0 < a.K;                 // (K % 8 == 0: checked by the launcher)
+            v[0] = on ? ldg4(p + k0) : z;
+            v[1] = on ? ldg4(p + k0 + 4) : z;
         }
+    };
+    auto fetch = [&](int c, float4 (&va)[2], float4 (&vb)[2]) {
+        fetch1(std::integral_constant<bool, AIC>{}, pa, a.sa_k, a_in, iok, c, va);
+        fetch1(std::integral_constant<bool, BIC>{}, pb, a.sb_k, b_in, jok, c, vb);
     };
     float4 va[2], vb[2], na[2], nb[2];
     if (c0 < c1) fetch(c0, va, vb);
@@ -149,17 +163,25 @@ __global__ __launch_bounds__(256) void gemm_split_ic_kernel(GemmArgs a) {
         if (c + 1 < c1) fetch(c + 1, na, nb);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            float *ra = &ta[8 * h + lk][lo4], *rb = &tb[8 * h + lk][lo4];
-            ra[0] = va[h].x; ra[1] = va[h].y; ra[2] = va[h].z; ra[3] = va[h].w;
-            rb[0] = vb[h].x; rb[1] = vb[h].y; rb[2] = vb[h].z; rb[3] = vb[h].w;
+            if constexpr (AIC) { float *ra = &ta[8 * h + lk][lo4]; ra[0] = va[h].x; ra[1] = va[h].y; ra[2] = va[h].z; ra[3] = va[h].w; }
+            if constexpr (BIC) { float *rb = &tb[8 * h + lk][lo4]; rb[0] = vb[h].x; rb[1] = vb[h].y; rb[2] = vb[h].z; rb[3] = vb[h].w; }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         float av[8], bv[8];
+        if constexpr (AIC) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            av[e] = ta[8 * kh + e][jl] * a_mul;
-            bv[e] = tb[8 * kh + e][jl];
+            for (int e = 0; e < 8; ++e) av[e] = ta[8 * kh + e][jl] * a_mul;
+        } else {
+            const float t[8] = {va[0].x, va[0].y, va[0].z, va[0].w, va[1].x, va[1].y, va[1].z, va[1].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) av[e] = t[e] * a_mul;
+        }
+        if constexpr (BIC) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bv[e] = tb[8 * kh + e][jl];
+        } else {
+            bv[0] = vb[0].x; bv[1] = vb[0].y; bv[2] = vb[0].z; bv[3] = vb[0].w; bv[4] = vb[1].x; bv[5] = vb[1].y; bv[6] = vb[1].z; bv[7] = vb[1].w;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -176,7 +198,6 @@ __global__ __launch_bounds__(256) void gemm_split_ic_kernel(GemmArgs a) {
         const int row = tm * 32 + mfma_row(r, kh);
         if (row < a.M && jok) cp[(int64_t)row * a.ldc + j] = acc[r] * c_mul;
     }
-    (void)i;
     split_guard_commit(guard, a.range_flag);
 }
 
@@ -193,9 +214,11 @@ extern "C" int nmrf_gemm_split_f32(const float *A, int64_t sa_i, int64_t sa_k, c
     const bool k8 = K % 8 == 0;
     const bool ak1 = k8 && sa_k == 1 && sa_i % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
     const bool bk1 = k8 && sb_k == 1 && sb_j % 4 == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0;
-    const bool ic = sa_i == 1 && sb_j == 1 && M % 4 == 0 && N % 4 == 0 && sa_k % 4 == 0 && sb_k % 4 == 0 &&
-                    ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
-    if (ic) hipLaunchKernelGGL(gemm_split_ic_kernel, grid, dim3(256), 0, st, a);
+    const bool aic = sa_i == 1 && M % 4 == 0 && sa_k % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
+    const bool bic = sb_j == 1 && N % 4 == 0 && sb_k % 4 == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0;
+    if (aic && bic) hipLaunchKernelGGL((gemm_split_ic_kernel<true, true>), grid, dim3(256), 0, st, a);          // wgrad
+    else if (ak1 && bic) hipLaunchKernelGGL((gemm_split_ic_kernel<false, true>), grid, dim3(256), 0, st, a);     // dgrad: dy rows . W
+    else if (aic && bk1) hipLaunchKernelGGL((gemm_split_ic_kernel<true, false>), grid, dim3(256), 0, st, a);
     else if (ak1 && bk1) hipLaunchKernelGGL((gemm_split_kernel<true, true>), grid, dim3(256), 0, st, a);
     else if (ak1) hipLaunchKernelGGL((gemm_split_kernel<true, false>), grid, dim3(256), 0, st, a);
     else if (bk1) hipLaunchKernelGGL((gemm_split_kernel<false, true>), grid, dim3(256), 0, st, a);
