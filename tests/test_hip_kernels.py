@@ -1225,7 +1225,8 @@ def test_conv1x1_strided_shortcut(b, ci, co, h, w, stride, bias):
 # --------------------------------------------------------------------------------------------------------------------
 # N4, first slice: backward pieces (csrc/backward.hip) and the autograd Functions over the fused forward launches
 # --------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("t_,n,k", [(64, 128, 128), (777, 64, 128), (5000, 512, 128), (33, 16, 128), (1030, 128, 512), (40000, 128, 128)])
+@pytest.mark.parametrize("t_,n,k", [(64, 128, 128), (777, 64, 128), (5000, 512, 128), (33, 16, 128), (1030, 128, 512), (40000, 128, 128),
+                                    (100, 20, 36), (50, 30, 31), (515, 384, 160), (300, 128, 159)])   # the last four: small / ragged tiles, widths that are no multiple of 4 (the strided fallback)
 def test_backward_gemm_pieces_vs_fp64(t_, n, k):
     """dgrad / wgrad / forward of an nn.Linear as the strided split-fp16 GEMM (nmrf_gemm_split_f32), bias gradient as column sums:
     against fp64 matmuls; wgrad's K-split reduction is deterministic (two runs: same bits)."""
