@@ -13,16 +13,23 @@ def pytest_configure(config):
 
 
 def pytest_sessionstart(session):
-    """Refuse built libraries that do not come from the sources in the tree (a stale tools library once cost a
-    GPU round): both libraries carry a hash of every source they were built from (nmrf_build_stamp, python -m nmrf_amd.build)."""
+    """Built libraries that do not come from the sources in the tree (a stale tools library once cost a GPU round)
+    are rebuilt incrementally, and refused if that is not possible: both libraries carry a hash of every source they were built from
+    (nmrf_build_stamp, python -m nmrf_amd.build)."""
     from nmrf_amd import build
     want = "abi%d-%s" % (__import__("nmrf_amd._lib", fromlist=["x"]).ABI_VERSION, build.source_stamp())
-    for path in (build.LIB, build.LIB.replace("libnmrf_hip.so", "libnmrf_hip_debug.so")):
-        if os.path.exists(path):
-            got = build.library_stamp(path)
-            if got != want:
-                pytest.exit("%s is stale: built from %s, the tree is %s -- run `python -m nmrf_amd.build`" % (
-                    os.path.relpath(path, ROOT), got, want), returncode=3)
+    libs = ((build.LIB, False), (build.LIB.replace("libnmrf_hip.so", "libnmrf_hip_debug.so"), True))
+    stale = [(p, dbg) for p, dbg in libs if os.path.exists(p) and build.library_stamp(p) != want]
+    for path, dbg in stale:                                  # an incremental rebuild first (seconds when little changed; hipcc needs no GPU)
+        try:
+            build.build_library(verbose=False, debug=dbg)
+        except Exception as e:                               # no hipcc here: fall through to the refusal below
+            sys.stderr.write("[conftest] rebuild of %s failed: %s\n" % (os.path.basename(path), str(e).splitlines()[0] if str(e) else repr(e)))
+    for path, _ in stale:
+        got = build.library_stamp(path)
+        if got != want:
+            pytest.exit("%s is stale: built from %s, the tree is %s -- run `python -m nmrf_amd.build`" % (
+                os.path.relpath(path, ROOT), got, want), returncode=3)
 
 
 def pytest_collection_modifyitems(config, items):
